@@ -1,0 +1,56 @@
+// Host-side plumbing of the C ABI: thread-local error message, launch check, descriptor self-checks.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void apad_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int apad_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        apad_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return -2;
+    }
+    return 0;
+}
+
+extern "C" const char* apad_last_error(void) { return g_err; }
+extern "C" int apad_abi_version(void) { return APAD_ABI_VERSION; }
+extern "C" int apad_sizeof_gemm_desc(void) { return (int)sizeof(apad_gemm_desc); }
+extern "C" int apad_sizeof_attn_desc(void) { return (int)sizeof(apad_attn_desc); }
+
+#define PUT(x)                          \
+    do {                                \
+        if (n < cap) out[n] = (double)(x); \
+        ++n;                            \
+    } while (0)
+#define PUTP(x) PUT((uintptr_t)(x))
+
+extern "C" int apad_echo_gemm_desc(const apad_gemm_desc* d, double* out, int cap) {
+    int n = 0;
+    PUTP(d->a); PUTP(d->w); PUTP(d->out); PUTP(d->bias); PUTP(d->residual); PUTP(d->rowgroup_bias); PUTP(d->step_ptr);
+    PUT(d->M); PUT(d->N); PUT(d->K); PUT(d->lda); PUT(d->ldw); PUT(d->ldo); PUT(d->ldr); PUT(d->ld_rg);
+    PUT(d->rows_per_group);
+    PUT(d->a_mode); PUT(d->epilogue); PUT(d->out_mode); PUT(d->dtype);
+    PUT(d->Hin); PUT(d->Win); PUT(d->Cin); PUT(d->Hout); PUT(d->Wout); PUT(d->stride); PUT(d->Hup); PUT(d->Wup);
+    PUT(d->src_batch_mod); PUT(d->heads); PUT(d->head_dim); PUT(d->L); PUT(d->Lpad);
+    return n;
+}
+
+extern "C" int apad_echo_attn_desc(const apad_attn_desc* d, double* out, int cap) {
+    int n = 0;
+    PUTP(d->q); PUTP(d->k); PUTP(d->vt); PUTP(d->k2); PUTP(d->vt2); PUTP(d->out); PUTP(d->key_bias);
+    PUT(d->q_stride_b); PUT(d->q_stride_n); PUT(d->k_stride_b); PUT(d->k_stride_l); PUT(d->vt_stride_b);
+    PUT(d->k2_stride_b); PUT(d->k2_stride_l); PUT(d->vt2_stride_b); PUT(d->o_stride_b); PUT(d->o_stride_n);
+    PUT(d->B); PUT(d->N); PUT(d->H); PUT(d->D); PUT(d->L); PUT(d->Lpad); PUT(d->L2); PUT(d->Lpad2);
+    PUT(d->kv_batch_div); PUT(d->kv2_batch_div); PUT(d->dtype); PUT(d->softmax_scale); PUT(d->scale2);
+    return n;
+}

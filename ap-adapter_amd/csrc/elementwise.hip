@@ -1,0 +1,155 @@
+// Small HBM-bound kernels of the path: AudioMAE token pooling, sinusoidal timestep embedding, fused
+// classifier-free-guidance + DDIM update, device-side step counter.
+#include "common.h"
+
+namespace {
+
+// rep [B][513][768] -> out [B][(64/tp)*(8/fp)][768]; token (t,f) of the 64x8 grid is row 1 + 8*t + f.
+// (avg + max) / 2 over (tp x fp) windows (reference AudioMAE.py:148-182).
+template <int DT, int ODT>
+__global__ __launch_bounds__(256) void pool_kernel(const uint8_t* rep, uint8_t* out, int B, int tp, int fp) {
+    const int nt = 64 / tp, nf = 8 / fp, La = nt * nf;
+    const int64_t total = (int64_t)B * La * 96;  // 96 vectors of 8 channels
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int vc = (int)(idx % 96);
+        const int64_t tok = idx / 96;
+        const int b = (int)(tok / La), o = (int)(tok % La);
+        const int ot = o / nf, of = o % nf;
+        float s[8], mx[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s[e] = 0.f;
+            mx[e] = -3.0e38f;
+        }
+        for (int dt = 0; dt < tp; ++dt)
+            for (int df = 0; df < fp; ++df) {
+                const int row = 1 + 8 * (ot * tp + dt) + (of * fp + df);
+                float v[8];
+                unpack8<DT>(*reinterpret_cast<const uint4*>(rep + (((int64_t)b * 513 + row) * 768 + vc * 8) * 2), v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    s[e] += v[e];
+                    mx[e] = fmaxf(mx[e], v[e]);
+                }
+            }
+        const float inv = 1.0f / (float)(tp * fp);
+        float y[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = (s[e] * inv + mx[e]) * 0.5f;
+        if (ODT == APAD_F32) {
+            float4* op = reinterpret_cast<float4*>(out + (tok * 768 + vc * 8) * 4);
+            op[0] = make_float4(y[0], y[1], y[2], y[3]);
+            op[1] = make_float4(y[4], y[5], y[6], y[7]);
+        } else {
+            constexpr int PD = (ODT == APAD_F32) ? APAD_BF16 : ODT;
+            *reinterpret_cast<uint4*>(out + (tok * 768 + vc * 8) * 2) = pack8<PD>(y);
+        }
+    }
+}
+
+// diffusers get_timestep_embedding: exponent = -ln(10000) * i / (half - freq_shift); [sin | cos], flipped to
+// [cos | sin] when flip_sin_to_cos.
+template <int DT>
+__global__ void timestep_kernel(const float* t, uint8_t* out, int n, int dim, int flip, float freq_shift) {
+    const int half = dim >> 1;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * half) return;
+    const int r = idx / half, i = idx - r * half;
+    const float freq = expf(-9.210340371976184f * (float)i / ((float)half - freq_shift));
+    const float a = t[r] * freq;
+    const float sv = sinf(a), cv = cosf(a);
+    const int64_t base = (int64_t)r * dim;
+    if (flip) {
+        st_elem<DT>(out, base + i, cv);
+        st_elem<DT>(out, base + half + i, sv);
+    } else {
+        st_elem<DT>(out, base + i, sv);
+        st_elem<DT>(out, base + half + i, cv);
+    }
+}
+
+// eps = e_u + g (e_c - e_u); x_prev = c0 * x + c1 * eps   (pipeline_audioldm2.py:1020-1025, DDIM eta = 0)
+template <int DT>
+__global__ __launch_bounds__(256) void cfg_ddim_kernel(const uint8_t* eps2, float* latents, uint8_t* unet_in, float* eps_out,
+                                                       const float* coef, const int32_t* step_ptr, float gs, int64_t total) {
+    const int step = step_ptr ? *step_ptr : 0;
+    const float c0 = coef[2 * step], c1 = coef[2 * step + 1];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const float eu = ld_elem<DT>(eps2, i), ec = ld_elem<DT>(eps2, total + i);
+        // the reference forms the guided noise in the model dtype
+        const float e = (float)(typename ET<DT>::elem)(eu + gs * (ec - eu));
+        const float x = c0 * latents[i] + c1 * e;
+        latents[i] = x;
+        st_elem<DT>(unet_in, i, x);
+        if (eps_out) eps_out[i] = e;
+    }
+}
+
+__global__ void step_advance_kernel(int32_t* p) { *p = *p + 1; }
+
+}  // namespace
+
+extern "C" int apad_audiomae_pool(const void* rep, void* out, int32_t B, int32_t tp, int32_t fp, int32_t dtype,
+                                  int32_t out_dtype, void* stream) {
+    APAD_CHECK(rep && out && B > 0, "apad_audiomae_pool: null operand / empty batch");
+    APAD_CHECK(dtype == APAD_BF16 || dtype == APAD_F16, "apad_audiomae_pool: dtype %d not supported", dtype);
+    APAD_CHECK(out_dtype == dtype || out_dtype == APAD_F32, "apad_audiomae_pool: out_dtype must equal dtype or be f32");
+    APAD_CHECK(tp > 0 && fp > 0 && 64 % tp == 0 && 8 % fp == 0, "apad_audiomae_pool: pooling (%d,%d) must divide (64,8)", tp, fp);
+    const int64_t total = (int64_t)B * (64 / tp) * (8 / fp) * 96;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t s = (hipStream_t)stream;
+    const uint8_t* r = (const uint8_t*)rep;
+    uint8_t* o = (uint8_t*)out;
+    if (dtype == APAD_BF16) {
+        if (out_dtype == APAD_F32)
+            hipLaunchKernelGGL((pool_kernel<APAD_BF16, APAD_F32>), dim3((unsigned)blocks), dim3(256), 0, s, r, o, B, tp, fp);
+        else
+            hipLaunchKernelGGL((pool_kernel<APAD_BF16, APAD_BF16>), dim3((unsigned)blocks), dim3(256), 0, s, r, o, B, tp, fp);
+    } else {
+        if (out_dtype == APAD_F32)
+            hipLaunchKernelGGL((pool_kernel<APAD_F16, APAD_F32>), dim3((unsigned)blocks), dim3(256), 0, s, r, o, B, tp, fp);
+        else
+            hipLaunchKernelGGL((pool_kernel<APAD_F16, APAD_F16>), dim3((unsigned)blocks), dim3(256), 0, s, r, o, B, tp, fp);
+    }
+    return apad_check_launch("apad_audiomae_pool");
+}
+
+extern "C" int apad_timestep_embedding(const float* t, void* out, int32_t n, int32_t dim, int32_t flip_sin_to_cos,
+                                       float freq_shift, int32_t dtype, void* stream) {
+    APAD_CHECK(t && out && n > 0 && dim > 0 && dim % 2 == 0, "apad_timestep_embedding: bad arguments");
+    APAD_CHECK(dtype == APAD_BF16 || dtype == APAD_F16, "apad_timestep_embedding: dtype %d not supported", dtype);
+    const int total = n * (dim / 2);
+    dim3 grid((total + 255) / 256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == APAD_BF16)
+        hipLaunchKernelGGL((timestep_kernel<APAD_BF16>), grid, dim3(256), 0, s, t, (uint8_t*)out, n, dim, flip_sin_to_cos, freq_shift);
+    else
+        hipLaunchKernelGGL((timestep_kernel<APAD_F16>), grid, dim3(256), 0, s, t, (uint8_t*)out, n, dim, flip_sin_to_cos, freq_shift);
+    return apad_check_launch("apad_timestep_embedding");
+}
+
+extern "C" int apad_cfg_ddim_step(const void* eps2, float* latents, void* unet_in, float* eps_out, const float* coef,
+                                  const int32_t* step_ptr, float guidance_scale, int32_t B, int64_t n, int32_t dtype,
+                                  void* stream) {
+    APAD_CHECK(eps2 && latents && unet_in && coef, "apad_cfg_ddim_step: null operand");
+    APAD_CHECK(dtype == APAD_BF16 || dtype == APAD_F16, "apad_cfg_ddim_step: dtype %d not supported", dtype);
+    APAD_CHECK(B > 0 && n > 0, "apad_cfg_ddim_step: empty problem");
+    const int64_t total = (int64_t)B * n;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == APAD_BF16)
+        hipLaunchKernelGGL((cfg_ddim_kernel<APAD_BF16>), dim3((unsigned)blocks), dim3(256), 0, s, (const uint8_t*)eps2, latents,
+                           (uint8_t*)unet_in, eps_out, coef, step_ptr, guidance_scale, total);
+    else
+        hipLaunchKernelGGL((cfg_ddim_kernel<APAD_F16>), dim3((unsigned)blocks), dim3(256), 0, s, (const uint8_t*)eps2, latents,
+                           (uint8_t*)unet_in, eps_out, coef, step_ptr, guidance_scale, total);
+    return apad_check_launch("apad_cfg_ddim_step");
+}
+
+extern "C" int apad_step_advance(int32_t* step_ptr, void* stream) {
+    APAD_CHECK(step_ptr, "apad_step_advance: null pointer");
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_ptr);
+    return apad_check_launch("apad_step_advance");
+}

@@ -1,0 +1,345 @@
+// apad_gemm: out = epilogue(A . W^T + bias + rowgroup_bias) + residual on MFMA 32x32x16 (bf16/f16, fp32 acc).
+//
+// One kernel family covers every dense contraction of the path: Linear layers, 1x1 and 3x3
+// convolutions as implicit GEMM over NHWC activations (the im2col gather happens while staging the A tile),
+// the AudioMAE patch embedding (16x16 fp32 mel patches gathered and converted while staging), GEGLU
+// (value|gate weight rows interleaved per block so a*gelu(g) is formed in the epilogue and the 8C-wide
+// intermediate never reaches HBM) and the per-head transposed V^T store apad_attention consumes.
+//
+// Tiling: 128x128 block tile, BK=64, 4 waves (2x2), each wave 64x64 = 2x2 MFMA 32x32x16 tiles.
+// Staging: global -> registers (16 B/lane, coalesced along K) -> XOR-swizzled LDS (conflict-free
+// ds_read_b128 fragment reads); next K-tile's global loads are issued before the MFMAs of the current one.
+// Epilogue: accumulators -> LDS tile -> full-row 16 B stores (residual read with the same coalescing).
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int A_BYTES = BM * BK * 2;           // 16 KiB
+constexpr int C_LD = BN + 8;                   // epilogue tile row stride (elements)
+constexpr int SMEM_BYTES = BM * C_LD * 2;      // 34816 >= 2*A_BYTES
+
+struct GemmP {
+    const uint8_t* a;
+    const uint8_t* w;
+    uint8_t* out;
+    const uint8_t* bias;
+    const uint8_t* residual;
+    const uint8_t* rg;
+    const int32_t* step_ptr;
+    int64_t M, N, K, lda, ldw, ldo, ldr, ld_rg, rows_per_group;
+    int32_t Hin, Win, Cin, Hout, Wout, stride, Hup, Wup, src_batch_mod;
+    int32_t heads, head_dim, L, Lpad;
+    int32_t wrows;  // rows of w (N, or 2N for GEGLU)
+};
+
+// byte offset of 16-byte chunk `chunk` (0..7) of tile row `row` (128-byte rows)
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <int AMODE> struct RowInfo {
+    int64_t base;  // PLAIN: element offset of the row; CONV/PATCH: source batch index
+    int oy, ox;
+    bool valid;
+};
+
+template <int DT, int AMODE>
+__device__ __forceinline__ uint4 load_a(const GemmP& p, const RowInfo<AMODE>& r, int k) {
+    uint4 z = make_uint4(0, 0, 0, 0);
+    if (!r.valid || k >= p.K) return z;
+    if (AMODE == APAD_A_PLAIN) {
+        return *reinterpret_cast<const uint4*>(p.a + (r.base + k) * 2);
+    } else if (AMODE == APAD_A_CONV3X3) {
+        int tap = k / p.Cin;
+        int c = k - tap * p.Cin;
+        int ky = tap / 3, kx = tap - ky * 3;
+        int iy = r.oy * p.stride + ky - 1, ix = r.ox * p.stride + kx - 1;
+        int H = p.Hup > 0 ? p.Hup : p.Hin, W = p.Hup > 0 ? p.Wup : p.Win;
+        if (iy < 0 || iy >= H || ix < 0 || ix >= W) return z;
+        if (p.Hup > 0) {  // nearest-neighbour source index, floor(dst * in / out)
+            iy = (int)(((int64_t)iy * p.Hin) / p.Hup);
+            ix = (int)(((int64_t)ix * p.Win) / p.Wup);
+        }
+        int64_t off = ((r.base * p.Hin + iy) * p.Win + ix) * p.Cin + c;
+        return *reinterpret_cast<const uint4*>(p.a + off * 2);
+    } else {  // PATCH16: fp32 mel [B][Hin][Win]; k = py*16 + px
+        int py = k >> 4, px = k & 15;
+        int64_t off = (r.base * p.Hin + r.oy * 16 + py) * p.Win + r.ox * 16 + px;
+        const float4* src = reinterpret_cast<const float4*>(p.a + off * 4);
+        float4 f0 = src[0], f1 = src[1];
+        float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+        return pack8<DT>(f);
+    }
+}
+
+template <int DT, int AMODE, int EPI, int OUTMODE>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
+    __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM_BYTES];
+    using E = ET<DT>;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    constexpr int BN_OUT = (EPI == APAD_EPI_GEGLU) ? 64 : BN;
+    const int64_t m0 = (int64_t)blockIdx.y * BM;
+    const int64_t n0 = (int64_t)blockIdx.x * BN_OUT;
+
+    // W row feeding local tile column nl
+    auto wrow = [&](int nl) -> int64_t {
+        if (EPI == APAD_EPI_GEGLU) return nl < 64 ? n0 + nl : p.N + n0 + (nl - 64);
+        return n0 + nl;
+    };
+    auto wrow_valid = [&](int nl) -> bool {
+        if (EPI == APAD_EPI_GEGLU) return (nl < 64 ? n0 + nl : n0 + nl - 64) < p.N;
+        return n0 + nl < p.N;
+    };
+
+    // per-thread staging assignment: rows (tid>>3) + 32*i, 16-byte chunk tid&7
+    const int chunk = tid & 7;
+    RowInfo<AMODE> ra[4];
+    int64_t wb[4];
+    bool wv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int rl = (tid >> 3) + 32 * i;
+        int64_t m = m0 + rl;
+        ra[i].valid = m < p.M;
+        ra[i].oy = ra[i].ox = 0;
+        ra[i].base = 0;
+        if (ra[i].valid) {
+            if (AMODE == APAD_A_PLAIN) {
+                ra[i].base = m * p.lda;
+            } else if (AMODE == APAD_A_CONV3X3) {
+                int64_t hw = (int64_t)p.Hout * p.Wout;
+                int64_t b = m / hw;
+                int rem = (int)(m - b * hw);
+                ra[i].oy = rem / p.Wout;
+                ra[i].ox = rem - ra[i].oy * p.Wout;
+                ra[i].base = p.src_batch_mod > 0 ? b % p.src_batch_mod : b;
+            } else {
+                int wp = p.Win >> 4, hp = p.Hin >> 4;
+                int64_t b = m / (hp * wp);
+                int rem = (int)(m - b * hp * wp);
+                ra[i].oy = rem / wp;
+                ra[i].ox = rem - ra[i].oy * wp;
+                ra[i].base = b;
+            }
+        }
+        wv[i] = wrow_valid(rl);
+        wb[i] = wv[i] ? wrow(rl) * p.ldw : 0;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (int)((p.K + BK - 1) / BK);
+    uint4 ga[4], gb[4];
+    auto gload = [&](int kt) {
+        int k = kt * BK + chunk * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ga[i] = load_a<DT, AMODE>(p, ra[i], k);
+            gb[i] = (wv[i] && k < p.K) ? *reinterpret_cast<const uint4*>(p.w + (wb[i] + k) * 2)
+                                       : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto sstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int rl = (tid >> 3) + 32 * i;
+            *reinterpret_cast<uint4*>(smem + lds_off(rl, chunk)) = ga[i];
+            *reinterpret_cast<uint4*>(smem + A_BYTES + lds_off(rl, chunk)) = gb[i];
+        }
+    };
+
+    gload(0);
+    sstore();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int ch = ks * 2 + half;
+            typename E::v8 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = as_v8<DT>(*reinterpret_cast<const uint4*>(smem + lds_off(wm * 64 + i * 32 + l31, ch)));
+                bf[i] = as_v8<DT>(
+                    *reinterpret_cast<const uint4*>(smem + A_BYTES + lds_off(wn * 64 + i * 32 + l31, ch)));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = E::mfma32(af[i], bf[j], acc[i][j]);
+        }
+        __syncthreads();
+        if (kt + 1 < nk) {
+            sstore();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: acc (+bias, +rowgroup bias, activation) -> LDS tile ----
+    typename E::elem* ct = reinterpret_cast<typename E::elem*>(smem);
+    int64_t step = p.step_ptr ? (int64_t)*p.step_ptr : 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int nl = wn * 64 + j * 32 + l31;
+        const bool nvalid = wrow_valid(nl);
+        const int64_t wr = nvalid ? wrow(nl) : 0;
+        const float bv = (p.bias && nvalid) ? ld_elem<DT>(p.bias, wr) : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                float v = acc[i][j][r] + bv;
+                if (p.rg) {
+                    int64_t m = m0 + ml;
+                    if (m < p.M && nvalid) v += ld_elem<DT>(p.rg, (m / p.rows_per_group + step) * p.ld_rg + wr);
+                }
+                if (EPI == APAD_EPI_SILU) v = silu_f(v);
+                if (EPI == APAD_EPI_GELU) v = gelu_erf_f(v);
+                ct[ml * C_LD + nl] = (typename E::elem)v;
+            }
+        }
+    }
+    __syncthreads();
+
+    if (OUTMODE == APAD_OUT_ROWMAJOR) {
+        constexpr int VPR = BN_OUT / 8;  // 16-byte vectors per output row
+        for (int idx = tid; idx < BM * VPR; idx += 256) {
+            const int rl = idx / VPR, vc = idx - rl * VPR;
+            const int64_t m = m0 + rl, n = n0 + vc * 8;
+            if (m >= p.M || n >= p.N) continue;
+            float f[8];
+            unpack8<DT>(*reinterpret_cast<const uint4*>(&ct[rl * C_LD + vc * 8]), f);
+            if (EPI == APAD_EPI_GEGLU) {
+                float g[8];
+                unpack8<DT>(*reinterpret_cast<const uint4*>(&ct[rl * C_LD + 64 + vc * 8]), g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = f[e] * gelu_erf_f(g[e]);
+            }
+            if (p.residual) {
+                float rr[8];
+                unpack8<DT>(*reinterpret_cast<const uint4*>(p.residual + (m * p.ldr + n) * 2), rr);
+                // the un-fused reference rounds the linear output to the storage type before the add
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = (float)(typename E::elem)f[e] + rr[e];
+            }
+            *reinterpret_cast<uint4*>(p.out + (m * p.ldo + n) * 2) = pack8<DT>(f);
+        }
+    } else {  // APAD_OUT_VT: consecutive lanes -> consecutive tokens of one (head, dd) row
+        typename E::elem* o = reinterpret_cast<typename E::elem*>(p.out);
+        for (int idx = tid; idx < BM * BN; idx += 256) {
+            const int nl = idx >> 7, rl = idx & 127;
+            const int64_t m = m0 + rl, n = n0 + nl;
+            if (m >= p.M || n >= p.N) continue;
+            const int64_t b = m / p.L;
+            const int l = (int)(m - b * p.L);
+            const int h = (int)(n / p.head_dim), dd = (int)(n - (int64_t)h * p.head_dim);
+            o[((b * p.heads + h) * p.head_dim + dd) * p.Lpad + l] = ct[rl * C_LD + nl];
+        }
+    }
+}
+
+template <int DT, int AMODE, int EPI, int OUTMODE>
+int launch(const GemmP& p, hipStream_t s) {
+    constexpr int BN_OUT = (EPI == APAD_EPI_GEGLU) ? 64 : BN;
+    dim3 grid((unsigned)((p.N + BN_OUT - 1) / BN_OUT), (unsigned)((p.M + BM - 1) / BM));
+    hipLaunchKernelGGL((gemm_kernel<DT, AMODE, EPI, OUTMODE>), grid, dim3(256), 0, s, p);
+    return apad_check_launch("apad_gemm");
+}
+
+template <int DT, int AMODE>
+int dispatch_epi(const GemmP& p, int epi, int outmode, hipStream_t s) {
+    if (outmode == APAD_OUT_VT) {
+        APAD_CHECK(epi == APAD_EPI_NONE, "apad_gemm: APAD_OUT_VT supports epilogue NONE only");
+        return launch<DT, AMODE, APAD_EPI_NONE, APAD_OUT_VT>(p, s);
+    }
+    switch (epi) {
+        case APAD_EPI_NONE: return launch<DT, AMODE, APAD_EPI_NONE, APAD_OUT_ROWMAJOR>(p, s);
+        case APAD_EPI_SILU: return launch<DT, AMODE, APAD_EPI_SILU, APAD_OUT_ROWMAJOR>(p, s);
+        case APAD_EPI_GELU: return launch<DT, AMODE, APAD_EPI_GELU, APAD_OUT_ROWMAJOR>(p, s);
+        case APAD_EPI_GEGLU: return launch<DT, AMODE, APAD_EPI_GEGLU, APAD_OUT_ROWMAJOR>(p, s);
+    }
+    apad_set_error("apad_gemm: unknown epilogue %d", epi);
+    return -1;
+}
+
+template <int DT> int dispatch_amode(const GemmP& p, const apad_gemm_desc* d, hipStream_t s) {
+    switch (d->a_mode) {
+        case APAD_A_PLAIN: return dispatch_epi<DT, APAD_A_PLAIN>(p, d->epilogue, d->out_mode, s);
+        case APAD_A_CONV3X3:
+            APAD_CHECK(d->epilogue == APAD_EPI_NONE && d->out_mode == APAD_OUT_ROWMAJOR,
+                       "apad_gemm: conv3x3 supports epilogue NONE / row-major output only");
+            return launch<DT, APAD_A_CONV3X3, APAD_EPI_NONE, APAD_OUT_ROWMAJOR>(p, s);
+        case APAD_A_PATCH16:
+            APAD_CHECK(d->epilogue == APAD_EPI_NONE && d->out_mode == APAD_OUT_ROWMAJOR,
+                       "apad_gemm: patch16 supports epilogue NONE / row-major output only");
+            return launch<DT, APAD_A_PATCH16, APAD_EPI_NONE, APAD_OUT_ROWMAJOR>(p, s);
+    }
+    apad_set_error("apad_gemm: unknown a_mode %d", d->a_mode);
+    return -1;
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int apad_gemm(const apad_gemm_desc* d, void* stream) {
+    APAD_CHECK(d != nullptr, "apad_gemm: null descriptor");
+    APAD_CHECK(d->dtype == APAD_BF16 || d->dtype == APAD_F16, "apad_gemm: dtype %d not supported (bf16/f16)", d->dtype);
+    APAD_CHECK(d->a && d->w && d->out, "apad_gemm: null operand");
+    APAD_CHECK(d->M > 0 && d->N > 0 && d->K > 0, "apad_gemm: empty problem M=%lld N=%lld K=%lld", (long long)d->M,
+               (long long)d->N, (long long)d->K);
+    APAD_CHECK(d->K % 8 == 0 && d->ldw % 8 == 0, "apad_gemm: K and ldw must be multiples of 8 (K=%lld ldw=%lld)",
+               (long long)d->K, (long long)d->ldw);
+    APAD_CHECK(al16(d->a) && al16(d->w) && al16(d->out) && al16(d->residual), "apad_gemm: pointers must be 16-byte aligned");
+    GemmP p;
+    p.a = (const uint8_t*)d->a;
+    p.w = (const uint8_t*)d->w;
+    p.out = (uint8_t*)d->out;
+    p.bias = (const uint8_t*)d->bias;
+    p.residual = (const uint8_t*)d->residual;
+    p.rg = (const uint8_t*)d->rowgroup_bias;
+    p.step_ptr = d->step_ptr;
+    p.M = d->M; p.N = d->N; p.K = d->K;
+    p.lda = d->lda; p.ldw = d->ldw; p.ldo = d->ldo; p.ldr = d->ldr; p.ld_rg = d->ld_rg;
+    p.rows_per_group = d->rows_per_group > 0 ? d->rows_per_group : 1;
+    p.Hin = d->Hin; p.Win = d->Win; p.Cin = d->Cin; p.Hout = d->Hout; p.Wout = d->Wout;
+    p.stride = d->stride; p.Hup = d->Hup; p.Wup = d->Wup; p.src_batch_mod = d->src_batch_mod;
+    p.heads = d->heads; p.head_dim = d->head_dim; p.L = d->L; p.Lpad = d->Lpad;
+    p.wrows = (int32_t)(d->epilogue == APAD_EPI_GEGLU ? 2 * d->N : d->N);
+    if (d->a_mode == APAD_A_PLAIN) {
+        APAD_CHECK(d->lda % 8 == 0, "apad_gemm: lda must be a multiple of 8");
+    } else if (d->a_mode == APAD_A_CONV3X3) {
+        APAD_CHECK(d->Cin > 0 && d->Cin % 8 == 0 && d->K == 9LL * d->Cin, "apad_gemm: conv3x3 needs Cin%%8==0 and K==9*Cin");
+        APAD_CHECK(d->stride == 1 || d->stride == 2, "apad_gemm: conv stride must be 1 or 2");
+        APAD_CHECK(d->Hin > 0 && d->Win > 0 && d->Hout > 0 && d->Wout > 0 && d->M % ((int64_t)d->Hout * d->Wout) == 0,
+                   "apad_gemm: conv geometry inconsistent with M");
+        APAD_CHECK((d->Hup > 0) == (d->Wup > 0), "apad_gemm: Hup/Wup must both be set or both 0");
+    } else if (d->a_mode == APAD_A_PATCH16) {
+        APAD_CHECK(d->K == 256 && d->Hin % 16 == 0 && d->Win % 16 == 0, "apad_gemm: patch16 needs K==256 and H,W %% 16 == 0");
+        APAD_CHECK(d->M % ((int64_t)(d->Hin / 16) * (d->Win / 16)) == 0, "apad_gemm: patch16 M inconsistent");
+    }
+    if (d->out_mode == APAD_OUT_ROWMAJOR) {
+        APAD_CHECK(d->N % 8 == 0 && d->ldo % 8 == 0, "apad_gemm: N and ldo must be multiples of 8");
+        if (d->residual) APAD_CHECK(d->ldr % 8 == 0, "apad_gemm: ldr must be a multiple of 8");
+        if (d->epilogue == APAD_EPI_GEGLU) APAD_CHECK(d->N % 64 == 0, "apad_gemm: GEGLU needs N %% 64 == 0");
+    } else if (d->out_mode == APAD_OUT_VT) {
+        APAD_CHECK(d->heads > 0 && d->head_dim > 0 && d->L > 0 && d->Lpad >= d->L && d->N == (int64_t)d->heads * d->head_dim &&
+                       d->M % d->L == 0,
+                   "apad_gemm: V^T output geometry inconsistent");
+        APAD_CHECK(!d->residual, "apad_gemm: V^T output takes no residual");
+    } else {
+        apad_set_error("apad_gemm: unknown out_mode %d", d->out_mode);
+        return -1;
+    }
+    if (d->rowgroup_bias) APAD_CHECK(d->ld_rg > 0, "apad_gemm: rowgroup_bias needs ld_rg");
+    hipStream_t s = (hipStream_t)stream;
+    return d->dtype == APAD_BF16 ? dispatch_amode<APAD_BF16>(p, d, s) : dispatch_amode<APAD_F16>(p, d, s);
+}

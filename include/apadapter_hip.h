@@ -1,0 +1,146 @@
+/*
+ * apadapter_hip.h -- C ABI of libapadapter_hip.so: the MI355X (gfx950) implementation of the AP-adapter
+ * audio-conditioned diffusion hot path.  Plain pointers and sizes only; no torch / C++ types.
+ *
+ * Every entry point enqueues on the caller's stream (a hipStream_t passed as void*; NULL = default
+ * stream), allocates nothing, performs no host synchronisation and is therefore hipGraph-capturable.
+ * All return 0 on success and a negative code on a rejected argument or launch failure; the message is
+ * available from apad_last_error() (thread-local).  Nothing aborts the process.
+ *
+ * What each entry point replaces in the reference (paths relative to fundwotsai2001/AP-adapter):
+ *   apad_attention      F.scaled_dot_product_attention x2 + blend in IPAttnProcessor2_0.__call__
+ *                       (APadapter/ap_adapter/attention_processor.py:429-431, :443-445, :454) and the single
+ *                       SDPA of AttnProcessor2_0.__call__ (:274-276); also timm Block attention inside
+ *                       forward_encoder_no_random_mask_no_average (audio_encoder/models_mae.py:566-568)
+ *   apad_gemm           attn.to_q/to_k/to_v/to_out, to_k_ip/to_v_ip (attention_processor.py:387,:406-407,
+ *                       :435-436,:457); diffusers GEGLU/FeedForward, proj_in/proj_out, ResnetBlock2D /
+ *                       Downsample2D / Upsample2D 3x3 convolutions and time_emb_proj
+ *                       (pipeline/modeling_audioldm2.py:1032-1068 call sites); PatchEmbed_org.proj
+ *                       (audio_encoder/models_mae.py:32-34,:42); timm Block qkv/proj/fc1/fc2
+ *   apad_layernorm      diffusers BasicTransformerBlock norm1/2/3; timm Block norm1/2, encoder norm
+ *   apad_groupnorm      Transformer2DModel.norm, ResnetBlock2D.norm1/norm2 (+SiLU), conv_norm_out
+ *                       (pipeline/modeling_audioldm2.py:865-867)
+ *   apad_audiomae_pool  AudioMAEConditionCTPoolRand.pool (audio_encoder/AudioMAE.py:148-182)
+ *   apad_timestep_embedding  diffusers Timesteps (pipeline/modeling_audioldm2.py:317, :761)
+ *   apad_cfg_ddim_step / apad_step_advance  CFG combine + DDIMScheduler.step
+ *                       (pipeline/pipeline_audioldm2.py:1020-1025)
+ */
+#ifndef APADAPTER_HIP_H
+#define APADAPTER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define APAD_ABI_VERSION 1
+
+/* element types of activations / weights */
+enum { APAD_BF16 = 0, APAD_F16 = 1, APAD_F32 = 2 };
+
+/* apad_gemm_desc.a_mode: how row m / column k of the A operand is fetched */
+enum {
+    APAD_A_PLAIN = 0,   /* A[m][k] = a[m*lda + k]                                                    */
+    APAD_A_CONV3X3 = 1, /* implicit GEMM over NHWC: m=(b,oy,ox), k=(ky,kx,c); zero padding 1; optional
+                           nearest-neighbour upsample of the source to (Hup,Wup) before the taps         */
+    APAD_A_PATCH16 = 2  /* AudioMAE patch embed: a = fp32 mel [B,Hin,Win]; m=(b,ty,fx), k=(py,px)       */
+};
+
+/* apad_gemm_desc.epilogue (applied to acc + bias + rowgroup_bias, before + residual) */
+enum { APAD_EPI_NONE = 0, APAD_EPI_SILU = 1, APAD_EPI_GELU = 2, APAD_EPI_GEGLU = 3 };
+
+/* apad_gemm_desc.out_mode */
+enum {
+    APAD_OUT_ROWMAJOR = 0, /* out[m*ldo + n]                                                          */
+    APAD_OUT_VT = 1        /* per-head transposed values for apad_attention: m=(b,l), n=(h,dd) ->
+                              out[((b*heads + h)*head_dim + dd)*Lpad + l]                               */
+};
+
+typedef struct apad_gemm_desc {
+    const void* a;             /* activations (dtype, or fp32 for APAD_A_PATCH16)                      */
+    const void* w;             /* weights [N][ldw] row-major, K contiguous (nn.Linear layout; conv
+                                  weights as [Cout][ky][kx][Cin])                                       */
+    void* out;
+    const void* bias;          /* [N] or NULL                                                          */
+    const void* residual;      /* [M][ldr] added after the activation, or NULL                         */
+    const void* rowgroup_bias; /* [groups][ld_rg] added before the activation (time-embedding
+                                  projection per sample), or NULL                                       */
+    const int32_t* step_ptr;   /* optional device int32: rowgroup_bias row offset += *step_ptr         */
+    int64_t M, N, K;           /* GEGLU: N = number of OUTPUT columns, w has 2N rows (value|gate)      */
+    int64_t lda, ldw, ldo, ldr, ld_rg;
+    int64_t rows_per_group;    /* rowgroup index = m / rows_per_group (+ *step_ptr)                    */
+    int32_t a_mode, epilogue, out_mode, dtype;
+    /* APAD_A_CONV3X3 / APAD_A_PATCH16 geometry */
+    int32_t Hin, Win, Cin;     /* source spatial size and channels (NHWC)                              */
+    int32_t Hout, Wout;        /* output spatial size                                                  */
+    int32_t stride;            /* 1 or 2                                                               */
+    int32_t Hup, Wup;          /* 0 = no upsample; else nearest upsample of source to (Hup,Wup)        */
+    int32_t src_batch_mod;     /* 0 = off; else source batch = b % src_batch_mod (CFG duplication)     */
+    /* APAD_OUT_VT */
+    int32_t heads, head_dim, L, Lpad;
+} apad_gemm_desc;
+
+typedef struct apad_attn_desc {
+    const void* q;         /* [B][N][H*D] via strides                                                  */
+    const void* k;         /* segment 1 keys   [Bk][L][H*D] via strides                                */
+    const void* vt;        /* segment 1 values, transposed [Bk][H][D][Lpad], zero padded               */
+    const void* k2;        /* segment 2 (audio) keys or NULL                                           */
+    const void* vt2;       /* segment 2 values                                                        */
+    void* out;             /* [B][N][H*D] via strides                                                  */
+    const float* key_bias; /* additive fp32 bias on segment-1 scores [B][L] (mask -> bias), or NULL    */
+    int64_t q_stride_b, q_stride_n;
+    int64_t k_stride_b, k_stride_l, vt_stride_b;
+    int64_t k2_stride_b, k2_stride_l, vt2_stride_b;
+    int64_t o_stride_b, o_stride_n;
+    int32_t B, N, H, D;
+    int32_t L, Lpad, L2, Lpad2; /* L2 = 0: single softmax segment                                      */
+    int32_t kv_batch_div;       /* K/V batch index = b / kv_batch_div (1 = one K/V set per sample)     */
+    int32_t kv2_batch_div;
+    int32_t dtype;
+    float softmax_scale;        /* 1/sqrt(D)                                                           */
+    float scale2;               /* out = softmax1.V1 + scale2 * softmax2.V2  (ap_scale)                */
+} apad_attn_desc;
+
+const char* apad_last_error(void);
+int apad_abi_version(void);
+/* size of the descriptor structs as compiled, for binding self-checks */
+int apad_sizeof_gemm_desc(void);
+int apad_sizeof_attn_desc(void);
+/* writes every field of the descriptor as a double into out[]; returns the number written (binding check,
+   host only, no GPU work) */
+int apad_echo_gemm_desc(const apad_gemm_desc* d, double* out, int cap);
+int apad_echo_attn_desc(const apad_attn_desc* d, double* out, int cap);
+
+int apad_gemm(const apad_gemm_desc* d, void* stream);
+int apad_attention(const apad_attn_desc* d, void* stream);
+
+int apad_layernorm(const void* x, const void* gamma, const void* beta, void* out, int64_t M, int32_t C,
+                   int64_t ldx, int64_t ldo, float eps, int32_t dtype, void* stream);
+
+/* GroupNorm over NHWC x[B][HW][C] with G groups, optional fused SiLU.  workspace: fp32, at least
+   apad_groupnorm_workspace_bytes(B, G) bytes. */
+int64_t apad_groupnorm_workspace_bytes(int32_t B, int32_t G);
+int apad_groupnorm(const void* x, const void* gamma, const void* beta, void* out, void* workspace, int32_t B,
+                   int32_t HW, int32_t C, int32_t G, float eps, int32_t silu, int32_t dtype, void* stream);
+
+/* rep [B][513][768] (dtype) -> out [B][(64/tp)*(8/fp)][768] (out_dtype): drop CLS, (avg + max)/2 */
+int apad_audiomae_pool(const void* rep, void* out, int32_t B, int32_t tp, int32_t fp, int32_t dtype,
+                       int32_t out_dtype, void* stream);
+
+/* t [n] fp32 -> out [n][dim] (dtype): sinusoidal embedding, diffusers Timesteps semantics */
+int apad_timestep_embedding(const float* t, void* out, int32_t n, int32_t dim, int32_t flip_sin_to_cos,
+                            float freq_shift, int32_t dtype, void* stream);
+
+/* eps2 [2B][n] (dtype, unconditional half first); latents [B][n] fp32 updated in place;
+   unet_in [B][n] (dtype) receives the new latents; eps_out (optional, fp32 [B][n]) the guided noise.
+   coef [steps][2] fp32: x_prev = coef[s][0]*x + coef[s][1]*eps, s = *step_ptr. */
+int apad_cfg_ddim_step(const void* eps2, float* latents, void* unet_in, float* eps_out, const float* coef,
+                       const int32_t* step_ptr, float guidance_scale, int32_t B, int64_t n, int32_t dtype,
+                       void* stream);
+int apad_step_advance(int32_t* step_ptr, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,99 @@
+"""Generate golden vectors for the attention processors by RUNNING THE REFERENCE ITSELF.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+It imports /root/reference/APadapter/ap_adapter/attention_processor.py (torch-only imports), drives
+``IPAttnProcessor2_0`` / ``AttnProcessor2_0`` with a minimal stand-in for diffusers' ``Attention`` module
+(the attributes the processors read: attention_processor.py:227-292, :359-468) on CPU, and records the
+outputs.  Inputs and weights are NOT stored: they are regenerated from ``numpy.random.RandomState(seed)``
+(a frozen stream) by ``tests/golden/cases.py``, which both this script and the tests import.  Only data
+(case table + expected outputs) is committed; no reference source travels.
+"""
+import json
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference")
+
+from cases import CASES, make_inputs  # noqa: E402
+from APadapter.ap_adapter.attention_processor import AttnProcessor2_0, IPAttnProcessor2_0  # noqa: E402
+from safetensors.torch import save_file  # noqa: E402
+
+
+class StubAttention(torch.nn.Module):
+    """What diffusers==0.21.2 ``Attention`` exposes to a processor on this path (SURVEY 8b 'Call')."""
+
+    def __init__(self, C, X, heads):
+        super().__init__()
+        self.heads = heads
+        self.to_q = torch.nn.Linear(C, C, bias=False)
+        self.to_k = torch.nn.Linear(X, C, bias=False)
+        self.to_v = torch.nn.Linear(X, C, bias=False)
+        self.to_out = torch.nn.ModuleList([torch.nn.Linear(C, C, bias=True), torch.nn.Dropout(0.0)])
+        self.spatial_norm = None
+        self.group_norm = None
+        self.norm_cross = None
+        self.residual_connection = False
+        self.rescale_output_factor = 1.0
+
+    def prepare_attention_mask(self, attention_mask, target_length, batch_size, out_dim=3):
+        if attention_mask is None:
+            return None
+        if attention_mask.shape[-1] != target_length:
+            attention_mask = torch.nn.functional.pad(attention_mask, (0, target_length), value=0.0)
+        if attention_mask.shape[0] < batch_size * self.heads:
+            attention_mask = attention_mask.repeat_interleave(self.heads, dim=0)
+        return attention_mask
+
+
+def run_case(case, dtype):
+    t = make_inputs(case)
+    C, X, heads = case["C"], case["X"], case["heads"]
+    attn = StubAttention(C, X, heads)
+    with torch.no_grad():
+        attn.to_q.weight.copy_(t["wq"])
+        attn.to_k.weight.copy_(t["wk"])
+        attn.to_v.weight.copy_(t["wv"])
+        attn.to_out[0].weight.copy_(t["wo"])
+        attn.to_out[0].bias.copy_(t["bo"])
+    attn = attn.to(dtype)
+    hs = t["hs"].to(dtype)
+    ehs = None if t["ehs"] is None else t["ehs"].to(dtype)
+    mask = None if t["mask_bias"] is None else t["mask_bias"].to(dtype)
+    if case["kind"] == "ip":
+        proc = IPAttnProcessor2_0(hidden_size=C, name="golden", cross_attention_dim=X,
+                                  num_tokens=case["num_tokens"], scale=case["scale"])
+        proc.to_k_ip.weight = torch.nn.Parameter(t["wk_ip"].clone())
+        proc.to_v_ip.weight = torch.nn.Parameter(t["wv_ip"].clone())
+        proc = proc.to(dtype)
+    else:
+        proc = AttnProcessor2_0()
+    with torch.no_grad():
+        out = proc(attn, hs, encoder_hidden_states=ehs, attention_mask=mask)
+    return out
+
+
+def main():
+    tensors = {}
+    for case in CASES:
+        tensors[case["name"] + ".fp32"] = run_case(case, torch.float32).contiguous()
+        if case.get("bf16"):
+            tensors[case["name"] + ".bf16"] = run_case(case, torch.bfloat16).contiguous()
+        print(case["name"], tuple(tensors[case["name"] + ".fp32"].shape))
+    meta = {"generator": "tests/golden/make_golden.py", "torch": torch.__version__,
+            "reference": "fundwotsai2001/AP-adapter @ 2024-10-22, APadapter/ap_adapter/attention_processor.py",
+            "cases": json.dumps([c["name"] for c in CASES])}
+    save_file(tensors, os.path.join(HERE, "attn_processors.safetensors"), metadata=meta)
+    sz = os.path.getsize(os.path.join(HERE, "attn_processors.safetensors"))
+    print("wrote attn_processors.safetensors", sz, "bytes")
+
+
+if __name__ == "__main__":
+    main()
