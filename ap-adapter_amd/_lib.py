@@ -1,0 +1,103 @@
+"""Loader for libapadapter_hip.so (the C ABI declared in include/apadapter_hip.h).
+
+The product path has NO fallback: if the library is missing or a call fails, a RuntimeError is raised.
+torch is imported first so that the library binds to the HIP runtime PyTorch already loaded (same SONAME),
+which is what makes torch streams / graph capture valid for our launches.
+"""
+import ctypes as C
+import os
+import subprocess
+import threading
+
+import torch  # noqa: F401  (must precede CDLL: shares libamdhip64 with PyTorch-ROCm)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libapadapter_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+BF16, F16, F32 = 0, 1, 2
+A_PLAIN, A_CONV3X3, A_PATCH16 = 0, 1, 2
+EPI_NONE, EPI_SILU, EPI_GELU, EPI_GEGLU = 0, 1, 2, 3
+OUT_ROWMAJOR, OUT_VT = 0, 1
+
+_vp, _i64, _i32, _f32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [(n, _vp) for n in ("a", "w", "out", "bias", "residual", "rowgroup_bias", "step_ptr")] + \
+               [(n, _i64) for n in ("M", "N", "K", "lda", "ldw", "ldo", "ldr", "ld_rg", "rows_per_group")] + \
+               [(n, _i32) for n in ("a_mode", "epilogue", "out_mode", "dtype", "Hin", "Win", "Cin", "Hout", "Wout",
+                                    "stride", "Hup", "Wup", "src_batch_mod", "residual_row_mod", "heads", "head_dim", "L", "Lpad")]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [(n, _vp) for n in ("q", "k", "vt", "k2", "vt2", "out", "key_bias")] + \
+               [(n, _i64) for n in ("q_stride_b", "q_stride_n", "k_stride_b", "k_stride_l", "vt_stride_b",
+                                    "k2_stride_b", "k2_stride_l", "vt2_stride_b", "o_stride_b", "o_stride_n")] + \
+               [(n, _i32) for n in ("B", "N", "H", "D", "L", "Lpad", "L2", "Lpad2", "kv_batch_div", "kv2_batch_div",
+                                    "dtype")] + \
+               [("softmax_scale", _f32), ("scale2", _f32)]
+
+
+# name -> (restype, argtypes); every symbol include/apadapter_hip.h declares
+SYMBOLS = {
+    "apad_last_error": (C.c_char_p, []),
+    "apad_abi_version": (C.c_int, []),
+    "apad_sizeof_gemm_desc": (C.c_int, []),
+    "apad_sizeof_attn_desc": (C.c_int, []),
+    "apad_echo_gemm_desc": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(C.c_double), C.c_int]),
+    "apad_echo_attn_desc": (C.c_int, [C.POINTER(AttnDesc), C.POINTER(C.c_double), C.c_int]),
+    "apad_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
+    "apad_attention": (C.c_int, [C.POINTER(AttnDesc), _vp]),
+    "apad_layernorm": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _i64, _f32, _i32, _vp]),
+    "apad_groupnorm_workspace_bytes": (_i64, [_i32, _i32]),
+    "apad_groupnorm": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp]),
+    "apad_audiomae_pool": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "apad_timestep_embedding": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "apad_cfg_ddim_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _i32, _i64, _i32, _vp]),
+    "apad_step_advance": (C.c_int, [_vp, _vp]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def build(verbose=False):
+    """Compile every HIP source for gfx950 into ap-adapter_amd/libapadapter_hip.so (hipcc cross-compiles; no GPU
+    needed)."""
+    r = subprocess.run(["make", "-C", CSRC, "-j4"], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-4000:])
+        print(r.stderr[-4000:])
+    if r.returncode != 0:
+        raise RuntimeError("building libapadapter_hip.so failed:\n" + r.stderr[-2000:])
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library.  Raises RuntimeError when it is absent -- there is no CPU or PyTorch fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(
+                    f"{LIB_PATH} is missing: the HIP extension is the product path and has no fallback; "
+                    "run `python -c 'import __graft_entry__ as g; g.build()'` (or `make -C ap-adapter_amd/csrc`).")
+            h = C.CDLL(LIB_PATH)
+            for name, (res, args) in SYMBOLS.items():
+                fn = getattr(h, name)  # AttributeError if the ABI lost a symbol
+                fn.restype = res
+                fn.argtypes = args
+            if h.apad_abi_version() != 1:
+                raise RuntimeError("libapadapter_hip.so ABI version mismatch")
+            if h.apad_sizeof_gemm_desc() != C.sizeof(GemmDesc) or h.apad_sizeof_attn_desc() != C.sizeof(AttnDesc):
+                raise RuntimeError("descriptor layout mismatch between include/apadapter_hip.h and _lib.py")
+            _lib = h
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (rc={rc}): {lib().apad_last_error().decode()}")

@@ -28,7 +28,7 @@ struct GemmP {
     const uint8_t* rg;
     const int32_t* step_ptr;
     int64_t M, N, K, lda, ldw, ldo, ldr, ld_rg, rows_per_group;
-    int32_t Hin, Win, Cin, Hout, Wout, stride, Hup, Wup, src_batch_mod;
+    int32_t Hin, Win, Cin, Hout, Wout, stride, Hup, Wup, src_batch_mod, res_mod;
     int32_t heads, head_dim, L, Lpad;
     int32_t wrows;  // rows of w (N, or 2N for GEGLU)
 };
@@ -225,7 +225,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
             }
             if (p.residual) {
                 float rr[8];
-                unpack8<DT>(*reinterpret_cast<const uint4*>(p.residual + (m * p.ldr + n) * 2), rr);
+                const int64_t rm = p.res_mod > 0 ? m % p.res_mod : m;
+                unpack8<DT>(*reinterpret_cast<const uint4*>(p.residual + (rm * p.ldr + n) * 2), rr);
                 // the un-fused reference rounds the linear output to the storage type before the add
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] = (float)(typename E::elem)f[e] + rr[e];
@@ -311,7 +312,7 @@ extern "C" int apad_gemm(const apad_gemm_desc* d, void* stream) {
     p.lda = d->lda; p.ldw = d->ldw; p.ldo = d->ldo; p.ldr = d->ldr; p.ld_rg = d->ld_rg;
     p.rows_per_group = d->rows_per_group > 0 ? d->rows_per_group : 1;
     p.Hin = d->Hin; p.Win = d->Win; p.Cin = d->Cin; p.Hout = d->Hout; p.Wout = d->Wout;
-    p.stride = d->stride; p.Hup = d->Hup; p.Wup = d->Wup; p.src_batch_mod = d->src_batch_mod;
+    p.stride = d->stride; p.Hup = d->Hup; p.Wup = d->Wup; p.src_batch_mod = d->src_batch_mod; p.res_mod = d->residual_row_mod;
     p.heads = d->heads; p.head_dim = d->head_dim; p.L = d->L; p.Lpad = d->Lpad;
     p.wrows = (int32_t)(d->epilogue == APAD_EPI_GEGLU ? 2 * d->N : d->N);
     if (d->a_mode == APAD_A_PLAIN) {

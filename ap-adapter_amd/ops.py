@@ -1,0 +1,211 @@
+"""Tensor-level wrappers over the C ABI (include/apadapter_hip.h).
+
+PyTorch is used only as plumbing here: device memory (torch.empty), the current HIP stream, dtype tags.  All
+arithmetic happens in libapadapter_hip.so.  Nothing in this module falls back to torch ops: a missing library
+or a CPU tensor raises.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+
+_DT = {torch.bfloat16: L.BF16, torch.float16: L.F16, torch.float32: L.F32}
+_EPI = {None: L.EPI_NONE, "none": L.EPI_NONE, "silu": L.EPI_SILU, "gelu": L.EPI_GELU, "geglu": L.EPI_GEGLU}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _req(t, name, dtype=None):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a GPU tensor; the HIP path has no CPU fallback")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"{name}: dtype {t.dtype} != {dtype}")
+    if t.stride(-1) != 1:
+        raise RuntimeError(f"{name}: last dim must be contiguous")
+    return t
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def gemm(a, w, *, M, N, K, lda, out, ldo, bias=None, residual=None, ldr=0, act=None, rowgroup_bias=None, ld_rg=0,
+         rows_per_group=0, step_ptr=None, a_mode=L.A_PLAIN, out_mode=L.OUT_ROWMAJOR, conv=None, vt=None, ldw=None,
+         residual_row_mod=0):
+    """Raw descriptor call; the typed helpers below are what the model code uses."""
+    d = L.GemmDesc()
+    d.a, d.w, d.out = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    d.bias, d.residual, d.rowgroup_bias, d.step_ptr = _ptr(bias), _ptr(residual), _ptr(rowgroup_bias), _ptr(step_ptr)
+    d.M, d.N, d.K, d.lda, d.ldw, d.ldo, d.ldr, d.ld_rg = M, N, K, lda, (K if ldw is None else ldw), ldo, ldr, ld_rg
+    d.rows_per_group = rows_per_group
+    d.residual_row_mod = residual_row_mod
+    d.a_mode, d.epilogue, d.out_mode, d.dtype = a_mode, _EPI[act], out_mode, _DT[w.dtype]
+    if conv is not None:
+        (d.Hin, d.Win, d.Cin, d.Hout, d.Wout, d.stride, d.Hup, d.Wup, d.src_batch_mod) = conv
+    if vt is not None:
+        d.heads, d.head_dim, d.L, d.Lpad = vt
+    L.check(L.lib().apad_gemm(C.byref(d), _stream()), "apad_gemm")
+    return out
+
+
+def linear(x, w, bias=None, residual=None, act=None, out=None, rowgroup_bias=None, rows_per_group=0, step_ptr=None,
+           residual_row_mod=0):
+    """x [..., K] (row stride = K) @ w[N(or 2N for geglu), K]^T -> [..., N]."""
+    _req(x, "linear.x", w.dtype)
+    _req(w, "linear.w")
+    K = x.shape[-1]
+    M = x.numel() // K
+    N = w.shape[0] // 2 if act == "geglu" else w.shape[0]
+    x2 = x.reshape(M, K)
+    if out is None:
+        out = torch.empty(*x.shape[:-1], N, dtype=w.dtype, device=x.device)
+    r2 = None if residual is None else _req(residual, "linear.residual", w.dtype).reshape(-1, N)
+    gemm(x2, w, M=M, N=N, K=K, lda=x2.stride(0), out=out, ldo=N, bias=bias, residual=r2, ldr=N, act=act,
+         rowgroup_bias=rowgroup_bias, ld_rg=(rowgroup_bias.stride(0) if rowgroup_bias is not None else 0),
+         rows_per_group=rows_per_group, step_ptr=step_ptr, ldw=w.stride(0), residual_row_mod=residual_row_mod)
+    return out
+
+
+def linear_vt(x, w, B, Lk, heads, out_vt, bias=None):
+    """Values projection stored per-head transposed: x [B*Lk, K] @ w[C,K]^T -> out_vt [B, heads, d, Lpad]
+    (zero padded by the caller; only l < Lk is written)."""
+    _req(x, "linear_vt.x", w.dtype)
+    K = x.shape[-1]
+    Cc = w.shape[0]
+    x2 = x.reshape(B * Lk, K)
+    gemm(x2, w, M=B * Lk, N=Cc, K=K, lda=x2.stride(0), out=out_vt, ldo=0, out_mode=L.OUT_VT, bias=bias,
+         vt=(heads, Cc // heads, Lk, out_vt.shape[-1]), ldw=w.stride(0))
+    return out_vt
+
+
+def conv3x3(x, w_packed, bias, B, Hin, Win, stride=1, up=None, residual=None, rowgroup_bias=None, rows_per_group=0,
+            step_ptr=None, src_batch_mod=0, out=None):
+    """NHWC implicit-GEMM 3x3 convolution, padding 1.  x [Bsrc, Hin*Win, Cin]; w_packed [Cout, 9*Cin] in
+    (ky, kx, cin) order; up=(Hup, Wup) applies a nearest-neighbour upsample to the source first.
+    Returns ([B, Hout*Wout, Cout], Hout, Wout)."""
+    _req(x, "conv3x3.x", w_packed.dtype)
+    Cin = x.shape[-1]
+    Cout = w_packed.shape[0]
+    Hs, Ws = (up if up is not None else (Hin, Win))
+    Hout = (Hs + 2 - 3) // stride + 1
+    Wout = (Ws + 2 - 3) // stride + 1
+    M = B * Hout * Wout
+    if out is None:
+        out = torch.empty(B, Hout * Wout, Cout, dtype=x.dtype, device=x.device)
+    gemm(x, w_packed, M=M, N=Cout, K=9 * Cin, lda=0, out=out, ldo=Cout, bias=bias,
+         residual=residual, ldr=Cout, rowgroup_bias=rowgroup_bias,
+         ld_rg=(rowgroup_bias.stride(0) if rowgroup_bias is not None else 0), rows_per_group=rows_per_group,
+         step_ptr=step_ptr, a_mode=L.A_CONV3X3,
+         conv=(Hin, Win, Cin, Hout, Wout, stride, (up[0] if up else 0), (up[1] if up else 0), src_batch_mod))
+    return out, Hout, Wout
+
+
+def patch_embed(mel, w, bias, dtype):
+    """mel fp32 [B, H, W] -> tokens [B, (H/16)*(W/16), 768]; w [768, 256] (= Conv2d weight [768,1,16,16] flattened)."""
+    _req(mel, "patch_embed.mel", torch.float32)
+    B, H, W = mel.shape
+    n_tok = (H // 16) * (W // 16)
+    out = torch.empty(B, n_tok, w.shape[0], dtype=dtype, device=mel.device)
+    gemm(mel, w, M=B * n_tok, N=w.shape[0], K=256, lda=0, out=out, ldo=w.shape[0], bias=bias, a_mode=L.A_PATCH16,
+         conv=(H, W, 1, H // 16, W // 16, 1, 0, 0, 0))
+    return out
+
+
+def attention(q, k, vt, Lk, heads, key_bias=None, k2=None, vt2=None, L2=0, scale2=0.0, kv_batch_div=1,
+              kv2_batch_div=1, out=None):
+    """q [B,N,C]; k [Bk,Lk,C]; vt [Bk,heads,d,Lpad]; optional second (audio) segment k2/vt2 with its own softmax,
+    blended as seg1 + scale2*seg2.  key_bias: fp32 [B,Lk] additive."""
+    _req(q, "attention.q")
+    _req(k, "attention.k", q.dtype)
+    _req(vt, "attention.vt", q.dtype)
+    B, N, Cc = q.shape
+    d_head = Cc // heads
+    if out is None:
+        out = torch.empty(B, N, Cc, dtype=q.dtype, device=q.device)
+    d = L.AttnDesc()
+    d.q, d.k, d.vt, d.out = q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr()
+    d.key_bias = _ptr(key_bias)
+    d.q_stride_b, d.q_stride_n = q.stride(0), q.stride(1)
+    d.k_stride_b, d.k_stride_l, d.vt_stride_b = k.stride(0), k.stride(1), vt.stride(0)
+    d.o_stride_b, d.o_stride_n = out.stride(0), out.stride(1)
+    d.B, d.N, d.H, d.D, d.L, d.Lpad = B, N, heads, d_head, Lk, vt.shape[-1]
+    d.kv_batch_div, d.kv2_batch_div = kv_batch_div, kv2_batch_div
+    d.dtype = _DT[q.dtype]
+    d.softmax_scale = 1.0 / math.sqrt(d_head)
+    d.scale2 = float(scale2)
+    if L2 > 0:
+        d.k2, d.vt2 = k2.data_ptr(), vt2.data_ptr()
+        d.k2_stride_b, d.k2_stride_l, d.vt2_stride_b = k2.stride(0), k2.stride(1), vt2.stride(0)
+        d.L2, d.Lpad2 = L2, vt2.shape[-1]
+    L.check(L.lib().apad_attention(C.byref(d), _stream()), "apad_attention")
+    return out
+
+
+def layer_norm(x, gamma, beta, eps, out=None):
+    _req(x, "layer_norm.x", gamma.dtype)
+    Cc = x.shape[-1]
+    M = x.numel() // Cc
+    if out is None:
+        out = torch.empty_like(x)
+    L.check(L.lib().apad_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), M, Cc, Cc, Cc,
+                                   eps, _DT[x.dtype], _stream()), "apad_layernorm")
+    return out
+
+
+_gn_ws = {}
+
+
+def group_norm(x, gamma, beta, groups, eps, silu=False, out=None):
+    """x [B, HW, C] (NHWC)."""
+    _req(x, "group_norm.x", gamma.dtype)
+    B, HW, Cc = x.shape
+    key = (x.device, B, groups)
+    ws = _gn_ws.get(key)
+    if ws is None:
+        ws = torch.empty(B * groups * 2, dtype=torch.float32, device=x.device)
+        _gn_ws[key] = ws
+    if out is None:
+        out = torch.empty_like(x)
+    L.check(L.lib().apad_groupnorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), ws.data_ptr(), B, HW,
+                                   Cc, groups, eps, 1 if silu else 0, _DT[x.dtype], _stream()), "apad_groupnorm")
+    return out
+
+
+def audiomae_pool(rep, tp, fp, out_dtype=None):
+    _req(rep, "audiomae_pool.rep")
+    B = rep.shape[0]
+    out_dtype = out_dtype or rep.dtype
+    out = torch.empty(B, (64 // tp) * (8 // fp), 768, dtype=out_dtype, device=rep.device)
+    L.check(L.lib().apad_audiomae_pool(rep.data_ptr(), out.data_ptr(), B, tp, fp, _DT[rep.dtype], _DT[out_dtype],
+                                       _stream()), "apad_audiomae_pool")
+    return out
+
+
+def timestep_embedding(t, dim, flip_sin_to_cos, freq_shift, dtype):
+    _req(t, "timestep_embedding.t", torch.float32)
+    out = torch.empty(t.numel(), dim, dtype=dtype, device=t.device)
+    L.check(L.lib().apad_timestep_embedding(t.data_ptr(), out.data_ptr(), t.numel(), dim, 1 if flip_sin_to_cos else 0,
+                                            float(freq_shift), _DT[dtype], _stream()), "apad_timestep_embedding")
+    return out
+
+
+def cfg_ddim_step(eps2, latents, unet_in, coef, step_ptr, guidance_scale, eps_out=None):
+    """eps2 [2B, n...]; latents fp32 [B, n...] (in place); unet_in [B, n...] model dtype."""
+    _req(latents, "cfg_ddim_step.latents", torch.float32)
+    B = latents.shape[0]
+    n = latents.numel() // B
+    L.check(L.lib().apad_cfg_ddim_step(eps2.data_ptr(), latents.data_ptr(), unet_in.data_ptr(), _ptr(eps_out),
+                                       coef.data_ptr(), _ptr(step_ptr), float(guidance_scale), B, n, _DT[eps2.dtype],
+                                       _stream()), "apad_cfg_ddim_step")
+
+
+def step_advance(step_ptr):
+    L.check(L.lib().apad_step_advance(step_ptr.data_ptr(), _stream()), "apad_step_advance")

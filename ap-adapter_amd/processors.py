@@ -1,0 +1,190 @@
+"""The plug-in operators: MI355X-native counterparts of the reference's attention processors.
+
+Same class names, constructor arguments, attributes and call signature as
+/root/reference/APadapter/ap_adapter/attention_processor.py (``AttnProcessor2_0`` :199-294,
+``IPAttnProcessor2_0`` :297-470) so that the reference wiring loop (inference.py:22-59) works unchanged:
+
+    proc = IPAttnProcessor2_0(hidden_size=C, name=name, cross_attention_dim=768, scale=ap_scale, num_tokens=8)
+    proc.to_k_ip.weight = torch.nn.Parameter(state_dict[name + ".to_k_ip.weight"].half())   # re-assignment is honoured
+    unet.set_attn_processor({...})
+
+The arithmetic runs in libapadapter_hip.so (apad_gemm + apad_attention); there is no PyTorch fallback.
+Weights are read through the attributes at call time.  The timestep-invariant K/V projections can be hoisted
+out of the denoise loop with ``kv_cache_enabled`` (the pipeline switches it on and clears it per call); with it
+off every call recomputes them exactly like the reference.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+_vt_pool = {}
+
+
+def vt_buffer(slot, B, heads, d, Lk, dtype, device):
+    """Zero-padded V^T scratch [B, heads, d, round_up(Lk,32)].  The pad columns are never written (apad_gemm
+    APAD_OUT_VT stores l < Lk only), so buffers are shared by shape across attention sites."""
+    Lpad = ops.round_up(Lk, 32)
+    key = (slot, B, heads, d, Lpad, dtype, device)
+    buf = _vt_pool.get(key)
+    if buf is None:
+        buf = torch.zeros(B, heads, d, Lpad, dtype=dtype, device=device)
+        _vt_pool[key] = buf
+    return buf
+
+
+def _key_bias(attention_mask, B, Lk):
+    """The UNet hands processors an additive bias [B,1,L] (modeling_audioldm2.py:741-747); apad_attention takes it
+    as fp32 [B,L]."""
+    if attention_mask is None:
+        return None
+    m = attention_mask
+    if m.shape[-1] != Lk:
+        raise ValueError(f"attention_mask has {m.shape[-1]} key positions, expected {Lk}")
+    if m.numel() != B * Lk:
+        raise ValueError("attention_mask must broadcast as [batch, 1, keys] (per-head masks are not on this path)")
+    return m.reshape(B, Lk).float().contiguous()
+
+
+class AttnProcessor2_0(nn.Module):
+    """Plain scaled-dot-product attention (reference :199-294).  Accepts dummy hidden_size / cross_attention_dim
+    like the reference so it can live in AttnProcsLayers."""
+
+    fuses_residual = True
+
+    def __init__(self, hidden_size=None, cross_attention_dim=None):
+        super().__init__()
+        self.kv_cache_enabled = False
+        self._kv_cache = None
+
+    def clear_kv_cache(self):
+        self._kv_cache = None
+
+    def _project_kv(self, attn, src, slot):
+        B, Lk, _ = src.shape
+        C_ = attn.to_k.weight.shape[0]
+        k = ops.linear(src, attn.to_k.weight)
+        if slot is None:  # persistent (cached) values own their buffer
+            vt = torch.zeros(B, attn.heads, C_ // attn.heads, ops.round_up(Lk, 32), dtype=src.dtype, device=src.device)
+        else:
+            vt = vt_buffer(slot, B, attn.heads, C_ // attn.heads, Lk, src.dtype, src.device)
+        ops.linear_vt(src, attn.to_v.weight, B, Lk, attn.heads, vt)
+        return k, vt
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
+                 _residual=None):
+        if attn.spatial_norm is not None or attn.group_norm is not None or attn.norm_cross:
+            raise NotImplementedError("spatial_norm / group_norm / norm_cross are not on the AudioLDM2 path")
+        if hidden_states.ndim != 3:
+            raise ValueError("hidden_states must be [batch, tokens, channels]")
+        B, N, _ = hidden_states.shape
+        q = ops.linear(hidden_states, attn.to_q.weight)
+        if encoder_hidden_states is None:
+            k, vt = self._project_kv(attn, hidden_states, "self")
+            Lk = N
+        else:
+            ehs = encoder_hidden_states
+            if ehs.dim() < 3:
+                ehs = ehs.unsqueeze(0)
+            Lk = ehs.shape[1]
+            if self.kv_cache_enabled and self._kv_cache is not None:
+                k, vt = self._kv_cache
+            else:
+                k, vt = self._project_kv(attn, ehs, None if self.kv_cache_enabled else "cross")
+                if self.kv_cache_enabled:
+                    self._kv_cache = (k, vt)
+        bias = _key_bias(attention_mask, B, Lk)
+        o = ops.attention(q, k, vt, Lk, attn.heads, key_bias=bias)
+        out = ops.linear(o, attn.to_out[0].weight, attn.to_out[0].bias, residual=_residual)
+        if attn.residual_connection:
+            raise NotImplementedError("residual_connection=True is not on the AudioLDM2 path")
+        if attn.rescale_output_factor != 1.0:
+            raise NotImplementedError("rescale_output_factor != 1 is not on the AudioLDM2 path")
+        return out
+
+
+class IPAttnProcessor2_0(nn.Module):
+    """Decoupled cross-attention (reference :297-470): text branch over the first ``num_tokens`` tokens with the frozen
+    ``attn.to_k/to_v``, audio branch over the remaining tokens with the trainable ``to_k_ip/to_v_ip``, blended
+    ``text + scale * audio`` inside one fused kernel."""
+
+    fuses_residual = True
+
+    def __init__(self, hidden_size, name, cross_attention_dim=None, num_tokens=4, scale=1.0, do_copy=False,
+                 copy_dir=None):
+        super().__init__()
+        self.hidden_size = hidden_size
+        self.cross_attention_dim = cross_attention_dim
+        self.num_tokens = num_tokens
+        self.scale = scale
+        self.name = name
+        self.to_k_ip = nn.Linear(cross_attention_dim or hidden_size, hidden_size, bias=False)
+        self.to_v_ip = nn.Linear(cross_attention_dim or hidden_size, hidden_size, bias=False)
+        self.kv_cache_enabled = False
+        self._kv_cache = None
+        if do_copy:
+            # reference :328-344 warm-starts from copied_cross_attention/{name}_{k,v}.bin
+            from .wiring import load_copied_cross_attention
+            load_copied_cross_attention(self, copy_dir)
+
+    def clear_kv_cache(self):
+        self._kv_cache = None
+
+    def _project(self, attn, ehs):
+        B = ehs.shape[0]
+        nt = self.num_tokens
+        txt = ehs[:, :nt, :]
+        aud = ehs[:, nt:, :]
+        Lt, La = txt.shape[1], aud.shape[1]
+        C_ = attn.to_k.weight.shape[0]
+        d = C_ // attn.heads
+        persistent = self.kv_cache_enabled
+        # ragged views -> dense rows for the GEMM A operand (plumbing copies of <= 520 x 768 tokens)
+        txt = txt.contiguous()
+        k_t = ops.linear(txt, attn.to_k.weight)
+        vt_t = (torch.zeros(B, attn.heads, d, ops.round_up(Lt, 32), dtype=ehs.dtype, device=ehs.device) if persistent
+                else vt_buffer("ip_txt", B, attn.heads, d, Lt, ehs.dtype, ehs.device))
+        ops.linear_vt(txt, attn.to_v.weight, B, Lt, attn.heads, vt_t)
+        k_a = vt_a = None
+        if La > 0:
+            aud = aud.contiguous()
+            k_a = ops.linear(aud, self.to_k_ip.weight)
+            vt_a = (torch.zeros(B, attn.heads, d, ops.round_up(La, 32), dtype=ehs.dtype, device=ehs.device)
+                    if persistent else vt_buffer("ip_aud", B, attn.heads, d, La, ehs.dtype, ehs.device))
+            ops.linear_vt(aud, self.to_v_ip.weight, B, La, attn.heads, vt_a)
+        return k_t, vt_t, Lt, k_a, vt_a, La
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale=1.0,
+                 _residual=None):
+        if scale != 1.0:
+            # the reference dereferences an undefined ``logger`` here (:356-357) -> NameError; reject loudly instead
+            raise ValueError("`scale` of IPAttnProcessor2_0 is set through the `scale` attribute, not the call kwarg")
+        if attn.spatial_norm is not None or attn.group_norm is not None or attn.norm_cross:
+            raise NotImplementedError("spatial_norm / group_norm / norm_cross are not on the AudioLDM2 path")
+        if hidden_states.ndim != 3:
+            raise ValueError("hidden_states must be [batch, tokens, channels]")
+        if encoder_hidden_states is None:
+            raise ValueError("IPAttnProcessor2_0 needs encoder_hidden_states = [text tokens | audio tokens]")
+        ehs = encoder_hidden_states
+        if ehs.dim() < 3:
+            ehs = ehs.unsqueeze(0)
+        B, N, _ = hidden_states.shape
+        q = ops.linear(hidden_states, attn.to_q.weight)
+        if self.kv_cache_enabled and self._kv_cache is not None:
+            kv = self._kv_cache
+        else:
+            kv = self._project(attn, ehs)
+            if self.kv_cache_enabled:
+                self._kv_cache = kv
+        k_t, vt_t, Lt, k_a, vt_a, La = kv
+        bias = None
+        if attention_mask is not None:
+            # reference :424-428 keeps only mask column 0 (split by the singleton query dim) and broadcasts it
+            # over the text keys
+            m = attention_mask.reshape(B, -1)[:, :1].float()
+            bias = m.expand(B, Lt).contiguous()
+        o = ops.attention(q, k_t, vt_t, Lt, attn.heads, key_bias=bias, k2=k_a, vt2=vt_a, L2=La, scale2=self.scale)
+        out = ops.linear(o, attn.to_out[0].weight, attn.to_out[0].bias, residual=_residual)
+        if attn.residual_connection or attn.rescale_output_factor != 1.0:
+            raise NotImplementedError("residual_connection / rescale_output_factor are not on the AudioLDM2 path")
+        return out

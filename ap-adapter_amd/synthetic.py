@@ -1,0 +1,53 @@
+"""Seeded synthetic weights and inputs: no checkpoint of AudioLDM2 / AudioMAE / the adapter is
+available offline, so parity tests and the benchmark run on random-init weights of the real shapes.  Everything is
+generated on CPU with a seeded torch.Generator and then moved, so every device sees identical bits."""
+import torch
+import torch.nn as nn
+
+
+def init_synthetic_(module: nn.Module, seed=100, w_std=0.02, bias_std=0.0, norm_jitter=0.0):
+    """Linear/Conv weights ~ N(0, w_std^2); biases ~ N(0, bias_std^2) (0 for the benchmark config); norm scales
+    1 (+ N(0, norm_jitter^2)), norm shifts N(0, norm_jitter^2)."""
+    g = torch.Generator().manual_seed(seed)
+
+    def rn(t, std):
+        if std == 0.0:
+            t.zero_()
+        else:
+            t.copy_(torch.randn(t.shape, generator=g, dtype=torch.float32) * std)
+
+    with torch.no_grad():
+        for _, m in module.named_modules():
+            if isinstance(m, (nn.Linear, nn.Conv2d)):
+                rn(m.weight, w_std)
+                if m.bias is not None:
+                    rn(m.bias, bias_std)
+            elif isinstance(m, (nn.LayerNorm, nn.GroupNorm)):
+                rn(m.weight, norm_jitter)
+                m.weight.add_(1.0)
+                rn(m.bias, norm_jitter)
+        for name, p in module.named_parameters():
+            if name.endswith("cls_token") or name.endswith("pos_embed"):
+                rn(p, w_std)
+    return module
+
+
+def synthetic_inputs(batch, La, t5_len=16, seed=0, latent_hw=(250, 16), channels=8):
+    """latents N(0,1) [B,8,250,16] (seed), GPT-2 embeds N(0,1) [2B,8,768] (seed+1), audio tokens N(0,1) [1,La,768] x2
+    (seed+2), T5 embeds N(0,1) [2B,t5_len,1024] with the last 4 positions of odd rows masked (seed+3),
+    mel N(0,0.5) [1,1024,128] (seed+4)."""
+    def gen(s):
+        return torch.Generator().manual_seed(s)
+    H, W = latent_hw
+    out = {}
+    out["latents"] = torch.randn(batch, channels, H, W, generator=gen(seed))
+    out["generated_prompt_embeds"] = torch.randn(2 * batch, 8, 768, generator=gen(seed + 1))
+    g2 = gen(seed + 2)
+    out["audio_tokens"] = torch.randn(1, La, 768, generator=g2)
+    out["uncond_audio_tokens"] = torch.randn(1, La, 768, generator=g2)
+    out["prompt_embeds"] = torch.randn(2 * batch, t5_len, 1024, generator=gen(seed + 3))
+    mask = torch.ones(2 * batch, t5_len, dtype=torch.long)
+    mask[1::2, -4:] = 0
+    out["attention_mask"] = mask
+    out["mel"] = torch.randn(1, 1024, 128, generator=gen(seed + 4)) * 0.5
+    return out

@@ -1,0 +1,476 @@
+"""Host-side module tree of the AudioLDM2 UNet, MI355X-native.
+
+Mirrors the surface the reference drives (/root/reference/pipeline/modeling_audioldm2.py):
+``AudioLDM2UNet2DConditionModel.forward`` (:663-873), ``attn_processors`` (:517-538), ``set_attn_processor``
+(:541-574), and diffusers' parameter names, so a diffusers state dict loads with ``load_state_dict``.  torch.nn
+modules are used as PARAMETER CONTAINERS only; every forward below calls the C ABI through ``ops`` and works on
+token-major NHWC activations ``[B, H*W, C]`` (so Transformer2DModel's permute/reshape is free and the 3x3
+convolutions run as implicit GEMMs).  There is no PyTorch compute fallback.
+"""
+from dataclasses import dataclass, field
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .processors import AttnProcessor2_0
+
+
+@dataclass
+class UNetConfig:
+    """AudioLDM2-large geometry (inferred from copied_cross_attention/ names and shapes)."""
+    in_channels: int = 8
+    out_channels: int = 8
+    block_out_channels: Tuple[int, ...] = (128, 256, 384, 640)
+    layers_per_block: int = 2
+    transformer_layers_per_block: int = 2
+    cross_attention_dim: Tuple[Optional[int], ...] = (None, 768, 1024, None)
+    attention_head_dim: int = 8  # used as the head COUNT (modeling_audioldm2.py:280)
+    norm_num_groups: int = 32
+    norm_eps: float = 1e-5
+    flip_sin_to_cos: bool = True
+    freq_shift: int = 0
+    down_block_types: Tuple[str, ...] = ("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D",
+                                         "CrossAttnDownBlock2D")
+    up_block_types: Tuple[str, ...] = ("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D")
+
+    def oracle_dict(self):
+        return dict(in_channels=self.in_channels, out_channels=self.out_channels,
+                    block_out_channels=tuple(self.block_out_channels), layers_per_block=self.layers_per_block,
+                    transformer_layers_per_block=self.transformer_layers_per_block,
+                    cross_attention_dim=tuple(self.cross_attention_dim), heads=self.attention_head_dim,
+                    norm_num_groups=self.norm_num_groups, flip_sin_to_cos=self.flip_sin_to_cos,
+                    freq_shift=self.freq_shift, down_block_types=tuple(self.down_block_types),
+                    up_block_types=tuple(self.up_block_types))
+
+
+class _Packed:
+    """Cache of a re-laid-out weight, invalidated when the parameter object, its storage or its version changes."""
+
+    def __init__(self):
+        self.key = None
+        self.val = None
+
+    def get(self, p, fn):
+        key = (id(p), p.data_ptr(), p._version, p.dtype, p.device)
+        if key != self.key:
+            self.val = fn(p.detach())
+            self.key = key
+        return self.val
+
+
+def _w2d(conv_or_linear):
+    w = conv_or_linear.weight
+    return w.detach().reshape(w.shape[0], -1) if w.dim() == 4 else w.detach()
+
+
+class Conv3x3(nn.Module):
+    """Parameter container ``conv`` ([Cout,Cin,3,3], diffusers layout) + packed [Cout, 9*Cin] (ky,kx,cin) copy."""
+
+    def __init__(self, cin, cout, stride=1):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, 3, stride=stride, padding=1)
+        self.stride = stride
+        self._pk = _Packed()
+
+    def packed(self):
+        return self._pk.get(self.conv.weight, lambda w: w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous())
+
+
+def _conv3x3(mod_conv, pk, x, B, H, W, stride=1, **kw):
+    wp = pk.get(mod_conv.weight, lambda w: w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous())
+    return ops.conv3x3(x, wp, mod_conv.bias, B, H, W, stride=stride, **kw)
+
+
+class Attention(nn.Module):
+    """What diffusers==0.21.2 ``Attention`` exposes to processors on this path."""
+
+    def __init__(self, query_dim, cross_attention_dim=None, heads=8, dim_head=64):
+        super().__init__()
+        inner = heads * dim_head
+        self.heads = heads
+        self.scale = dim_head ** -0.5
+        self.to_q = nn.Linear(query_dim, inner, bias=False)
+        self.to_k = nn.Linear(cross_attention_dim or query_dim, inner, bias=False)
+        self.to_v = nn.Linear(cross_attention_dim or query_dim, inner, bias=False)
+        self.to_out = nn.ModuleList([nn.Linear(inner, query_dim), nn.Dropout(0.0)])
+        self.spatial_norm = None
+        self.group_norm = None
+        self.norm_cross = None
+        self.residual_connection = False
+        self.rescale_output_factor = 1.0
+        self.set_processor(AttnProcessor2_0())
+
+    def set_processor(self, processor):
+        if hasattr(self, "processor") and isinstance(self.processor, nn.Module) and not isinstance(processor, nn.Module):
+            self._modules.pop("processor")
+        self.processor = processor
+
+    def get_processor(self, return_deprecated_lora=False):
+        return self.processor
+
+    def prepare_attention_mask(self, attention_mask, target_length, batch_size, out_dim=3):
+        if attention_mask is None:
+            return None
+        if attention_mask.shape[-1] != target_length:
+            attention_mask = torch.nn.functional.pad(attention_mask, (0, target_length), value=0.0)
+        if out_dim == 3 and attention_mask.shape[0] < batch_size * self.heads:
+            attention_mask = attention_mask.repeat_interleave(self.heads, dim=0)
+        return attention_mask
+
+    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, residual=None, **kw):
+        proc = self.processor
+        if residual is not None and getattr(proc, "fuses_residual", False):
+            return proc(self, hidden_states, encoder_hidden_states=encoder_hidden_states,
+                        attention_mask=attention_mask, _residual=residual, **kw)
+        out = proc(self, hidden_states, encoder_hidden_states=encoder_hidden_states, attention_mask=attention_mask, **kw)
+        return out if residual is None else out + residual  # foreign (non-HIP) processor: its own tensors
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim, inner):
+        super().__init__()
+        self.proj = nn.Linear(dim, inner * 2)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.net = nn.ModuleList([GEGLU(dim, dim * 4), nn.Dropout(0.0), nn.Linear(dim * 4, dim)])
+
+    def forward(self, x, residual):
+        h = ops.linear(x, self.net[0].proj.weight, self.net[0].proj.bias, act="geglu")
+        return ops.linear(h, self.net[2].weight, self.net[2].bias, residual=residual)
+
+
+class BasicTransformerBlock(nn.Module):
+    """diffusers BasicTransformerBlock, pre-LN x3 + GEGLU FF; attn2 is self-attention when cross_attention_dim is
+    None (double_self_attention, modeling_audioldm2.py:1058)."""
+
+    def __init__(self, dim, heads, dim_head, cross_attention_dim):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn1 = Attention(dim, None, heads, dim_head)
+        self.norm2 = nn.LayerNorm(dim)
+        self.attn2 = Attention(dim, cross_attention_dim, heads, dim_head)
+        self.norm3 = nn.LayerNorm(dim)
+        self.ff = FeedForward(dim)
+
+    def forward(self, x, ehs, emask):
+        n = ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        x = self.attn1(n, residual=x)
+        n = ops.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        x = self.attn2(n, encoder_hidden_states=ehs, attention_mask=emask, residual=x)
+        n = ops.layer_norm(x, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+        return self.ff(n, x)
+
+
+class Transformer2DModel(nn.Module):
+    def __init__(self, heads, dim_head, in_channels, num_layers, cross_attention_dim, groups):
+        super().__init__()
+        inner = heads * dim_head
+        self.groups = groups
+        self.norm = nn.GroupNorm(groups, in_channels, eps=1e-6, affine=True)
+        self.proj_in = nn.Conv2d(in_channels, inner, 1)
+        self.transformer_blocks = nn.ModuleList(
+            [BasicTransformerBlock(inner, heads, dim_head, cross_attention_dim) for _ in range(num_layers)])
+        self.proj_out = nn.Conv2d(inner, in_channels, 1)
+
+    def forward(self, x, ehs, emask):
+        h = ops.group_norm(x, self.norm.weight, self.norm.bias, self.groups, self.norm.eps, silu=False)
+        h = ops.linear(h, _w2d(self.proj_in), self.proj_in.bias)
+        for blk in self.transformer_blocks:
+            h = blk(h, ehs, emask)
+        return ops.linear(h, _w2d(self.proj_out), self.proj_out.bias, residual=x)
+
+
+class ResnetBlock2D(nn.Module):
+    def __init__(self, cin, cout, temb_channels, groups, eps):
+        super().__init__()
+        self.groups = groups
+        self.norm1 = nn.GroupNorm(groups, cin, eps=eps)
+        self.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
+        self.time_emb_proj = nn.Linear(temb_channels, cout)
+        self.norm2 = nn.GroupNorm(groups, cout, eps=eps)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
+        self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
+        self._pk1, self._pk2 = _Packed(), _Packed()
+
+    def time_proj(self, emb_act):
+        """emb_act = SiLU(time embedding) [rows, 512] -> [rows, Cout]"""
+        return ops.linear(emb_act, self.time_emb_proj.weight, self.time_emb_proj.bias)
+
+    def forward(self, x, B, H, W, tproj, rows_per_group, step_ptr=None):
+        h = ops.group_norm(x, self.norm1.weight, self.norm1.bias, self.groups, self.norm1.eps, silu=True)
+        h, _, _ = _conv3x3(self.conv1, self._pk1, h, B, H, W, rowgroup_bias=tproj, rows_per_group=rows_per_group,
+                           step_ptr=step_ptr)
+        h = ops.group_norm(h, self.norm2.weight, self.norm2.bias, self.groups, self.norm2.eps, silu=True)
+        sc = x if self.conv_shortcut is None else ops.linear(x, _w2d(self.conv_shortcut), self.conv_shortcut.bias)
+        out, _, _ = _conv3x3(self.conv2, self._pk2, h, B, H, W, residual=sc)
+        return out
+
+
+class Downsample2D(nn.Module):
+    def __init__(self, channels):
+        super().__init__()
+        self.conv = nn.Conv2d(channels, channels, 3, stride=2, padding=1)
+        self._pk = _Packed()
+
+    def forward(self, x, B, H, W):
+        return _conv3x3(self.conv, self._pk, x, B, H, W, stride=2)
+
+
+class Upsample2D(nn.Module):
+    def __init__(self, channels):
+        super().__init__()
+        self.conv = nn.Conv2d(channels, channels, 3, padding=1)
+        self._pk = _Packed()
+
+    def forward(self, x, B, H, W, output_size=None):
+        up = tuple(output_size) if output_size is not None else (2 * H, 2 * W)
+        return _conv3x3(self.conv, self._pk, x, B, H, W, up=up)
+
+
+class _Block(nn.Module):
+    """Shared body of DownBlock2D / CrossAttnDownBlock2D / UNetMidBlock2DCrossAttn / CrossAttnUpBlock2D / UpBlock2D."""
+
+    def __init__(self, cfg: UNetConfig, resnet_io, channels, with_attn, temb_channels):
+        super().__init__()
+        g, eps = cfg.norm_num_groups, cfg.norm_eps
+        self.cad = tuple(cfg.cross_attention_dim)
+        self.resnets = nn.ModuleList([ResnetBlock2D(ci, co, temb_channels, g, eps) for ci, co in resnet_io])
+        self.has_cross_attention = with_attn
+        if with_attn:
+            heads = cfg.attention_head_dim
+            n_layers = len(resnet_io) if not isinstance(self, UNetMidBlock2DCrossAttn) else len(resnet_io) - 1
+            self.attentions = nn.ModuleList([
+                Transformer2DModel(heads, channels // heads, channels, cfg.transformer_layers_per_block, self.cad[j], g)
+                for _ in range(n_layers) for j in range(len(self.cad))])
+
+    def _attn_stack(self, layer, x, ehs, emask, ehs1, emask1):
+        n_per = len(self.cad)
+        for idx, cad in enumerate(self.cad):  # routing modeling_audioldm2.py:1140-1149
+            if cad is not None and idx <= 1:
+                e, m = ehs, emask
+            elif cad is not None and idx > 1:
+                e, m = ehs1, emask1
+            else:
+                e, m = None, None
+            x = self.attentions[layer * n_per + idx](x, e, m)
+        return x
+
+
+class DownBlock(_Block):
+    def __init__(self, cfg, cin, cout, with_attn, add_downsample, temb_channels):
+        io = [(cin if i == 0 else cout, cout) for i in range(cfg.layers_per_block)]
+        super().__init__(cfg, io, cout, with_attn, temb_channels)
+        self.downsamplers = nn.ModuleList([Downsample2D(cout)]) if add_downsample else None
+
+
+class UNetMidBlock2DCrossAttn(_Block):
+    def __init__(self, cfg, channels, temb_channels):
+        super().__init__(cfg, [(channels, channels), (channels, channels)], channels, True, temb_channels)
+
+
+class UpBlock(_Block):
+    def __init__(self, cfg, cin, cout, prev, with_attn, add_upsample, temb_channels):
+        n = cfg.layers_per_block + 1
+        io = []
+        for i in range(n):
+            skip = cin if i == n - 1 else cout
+            rin = prev if i == 0 else cout
+            io.append((rin + skip, cout))
+        super().__init__(cfg, io, cout, with_attn, temb_channels)
+        self.upsamplers = nn.ModuleList([Upsample2D(cout)]) if add_upsample else None
+
+
+class TimestepEmbedding(nn.Module):
+    def __init__(self, cin, dim):
+        super().__init__()
+        self.linear_1 = nn.Linear(cin, dim)
+        self.linear_2 = nn.Linear(dim, dim)
+
+
+class AudioLDM2UNet2DConditionModel(nn.Module):
+    def __init__(self, config: Optional[UNetConfig] = None):
+        super().__init__()
+        cfg = config or UNetConfig()
+        self.config = cfg
+        boc = cfg.block_out_channels
+        temb_dim = boc[0] * 4
+        self.conv_in = nn.Conv2d(cfg.in_channels, boc[0], 3, padding=1)
+        self.time_embedding = TimestepEmbedding(boc[0], temb_dim)
+        self.down_blocks = nn.ModuleList()
+        out_ch = boc[0]
+        for i, typ in enumerate(cfg.down_block_types):
+            in_ch, out_ch = out_ch, boc[i]
+            self.down_blocks.append(DownBlock(cfg, in_ch, out_ch, typ == "CrossAttnDownBlock2D", i != len(boc) - 1, temb_dim))
+        self.up_blocks = nn.ModuleList()
+        self.mid_block = UNetMidBlock2DCrossAttn(cfg, boc[-1], temb_dim)
+        rev = list(reversed(boc))
+        out_ch = rev[0]
+        for i, typ in enumerate(cfg.up_block_types):
+            prev, out_ch = out_ch, rev[i]
+            in_ch = rev[min(i + 1, len(boc) - 1)]
+            self.up_blocks.append(UpBlock(cfg, in_ch, out_ch, prev, typ == "CrossAttnUpBlock2D", i != len(boc) - 1, temb_dim))
+        self.conv_norm_out = nn.GroupNorm(cfg.norm_num_groups, boc[0], eps=cfg.norm_eps)
+        self.conv_out = nn.Conv2d(boc[0], cfg.out_channels, 3, padding=1)
+        self._pk_in, self._pk_out = _Packed(), _Packed()
+        self._time_tables = None
+
+    # ---- processor plumbing (modeling_audioldm2.py:517-574) ----
+    @property
+    def attn_processors(self) -> Dict[str, object]:
+        procs = {}
+
+        def rec(name, module):
+            if hasattr(module, "get_processor"):
+                procs[f"{name}.processor"] = module.get_processor(return_deprecated_lora=True)
+            for sub, child in module.named_children():
+                rec(f"{name}.{sub}", child)
+
+        for name, module in self.named_children():
+            rec(name, module)
+        return procs
+
+    def set_attn_processor(self, processor):
+        count = len(self.attn_processors.keys())
+        if isinstance(processor, dict) and len(processor) != count:
+            raise ValueError(
+                f"A dict of processors was passed, but the number of processors {len(processor)} does not match the"
+                f" number of attention layers: {count}. Please make sure to pass {count} processor classes.")
+
+        def rec(name, module):
+            if hasattr(module, "set_processor"):
+                module.set_processor(processor if not isinstance(processor, dict) else processor.pop(f"{name}.processor"))
+            for sub, child in module.named_children():
+                rec(f"{name}.{sub}", child)
+
+        for name, module in self.named_children():
+            rec(name, module)
+
+    def set_kv_cache(self, enabled: bool):
+        """Hoist the timestep-invariant K/V projections of every cross-attention out of the denoise loop (clears any
+        cached K/V).  The caller must clear again whenever the condition tensors or the weights change."""
+        for p in self.attn_processors.values():
+            if hasattr(p, "kv_cache_enabled"):
+                p.kv_cache_enabled = enabled
+                p.clear_kv_cache()
+
+    # ---- time embedding ----
+    def _resnets(self):
+        for name, m in self.named_modules():
+            if isinstance(m, ResnetBlock2D):
+                yield name, m
+
+    def _emb_act(self, timesteps_f32, dtype):
+        """SiLU(time_embedding(time_proj(t))) [n, 512]: every consumer (ResnetBlock2D) applies SiLU first, so the
+        activation rides in the second GEMM's epilogue."""
+        cfg = self.config
+        te = ops.timestep_embedding(timesteps_f32, cfg.block_out_channels[0], cfg.flip_sin_to_cos, cfg.freq_shift, dtype)
+        h = ops.linear(te, self.time_embedding.linear_1.weight, self.time_embedding.linear_1.bias, act="silu")
+        return ops.linear(h, self.time_embedding.linear_2.weight, self.time_embedding.linear_2.bias, act="silu")
+
+    def precompute_time_tables(self, timesteps, step_ptr):
+        """Tabulate time_emb_proj(SiLU(emb(t))) for all denoise steps: [steps, Cout] per resnet.  In the loop the
+        conv epilogue reads row *step_ptr, so a captured step has no host-side timestep dependence."""
+        dtype = self.conv_in.weight.dtype
+        emb = self._emb_act(timesteps.float().contiguous(), dtype)
+        self._time_tables = ({name: m.time_proj(emb) for name, m in self._resnets()}, step_ptr)
+
+    def clear_time_tables(self):
+        self._time_tables = None
+
+    # ---- forward ----
+    def forward(self, sample, timestep=None, encoder_hidden_states=None, class_labels=None, timestep_cond=None,
+                attention_mask=None, cross_attention_kwargs=None, encoder_attention_mask=None, return_dict=True,
+                encoder_hidden_states_1=None, encoder_attention_mask_1=None):
+        """Reference signature (modeling_audioldm2.py:663-676); sample NCHW [B,C,H,W] -> (noise_pred NCHW,)."""
+        B, Cc, H, W = sample.shape
+        x = sample.permute(0, 2, 3, 1).reshape(B, H * W, Cc).contiguous()
+        out = self.forward_nhwc(x, H, W, timestep, encoder_hidden_states, encoder_hidden_states_1,
+                                encoder_attention_mask, encoder_attention_mask_1)
+        out = out.reshape(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
+        if not return_dict:
+            return (out,)
+        return UNet2DConditionOutput(sample=out)
+
+    def forward_nhwc(self, x, H, W, timestep, ehs, ehs1=None, emask=None, emask1=None, batch_repeat=1):
+        """x [Bsrc, H*W, Cin] token-major; the effective batch is Bsrc*batch_repeat (CFG duplication is done by the
+        first convolution's gather instead of a cat).  timestep None -> use the precomputed tables."""
+        cfg = self.config
+        dtype = self.conv_in.weight.dtype
+        Bs = x.shape[0]
+        B = Bs * batch_repeat
+        # mask (1 keep / 0 drop) -> additive bias [B,1,L]  (:741-747)
+        if emask is not None:
+            emask = ((1 - emask.to(dtype)) * -10000.0).unsqueeze(1)
+        if emask1 is not None:
+            emask1 = ((1 - emask1.to(dtype)) * -10000.0).unsqueeze(1)
+        if ehs1 is None:
+            ehs1, emask1 = ehs, emask
+
+        if timestep is None:
+            if self._time_tables is None:
+                raise RuntimeError("forward_nhwc(timestep=None) needs precompute_time_tables()")
+            tables, step_ptr = self._time_tables
+            tp = lambda name, m: (tables[name], 1 << 40)
+        else:
+            t = timestep if torch.is_tensor(timestep) else torch.tensor([timestep])
+            t = t.reshape(-1).to(device=x.device, dtype=torch.float32)
+            t = t.expand(B).contiguous() if t.numel() == 1 else t.contiguous()
+            emb = self._emb_act(t, dtype)
+            step_ptr = None
+            tp = lambda name, m: (m.time_proj(emb), None)
+
+        def resnet(name, m, x, H, W):
+            tab, rpg = tp(name, m)
+            return m(x, B, H, W, tab, rpg if rpg is not None else H * W, step_ptr)
+
+        wp = self._pk_in.get(self.conv_in.weight, lambda w: w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous())
+        x, _, _ = ops.conv3x3(x, wp, self.conv_in.bias, B, H, W, src_batch_mod=(Bs if batch_repeat > 1 else 0))
+        skips = [(x, H, W)]
+        nb = len(cfg.block_out_channels)
+        n_up = nb - 1
+        fwd_up = (H % (2 ** n_up) != 0) or (W % (2 ** n_up) != 0)
+
+        for i, blk in enumerate(self.down_blocks):
+            for layer, rn in enumerate(blk.resnets):
+                x = resnet(f"down_blocks.{i}.resnets.{layer}", rn, x, H, W)
+                if blk.has_cross_attention:
+                    x = blk._attn_stack(layer, x, ehs, emask, ehs1, emask1)
+                skips.append((x, H, W))
+            if blk.downsamplers is not None:
+                x, H, W = blk.downsamplers[0](x, B, H, W)
+                skips.append((x, H, W))
+
+        mb = self.mid_block
+        x = resnet("mid_block.resnets.0", mb.resnets[0], x, H, W)
+        x = mb._attn_stack(0, x, ehs, emask, ehs1, emask1)
+        x = resnet("mid_block.resnets.1", mb.resnets[1], x, H, W)
+
+        for i, blk in enumerate(self.up_blocks):
+            n = len(blk.resnets)
+            res, skips = skips[-n:], skips[:-n]
+            final = i == nb - 1
+            up_size = skips[-1][1:] if (not final and fwd_up) else None
+            for layer, rn in enumerate(blk.resnets):
+                s, _, _ = res.pop()
+                x = torch.cat([x, s], dim=-1)  # channel concat of NHWC rows (data movement only)
+                x = resnet(f"up_blocks.{i}.resnets.{layer}", rn, x, H, W)
+                if blk.has_cross_attention:
+                    x = blk._attn_stack(layer, x, ehs, emask, ehs1, emask1)
+            if blk.upsamplers is not None:
+                x, H, W = blk.upsamplers[0](x, B, H, W, up_size)
+
+        x = ops.group_norm(x, self.conv_norm_out.weight, self.conv_norm_out.bias, cfg.norm_num_groups,
+                           self.conv_norm_out.eps, silu=True)
+        wp = self._pk_out.get(self.conv_out.weight, lambda w: w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous())
+        x, _, _ = ops.conv3x3(x, wp, self.conv_out.bias, B, H, W)
+        return x
+
+
+@dataclass
+class UNet2DConditionOutput:
+    sample: torch.Tensor = None

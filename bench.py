@@ -1,0 +1,248 @@
+"""Benchmark of the AP-adapter hot path on MI355X: 10 s clips / second at 200 DDIM steps, AudioLDM2-large + AP.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--la La]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A bench "step" is one DDIM step of the captured hot path over one batch: UNet on the CFG-duplicated batch (2B
+sample-forwards), CFG combine, DDIM update -- replayed as one hipGraph.  value = clips/s = (B * N) / (200 * t_step),
+t_step = max over ranks of (elapsed / K).  Inputs (latents, GPT-2 / T5 embeddings, audio tokens) are resident in HBM
+before the timed region; weights are random-init of the AudioLDM2-large geometry (no checkpoint offline).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+DDIM_STEPS_PER_CLIP = 200
+MFMA_PEAK_TFLOPS = 2500.0   # bf16 dense, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def unet_flops_per_sample(La, t5_len=16):
+    """Algorithmic FLOPs (2*MACs) of one UNet sample-forward, AudioLDM2-large geometry at 10 s (DESIGN.md 'FLOP model')."""
+    boc = (128, 256, 384, 640)
+    hw = [250 * 16, 125 * 8, 63 * 4, 32 * 2]
+    fl = 0.0
+    conv = lambda n, cin, cout, k=9: 2.0 * n * cin * cout * k
+
+    def resnet(n, cin, cout):
+        f = conv(n, cin, cout) + conv(n, cout, cout) + 2.0 * 512 * cout
+        if cin != cout:
+            f += conv(n, cin, cout, 1)
+        return f
+
+    def tblock(n, c, kind):
+        f = 8.0 * n * c * c + 4.0 * n * n * c                       # attn1 (q,k,v,out + core)
+        if kind == "self":
+            f += 8.0 * n * c * c + 4.0 * n * n * c
+        elif kind == "ip":                                          # K/V hoisted out of the loop
+            f += 4.0 * n * c * c + 4.0 * n * (8 + La) * c
+        else:
+            f += 4.0 * n * c * c + 4.0 * n * t5_len * c
+        return f + 24.0 * n * c * c                                 # GEGLU FF
+
+    def layer(n, c):
+        f = 0.0
+        for kind in ("self", "ip", "t5", "self"):
+            f += 4.0 * n * c * c + 2 * tblock(n, c, kind)           # proj_in/out + 2 blocks
+        return f
+
+    fl += conv(hw[0], 8, 128)
+    # down
+    fl += 2 * resnet(hw[0], 128, 128) + conv(hw[1], 128, 128)
+    fl += resnet(hw[1], 128, 256) + resnet(hw[1], 256, 256) + 2 * layer(hw[1], 256) + conv(hw[2], 256, 256)
+    fl += resnet(hw[2], 256, 384) + resnet(hw[2], 384, 384) + 2 * layer(hw[2], 384) + conv(hw[3], 384, 384)
+    fl += resnet(hw[3], 384, 640) + resnet(hw[3], 640, 640) + 2 * layer(hw[3], 640)
+    # mid
+    fl += 2 * resnet(hw[3], 640, 640) + layer(hw[3], 640)
+    # up
+    fl += resnet(hw[3], 1280, 640) * 2 + resnet(hw[3], 1024, 640) + 3 * layer(hw[3], 640) + conv(hw[2], 640, 640)
+    fl += resnet(hw[2], 1024, 384) + resnet(hw[2], 768, 384) + resnet(hw[2], 640, 384) + 3 * layer(hw[2], 384) + conv(hw[1], 384, 384)
+    fl += resnet(hw[1], 640, 256) + resnet(hw[1], 512, 256) + resnet(hw[1], 384, 256) + 3 * layer(hw[1], 256) + conv(hw[0], 256, 256)
+    fl += resnet(hw[0], 384, 128) + 2 * resnet(hw[0], 256, 128)
+    fl += conv(hw[0], 128, 8)
+    return fl
+
+
+def time_kernel(fn, iters=20):
+    """average duration (ms) of one launch, HIP events on the launching stream"""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def dominant_kernel_roofline(dev, dtype, B2):
+    """Roofline of the kernel that dominates the step (profiles/: gemm_kernel GEGLU instance at the 1000-token level):
+    out[B2*1000, 1024] = geglu(x[B2*1000, 256] . W[2048, 256]^T + b).  Algorithmic FLOPs = 2*M*K*2N."""
+    from ap_adapter_amd import ops
+    M, K, N = B2 * 1000, 256, 1024
+    x = torch.randn(M, K, device=dev).to(dtype)
+    w = (torch.randn(2 * N, K, device=dev) * 0.02).to(dtype)
+    b = torch.zeros(2 * N, device=dev, dtype=dtype)
+    out = torch.empty(M, N, device=dev, dtype=dtype)
+    ms = time_kernel(lambda: ops.linear(x, w, b, act="geglu", out=out))
+    flops = 2.0 * M * K * 2 * N
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"kernel": "gemm_kernel<bf16,plain,GEGLU> M=%d K=%d N=2x%d" % (M, K, N), "bound": "mfma",
+            "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+            "avg_launch_ms": round(ms, 4), "traffic": None}
+
+
+def cpu_baseline(La, gs, steps=2):
+    """Oracle (reference-equivalent CPU restatement, fp32) on the host cores: BASELINE config-1 shape (B=1, CFG) for a
+    bounded number of DDIM steps."""
+    import ap_adapter_amd as A
+    from ap_adapter_amd.synthetic import init_synthetic_, synthetic_inputs
+    from oracle import unet as OU, ddim
+    u = A.AudioLDM2UNet2DConditionModel()
+    A.install_ap_adapter(u, None, scale=0.5)
+    init_synthetic_(u, 100)
+    sd = {k: v.detach() for k, v in u.state_dict().items()}
+    procs = {n: dict(scale=p.scale, num_tokens=p.num_tokens) for n, p in u.attn_processors.items() if hasattr(p, "to_k_ip")}
+    cfg = u.config.oracle_dict()
+    inp = synthetic_inputs(1, La)
+    ehs = torch.cat([torch.cat([inp["generated_prompt_embeds"][:1], inp["uncond_audio_tokens"]], 1),
+                     torch.cat([inp["generated_prompt_embeds"][1:], inp["audio_tokens"]], 1)], 0)
+    fn = lambda x, t: OU.unet_forward(sd, cfg, x, t, ehs, inp["prompt_embeds"], None, inp["attention_mask"].float(), procs)
+    cores = torch.get_num_threads()
+    with torch.no_grad():
+        t0 = time.time()
+        ddim.denoise_loop(fn, inp["latents"], steps, gs)
+        dt = time.time() - t0
+    s_per_step = dt / steps
+    return {"value": round(1.0 / (DDIM_STEPS_PER_CLIP * s_per_step), 6), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 UNet+CFG+DDIM, batch 1 (2 sample-forwards/step), La={La}, {steps} DDIM steps "
+                      f"({s_per_step:.2f} s/step), extrapolated x{DDIM_STEPS_PER_CLIP // steps} to 200 steps"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--la", type=int, default=32, help="audio tokens (32 = style_transfer preset, pooling 4x4)")
+    ap.add_argument("--guidance", type=float, default=9.5)
+    ap.add_argument("--ap-scale", type=float, default=0.55)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    args = ap.parse_args()
+
+    import ap_adapter_amd as A
+    from ap_adapter_amd import ops
+    from ap_adapter_amd.synthetic import init_synthetic_, synthetic_inputs
+    import torch.distributed as dist
+
+    rank, world, local = A.distributed.init_from_env("nccl" if args.gpus > 1 else None)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dtype = torch.bfloat16
+    B = args.batch
+
+    unet = A.AudioLDM2UNet2DConditionModel()
+    A.install_ap_adapter(unet, None, scale=args.ap_scale)
+    init_synthetic_(unet, 100)
+    unet = unet.to(dev, dtype)
+    inp = synthetic_inputs(B, args.la, seed=1000 * rank)
+    pipe = A.AudioLDM2Pipeline(unet)
+    ge = pipe.assemble_condition(inp["generated_prompt_embeds"].to(dev), inp["audio_tokens"].to(dev),
+                                 inp["uncond_audio_tokens"].to(dev), dtype)
+    pe = inp["prompt_embeds"].to(dev, dtype)
+    am = inp["attention_mask"].to(dev)
+    H, W, Cc = 250, 16, 8
+    sched = pipe.scheduler
+    sched.set_timesteps(DDIM_STEPS_PER_CLIP)
+    coef = sched.coef_table().to(dev)
+    step_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
+    lat = inp["latents"].to(dev).float().permute(0, 2, 3, 1).reshape(B, H * W, Cc).contiguous()
+    lat0 = lat.clone()
+    unet_in = lat.to(dtype)
+    unet.set_kv_cache(True)
+    unet.precompute_time_tables(sched.timesteps.to(dev), step_ptr)
+
+    def step():
+        eps2 = unet.forward_nhwc(unet_in, H, W, None, ge, pe, None, am, batch_repeat=2)
+        ops.cfg_ddim_step(eps2, lat, unet_in, coef, step_ptr, args.guidance)
+        ops.step_advance(step_ptr)
+
+    with torch.no_grad():
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            step()
+
+    def reset():
+        lat.copy_(lat0)
+        unet_in.copy_(lat0.to(dtype))
+        step_ptr.zero_()
+
+    def run(n):
+        for i in range(n):
+            if int(i) % DDIM_STEPS_PER_CLIP == 0:
+                reset()  # a new batch of clips starts every 200 steps (table index stays in range)
+            g.replay()
+
+    reset()
+    run(args.warmup)
+    reset()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    finite = bool(torch.isfinite(lat).all().item())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        clips_per_s = (B * world) / (DDIM_STEPS_PER_CLIP * ms_per_step * 1e-3)
+        fl = unet_flops_per_sample(args.la) * 2 * B
+        line = {
+            "metric": "10s-clips/sec @200 DDIM steps, AudioLDM2-large+AP", "value": round(clips_per_s, 4), "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"AudioLDM2-large geometry + 32 AP processors, style_transfer preset "
+                                   f"(ap_scale {args.ap_scale}, La={args.la}, CFG {args.guidance}), batch {B}/GPU, 10 s clips "
+                                   f"(latents 8x250x16), 200-step DDIM, hipGraph-captured step; one bench step = one DDIM step",
+                       "global_batch": B * world, "parallelism": f"dp{world} (independent clips, no collective in the loop)",
+                       "weights": "random-init N(0,0.02^2), real shapes (no checkpoint offline)"},
+            "step_tflops": round(fl / (ms_per_step * 1e-3) / 1e12, 2),
+            "mfma_frac_whole_step": round(fl / (ms_per_step * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+            "finite": finite,
+        }
+        line["roofline"] = dominant_kernel_roofline(dev, dtype, 2 * B)
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.la, args.guidance, args.cpu_steps)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -77,6 +77,7 @@ typedef struct apad_gemm_desc {
     int32_t stride;            /* 1 or 2                                                               */
     int32_t Hup, Wup;          /* 0 = no upsample; else nearest upsample of source to (Hup,Wup)        */
     int32_t src_batch_mod;     /* 0 = off; else source batch = b % src_batch_mod (CFG duplication)     */
+    int32_t residual_row_mod;  /* 0 = off; else residual row = m % residual_row_mod (e.g. pos_embed)    */
     /* APAD_OUT_VT */
     int32_t heads, head_dim, L, Lpad;
 } apad_gemm_desc;

@@ -1,0 +1,300 @@
+"""-m gpu: every C-ABI kernel against the oracle / plain fp32 torch on identical (storage-rounded) operands.
+Tolerance: max-abs error <= TOL[dtype] * max|ref| (bf16 2e-2, f16 3e-3): outputs are rounded once to the storage
+type (2^-8 / 2^-11 relative) after fp32 accumulation."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import TOL, q, rel_err
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.bfloat16, torch.float16]
+
+
+def R(*shape, seed=0, std=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * std
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 256), (1000, 384, 768), (77, 8, 72), (513, 640, 2560)])
+def test_gemm_plain_bias_residual(dev, dtype, M, N, K):
+    from ap_adapter_amd import ops
+    x, w, b, r = q(R(M, K, seed=1), dtype), q(R(N, K, seed=2, std=0.05), dtype), q(R(N, seed=3), dtype), q(R(M, N, seed=4), dtype)
+    ref = F.linear(x, w, b)
+    out = ops.linear(x.to(dev, dtype), w.to(dev, dtype), b.to(dev, dtype))
+    assert rel_err(out, ref) < TOL[dtype]
+    out = ops.linear(x.to(dev, dtype), w.to(dev, dtype), None, residual=r.to(dev, dtype))
+    assert rel_err(out, F.linear(x, w) + r) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("act", ["silu", "gelu", "geglu"])
+def test_gemm_activations(dev, dtype, act):
+    from ap_adapter_amd import ops
+    M, K, N = 260, 256, 192
+    rows = 2 * N if act == "geglu" else N
+    x, w, b = q(R(M, K, seed=5), dtype), q(R(rows, K, seed=6, std=0.08), dtype), q(R(rows, seed=7, std=0.5), dtype)
+    y = F.linear(x, w, b)
+    if act == "silu":
+        ref = F.silu(y)
+    elif act == "gelu":
+        ref = F.gelu(y)
+    else:
+        a, g = y.chunk(2, dim=-1)
+        ref = a * F.gelu(g)
+    out = ops.linear(x.to(dev, dtype), w.to(dev, dtype), b.to(dev, dtype), act=act)
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_rowgroup_bias_and_step(dev, dtype):
+    from ap_adapter_amd import ops
+    B, HW, K, N = 3, 50, 64, 128
+    x, w = q(R(B * HW, K, seed=8), dtype), q(R(N, K, seed=9, std=0.1), dtype)
+    rg = q(R(B, N, seed=10), dtype)
+    ref = (F.linear(x, w).view(B, HW, N) + rg[:, None, :]).view(B * HW, N)
+    out = ops.linear(x.to(dev, dtype), w.to(dev, dtype), rowgroup_bias=rg.to(dev, dtype), rows_per_group=HW)
+    assert rel_err(out, ref) < TOL[dtype]
+    # table mode: every row uses table[*step_ptr]
+    step = torch.tensor([2], dtype=torch.int32, device=dev)
+    out = ops.linear(x.to(dev, dtype), w.to(dev, dtype), rowgroup_bias=rg.to(dev, dtype), rows_per_group=1 << 40, step_ptr=step)
+    assert rel_err(out, F.linear(x, w) + rg[2][None, :]) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,L,heads,d", [(2, 100, 8, 32), (1, 513, 12, 64), (2, 8, 8, 80), (3, 40, 8, 48)])
+def test_gemm_vt_output(dev, dtype, B, L, heads, d):
+    from ap_adapter_amd import ops
+    C_, K = heads * d, 128
+    x, w, b = q(R(B * L, K, seed=11), dtype), q(R(C_, K, seed=12, std=0.1), dtype), q(R(C_, seed=13), dtype)
+    Lpad = ops.round_up(L, 32)
+    vt = torch.zeros(B, heads, d, Lpad, dtype=dtype, device=dev)
+    ops.linear_vt(x.to(dev, dtype), w.to(dev, dtype), B, L, heads, vt, bias=b.to(dev, dtype))
+    ref = F.linear(x, w, b).view(B, L, heads, d).permute(0, 2, 3, 1)
+    assert rel_err(vt[..., :L], ref) < TOL[dtype]
+    assert float(vt[..., L:].float().abs().max()) == 0.0 if Lpad > L else True
+
+
+def _conv_ref(x_nchw, w, b, stride=1, up=None):
+    if up is not None:
+        x_nchw = F.interpolate(x_nchw, size=up, mode="nearest")
+    return F.conv2d(x_nchw, w, b, stride=stride, padding=1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,up", [
+    (2, 10, 16, 8, 128, 1, None), (2, 25, 16, 128, 128, 2, None), (1, 63, 4, 384, 384, 2, None),
+    (2, 32, 2, 640, 640, 1, (63, 4)), (2, 13, 8, 64, 96, 1, (26, 16)), (1, 250, 16, 128, 8, 1, None)])
+def test_conv3x3_implicit_gemm(dev, dtype, B, H, W, Cin, Cout, stride, up):
+    from ap_adapter_amd import ops
+    x = q(R(B, Cin, H, W, seed=14), dtype)
+    w = q(R(Cout, Cin, 3, 3, seed=15, std=0.05), dtype)
+    b = q(R(Cout, seed=16), dtype)
+    ref = _conv_ref(x, w, b, stride, up)
+    xn = x.permute(0, 2, 3, 1).reshape(B, H * W, Cin).contiguous().to(dev, dtype)
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(dev, dtype)
+    out, Ho, Wo = ops.conv3x3(xn, wp, b.to(dev, dtype), B, H, W, stride=stride, up=up)
+    assert (Ho, Wo) == tuple(ref.shape[2:])
+    out = out.reshape(B, Ho, Wo, Cout).permute(0, 3, 1, 2)
+    assert rel_err(out, ref) < TOL[dtype]
+
+
+def test_conv3x3_cfg_duplication_and_temb(dev):
+    from ap_adapter_amd import ops
+    dtype = torch.bfloat16
+    B, H, W, Cin, Cout = 2, 12, 16, 8, 128
+    x, w = q(R(B, Cin, H, W, seed=17), dtype), q(R(Cout, Cin, 3, 3, seed=18, std=0.1), dtype)
+    t = q(R(2 * B, Cout, seed=19), dtype)
+    ref = F.conv2d(torch.cat([x, x]), w, None, padding=1) + t[:, :, None, None]
+    xn = x.permute(0, 2, 3, 1).reshape(B, H * W, Cin).contiguous().to(dev, dtype)
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(dev, dtype)
+    out, _, _ = ops.conv3x3(xn, wp, None, 2 * B, H, W, src_batch_mod=B, rowgroup_bias=t.to(dev, dtype), rows_per_group=H * W)
+    out = out.reshape(2 * B, H, W, Cout).permute(0, 3, 1, 2)
+    assert rel_err(out, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_patch_embed(dev, dtype):
+    from ap_adapter_amd import ops
+    mel = R(2, 1024, 128, seed=20, std=0.5)
+    w, b = q(R(768, 1, 16, 16, seed=21, std=0.05), dtype), q(R(768, seed=22, std=0.1), dtype)
+    ref = F.conv2d(q(mel, dtype).unsqueeze(1), w, b, stride=16).flatten(2).transpose(1, 2)
+    out = ops.patch_embed(mel.to(dev), w.reshape(768, 256).to(dev, dtype), b.to(dev, dtype), dtype)
+    assert rel_err(out, ref) < TOL[dtype]
+
+
+def _attn_ref(qh, kh, vh, bias=None):
+    s = qh @ kh.transpose(-1, -2) / math.sqrt(qh.shape[-1])
+    if bias is not None:
+        s = s + bias[:, None, None, :]
+    return torch.softmax(s, -1) @ vh
+
+
+def _heads(x, h):
+    b, n, c = x.shape
+    return x.view(b, n, h, c // h).transpose(1, 2)
+
+
+def _vt(v, heads, dev, dtype):
+    from ap_adapter_amd import ops
+    B, L, C_ = v.shape
+    buf = torch.zeros(B, heads, C_ // heads, ops.round_up(L, 32), dtype=dtype, device=dev)
+    buf[..., :L] = _heads(v, heads).transpose(-1, -2).to(dev, dtype)
+    return buf
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,N,L,heads,d,masked", [
+    (2, 100, 100, 8, 32, False), (1, 1000, 1000, 8, 32, False), (2, 252, 252, 8, 48, False), (2, 64, 64, 8, 80, False),
+    (2, 64, 16, 8, 80, True), (1, 513, 513, 12, 64, False), (2, 130, 33, 4, 64, True), (1, 40, 7, 2, 16, False),
+    (1, 33, 70, 2, 128, False), (1, 64, 45, 2, 96, False)])
+def test_attention_single_segment(dev, dtype, B, N, L, heads, d, masked):
+    from ap_adapter_amd import ops
+    C_ = heads * d
+    qq, kk, vv = q(R(B, N, C_, seed=23), dtype), q(R(B, L, C_, seed=24), dtype), q(R(B, L, C_, seed=25), dtype)
+    bias = None
+    if masked:
+        bias = torch.zeros(B, L)
+        bias[1::2, -4:] = -10000.0
+        bias[0, 1] = -3.0
+    ref = _attn_ref(_heads(qq, heads), _heads(kk, heads), _heads(vv, heads), bias).transpose(1, 2).reshape(B, N, C_)
+    out = ops.attention(qq.to(dev, dtype), kk.to(dev, dtype), _vt(vv, heads, dev, dtype), L, heads,
+                        key_bias=None if bias is None else bias.to(dev))
+    assert rel_err(out, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,N,heads,d,Lt,La,scale", [
+    (2, 100, 8, 32, 8, 32, 0.55), (1, 1000, 8, 32, 8, 512, 0.5), (2, 252, 8, 48, 8, 128, 0.5), (2, 64, 8, 80, 8, 8, 1.0),
+    (2, 64, 8, 80, 8, 512, 0.5), (2, 100, 8, 32, 8, 0, 0.5), (2, 100, 8, 32, 8, 32, 0.0), (2, 70, 4, 64, 4, 33, 0.7)])
+def test_attention_decoupled(dev, dtype, B, N, heads, d, Lt, La, scale):
+    """two independently normalised key segments blended text + scale * audio (attention_processor.py:429-454)"""
+    from ap_adapter_amd import ops
+    C_ = heads * d
+    qq = q(R(B, N, C_, seed=26), dtype)
+    kt, vt_ = q(R(B, Lt, C_, seed=27), dtype), q(R(B, Lt, C_, seed=28), dtype)
+    ka, va = q(R(B, max(La, 1), C_, seed=29), dtype)[:, :La], q(R(B, max(La, 1), C_, seed=30), dtype)[:, :La]
+    qh = _heads(qq, heads)
+    ref = _attn_ref(qh, _heads(kt, heads), _heads(vt_, heads))
+    if La > 0:
+        ref = ref + scale * _attn_ref(qh, _heads(ka, heads), _heads(va, heads))
+    ref = ref.transpose(1, 2).reshape(B, N, C_)
+    kw = {}
+    if La > 0:
+        kw = dict(k2=ka.contiguous().to(dev, dtype), vt2=_vt(va, heads, dev, dtype), L2=La, scale2=scale)
+    out = ops.attention(qq.to(dev, dtype), kt.to(dev, dtype), _vt(vt_, heads, dev, dtype), Lt, heads, **kw)
+    assert rel_err(out, ref) < TOL[dtype]
+
+
+def test_attention_shared_kv_batch_div(dev):
+    """kv_batch_div: one K/V set shared by a group of consecutive samples (one audio prompt per CFG half)"""
+    from ap_adapter_amd import ops
+    dtype, B, N, heads, d, L = torch.bfloat16, 4, 64, 8, 32, 40
+    C_ = heads * d
+    qq, kk, vv = q(R(B, N, C_, seed=31), dtype), q(R(2, L, C_, seed=32), dtype), q(R(2, L, C_, seed=33), dtype)
+    kf, vf = kk.repeat_interleave(2, 0), vv.repeat_interleave(2, 0)
+    ref = _attn_ref(_heads(qq, heads), _heads(kf, heads), _heads(vf, heads)).transpose(1, 2).reshape(B, N, C_)
+    out = ops.attention(qq.to(dev, dtype), kk.to(dev, dtype), _vt(vv, heads, dev, dtype), L, heads, kv_batch_div=2)
+    assert rel_err(out, ref) < TOL[dtype]
+
+
+def test_attention_online_softmax_rescale_forced(dev):
+    """a late key tile carries a much larger score than the early ones, forcing the running-max rescale branch"""
+    from ap_adapter_amd import ops
+    dtype, B, N, heads, d, L = torch.bfloat16, 1, 64, 2, 32, 200
+    C_ = heads * d
+    qq, kk, vv = q(R(B, N, C_, seed=34), dtype), q(R(B, L, C_, seed=35), dtype), q(R(B, L, C_, seed=36), dtype)
+    kk[:, 150] = qq[:, 5] * 4.0  # spikes q.k for query 5 (and others) in tile 4
+    kk = q(kk, dtype)
+    ref = _attn_ref(_heads(qq, heads), _heads(kk, heads), _heads(vv, heads)).transpose(1, 2).reshape(B, N, C_)
+    out = ops.attention(qq.to(dev, dtype), kk.to(dev, dtype), _vt(vv, heads, dev, dtype), L, heads)
+    assert rel_err(out, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,C_", [(1000, 256), (252, 384), (130, 640), (513, 768), (7, 1280)])
+def test_layernorm(dev, dtype, M, C_):
+    from ap_adapter_amd import ops
+    x, g, b = q(R(M, C_, seed=37) * 2 + 0.5, dtype), q(1 + 0.1 * R(C_, seed=38), dtype), q(0.1 * R(C_, seed=39), dtype)
+    for eps in (1e-5, 1e-6):
+        ref = F.layer_norm(x, (C_,), g, b, eps)
+        out = ops.layer_norm(x.to(dev, dtype), g.to(dev, dtype), b.to(dev, dtype), eps)
+        assert rel_err(out, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,HW,C_,silu", [(2, 4000, 128, True), (3, 1000, 256, False), (2, 252, 384, True),
+                                          (2, 64, 1280, True), (1, 1000, 640, True), (2, 64, 896, False)])
+def test_groupnorm(dev, dtype, B, HW, C_, silu):
+    from ap_adapter_amd import ops
+    x = q(R(B, HW, C_, seed=40) * 1.5 + 0.3, dtype)
+    g, b = q(1 + 0.1 * R(C_, seed=41), dtype), q(0.1 * R(C_, seed=42), dtype)
+    for eps in (1e-5, 1e-6):
+        ref = F.group_norm(x.transpose(1, 2), 32, g, b, eps)
+        ref = (F.silu(ref) if silu else ref).transpose(1, 2)
+        out = ops.group_norm(x.to(dev, dtype), g.to(dev, dtype), b.to(dev, dtype), 32, eps, silu=silu)
+        assert rel_err(out, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("tp,fp", [(1, 1), (2, 2), (4, 4), (8, 8), (8, 1), (2, 8)])
+def test_audiomae_pool(dev, tp, fp):
+    from ap_adapter_amd import ops
+    from oracle.audiomae import pool
+    dtype = torch.bfloat16
+    rep = q(R(2, 513, 768, seed=43), dtype)
+    ref = pool(rep, tp, fp)
+    out = ops.audiomae_pool(rep.to(dev, dtype), tp, fp, out_dtype=torch.float32)
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < 1e-6
+    out = ops.audiomae_pool(rep.to(dev, dtype), tp, fp)
+    assert rel_err(out, ref) < TOL[dtype]
+
+
+def test_timestep_embedding(dev):
+    from ap_adapter_amd import ops
+    from oracle.blocks import timestep_embedding
+    t = torch.tensor([996.0, 991.0, 501.0, 1.0, 0.0])
+    ref = timestep_embedding(t, 128, True, 0.0)
+    out = ops.timestep_embedding(t.to(dev), 128, True, 0.0, torch.bfloat16)
+    assert rel_err(out, ref) < TOL[torch.bfloat16]
+    out = ops.timestep_embedding(t.to(dev), 128, False, 1.0, torch.float16)
+    assert rel_err(out, timestep_embedding(t, 128, False, 1.0)) < TOL[torch.float16]
+
+
+def test_cfg_ddim_step_matches_oracle(dev):
+    from ap_adapter_amd import ops
+    from ap_adapter_amd.scheduler import DDIMScheduler
+    from oracle import ddim
+    dtype, B, n, steps, gs = torch.bfloat16, 3, 4000 * 8, 10, 7.5
+    s = DDIMScheduler()
+    s.set_timesteps(steps)
+    coef = s.coef_table().to(dev)
+    lat = R(B, n, seed=44)
+    lat_d = lat.clone().to(dev)
+    unet_in = torch.empty(B, n, dtype=dtype, device=dev)
+    eps_out = torch.empty(B, n, dtype=torch.float32, device=dev)
+    step_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
+    acp = ddim.alphas_cumprod()
+    for i, t in enumerate(ddim.timesteps(steps)):
+        eps2 = q(R(2 * B, n, seed=100 + i) * 0.5, dtype)
+        e = q(ddim.cfg_combine(eps2, gs), dtype)
+        lat = ddim.ddim_step(e, t, lat, steps, acp)
+        ops.cfg_ddim_step(eps2.to(dev, dtype), lat_d, unet_in, coef, step_ptr, gs, eps_out)
+        ops.step_advance(step_ptr)
+        assert rel_err(eps_out, e) < 1e-6
+        assert rel_err(lat_d, lat) < 1e-5
+        assert rel_err(unet_in, lat) < TOL[dtype]
+    assert int(step_ptr.item()) == steps
+
+
+def test_errors_are_python_exceptions(dev):
+    from ap_adapter_amd import ops
+    x = torch.zeros(4, 12, dtype=torch.bfloat16, device=dev)  # K % 8 != 0
+    w = torch.zeros(8, 12, dtype=torch.bfloat16, device=dev)
+    with pytest.raises(RuntimeError, match="multiples of 8"):
+        ops.linear(x, w)
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        ops.linear(torch.zeros(4, 16, dtype=torch.bfloat16), w)

@@ -1,0 +1,80 @@
+"""-m gpu: UNet / AudioMAE / pipeline on the HIP path against the oracle chain on the same seeded weights and inputs."""
+import pytest
+import torch
+
+from util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _small_unet(dev, dtype, seed=100):
+    import ap_adapter_amd as A
+    from ap_adapter_amd.synthetic import init_synthetic_
+    cfg = A.UNetConfig(block_out_channels=(64, 128, 192, 256), attention_head_dim=4, norm_num_groups=16)
+    u = A.AudioLDM2UNet2DConditionModel(cfg)
+    A.install_ap_adapter(u, None, scale=0.5)
+    init_synthetic_(u, seed, w_std=0.05, bias_std=0.02, norm_jitter=0.1)
+    # oracle sees exactly the storage-rounded weights
+    u = u.to(dtype)
+    sd = {k: v.detach().float().cpu() for k, v in u.state_dict().items()}
+    procs = {n: dict(scale=p.scale, num_tokens=p.num_tokens) for n, p in u.attn_processors.items() if hasattr(p, "to_k_ip")}
+    return u.to(dev), cfg, sd, procs
+
+
+def _cond(B, La, dtype, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    ehs = torch.randn(B, 8 + La, 768, generator=g).to(dtype).float()
+    ehs1 = torch.randn(B, 16, 1024, generator=g).to(dtype).float()
+    m1 = torch.ones(B, 16)
+    m1[1::2, -4:] = 0
+    return ehs, ehs1, m1
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 6e-2), (torch.float16, 1e-2)])
+def test_small_unet_forward_vs_oracle(dev, dtype, tol):
+    from oracle import unet as OU
+    u, cfg, sd, procs = _small_unet(dev, dtype)
+    B, H, W = 2, 26, 16
+    x = torch.randn(B, 8, H, W, generator=torch.Generator().manual_seed(1)).to(dtype).float()
+    ehs, ehs1, m1 = _cond(B, 32, dtype)
+    t = torch.tensor(991)
+    ref = OU.unet_forward(sd, cfg.oracle_dict(), x, t, ehs, ehs1, None, m1, procs)
+    out = u(x.to(dev, dtype), t, encoder_hidden_states=ehs.to(dev, dtype), encoder_hidden_states_1=ehs1.to(dev, dtype),
+            encoder_attention_mask_1=m1.to(dev), return_dict=False)[0]
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < tol
+
+
+def test_small_unet_graph_loop_vs_oracle_loop(dev):
+    """5-step CFG + DDIM loop (BASELINE config 1 shape of plumbing): hipGraph replay == eager, and both track the
+    oracle loop."""
+    import ap_adapter_amd as A
+    from oracle import unet as OU, ddim
+    dtype = torch.float16
+    u, cfg, sd, procs = _small_unet(dev, dtype)
+    B, H, W, steps, gs = 2, 26, 16, 5, 7.5
+    lat = torch.randn(B, 8, H, W, generator=torch.Generator().manual_seed(2))
+    ehs, ehs1, m1 = _cond(2 * B, 32, dtype)
+    pipe = A.AudioLDM2Pipeline(u)
+    a = pipe.denoise(lat.to(dev), ehs.to(dev), ehs1.to(dev), m1.to(dev), steps, gs, use_graph=True)
+    b = pipe.denoise(lat.to(dev), ehs.to(dev), ehs1.to(dev), m1.to(dev), steps, gs, use_graph=False)
+    assert torch.equal(a, b)
+    fn = lambda x, t: OU.unet_forward(sd, cfg.oracle_dict(), x, t, ehs, ehs1, None, m1, procs)
+    ref, _ = ddim.denoise_loop(fn, lat, steps, gs)
+    assert rel_err(a, ref) < 3e-2
+
+
+def test_audiomae_vs_oracle(dev):
+    import ap_adapter_amd as A
+    from ap_adapter_amd.synthetic import init_synthetic_
+    from oracle import audiomae as OA
+    dtype = torch.bfloat16
+    m = A.AudioMAEConditionCTPoolRand(depth=3)
+    init_synthetic_(m, 7, w_std=0.03, bias_std=0.02, norm_jitter=0.1)
+    m = m.to(dtype)
+    sd = {k[len("audiomae.model."):]: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    mel = (torch.randn(2, 1024, 128, generator=torch.Generator().manual_seed(3)) * 0.5)
+    ref = OA.audio_condition(sd, mel.to(dtype).float(), 4, 4, depth=3)
+    out, ones = m.to(dev)(mel, time_pool=4, freq_pool=4)
+    assert out.shape == ref.shape == (2, 32, 768) and ones.shape == (2, 32)
+    assert rel_err(out, ref) < 5e-2

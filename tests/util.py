@@ -1,0 +1,15 @@
+import torch
+
+
+def rel_err(out, ref):
+    """max-abs error relative to the reference's max magnitude"""
+    ref = ref.float()
+    return float((out.float().cpu() - ref.cpu()).abs().max() / ref.abs().max().clamp_min(1e-12))
+
+
+def q(t, dtype):
+    """round a fp32 CPU tensor to the storage dtype and back (so oracle and HIP path see the same operand bits)"""
+    return t.to(dtype).float()
+
+
+TOL = {torch.bfloat16: 2e-2, torch.float16: 3e-3}
