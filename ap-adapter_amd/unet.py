@@ -35,7 +35,7 @@ class UNetConfig:
                                          "CrossAttnDownBlock2D")
     up_block_types: Tuple[str, ...] = ("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D")
 
-    def oracle_dict(self):
+    def geometry_dict(self):
         return dict(in_channels=self.in_channels, out_channels=self.out_channels,
                     block_out_channels=tuple(self.block_out_channels), layers_per_block=self.layers_per_block,
                     transformer_layers_per_block=self.transformer_layers_per_block,

@@ -112,7 +112,7 @@ def cpu_baseline(La, gs, steps=2):
     init_synthetic_(u, 100)
     sd = {k: v.detach() for k, v in u.state_dict().items()}
     procs = {n: dict(scale=p.scale, num_tokens=p.num_tokens) for n, p in u.attn_processors.items() if hasattr(p, "to_k_ip")}
-    cfg = u.config.oracle_dict()
+    cfg = u.config.geometry_dict()
     inp = synthetic_inputs(1, La)
     ehs = torch.cat([torch.cat([inp["generated_prompt_embeds"][:1], inp["uncond_audio_tokens"]], 1),
                      torch.cat([inp["generated_prompt_embeds"][1:], inp["audio_tokens"]], 1)], 0)

@@ -97,3 +97,17 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def write_copied_cross_attention_index():
+    """File names + tensor shapes of the reference's copied_cross_attention/ directory (no weights): pins which 32 attn2
+    sites take the adapter and their widths (SURVEY 2 row 'copied_cross_attention/')."""
+    d = "/root/reference/copied_cross_attention"
+    shapes = {n: list(torch.load(os.path.join(d, n), weights_only=True, map_location="cpu").shape) for n in sorted(os.listdir(d))}
+    with open(os.path.join(HERE, "copied_cross_attention_index.json"), "w") as f:
+        json.dump({"source": "ls /root/reference/copied_cross_attention (file names + tensor shapes only; no weights)",
+                   "files": shapes}, f, indent=0)
+
+
+if __name__ == "__main__":
+    write_copied_cross_attention_index()

@@ -1,0 +1,75 @@
+"""CPU, world_size 2 over gloo: the data-parallel plumbing (clip sharding, weight broadcast, one flat adapter-gradient
+all-reduce, latent gather)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import ap_adapter_amd as A
+    from ap_adapter_amd import distributed as D
+    from ap_adapter_amd.synthetic import init_synthetic_
+    r, w, _ = D.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    cfg = A.UNetConfig(block_out_channels=(32, 64, 96, 128), attention_head_dim=4, transformer_layers_per_block=1)
+    u = A.AudioLDM2UNet2DConditionModel(cfg)
+    A.install_ap_adapter(u, None, scale=0.5)
+    init_synthetic_(u, seed=100 + rank)              # ranks start DIFFERENT ...
+    D.broadcast_module(u, src=0)                     # ... and end equal to rank 0
+    ref = A.AudioLDM2UNet2DConditionModel(cfg)
+    A.install_ap_adapter(ref, None, scale=0.5)
+    init_synthetic_(ref, seed=100)
+    same = all(torch.equal(a, b) for a, b in zip(u.state_dict().values(), ref.state_dict().values()))
+    params = D.adapter_parameters(u)
+    for i, p in enumerate(params):
+        p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+    D.allreduce_adapter_grads(params)                # mean over ranks: (1+2)/2 * (i+1)
+    ok_grads = all(torch.allclose(p.grad, torch.full_like(p, 1.5 * (i + 1))) for i, p in enumerate(params))
+    clips = D.shard_clips(7, rank, world)
+    lat = torch.full((len(clips[:3]), 2), float(rank))
+    gathered = D.gather_latents(lat)
+    q.put((rank, same, ok_grads, clips, gathered.tolist(), len(params)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, same0, g0, c0, gat0, n0), (r1, same1, g1, c1, gat1, n1) = res
+    assert same0 and same1 and g0 and g1
+    assert c0 == [0, 2, 4, 6] and c1 == [1, 3, 5] and sorted(c0 + c1) == list(range(7))
+    assert gat0 == gat1 == [[0.0, 0.0]] * 3 + [[1.0, 1.0]] * 3
+    assert n0 == n1 == 32
+
+
+def test_single_process_is_a_noop():
+    from ap_adapter_amd import distributed as D
+    assert D.shard_clips(5, 0, 1) == [0, 1, 2, 3, 4]
+    t = torch.ones(2, 3)
+    assert D.gather_latents(t) is t
+    p = torch.nn.Parameter(torch.ones(3))
+    p.grad = torch.ones(3)
+    D.allreduce_adapter_grads([p])
+    assert torch.equal(p.grad, torch.ones(3))

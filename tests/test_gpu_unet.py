@@ -38,7 +38,7 @@ def test_small_unet_forward_vs_oracle(dev, dtype, tol):
     x = torch.randn(B, 8, H, W, generator=torch.Generator().manual_seed(1)).to(dtype).float()
     ehs, ehs1, m1 = _cond(B, 32, dtype)
     t = torch.tensor(991)
-    ref = OU.unet_forward(sd, cfg.oracle_dict(), x, t, ehs, ehs1, None, m1, procs)
+    ref = OU.unet_forward(sd, cfg.geometry_dict(), x, t, ehs, ehs1, None, m1, procs)
     out = u(x.to(dev, dtype), t, encoder_hidden_states=ehs.to(dev, dtype), encoder_hidden_states_1=ehs1.to(dev, dtype),
             encoder_attention_mask_1=m1.to(dev), return_dict=False)[0]
     assert out.shape == ref.shape
@@ -59,7 +59,7 @@ def test_small_unet_graph_loop_vs_oracle_loop(dev):
     a = pipe.denoise(lat.to(dev), ehs.to(dev), ehs1.to(dev), m1.to(dev), steps, gs, use_graph=True)
     b = pipe.denoise(lat.to(dev), ehs.to(dev), ehs1.to(dev), m1.to(dev), steps, gs, use_graph=False)
     assert torch.equal(a, b)
-    fn = lambda x, t: OU.unet_forward(sd, cfg.oracle_dict(), x, t, ehs, ehs1, None, m1, procs)
+    fn = lambda x, t: OU.unet_forward(sd, cfg.geometry_dict(), x, t, ehs, ehs1, None, m1, procs)
     ref, _ = ddim.denoise_loop(fn, lat, steps, gs)
     assert rel_err(a, ref) < 3e-2
 

@@ -1,0 +1,78 @@
+"""CPU: the oracle's attention processors against the reference's own outputs (golden vectors produced by running
+/root/reference/APadapter/ap_adapter/attention_processor.py, see tests/golden/make_golden.py)."""
+import os
+
+import pytest
+import torch
+from safetensors.torch import load_file
+
+from cases import CASES, make_inputs
+from oracle.attention import attn_processor_2_0, ip_attn_processor_2_0
+
+GOLD = load_file(os.path.join(os.path.dirname(__file__), "golden", "attn_processors.safetensors"))
+
+
+def run_oracle(c, t, **over):
+    a = dict(t)
+    a.update(over)
+    if c["kind"] == "ip":
+        return ip_attn_processor_2_0(a["hs"], a["ehs"], a["wq"], a["wk"], a["wv"], a["wo"], a["bo"], a["wk_ip"], a["wv_ip"],
+                                     c["heads"], c["num_tokens"], over.get("scale", c["scale"]), a["mask_bias"])
+    return attn_processor_2_0(a["hs"], a["ehs"], a["wq"], a["wk"], a["wv"], a["wo"], a["bo"], c["heads"], a["mask_bias"])
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_oracle_matches_reference_fp32(case):
+    out = run_oracle(case, make_inputs(case))
+    ref = GOLD[case["name"] + ".fp32"]
+    assert out.shape == ref.shape
+    assert float((out - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
+def test_every_case_has_a_golden_vector():
+    assert {c["name"] + ".fp32" for c in CASES} <= set(GOLD.keys())
+
+
+def test_no_audio_tokens_equals_plain_processor():
+    """with exactly num_tokens tokens the IP processor reduces to the plain one"""
+    c = next(c for c in CASES if c["name"] == "ip_640_La0")
+    t = make_inputs(c)
+    a = run_oracle(c, t)
+    b = attn_processor_2_0(t["hs"], t["ehs"], t["wq"], t["wk"], t["wv"], t["wo"], t["bo"], c["heads"])
+    assert torch.equal(a, b)
+
+
+def test_scale_zero_equals_plain_on_text_tokens():
+    """SURVEY 4-2"""
+    c = next(c for c in CASES if c["name"] == "ip_256_scale0")
+    t = make_inputs(c)
+    a = run_oracle(c, t)
+    b = attn_processor_2_0(t["hs"], t["ehs"][:, :8], t["wq"], t["wk"], t["wv"], t["wo"], t["bo"], c["heads"])
+    assert torch.allclose(a, b, atol=1e-6)
+    assert torch.allclose(a, GOLD["ip_256_scale0.fp32"], atol=1e-5)
+
+
+def test_masked_ip_keeps_only_first_mask_column():
+    """attention_processor.py:424-428: the mask is split by its singleton query dim, so only column 0 survives and a
+    per-row constant bias cannot change the softmax"""
+    c = next(c for c in CASES if c["name"] == "ip_256_masked")
+    t = make_inputs(c)
+    a = run_oracle(c, t)
+    b = run_oracle(c, t, mask_bias=None)
+    assert torch.allclose(a, b, atol=1e-5)
+
+
+def test_linearity_in_scale():
+    c = next(c for c in CASES if c["name"] == "ip_384_La32")
+    t = make_inputs(c)
+    o0, o1, o2 = (run_oracle(c, t, scale=s) for s in (0.0, 1.0, 2.0))
+    assert torch.allclose(o2 - o1, o1 - o0, atol=2e-5)
+
+
+def test_reference_bf16_gap_is_what_the_tolerance_assumes():
+    """the reference's own bf16 run differs from its fp32 run by ~1e-2 of max|out|"""
+    for c in CASES:
+        if c["bf16"]:
+            r32, r16 = GOLD[c["name"] + ".fp32"], GOLD[c["name"] + ".bf16"].float()
+            rel = float((r32 - r16).abs().max() / r32.abs().max())
+            assert 1e-4 < rel < 3e-2, (c["name"], rel)
