@@ -12,7 +12,7 @@ import threading
 import torch  # noqa: F401  (must precede CDLL: shares libamdhip64 with PyTorch-ROCm)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libapadapter_hip.so")
+LIB_PATH = os.environ.get("APAD_LIB_PATH") or os.path.join(_HERE, "libapadapter_hip.so")  # override: kernel A/B experiments
 CSRC = os.path.join(_HERE, "csrc")
 
 BF16, F16, F32 = 0, 1, 2
@@ -39,6 +39,17 @@ class AttnDesc(C.Structure):
                [("softmax_scale", _f32), ("scale2", _f32)]
 
 
+class RpSegment(C.Structure):
+    _fields_ = [("out", _vp), ("bias", _vp), ("ldo", _i64), ("n_cols", _i32), ("mode", _i32)]
+
+
+class RpDesc(C.Structure):
+    _fields_ = [(n, _vp) for n in ("x", "w", "ln_gamma", "ln_beta", "residual")] + \
+               [(n, _i64) for n in ("M", "lda", "ldw", "ldr")] + \
+               [(n, _i32) for n in ("K", "epilogue", "dtype", "n_segments")] + [("ln_eps", _f32)] + \
+               [(n, _i32) for n in ("heads", "head_dim", "L", "Lpad")] + [("seg", RpSegment * 3)]
+
+
 # name -> (restype, argtypes); every symbol include/apadapter_hip.h declares
 SYMBOLS = {
     "apad_last_error": (C.c_char_p, []),
@@ -47,6 +58,9 @@ SYMBOLS = {
     "apad_sizeof_attn_desc": (C.c_int, []),
     "apad_echo_gemm_desc": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(C.c_double), C.c_int]),
     "apad_echo_attn_desc": (C.c_int, [C.POINTER(AttnDesc), C.POINTER(C.c_double), C.c_int]),
+    "apad_sizeof_rp_desc": (C.c_int, []),
+    "apad_echo_rp_desc": (C.c_int, [C.POINTER(RpDesc), C.POINTER(C.c_double), C.c_int]),
+    "apad_rowpanel_gemm": (C.c_int, [C.POINTER(RpDesc), _vp]),
     "apad_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "apad_attention": (C.c_int, [C.POINTER(AttnDesc), _vp]),
     "apad_layernorm": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _i64, _f32, _i32, _vp]),
@@ -92,7 +106,8 @@ def lib():
                 fn.argtypes = args
             if h.apad_abi_version() != 1:
                 raise RuntimeError("libapadapter_hip.so ABI version mismatch")
-            if h.apad_sizeof_gemm_desc() != C.sizeof(GemmDesc) or h.apad_sizeof_attn_desc() != C.sizeof(AttnDesc):
+            if h.apad_sizeof_gemm_desc() != C.sizeof(GemmDesc) or h.apad_sizeof_attn_desc() != C.sizeof(AttnDesc) \
+                    or h.apad_sizeof_rp_desc() != C.sizeof(RpDesc):
                 raise RuntimeError("descriptor layout mismatch between include/apadapter_hip.h and _lib.py")
             _lib = h
     return _lib

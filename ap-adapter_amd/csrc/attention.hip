@@ -5,18 +5,26 @@
 //
 // Mapping (wave64, MFMA 32x32x16, fp32 accumulate):
 //   * one wave owns 32 queries of one (batch, head); 4 waves per workgroup -> 128 queries per workgroup
-//   * scores are computed TRANSPOSED, S^T = K . Q^T, so that after the MFMA each lane holds 16 keys of ONE
-//     query (column = lane&31): the softmax max/sum are in-lane reductions plus one cross-half exchange
-//   * P^T stays in registers: the C-layout of S^T (keys (r&3)+8*(r>>2)+4*half) is re-used directly as the
-//     B operand of O^T = V^T . P^T by loading V^T with the SAME key permutation (two 8-byte pieces per lane),
-//     so no LDS round trip and no cross-lane shuffle sits between the two MFMAs
-//   * K rows (A operand of S^T) and V^T rows (A operand of O^T) are 16 B / 8 B contiguous loads; K/V of one
-//     (batch, head) are <= 66 KB (<= 520 audio+text keys) and stay L2/L1 resident across the query tiles
-//   * online softmax over 32-key tiles in the exp2 domain (scale*log2e folded into the scores)
-// V must be supplied transposed per head, [Bk][H][D][Lpad] with zero padding (apad_gemm APAD_OUT_VT).
+//   * K / V^T tiles of 64 keys are staged ONCE per workgroup in LDS (coalesced 16-byte global loads issued one tile
+//     ahead into registers, written after the MFMAs of the current tile: global latency hides under compute) and
+//     shared by the 4 waves; row strides are padded to an odd number of slots, so the ds_read_b128 (K rows) and
+//     ds_read_b64 (V^T rows) fragment reads are bank-conflict free
+//   * scores are computed TRANSPOSED, S^T = K . Q^T, so that after the MFMA each lane holds 32 keys of ONE query
+//     (column = lane&31): the softmax max/sum are in-lane reductions plus one cross-half exchange per 64 keys
+//   * P^T stays in registers: the C-layout of S^T (keys (r&3)+8*(r>>2)+4*half) is re-used directly as the B operand
+//     of O^T = V^T . P^T by reading V^T with the SAME key permutation (two 8-byte pieces per lane) -- no LDS round
+//     trip and no cross-lane shuffle between the two MFMAs
+//   * online softmax in the exp2 domain with the scale folded into one FMA per score; the O rescale is skipped
+//     (wave-uniform branch) whenever no lane's running max moved
+// V must be supplied transposed per head, [Bk][H][D][Lpad] with zero padding (apad_gemm / apad_rowpanel_gemm
+// APAD_OUT_VT).
 #include "common.h"
 
 namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct AttnP {
     const uint8_t* q;
@@ -33,137 +41,271 @@ struct AttnP {
 
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float NEG_BIG = -1.0e30f;
+constexpr int KT = 64;  // keys per LDS tile
 
-// One softmax segment: accumulates un-normalised O^T into o[] and the per-lane partial row sum into lsum;
-// m is the running max (log2 domain).  kbase/vbase point at this (batch, head)'s K rows / V^T rows.
-template <int DT, int D>
-__device__ __forceinline__ void segment(const uint8_t* kbase, int64_t k_sl, const uint8_t* vbase, int L, int Lpad,
-                                        const float* bias, float scale_log2, const typename ET<DT>::v8* qf,
-                                        f32x16* o, float& m, float& lsum, int l31, int half) {
+template <int D> struct Lay {
+    static constexpr int KROW = (D + 8) * 2;           // K tile row stride (bytes): D/8 + 1 sixteen-byte slots (odd)
+    static constexpr int K_BYTES = KT * KROW;
+    static constexpr int DT_TILES = (D + 31) / 32;
+    static constexpr int VROWS = DT_TILES * 32;        // rows >= D are zeroed once; they feed discarded output rows
+    static constexpr int VROW = (KT + 4) * 2;          // V^T tile row stride (bytes): 17 eight-byte slots (odd)
+    static constexpr int V_BYTES = VROWS * VROW;
+    static constexpr int BUF = K_BYTES + V_BYTES;
+    static constexpr int KCH = KT * (D / 8);           // 16-byte chunks of a K tile
+    static constexpr int VCH = D * (KT / 8);           // 16-byte chunks of a V^T tile
+    static constexpr int NK = (KCH + 255) / 256;       // staging registers per thread
+    static constexpr int NV = (VCH + 255) / 256;
+};
+
+// global -> registers for key tile starting at key0 (rows / columns outside the segment read as zero)
+template <int D>
+__device__ __forceinline__ void tile_load(u32x4 (&rk)[Lay<D>::NK], u32x4 (&rv)[Lay<D>::NV], const uint8_t* kbase, int64_t k_sl,
+                                          const uint8_t* vbase, int L, int Lpad, int key0, int tid) {
+    using Y = Lay<D>;
+#pragma unroll
+    for (int i = 0; i < Y::NK; ++i) {
+        const int idx = tid + 256 * i;
+        const int row = idx / (D / 8), ch = idx - row * (D / 8);
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (idx < Y::KCH && key0 + row < L) v = *reinterpret_cast<const u32x4*>(kbase + ((int64_t)(key0 + row) * k_sl + ch * 8) * 2);
+        rk[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < Y::NV; ++i) {
+        const int idx = tid + 256 * i;
+        const int row = idx >> 3, ch = idx & 7;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (idx < Y::VCH && key0 + ch * 8 < Lpad) v = *reinterpret_cast<const u32x4*>(vbase + ((int64_t)row * Lpad + key0 + ch * 8) * 2);
+        rv[i] = v;
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void tile_store(const u32x4 (&rk)[Lay<D>::NK], const u32x4 (&rv)[Lay<D>::NV], uint8_t* buf, int tid) {
+    using Y = Lay<D>;
+#pragma unroll
+    for (int i = 0; i < Y::NK; ++i) {
+        const int idx = tid + 256 * i;
+        const int row = idx / (D / 8), ch = idx - row * (D / 8);
+        if (idx < Y::KCH) *reinterpret_cast<u32x4*>(buf + row * Y::KROW + ch * 16) = rk[i];
+    }
+#pragma unroll
+    for (int i = 0; i < Y::NV; ++i) {
+        const int idx = tid + 256 * i;
+        const int row = idx >> 3, ch = idx & 7;
+        if (idx < Y::VCH) {  // row stride is 8 (mod 16): two 8-byte stores
+            u32x2 lo = {rv[i][0], rv[i][1]}, hi = {rv[i][2], rv[i][3]};
+            uint8_t* dst = buf + Y::K_BYTES + row * Y::VROW + ch * 16;
+            *reinterpret_cast<u32x2*>(dst) = lo;
+            *reinterpret_cast<u32x2*>(dst + 8) = hi;
+        }
+    }
+}
+
+// Scores, softmax and P.V for ONE staged 64-key tile.  MASK = false is the steady-state path (all 64 keys valid, no
+// bias): max on the raw scores, one packed FMA per two scores folds scale and running max into the exp2 argument.
+// MASK = true handles the additive key bias and the ragged last tile.  Softmax denominators ride on the matrix pipe:
+// one extra MFMA per step against a constant "ones" A-fragment makes row 0 of osum = sum_k P[k][query].
+template <int DT, int D, bool MASK>
+__device__ __forceinline__ void tile_compute(const uint8_t* buf, int key0, int L, const float* bias, float c,
+                                             const typename ET<DT>::v8* qf, f32x16* o, f32x16& osum, float& m,
+                                             const typename ET<DT>::v8& ones, int l31, int half) {
     using E = ET<DT>;
-    constexpr int KC = D / 16;         // 16-wide chunks of the head dim (QK^T reduction)
-    constexpr int DT_TILES = (D + 31) / 32;  // 32-row tiles of V^T (output head-dim rows)
-    const int ntiles = (L + 31) >> 5;
-    for (int t = 0; t < ntiles; ++t) {
-        const int key0 = t * 32;
-        // ---- S^T tile = K[key0..key0+32) . Q^T ----
-        int krow = key0 + l31;
-        krow = krow < L ? krow : L - 1;
-        const uint8_t* kp = kbase + ((int64_t)krow * k_sl + half * 8) * 2;
-        f32x16 s;
+    using Y = Lay<D>;
+    constexpr int KC = D / 16;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // ---- S^T (two 32-key sub-tiles) = K . Q^T ----
+    f32x16 s[2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    for (int u = 0; u < 2; ++u) {
+        const uint8_t* kp = buf + (u * 32 + l31) * Y::KROW + half * 16;
+        s[u] = E::mfma32(as_v8<DT>(*reinterpret_cast<const uint4*>(kp)), qf[0], zero16);
 #pragma unroll
-        for (int c = 0; c < KC; ++c) {
-            typename E::v8 kf = as_v8<DT>(*reinterpret_cast<const uint4*>(kp + c * 32));
-            s = E::mfma32(kf, qf[c], s);
+        for (int cc = 1; cc < KC; ++cc) {
+            typename E::v8 kf = as_v8<DT>(*reinterpret_cast<const uint4*>(kp + cc * 32));
+            s[u] = E::mfma32(kf, qf[cc], s[u]);
         }
-        // ---- scale, bias, mask, tile max ----
-        float tmax = NEG_BIG;
+    }
+    float tmax = NEG_BIG;
+    if (MASK) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            float v = s[r] * scale_log2;
-            if (bias) v += bias[key < L ? key : L - 1] * LOG2E;
-            v = key < L ? v : NEG_BIG;
-            s[r] = v;
-            tmax = fmaxf(tmax, v);
-        }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float mnew = fmaxf(m, tmax);
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = key0 + u * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                float v = s[u][r] * c;
+                if (bias) v += bias[key < L ? key : L - 1] * LOG2E;
+                v = key < L ? v : NEG_BIG;
+                s[u][r] = v;
+                tmax = fmaxf(tmax, v);
+            }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[u][r]);
+        tmax *= c;  // c > 0
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float mnew = fmaxf(m, tmax);
+    if (__any(mnew > m)) {  // wave-uniform: the O rescale is skipped whenever no lane's running max moved
         const float alpha = __builtin_amdgcn_exp2f(m - mnew);
-        m = mnew;
-        float psum = 0.f;
+        osum[0] *= alpha;  // only row 0 of the denominator tile is ever read
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float pv = __builtin_amdgcn_exp2f(s[r] - mnew);
-            s[r] = pv;
-            psum += pv;
-        }
-        lsum = lsum * alpha + psum;
-#pragma unroll
-        for (int dt = 0; dt < DT_TILES; ++dt)
+        for (int dt = 0; dt < Y::DT_TILES; ++dt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-        // ---- O^T += V^T . P^T : two K=16 steps; B operand = P^T in its C-layout key order ----
+        m = mnew;
+    }
+    if (MASK) {
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            typename E::v8 pf;
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pf[j] = (typename E::elem)s[st * 8 + j];
-            const int kcol = key0 + st * 16 + 4 * half;  // keys kcol..kcol+3 and kcol+8..kcol+11
+            for (int r = 0; r < 16; ++r) s[u][r] = __builtin_amdgcn_exp2f(s[u][r] - m);
+    } else {
+        const f32x2 c2 = {c, c}, nm2 = {-m, -m};
 #pragma unroll
-            for (int dt = 0; dt < DT_TILES; ++dt) {
-                int drow = dt * 32 + l31;
-                drow = drow < D ? drow : D - 1;
-                const uint8_t* vp = vbase + ((int64_t)drow * Lpad + kcol) * 2;
-                uint2 v0 = *reinterpret_cast<const uint2*>(vp);
-                uint2 v1 = *reinterpret_cast<const uint2*>(vp + 16);
-                typename E::v8 vf = as_v8<DT>(make_uint4(v0.x, v0.y, v1.x, v1.y));
-                o[dt] = E::mfma32(vf, pf, o[dt]);
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                f32x2 v = {s[u][r], s[u][r + 1]};
+                v = __builtin_elementwise_fma(v, c2, nm2);
+                s[u][r] = __builtin_amdgcn_exp2f(v[0]);
+                s[u][r + 1] = __builtin_amdgcn_exp2f(v[1]);
             }
+    }
+    // ---- O^T += V^T . P^T : four K=16 steps; B operand = P^T in its C-layout key order ----
+    const uint8_t* vtile = buf + Y::K_BYTES;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        typename E::v8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (typename E::elem)s[st >> 1][(st & 1) * 8 + j];
+        const int kcol = st * 16 + 4 * half;  // tile-local keys kcol..kcol+3 and kcol+8..kcol+11
+#pragma unroll
+        for (int dt = 0; dt < Y::DT_TILES; ++dt) {
+            const uint8_t* vp = vtile + (dt * 32 + l31) * Y::VROW + kcol * 2;
+            uint2 v0 = *reinterpret_cast<const uint2*>(vp);
+            uint2 v1 = *reinterpret_cast<const uint2*>(vp + 16);
+            typename E::v8 vf = as_v8<DT>(make_uint4(v0.x, v0.y, v1.x, v1.y));
+            o[dt] = E::mfma32(vf, pf, o[dt]);
         }
+        osum = E::mfma32(ones, pf, osum);
+    }
+}
+
+// One softmax segment over L keys: accumulates un-normalised O^T into o[] and the denominators into osum; m is the
+// running max in the scaled log2 domain.  All 256 threads of the workgroup must call it (LDS staging).
+template <int DT, int D>
+__device__ __forceinline__ void segment(uint8_t* smem, const uint8_t* kbase, int64_t k_sl, const uint8_t* vbase, int L, int Lpad,
+                                        const float* bias, float c, const typename ET<DT>::v8* qf, f32x16* o, f32x16& osum,
+                                        float& m, int tid) {
+    using E = ET<DT>;
+    using Y = Lay<D>;
+    const int lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int ntiles = (L + KT - 1) / KT;
+    const int nfull = bias ? 0 : L / KT;  // tiles that need neither bias nor tail masking
+    // A-fragment whose row 0 is all ones (lane l31 == 0 of both halves), every other row zero
+    typename E::v8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (typename E::elem)(l31 == 0 ? 1.0f : 0.0f);
+    u32x4 rk[Y::NK], rv[Y::NV];
+    tile_load<D>(rk, rv, kbase, k_sl, vbase, L, Lpad, 0, tid);
+    __syncthreads();  // previous users of the LDS buffers (other segment / zero fill) are done
+    tile_store<D>(rk, rv, smem, tid);
+    __syncthreads();
+    // two loops instead of one loop with a per-tile branch: the accumulators then live in fixed registers inside
+    // each loop (a merged loop made the compiler copy o/osum around every tile)
+    int t = 0;
+    for (; t < nfull; ++t) {
+        const uint8_t* buf = smem + (t & 1) * Y::BUF;
+        if (t + 1 < ntiles) tile_load<D>(rk, rv, kbase, k_sl, vbase, L, Lpad, (t + 1) * KT, tid);
+        tile_compute<DT, D, false>(buf, t * KT, L, bias, c, qf, o, osum, m, ones, l31, half);
+        if (t + 1 < ntiles) tile_store<D>(rk, rv, smem + ((t + 1) & 1) * Y::BUF, tid);
+        __syncthreads();
+    }
+    for (; t < ntiles; ++t) {
+        const uint8_t* buf = smem + (t & 1) * Y::BUF;
+        if (t + 1 < ntiles) tile_load<D>(rk, rv, kbase, k_sl, vbase, L, Lpad, (t + 1) * KT, tid);
+        tile_compute<DT, D, true>(buf, t * KT, L, bias, c, qf, o, osum, m, ones, l31, half);
+        if (t + 1 < ntiles) tile_store<D>(rk, rv, smem + ((t + 1) & 1) * Y::BUF, tid);
+        __syncthreads();
     }
 }
 
 template <int DT, int D, bool DUAL>
 __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
     using E = ET<DT>;
+    using Y = Lay<D>;
     constexpr int KC = D / 16;
-    constexpr int DT_TILES = (D + 31) / 32;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ __attribute__((aligned(16))) uint8_t smem[2 * Y::BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * 128 + wave * 32;
-    if (q0 >= p.N) return;
+    // 1-D grid ordered for the 8 XCD-private L2s: workgroup id w runs on XCD w % 8 (observed, speed only).  Consecutive
+    // ids on ONE XCD walk the query tiles of ONE (batch, head), so its K/V are fetched into that L2 once and reused
+    // while hot.
+    const int nbh = p.B * p.H;
+    const int nqt = (p.N + 127) >> 7;
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int bh = (seq / nqt) * 8 + xcd, qt = seq % nqt;
+    if (bh >= nbh) return;
+    const int h = bh % p.H, b = bh / p.H;
+    const int q0 = qt * 128 + wave * 32;
     int qi = q0 + l31;
     const bool qvalid = qi < p.N;
     qi = qvalid ? qi : p.N - 1;
+
+    // zero the V^T tile rows >= D once (they are read as A-operand rows whose outputs are discarded; keep them finite)
+    if (Y::VROWS > D) {
+        for (int i = tid; i < 2 * Y::BUF / 4; i += 256) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
+    }
 
     // Q^T B-operand fragments: lane holds Q[qi][c*16 + half*8 .. +8)
     typename E::v8 qf[KC];
     const uint8_t* qp = p.q + ((int64_t)b * p.q_sb + (int64_t)qi * p.q_sn + h * D + half * 8) * 2;
 #pragma unroll
-    for (int c = 0; c < KC; ++c) qf[c] = as_v8<DT>(*reinterpret_cast<const uint4*>(qp + c * 32));
+    for (int cc = 0; cc < KC; ++cc) qf[cc] = as_v8<DT>(*reinterpret_cast<const uint4*>(qp + cc * 32));
 
-    f32x16 o[DT_TILES];
+    f32x16 o[Y::DT_TILES];
 #pragma unroll
-    for (int dt = 0; dt < DT_TILES; ++dt)
+    for (int dt = 0; dt < Y::DT_TILES; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-    float m = NEG_BIG, lsum = 0.f;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 osum = zero16;
+    float m = NEG_BIG;
 
     {
         const int bk = b / p.kvdiv;
         const uint8_t* kbase = p.k + ((int64_t)bk * p.k_sb + h * D) * 2;
         const uint8_t* vbase = p.vt + ((int64_t)bk * p.vt_sb + (int64_t)h * D * p.Lpad) * 2;
         const float* bias = p.key_bias ? p.key_bias + (int64_t)b * p.L : nullptr;
-        segment<DT, D>(kbase, p.k_sl, vbase, p.L, p.Lpad, bias, p.scale_log2, qf, o, m, lsum, l31, half);
+        segment<DT, D>(smem, kbase, p.k_sl, vbase, p.L, p.Lpad, bias, p.scale_log2, qf, o, osum, m, tid);
     }
-    lsum += __shfl_xor(lsum, 32, 64);
-    float inv = 1.0f / lsum;
+    // denominator of query l31 = row 0 of osum = register 0 of the half-0 lane
+    float inv = 1.0f / __shfl(osum[0], l31, 64);
 #pragma unroll
-    for (int dt = 0; dt < DT_TILES; ++dt)
+    for (int dt = 0; dt < Y::DT_TILES; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] *= inv;
 
     if (DUAL) {
         if (p.L2 > 0) {
-            f32x16 o2[DT_TILES];
+            f32x16 o2[Y::DT_TILES];
 #pragma unroll
-            for (int dt = 0; dt < DT_TILES; ++dt)
+            for (int dt = 0; dt < Y::DT_TILES; ++dt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o2[dt][r] = 0.f;
-            float m2 = NEG_BIG, l2 = 0.f;
+            f32x16 osum2 = zero16;
+            float m2 = NEG_BIG;
             const int bk = b / p.kvdiv2;
             const uint8_t* kbase = p.k2 + ((int64_t)bk * p.k2_sb + h * D) * 2;
             const uint8_t* vbase = p.vt2 + ((int64_t)bk * p.vt2_sb + (int64_t)h * D * p.Lpad2) * 2;
-            segment<DT, D>(kbase, p.k2_sl, vbase, p.L2, p.Lpad2, nullptr, p.scale_log2, qf, o2, m2, l2, l31, half);
-            l2 += __shfl_xor(l2, 32, 64);
-            const float inv2 = 1.0f / l2;
+            segment<DT, D>(smem, kbase, p.k2_sl, vbase, p.L2, p.Lpad2, nullptr, p.scale_log2, qf, o2, osum2, m2, tid);
+            const float inv2 = 1.0f / __shfl(osum2[0], l31, 64);
             // the un-fused reference rounds each branch, and scale * audio, to the storage type before the add
 #pragma unroll
-            for (int dt = 0; dt < DT_TILES; ++dt)
+            for (int dt = 0; dt < Y::DT_TILES; ++dt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float t = (float)(typename E::elem)o[dt][r];
@@ -173,11 +315,12 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
         }
     }
 
-    // ---- store: lane owns query qi; regs 4g..4g+3 are 4 consecutive head-dim columns ----
-    if (!qvalid) return;
-    uint8_t* op = p.out + ((int64_t)b * p.o_sb + (int64_t)qi * p.o_sn + h * D) * 2;
+    // ---- store: transpose through LDS (the K/V buffers are free after the last tile's barrier) so that each store
+    //      instruction writes whole D*2-byte row segments with 16 bytes per lane instead of 32 rows x 16 bytes ----
+    constexpr int OROW = D * 2 + 8;  // odd number of 8-byte slots per row
+    uint8_t* scr = smem + wave * (32 * OROW);
 #pragma unroll
-    for (int dt = 0; dt < DT_TILES; ++dt) {
+    for (int dt = 0; dt < Y::DT_TILES; ++dt) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int dcol = dt * 32 + 8 * g + 4 * half;
@@ -185,8 +328,19 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
                 typename E::v4 pk;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) pk[j] = (typename E::elem)o[dt][g * 4 + j];
-                *reinterpret_cast<uint2*>(op + dcol * 2) = __builtin_bit_cast(uint2, pk);
+                *reinterpret_cast<uint2*>(scr + l31 * OROW + dcol * 2) = __builtin_bit_cast(uint2, pk);
             }
+        }
+    }
+    constexpr int CPR = D / 8;  // 16-byte chunks per row
+    uint8_t* ob = p.out + ((int64_t)b * p.o_sb + h * D) * 2;
+    for (int idx = lane; idx < 32 * CPR; idx += 64) {
+        const int row = idx / CPR, ch = idx - row * CPR;
+        const int q = q0 + row;
+        if (q < p.N) {
+            const uint2 lo = *reinterpret_cast<const uint2*>(scr + row * OROW + ch * 16);
+            const uint2 hi = *reinterpret_cast<const uint2*>(scr + row * OROW + ch * 16 + 8);
+            *reinterpret_cast<uint4*>(ob + ((int64_t)q * p.o_sn + ch * 8) * 2) = make_uint4(lo.x, lo.y, hi.x, hi.y);
         }
     }
 }
@@ -228,7 +382,7 @@ extern "C" int apad_attention(const apad_attn_desc* d, void* stream) {
     APAD_CHECK(al16(d->q) && al16(d->k) && al16(d->vt) && al16(d->out) && al16(d->k2) && al16(d->vt2),
                "apad_attention: pointers must be 16-byte aligned");
     APAD_CHECK(d->q_stride_n % 8 == 0 && d->q_stride_b % 8 == 0 && d->k_stride_l % 8 == 0 && d->k_stride_b % 8 == 0 &&
-                   d->o_stride_n % 4 == 0 && d->o_stride_b % 4 == 0 && d->vt_stride_b % 8 == 0,
+                   d->o_stride_n % 8 == 0 && d->o_stride_b % 8 == 0 && d->vt_stride_b % 8 == 0,
                "apad_attention: strides must keep 16-byte alignment");
     const bool dual = d->L2 > 0;
     if (dual) {
@@ -248,7 +402,7 @@ extern "C" int apad_attention(const apad_attn_desc* d, void* stream) {
     p.kvdiv = d->kv_batch_div; p.kvdiv2 = dual ? d->kv2_batch_div : 1;
     p.scale_log2 = d->softmax_scale * 1.4426950408889634f;
     p.scale2 = d->scale2;
-    dim3 grid((unsigned)((d->N + 127) / 128), (unsigned)d->H, (unsigned)d->B);
+    dim3 grid((unsigned)(((d->N + 127) / 128) * (((d->H * d->B) + 7) / 8 * 8)));
     hipStream_t s = (hipStream_t)stream;
     return d->dtype == APAD_BF16 ? launch_dt<APAD_BF16>(p, d->D, dual, grid, s) : launch_dt<APAD_F16>(p, d->D, dual, grid, s);
 }

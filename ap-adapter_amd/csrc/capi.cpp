@@ -54,3 +54,16 @@ extern "C" int apad_echo_attn_desc(const apad_attn_desc* d, double* out, int cap
     PUT(d->kv_batch_div); PUT(d->kv2_batch_div); PUT(d->dtype); PUT(d->softmax_scale); PUT(d->scale2);
     return n;
 }
+
+extern "C" int apad_sizeof_rp_desc(void) { return (int)sizeof(apad_rp_desc); }
+extern "C" int apad_echo_rp_desc(const apad_rp_desc* d, double* out, int cap) {
+    int n = 0;
+    PUTP(d->x); PUTP(d->w); PUTP(d->ln_gamma); PUTP(d->ln_beta); PUTP(d->residual);
+    PUT(d->M); PUT(d->lda); PUT(d->ldw); PUT(d->ldr);
+    PUT(d->K); PUT(d->epilogue); PUT(d->dtype); PUT(d->n_segments); PUT(d->ln_eps);
+    PUT(d->heads); PUT(d->head_dim); PUT(d->L); PUT(d->Lpad);
+    for (int i = 0; i < 3; ++i) {
+        PUTP(d->seg[i].out); PUTP(d->seg[i].bias); PUT(d->seg[i].ldo); PUT(d->seg[i].n_cols); PUT(d->seg[i].mode);
+    }
+    return n;
+}

@@ -31,6 +31,7 @@ struct GemmP {
     int32_t Hin, Win, Cin, Hout, Wout, stride, Hup, Wup, src_batch_mod, res_mod;
     int32_t heads, head_dim, L, Lpad;
     int32_t wrows;  // rows of w (N, or 2N for GEGLU)
+    int32_t m_tiles, n_tiles;
 };
 
 // byte offset of 16-byte chunk `chunk` (0..7) of tile row `row` (128-byte rows)
@@ -79,8 +80,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int half = lane >> 5, l31 = lane & 31;
     constexpr int BN_OUT = (EPI == APAD_EPI_GEGLU) ? 64 : BN;
-    const int64_t m0 = (int64_t)blockIdx.y * BM;
-    const int64_t n0 = (int64_t)blockIdx.x * BN_OUT;
+    // XCD-aware tile order: workgroup id b runs on XCD b % 8 (observed dispatch order, speed only).  Tiles are
+    // numbered so that all N-tiles of one M-tile share b % 8, i.e. one XCD's L2 fetches each A row-panel once.
+    int mt, nt;
+    {
+        const int nN = p.n_tiles, nM = p.m_tiles;
+        const int b = blockIdx.x;
+        const int full = (nM / 8) * 8 * nN;  // blocks covered by complete groups of 8 M-tiles
+        if (b < full) {
+            const int grp = b / (8 * nN), rem = b - grp * 8 * nN;
+            nt = rem >> 3;
+            mt = grp * 8 + (rem & 7);
+        } else {
+            const int rem = b - full, tail = nM - (nM / 8) * 8;  // < 8 leftover M-tiles
+            nt = rem / tail;
+            mt = (nM / 8) * 8 + rem - nt * tail;
+        }
+    }
+    const int64_t m0 = (int64_t)mt * BM;
+    const int64_t n0 = (int64_t)nt * BN_OUT;
 
     // W row feeding local tile column nl
     auto wrow = [&](int nl) -> int64_t {
@@ -221,7 +239,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
                 float g[8];
                 unpack8<DT>(*reinterpret_cast<const uint4*>(&ct[rl * C_LD + 64 + vc * 8]), g);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] = f[e] * gelu_erf_f(g[e]);
+                for (int e = 0; e < 8; e += 2) {
+                    const apad_f32x2 ge = gelu_erf_2((apad_f32x2){g[e], g[e + 1]});
+                    f[e] *= ge[0];
+                    f[e + 1] *= ge[1];
+                }
             }
             if (p.residual) {
                 float rr[8];
@@ -250,8 +272,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 template <int DT, int AMODE, int EPI, int OUTMODE>
 int launch(const GemmP& p, hipStream_t s) {
     constexpr int BN_OUT = (EPI == APAD_EPI_GEGLU) ? 64 : BN;
-    dim3 grid((unsigned)((p.N + BN_OUT - 1) / BN_OUT), (unsigned)((p.M + BM - 1) / BM));
-    hipLaunchKernelGGL((gemm_kernel<DT, AMODE, EPI, OUTMODE>), grid, dim3(256), 0, s, p);
+    GemmP q = p;
+    q.n_tiles = (int)((p.N + BN_OUT - 1) / BN_OUT);
+    q.m_tiles = (int)((p.M + BM - 1) / BM);
+    dim3 grid((unsigned)(q.n_tiles * q.m_tiles));
+    hipLaunchKernelGGL((gemm_kernel<DT, AMODE, EPI, OUTMODE>), grid, dim3(256), 0, s, q);
     return apad_check_launch("apad_gemm");
 }
 

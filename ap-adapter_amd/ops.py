@@ -74,6 +74,48 @@ def linear(x, w, bias=None, residual=None, act=None, out=None, rowgroup_bias=Non
     return out
 
 
+RP_K = (256, 384)  # reduction dims the row-panel kernel covers
+
+
+def rowpanel(x, w, segs, ln=None, residual=None, act=None, vt_geom=None):
+    """Fused projection: x [M,K] (K in RP_K) @ w^T with up to 3 output column segments.
+    segs: list of (out_tensor, bias_or_None, n_cols, "row" | "vt").  ln = (gamma, beta, eps) applies LayerNorm to x
+    first.  vt_geom = (heads, head_dim, L, Lpad) for "vt" segments.  Returns the list of outputs."""
+    _req(x, "rowpanel.x", w.dtype)
+    K = x.shape[-1]
+    M = x.numel() // K
+    d = L.RpDesc()
+    d.x, d.w = x.data_ptr(), w.data_ptr()
+    if ln is not None:
+        d.ln_gamma, d.ln_beta, d.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), float(ln[2])
+    d.residual = _ptr(residual)
+    d.M, d.lda, d.ldw, d.ldr = M, x.reshape(M, K).stride(0), w.stride(0), (residual.shape[-1] if residual is not None else 0)
+    d.K, d.epilogue, d.dtype, d.n_segments = K, _EPI[act], _DT[w.dtype], len(segs)
+    if vt_geom is not None:
+        d.heads, d.head_dim, d.L, d.Lpad = vt_geom
+    for i, (out, bias, n_cols, mode) in enumerate(segs):
+        d.seg[i].out, d.seg[i].bias = out.data_ptr(), _ptr(bias)
+        d.seg[i].ldo = out.shape[-1] if mode == "row" else 0
+        d.seg[i].n_cols, d.seg[i].mode = n_cols, (L.OUT_ROWMAJOR if mode == "row" else L.OUT_VT)
+    L.check(L.lib().apad_rowpanel_gemm(C.byref(d), _stream()), "apad_rowpanel_gemm")
+    return [s[0] for s in segs]
+
+
+def fused_linear(x, w, bias=None, ln=None, residual=None, act=None, out=None):
+    """LayerNorm? -> Linear -> activation? (+ residual).  One row-panel launch when K is in its envelope, otherwise
+    apad_layernorm + apad_gemm."""
+    K = x.shape[-1]
+    N = w.shape[0] // 2 if act == "geglu" else w.shape[0]
+    if K in RP_K and N % 64 == 0:
+        if out is None:
+            out = torch.empty(*x.shape[:-1], N, dtype=w.dtype, device=x.device)
+        rowpanel(x, w, [(out, bias, N, "row")], ln=ln, residual=residual, act=act)
+        return out
+    if ln is not None:
+        x = layer_norm(x, ln[0], ln[1], ln[2])
+    return linear(x, w, bias, residual=residual, act=act, out=out)
+
+
 def linear_vt(x, w, B, Lk, heads, out_vt, bias=None):
     """Values projection stored per-head transposed: x [B*Lk, K] @ w[C,K]^T -> out_vt [B, heads, d, Lpad]
     (zero padded by the caller; only l < Lk is written)."""

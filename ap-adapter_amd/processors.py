@@ -71,18 +71,41 @@ class AttnProcessor2_0(nn.Module):
         ops.linear_vt(src, attn.to_v.weight, B, Lk, attn.heads, vt)
         return k, vt
 
+    def _qkv_weight(self, attn):
+        ps = (attn.to_q.weight, attn.to_k.weight, attn.to_v.weight)
+        key = tuple((id(p), p.data_ptr(), p._version, p.dtype, p.device) for p in ps)
+        # cached on the Attention module (a processor instance may be shared by many sites)
+        if getattr(attn, "_qkv_key", None) != key:
+            attn._qkv_w = torch.cat([p.detach() for p in ps], dim=0).contiguous()
+            attn._qkv_key = key
+        return attn._qkv_w
+
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
-                 _residual=None):
+                 _residual=None, _ln=None):
+        """``_residual`` (added after to_out) and ``_ln`` = (gamma, beta, eps) (LayerNorm applied to hidden_states
+        first) are private fusion hooks used by this package's BasicTransformerBlock; without them the call is the
+        reference's."""
         if attn.spatial_norm is not None or attn.group_norm is not None or attn.norm_cross:
             raise NotImplementedError("spatial_norm / group_norm / norm_cross are not on the AudioLDM2 path")
         if hidden_states.ndim != 3:
             raise ValueError("hidden_states must be [batch, tokens, channels]")
-        B, N, _ = hidden_states.shape
-        q = ops.linear(hidden_states, attn.to_q.weight)
+        B, N, C_ = hidden_states.shape
+        heads = attn.heads
         if encoder_hidden_states is None:
-            k, vt = self._project_kv(attn, hidden_states, "self")
             Lk = N
+            if C_ in ops.RP_K and attn.to_q.weight.shape[0] == C_:
+                # LayerNorm + q|k|v in ONE launch: x is read once, V lands per-head transposed
+                q = torch.empty(B, N, C_, dtype=hidden_states.dtype, device=hidden_states.device)
+                k = torch.empty_like(q)
+                vt = vt_buffer("self", B, heads, C_ // heads, N, hidden_states.dtype, hidden_states.device)
+                ops.rowpanel(hidden_states, self._qkv_weight(attn), [(q, None, C_, "row"), (k, None, C_, "row"), (vt, None, C_, "vt")],
+                             ln=_ln, vt_geom=(heads, C_ // heads, N, vt.shape[-1]))
+            else:
+                hs = hidden_states if _ln is None else ops.layer_norm(hidden_states, *_ln)
+                q = ops.linear(hs, attn.to_q.weight)
+                k, vt = self._project_kv(attn, hs, "self")
         else:
+            q = ops.fused_linear(hidden_states, attn.to_q.weight, ln=_ln)
             ehs = encoder_hidden_states
             if ehs.dim() < 3:
                 ehs = ehs.unsqueeze(0)
@@ -94,8 +117,8 @@ class AttnProcessor2_0(nn.Module):
                 if self.kv_cache_enabled:
                     self._kv_cache = (k, vt)
         bias = _key_bias(attention_mask, B, Lk)
-        o = ops.attention(q, k, vt, Lk, attn.heads, key_bias=bias)
-        out = ops.linear(o, attn.to_out[0].weight, attn.to_out[0].bias, residual=_residual)
+        o = ops.attention(q, k, vt, Lk, heads, key_bias=bias)
+        out = ops.fused_linear(o, attn.to_out[0].weight, attn.to_out[0].bias, residual=_residual)
         if attn.residual_connection:
             raise NotImplementedError("residual_connection=True is not on the AudioLDM2 path")
         if attn.rescale_output_factor != 1.0:
@@ -155,7 +178,7 @@ class IPAttnProcessor2_0(nn.Module):
         return k_t, vt_t, Lt, k_a, vt_a, La
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale=1.0,
-                 _residual=None):
+                 _residual=None, _ln=None):
         if scale != 1.0:
             # the reference dereferences an undefined ``logger`` here (:356-357) -> NameError; reject loudly instead
             raise ValueError("`scale` of IPAttnProcessor2_0 is set through the `scale` attribute, not the call kwarg")
@@ -169,7 +192,7 @@ class IPAttnProcessor2_0(nn.Module):
         if ehs.dim() < 3:
             ehs = ehs.unsqueeze(0)
         B, N, _ = hidden_states.shape
-        q = ops.linear(hidden_states, attn.to_q.weight)
+        q = ops.fused_linear(hidden_states, attn.to_q.weight, ln=_ln)
         if self.kv_cache_enabled and self._kv_cache is not None:
             kv = self._kv_cache
         else:
@@ -184,7 +207,7 @@ class IPAttnProcessor2_0(nn.Module):
             m = attention_mask.reshape(B, -1)[:, :1].float()
             bias = m.expand(B, Lt).contiguous()
         o = ops.attention(q, k_t, vt_t, Lt, attn.heads, key_bias=bias, k2=k_a, vt2=vt_a, L2=La, scale2=self.scale)
-        out = ops.linear(o, attn.to_out[0].weight, attn.to_out[0].bias, residual=_residual)
+        out = ops.fused_linear(o, attn.to_out[0].weight, attn.to_out[0].bias, residual=_residual)
         if attn.residual_connection or attn.rescale_output_factor != 1.0:
             raise NotImplementedError("residual_connection / rescale_output_factor are not on the AudioLDM2 path")
         return out

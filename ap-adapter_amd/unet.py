@@ -119,11 +119,15 @@ class Attention(nn.Module):
             attention_mask = attention_mask.repeat_interleave(self.heads, dim=0)
         return attention_mask
 
-    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, residual=None, **kw):
+    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, residual=None, ln=None, **kw):
+        """``ln`` = (gamma, beta, eps) of the block's pre-attention LayerNorm and ``residual`` are fused into this
+        package's processors; a foreign processor gets the reference call (normalised input, plain output)."""
         proc = self.processor
-        if residual is not None and getattr(proc, "fuses_residual", False):
+        if getattr(proc, "fuses_residual", False):
             return proc(self, hidden_states, encoder_hidden_states=encoder_hidden_states,
-                        attention_mask=attention_mask, _residual=residual, **kw)
+                        attention_mask=attention_mask, _residual=residual, _ln=ln, **kw)
+        if ln is not None:
+            hidden_states = ops.layer_norm(hidden_states, *ln)
         out = proc(self, hidden_states, encoder_hidden_states=encoder_hidden_states, attention_mask=attention_mask, **kw)
         return out if residual is None else out + residual  # foreign (non-HIP) processor: its own tensors
 
@@ -139,9 +143,10 @@ class FeedForward(nn.Module):
         super().__init__()
         self.net = nn.ModuleList([GEGLU(dim, dim * 4), nn.Dropout(0.0), nn.Linear(dim * 4, dim)])
 
-    def forward(self, x, residual):
-        h = ops.linear(x, self.net[0].proj.weight, self.net[0].proj.bias, act="geglu")
-        return ops.linear(h, self.net[2].weight, self.net[2].bias, residual=residual)
+    def forward(self, x, ln):
+        """x un-normalised; ln = norm3.  LayerNorm + GEGLU projection in one launch, then the 4C->C GEMM + residual."""
+        h = ops.fused_linear(x, self.net[0].proj.weight, self.net[0].proj.bias, ln=ln, act="geglu")
+        return ops.linear(h, self.net[2].weight, self.net[2].bias, residual=x)
 
 
 class BasicTransformerBlock(nn.Module):
@@ -158,12 +163,10 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim)
 
     def forward(self, x, ehs, emask):
-        n = ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        x = self.attn1(n, residual=x)
-        n = ops.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        x = self.attn2(n, encoder_hidden_states=ehs, attention_mask=emask, residual=x)
-        n = ops.layer_norm(x, self.norm3.weight, self.norm3.bias, self.norm3.eps)
-        return self.ff(n, x)
+        x = self.attn1(x, residual=x, ln=(self.norm1.weight, self.norm1.bias, self.norm1.eps))
+        x = self.attn2(x, encoder_hidden_states=ehs, attention_mask=emask, residual=x,
+                       ln=(self.norm2.weight, self.norm2.bias, self.norm2.eps))
+        return self.ff(x, (self.norm3.weight, self.norm3.bias, self.norm3.eps))
 
 
 class Transformer2DModel(nn.Module):
@@ -179,10 +182,10 @@ class Transformer2DModel(nn.Module):
 
     def forward(self, x, ehs, emask):
         h = ops.group_norm(x, self.norm.weight, self.norm.bias, self.groups, self.norm.eps, silu=False)
-        h = ops.linear(h, _w2d(self.proj_in), self.proj_in.bias)
+        h = ops.fused_linear(h, _w2d(self.proj_in), self.proj_in.bias)
         for blk in self.transformer_blocks:
             h = blk(h, ehs, emask)
-        return ops.linear(h, _w2d(self.proj_out), self.proj_out.bias, residual=x)
+        return ops.fused_linear(h, _w2d(self.proj_out), self.proj_out.bias, residual=x)
 
 
 class ResnetBlock2D(nn.Module):

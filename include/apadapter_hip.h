@@ -103,6 +103,36 @@ typedef struct apad_attn_desc {
     float scale2;               /* out = softmax1.V1 + scale2 * softmax2.V2  (ap_scale)                */
 } apad_attn_desc;
 
+/* Row-panel GEMM: the fused projection kernel of the transformer blocks.  Each workgroup keeps a 128-row panel of
+ * x (all K <= 640 columns) in registers -- optionally LayerNorm-ed in place (BasicTransformerBlock norm1/2/3) --
+ * and streams the weight rows through LDS, so x is read from HBM once for ALL output columns (q|k|v fused, or the
+ * 8C-wide GEGLU projection) and LayerNorm costs no extra pass.  Up to 3 column segments with their own output
+ * (row-major, or the per-head transposed V^T apad_attention consumes).
+ * Replaces: norm + attn.to_q/to_k/to_v (attention_processor.py:387,:406-407), to_out[0] (:457), diffusers
+ * GEGLU.proj, Transformer2DModel.proj_in/proj_out. */
+typedef struct apad_rp_segment {
+    void* out;
+    const void* bias;   /* [n_cols] or NULL (GEGLU: [2*n_cols], value|gate)                                */
+    int64_t ldo;        /* row stride of a row-major output                                                */
+    int32_t n_cols;     /* output columns of this segment (multiple of 64)                                 */
+    int32_t mode;       /* APAD_OUT_ROWMAJOR or APAD_OUT_VT                                                */
+} apad_rp_segment;
+
+typedef struct apad_rp_desc {
+    const void* x;        /* [M][lda]                                                                      */
+    const void* w;        /* [sum n_cols (x2 for GEGLU)][ldw], rows in segment order                       */
+    const void* ln_gamma; /* [K] or NULL: LayerNorm(x) before the projection                               */
+    const void* ln_beta;
+    const void* residual; /* [M][ldr] or NULL; single row-major segment only                               */
+    int64_t M, lda, ldw, ldr;
+    int32_t K;            /* 256 or 384 (else -3)                                                               */
+    int32_t epilogue;     /* APAD_EPI_NONE / SILU / GELU / GEGLU                                           */
+    int32_t dtype, n_segments;
+    float ln_eps;
+    int32_t heads, head_dim, L, Lpad; /* APAD_OUT_VT segments: m = (b, l)                                  */
+    apad_rp_segment seg[3];
+} apad_rp_desc;
+
 const char* apad_last_error(void);
 int apad_abi_version(void);
 /* size of the descriptor structs as compiled, for binding self-checks */
@@ -112,9 +142,13 @@ int apad_sizeof_attn_desc(void);
    host only, no GPU work) */
 int apad_echo_gemm_desc(const apad_gemm_desc* d, double* out, int cap);
 int apad_echo_attn_desc(const apad_attn_desc* d, double* out, int cap);
+int apad_sizeof_rp_desc(void);
+int apad_echo_rp_desc(const apad_rp_desc* d, double* out, int cap);
 
 int apad_gemm(const apad_gemm_desc* d, void* stream);
 int apad_attention(const apad_attn_desc* d, void* stream);
+/* returns -3 (and sets the error text) when the shape is outside the kernel's envelope; callers then use apad_gemm */
+int apad_rowpanel_gemm(const apad_rp_desc* d, void* stream);
 
 int apad_layernorm(const void* x, const void* gamma, const void* beta, void* out, int64_t M, int32_t C,
                    int64_t ldx, int64_t ldo, float eps, int32_t dtype, void* stream);

@@ -298,3 +298,66 @@ def test_errors_are_python_exceptions(dev):
         ops.linear(x, w)
     with pytest.raises(RuntimeError, match="GPU tensor"):
         ops.linear(torch.zeros(4, 16, dtype=torch.bfloat16), w)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,K", [(1000, 256), (333, 384), (128, 256), (4000, 384)])
+@pytest.mark.parametrize("ln", [False, True])
+def test_rowpanel_plain_bias_act_residual(dev, dtype, M, K, ln):
+    from ap_adapter_amd import ops
+    N = K
+    x = q(R(M, K, seed=50) * 1.5 + 0.2, dtype)
+    w, b, r = q(R(N, K, seed=51, std=0.05), dtype), q(R(N, seed=52, std=0.3), dtype), q(R(M, N, seed=53), dtype)
+    g, be = q(1 + 0.1 * R(K, seed=54), dtype), q(0.1 * R(K, seed=55), dtype)
+    xin = q(F.layer_norm(x, (K,), g, be, 1e-5), dtype) if ln else x
+    lnp = (g.to(dev, dtype), be.to(dev, dtype), 1e-5) if ln else None
+    for act, fn in ((None, lambda t: t), ("silu", F.silu), ("gelu", F.gelu)):
+        ref = fn(F.linear(xin, w, b))
+        out = ops.fused_linear(x.to(dev, dtype), w.to(dev, dtype), b.to(dev, dtype), ln=lnp, act=act)
+        assert rel_err(out, ref) < TOL[dtype]
+    ref = F.linear(xin, w, b) + r
+    out = ops.fused_linear(x.to(dev, dtype), w.to(dev, dtype), b.to(dev, dtype), ln=lnp, residual=r.to(dev, dtype))
+    assert rel_err(out, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,K", [(1000, 256), (300, 384)])
+@pytest.mark.parametrize("ln", [False, True])
+def test_rowpanel_geglu(dev, dtype, M, K, ln):
+    from ap_adapter_amd import ops
+    N = 4 * K
+    x = q(R(M, K, seed=56), dtype)
+    w, b = q(R(2 * N, K, seed=57, std=0.08), dtype), q(R(2 * N, seed=58, std=0.5), dtype)
+    g, be = q(1 + 0.1 * R(K, seed=59), dtype), q(0.1 * R(K, seed=60), dtype)
+    xin = q(F.layer_norm(x, (K,), g, be, 1e-5), dtype) if ln else x
+    a, gate = F.linear(xin, w, b).chunk(2, dim=-1)
+    ref = a * F.gelu(gate)
+    out = ops.fused_linear(x.to(dev, dtype), w.to(dev, dtype), b.to(dev, dtype),
+                           ln=(g.to(dev, dtype), be.to(dev, dtype), 1e-5) if ln else None, act="geglu")
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,L,K,heads", [(2, 1000, 256, 8), (3, 252, 384, 8), (2, 100, 256, 4), (1, 513, 384, 12), (2, 63, 256, 8)])
+def test_rowpanel_fused_qkv_with_vt(dev, dtype, B, L, K, heads):
+    """LayerNorm + q|k|v in one launch; V per-head transposed (incl. token counts that are not multiples of 4)"""
+    from ap_adapter_amd import ops
+    M, d = B * L, K // heads
+    x = q(R(M, K, seed=61), dtype)
+    w = q(R(3 * K, K, seed=62, std=0.06), dtype)
+    g, be = q(1 + 0.1 * R(K, seed=63), dtype), q(0.1 * R(K, seed=64), dtype)
+    xin = q(F.layer_norm(x, (K,), g, be, 1e-5), dtype)
+    y = F.linear(xin, w)
+    qo = torch.empty(M, K, dtype=dtype, device=dev)
+    ko = torch.empty(M, K, dtype=dtype, device=dev)
+    Lpad = ops.round_up(L, 32)
+    vt = torch.zeros(B, heads, d, Lpad, dtype=dtype, device=dev)
+    ops.rowpanel(x.to(dev, dtype), w.to(dev, dtype), [(qo, None, K, "row"), (ko, None, K, "row"), (vt, None, K, "vt")],
+                 ln=(g.to(dev, dtype), be.to(dev, dtype), 1e-5), vt_geom=(heads, d, L, Lpad))
+    assert rel_err(qo, y[:, :K]) < TOL[dtype]
+    assert rel_err(ko, y[:, K:2 * K]) < TOL[dtype]
+    ref_vt = y[:, 2 * K:].view(B, L, heads, d).permute(0, 2, 3, 1)
+    assert rel_err(vt[..., :L], ref_vt) < TOL[dtype]
+    if Lpad > L:
+        assert float(vt[..., L:].float().abs().max()) == 0.0

@@ -1,0 +1,34 @@
+"""Run ONE op at its real shape a few times (for rocprofv3 --pmc passes).  usage: python tools/one_op.py <op> [iters]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ap_adapter_amd import ops
+dev = torch.device("cuda:0"); dt = torch.bfloat16
+op = sys.argv[1]; iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+B2 = 64
+R = lambda *s, std=1.0: (torch.randn(*s, device=dev) * std).to(dt)
+if op == "attn_self":
+    N, C = 1000, 256
+    q = R(B2, N, C); k = R(B2, N, C); v = R(B2, 8, C // 8, ops.round_up(N, 32)); out = torch.empty_like(q)
+    fn = lambda: ops.attention(q, k, v, N, 8, out=out)
+elif op == "attn_ip":
+    N, C, La = 1000, 256, 32
+    q = R(B2, N, C); kt = R(B2, 8, C); vt_ = R(B2, 8, C // 8, 32); ka = R(B2, La, C); va = R(B2, 8, C // 8, ops.round_up(La, 32)); out = torch.empty_like(q)
+    fn = lambda: ops.attention(q, kt, vt_, 8, 8, k2=ka, vt2=va, L2=La, scale2=0.5, out=out)
+elif op == "rp_geglu":
+    M, C = B2 * 1000, 256
+    x = R(M, C); g = R(C); be = R(C); wg = R(8 * C, C, std=0.02); bg = R(8 * C, std=0.02); og = torch.empty(M, 4 * C, device=dev, dtype=dt)
+    fn = lambda: ops.fused_linear(x, wg, bg, ln=(g, be, 1e-5), act="geglu", out=og)
+elif op == "rp_qkv":
+    M, C, N = B2 * 1000, 256, 1000
+    x = R(M, C); g = R(C); be = R(C); w = R(3 * C, C, std=0.02)
+    qo = torch.empty(M, C, device=dev, dtype=dt); ko = torch.empty(M, C, device=dev, dtype=dt)
+    vt = torch.zeros(B2, 8, C // 8, ops.round_up(N, 32), device=dev, dtype=dt)
+    fn = lambda: ops.rowpanel(x, w, [(qo, None, C, "row"), (ko, None, C, "row"), (vt, None, C, "vt")], ln=(g, be, 1e-5), vt_geom=(8, C // 8, N, vt.shape[-1]))
+elif op == "gemm_ff2":
+    M, C = B2 * 1000, 256
+    h = R(M, 4 * C); w2 = R(C, 4 * C, std=0.02); b2 = R(C, std=0.02); x = R(M, C); out = torch.empty(M, C, device=dev, dtype=dt)
+    fn = lambda: ops.linear(h, w2, b2, residual=x, out=out)
+for _ in range(iters):
+    fn()
+torch.cuda.synchronize()
