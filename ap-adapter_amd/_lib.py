@@ -64,7 +64,7 @@ SYMBOLS = {
     "apad_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "apad_attention": (C.c_int, [C.POINTER(AttnDesc), _vp]),
     "apad_layernorm": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _i64, _f32, _i32, _vp]),
-    "apad_groupnorm_workspace_bytes": (_i64, [_i32, _i32]),
+    "apad_groupnorm_workspace_bytes": (_i64, [_i32, _i32, _i32]),
     "apad_groupnorm": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp]),
     "apad_audiomae_pool": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "apad_timestep_embedding": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),

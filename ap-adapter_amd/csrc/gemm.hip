@@ -14,10 +14,18 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int A_BYTES = BM * BK * 2;           // 16 KiB
-constexpr int C_LD = BN + 8;                   // epilogue tile row stride (elements)
-constexpr int SMEM_BYTES = BM * C_LD * 2;      // 34816 >= 2*A_BYTES
+constexpr int BK = 64;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// TM = block tile edge: 128 (4 waves x 64x64) for big problems, 64 (4 waves x 32x32) when a 128-tiling would leave
+// most of the 256 CUs idle (the 64-token / 4096-row level of the UNet, 32x2 convolutions)
+template <int TM> struct Tile {
+    static constexpr int BM = TM, BN = TM;
+    static constexpr int MI = TM / 64;              // MFMA tiles per wave per dimension
+    static constexpr int A_BYTES = TM * BK * 2;
+    static constexpr int C_LD = TM + 8;             // epilogue tile row stride (elements)
+    static constexpr int SMEM_BYTES = (TM * C_LD * 2 > 2 * A_BYTES) ? TM * C_LD * 2 : 2 * A_BYTES;
+    static constexpr int NLD = TM / 32;             // staging vectors per thread per operand
+};
 
 struct GemmP {
     const uint8_t* a;
@@ -72,14 +80,17 @@ __device__ __forceinline__ uint4 load_a(const GemmP& p, const RowInfo<AMODE>& r,
     }
 }
 
-template <int DT, int AMODE, int EPI, int OUTMODE>
+template <int DT, int AMODE, int EPI, int OUTMODE, int TM>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
-    __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM_BYTES];
+    using T = Tile<TM>;
+    constexpr int BM = T::BM, BN = T::BN, MI = T::MI, A_BYTES = T::A_BYTES, C_LD = T::C_LD, NLD = T::NLD, WT = TM / 2;
+    __shared__ __attribute__((aligned(16))) uint8_t smem[T::SMEM_BYTES];
     using E = ET<DT>;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int half = lane >> 5, l31 = lane & 31;
-    constexpr int BN_OUT = (EPI == APAD_EPI_GEGLU) ? 64 : BN;
+    constexpr int BN_OUT = (EPI == APAD_EPI_GEGLU) ? BN / 2 : BN;
+    constexpr int GH = BN / 2;  // GEGLU: first half of the tile columns = value rows, second half = gate rows
     // XCD-aware tile order: workgroup id b runs on XCD b % 8 (observed dispatch order, speed only).  Tiles are
     // numbered so that all N-tiles of one M-tile share b % 8, i.e. one XCD's L2 fetches each A row-panel once.
     int mt, nt;
@@ -102,21 +113,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 
     // W row feeding local tile column nl
     auto wrow = [&](int nl) -> int64_t {
-        if (EPI == APAD_EPI_GEGLU) return nl < 64 ? n0 + nl : p.N + n0 + (nl - 64);
+        if (EPI == APAD_EPI_GEGLU) return nl < GH ? n0 + nl : p.N + n0 + (nl - GH);
         return n0 + nl;
     };
     auto wrow_valid = [&](int nl) -> bool {
-        if (EPI == APAD_EPI_GEGLU) return (nl < 64 ? n0 + nl : n0 + nl - 64) < p.N;
+        if (EPI == APAD_EPI_GEGLU) return (nl < GH ? n0 + nl : n0 + nl - GH) < p.N;
         return n0 + nl < p.N;
     };
 
     // per-thread staging assignment: rows (tid>>3) + 32*i, 16-byte chunk tid&7
     const int chunk = tid & 7;
-    RowInfo<AMODE> ra[4];
-    int64_t wb[4];
-    bool wv[4];
+    RowInfo<AMODE> ra[NLD];
+    int64_t wb[NLD];
+    bool wv[NLD];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NLD; ++i) {
         int rl = (tid >> 3) + 32 * i;
         int64_t m = m0 + rl;
         ra[i].valid = m < p.M;
@@ -145,31 +156,31 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         wb[i] = wv[i] ? wrow(rl) * p.ldw : 0;
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][MI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < MI; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (int)((p.K + BK - 1) / BK);
-    uint4 ga[4], gb[4];
+    u32x4 ga[NLD], gb[NLD];  // (native vectors: HIP's uint4 class type kept such arrays in scratch)
     auto gload = [&](int kt) {
         int k = kt * BK + chunk * 8;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ga[i] = load_a<DT, AMODE>(p, ra[i], k);
-            gb[i] = (wv[i] && k < p.K) ? *reinterpret_cast<const uint4*>(p.w + (wb[i] + k) * 2)
-                                       : make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < NLD; ++i) {
+            ga[i] = __builtin_bit_cast(u32x4, load_a<DT, AMODE>(p, ra[i], k));
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            gb[i] = (wv[i] && k < p.K) ? *reinterpret_cast<const u32x4*>(p.w + (wb[i] + k) * 2) : z;
         }
     };
     auto sstore = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NLD; ++i) {
             int rl = (tid >> 3) + 32 * i;
-            *reinterpret_cast<uint4*>(smem + lds_off(rl, chunk)) = ga[i];
-            *reinterpret_cast<uint4*>(smem + A_BYTES + lds_off(rl, chunk)) = gb[i];
+            *reinterpret_cast<u32x4*>(smem + lds_off(rl, chunk)) = ga[i];
+            *reinterpret_cast<u32x4*>(smem + A_BYTES + lds_off(rl, chunk)) = gb[i];
         }
     };
 
@@ -181,17 +192,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int ch = ks * 2 + half;
-            typename E::v8 af[2], bf[2];
+            typename E::v8 af[MI], bf[MI];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                af[i] = as_v8<DT>(*reinterpret_cast<const uint4*>(smem + lds_off(wm * 64 + i * 32 + l31, ch)));
+            for (int i = 0; i < MI; ++i) {
+                af[i] = as_v8<DT>(*reinterpret_cast<const uint4*>(smem + lds_off(wm * WT + i * 32 + l31, ch)));
                 bf[i] = as_v8<DT>(
-                    *reinterpret_cast<const uint4*>(smem + A_BYTES + lds_off(wn * 64 + i * 32 + l31, ch)));
+                    *reinterpret_cast<const uint4*>(smem + A_BYTES + lds_off(wn * WT + i * 32 + l31, ch)));
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = E::mfma32(af[i], bf[j], acc[i][j]);
+                for (int j = 0; j < MI; ++j) acc[i][j] = E::mfma32(af[i], bf[j], acc[i][j]);
         }
         __syncthreads();
         if (kt + 1 < nk) {
@@ -203,19 +214,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     // ---- epilogue: acc (+bias, +rowgroup bias, activation) -> LDS tile ----
     typename E::elem* ct = reinterpret_cast<typename E::elem*>(smem);
     int64_t step = p.step_ptr ? (int64_t)*p.step_ptr : 0;
+    const bool one_group = p.rows_per_group >= p.M;  // table mode: every row reads row `step` (no 64-bit divisions)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int nl = wn * 64 + j * 32 + l31;
+    for (int j = 0; j < MI; ++j) {
+        const int nl = wn * WT + j * 32 + l31;
         const bool nvalid = wrow_valid(nl);
         const int64_t wr = nvalid ? wrow(nl) : 0;
         const float bv = (p.bias && nvalid) ? ld_elem<DT>(p.bias, wr) : 0.f;
+        const float rg0 = (p.rg && one_group && nvalid) ? ld_elem<DT>(p.rg, step * p.ld_rg + wr) : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                float v = acc[i][j][r] + bv;
-                if (p.rg) {
+                const int ml = wm * WT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                float v = acc[i][j][r] + bv + rg0;
+                if (p.rg && !one_group) {
                     int64_t m = m0 + ml;
                     if (m < p.M && nvalid) v += ld_elem<DT>(p.rg, (m / p.rows_per_group + step) * p.ld_rg + wr);
                 }
@@ -237,7 +250,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
             unpack8<DT>(*reinterpret_cast<const uint4*>(&ct[rl * C_LD + vc * 8]), f);
             if (EPI == APAD_EPI_GEGLU) {
                 float g[8];
-                unpack8<DT>(*reinterpret_cast<const uint4*>(&ct[rl * C_LD + 64 + vc * 8]), g);
+                unpack8<DT>(*reinterpret_cast<const uint4*>(&ct[rl * C_LD + GH + vc * 8]), g);
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
                     const apad_f32x2 ge = gelu_erf_2((apad_f32x2){g[e], g[e + 1]});
@@ -258,7 +271,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     } else {  // APAD_OUT_VT: consecutive lanes -> consecutive tokens of one (head, dd) row
         typename E::elem* o = reinterpret_cast<typename E::elem*>(p.out);
         for (int idx = tid; idx < BM * BN; idx += 256) {
-            const int nl = idx >> 7, rl = idx & 127;
+            const int nl = idx / BM, rl = idx % BM;
             const int64_t m = m0 + rl, n = n0 + nl;
             if (m >= p.M || n >= p.N) continue;
             const int64_t b = m / p.L;
@@ -269,15 +282,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     }
 }
 
-template <int DT, int AMODE, int EPI, int OUTMODE>
-int launch(const GemmP& p, hipStream_t s) {
-    constexpr int BN_OUT = (EPI == APAD_EPI_GEGLU) ? 64 : BN;
+template <int DT, int AMODE, int EPI, int OUTMODE, int TM>
+int launch_tm(const GemmP& p, hipStream_t s) {
+    constexpr int BN_OUT = (EPI == APAD_EPI_GEGLU) ? TM / 2 : TM;
     GemmP q = p;
     q.n_tiles = (int)((p.N + BN_OUT - 1) / BN_OUT);
-    q.m_tiles = (int)((p.M + BM - 1) / BM);
+    q.m_tiles = (int)((p.M + TM - 1) / TM);
     dim3 grid((unsigned)(q.n_tiles * q.m_tiles));
-    hipLaunchKernelGGL((gemm_kernel<DT, AMODE, EPI, OUTMODE>), grid, dim3(256), 0, s, q);
+    hipLaunchKernelGGL((gemm_kernel<DT, AMODE, EPI, OUTMODE, TM>), grid, dim3(256), 0, s, q);
     return apad_check_launch("apad_gemm");
+}
+
+template <int DT, int AMODE, int EPI, int OUTMODE>
+int launch(const GemmP& p, hipStream_t s) {
+    // 128-tiles unless they would leave the chip under-filled (< ~2 workgroups per CU)
+    constexpr int BN_OUT = (EPI == APAD_EPI_GEGLU) ? 64 : 128;
+    const int64_t blocks128 = ((p.N + BN_OUT - 1) / BN_OUT) * ((p.M + 127) / 128);
+    if (blocks128 >= 512) return launch_tm<DT, AMODE, EPI, OUTMODE, 128>(p, s);
+    return launch_tm<DT, AMODE, EPI, OUTMODE, 64>(p, s);
 }
 
 template <int DT, int AMODE>

@@ -51,66 +51,104 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const uint8_t* x, const 
     }
 }
 
-// ---------------- GroupNorm statistics: one workgroup per (group, batch) ----------------
-// x [B][HW][C], channels of group g are the contiguous slice [g*cg, (g+1)*cg), cg % 4 == 0.
+// ---------------- GroupNorm over NHWC x[B][HW][C] ----------------
+// Pass 1 (gn_partial_kernel): workgroup = (pixel chunk, batch); thread (vc, py) owns ONE 16-byte channel vector vc and
+// walks pixels py, py+PY, ... of the chunk, so every load instruction reads whole contiguous pixel rows; per-channel
+// partial sums are folded to per-group sums through LDS and written as partial[b][chunk][g] = (sum, sumsq).
+// Pass 2 (gn_apply_kernel): workgroup = (pixel chunk, batch); the first G threads reduce the chunk partials of their
+// group to mean / rstd in LDS, then all threads normalise (+ optional SiLU) with 16-byte loads/stores.
+constexpr int GN_CHUNK = 64;  // pixels per workgroup
+
 template <int DT>
-__global__ __launch_bounds__(256) void gn_stats_kernel(const uint8_t* x, float* ws, int HW, int C, int G) {
-    __shared__ float red[2][4];
-    const int g = blockIdx.x, b = blockIdx.y;
-    const int cg = C / G, q = cg >> 2;  // 4-element (8-byte) pieces per pixel
-    const uint8_t* base = x + ((int64_t)b * HW * C + (int64_t)g * cg) * 2;
-    const float shift = ld_elem<DT>(base, 0);
-    float s = 0.f, ss = 0.f;
-    const int total = HW * q;
-    for (int idx = threadIdx.x; idx < total; idx += 256) {
-        const int px = idx / q, pc = idx - px * q;
-        uint2 u = *reinterpret_cast<const uint2*>(base + ((int64_t)px * C + pc * 4) * 2);
-        typename ET<DT>::v4 v = __builtin_bit_cast(typename ET<DT>::v4, u);
+__global__ __launch_bounds__(256) void gn_partial_kernel(const uint8_t* x, float* partial, int HW, int C, int G, int nchunk) {
+    __shared__ float ls[2][2048];  // [sum|sumsq][thread * 8 + e]: per-thread channel partials (deterministic reduction)
+    __shared__ float lc[2][1280];  // per-channel sums of this workgroup (C <= 1280)
+    const int vpr = C >> 3;        // 16-byte vectors per pixel (<= 160)
+    const int PY = 256 / vpr;      // pixel lanes
+    const int chunk = blockIdx.x, b = blockIdx.y;
+    const int p0 = chunk * GN_CHUNK, p1 = min(p0 + GN_CHUNK, HW);
+    const int tid = threadIdx.x;
+    const int vc = tid % vpr, py = tid / vpr;
+    float s[8], ss[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float d = (float)v[e] - shift;
-            s += d;
-            ss += d * d;
+    for (int e = 0; e < 8; ++e) s[e] = ss[e] = 0.f;
+    if (py < PY) {
+        const uint8_t* base = x + (((int64_t)b * HW) * C + vc * 8) * 2;
+        for (int px = p0 + py; px < p1; px += PY) {
+            float v[8];
+            unpack8<DT>(*reinterpret_cast<const uint4*>(base + (int64_t)px * C * 2), v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                s[e] += v[e];
+                ss[e] += v[e] * v[e];
+            }
         }
     }
-    s = wave_sum(s);
-    ss = wave_sum(ss);
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
-        red[0][wave] = s;
-        red[1][wave] = ss;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        ls[0][tid * 8 + e] = s[e];
+        ls[1][tid * 8 + e] = ss[e];
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const float n = (float)HW * (float)cg;
-        const float ts = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        const float tss = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-        const float md = ts / n;  // mean of (x - shift)
-        float var = tss / n - md * md;
-        var = var > 0.f ? var : 0.f;
-        ws[((int64_t)b * G + g) * 2 + 0] = md + shift;
-        ws[((int64_t)b * G + g) * 2 + 1] = var;
+    for (int c = tid; c < C; c += 256) {  // fixed-order sum over the pixel lanes
+        const int cv = c >> 3, e = c & 7;
+        float a0 = 0.f, a1 = 0.f;
+        for (int q = 0; q < PY; ++q) {
+            a0 += ls[0][(q * vpr + cv) * 8 + e];
+            a1 += ls[1][(q * vpr + cv) * 8 + e];
+        }
+        lc[0][c] = a0;
+        lc[1][c] = a1;
+    }
+    __syncthreads();
+    const int cg = C / G;
+    if (tid < G) {
+        float a0 = 0.f, a1 = 0.f;
+        for (int c = tid * cg; c < (tid + 1) * cg; ++c) {
+            a0 += lc[0][c];
+            a1 += lc[1][c];
+        }
+        float* o = partial + (((int64_t)b * nchunk + chunk) * G + tid) * 2;
+        o[0] = a0;
+        o[1] = a1;
     }
 }
 
 template <int DT, bool SILU>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const uint8_t* x, const float* ws, const uint8_t* gamma,
-                                                       const uint8_t* beta, uint8_t* out, int64_t nvec_total, int HW, int C,
-                                                       int G, float eps) {
+__global__ __launch_bounds__(256) void gn_apply_kernel(const uint8_t* x, const float* partial, const uint8_t* gamma,
+                                                       const uint8_t* beta, uint8_t* out, int HW, int C, int G, int nchunk,
+                                                       float eps) {
+    __shared__ float lm[64], lr[64];
+    const int chunk = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x;
     const int cg = C / G, vpr = C >> 3;
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < nvec_total; idx += stride) {
-        const int64_t pix = idx / vpr;
-        const int vc = (int)(idx - pix * vpr);
-        const int64_t b = pix / HW;
+    if (tid < G) {
+        float s = 0.f, ss = 0.f;
+        const float* pp = partial + ((int64_t)b * nchunk * G + tid) * 2;
+        for (int k = 0; k < nchunk; ++k) {
+            s += pp[(int64_t)k * G * 2];
+            ss += pp[(int64_t)k * G * 2 + 1];
+        }
+        const float n = (float)HW * (float)cg;
+        const float mean = s / n;
+        const float var = fmaxf(ss / n - mean * mean, 0.f);
+        lm[tid] = mean;
+        lr[tid] = rsqrtf(var + eps);
+    }
+    __syncthreads();
+    const int p0 = chunk * GN_CHUNK, p1 = min(p0 + GN_CHUNK, HW);
+    const int nv = (p1 - p0) * vpr;
+    const uint8_t* xb = x + (((int64_t)b * HW + p0) * C) * 2;
+    uint8_t* ob = out + (((int64_t)b * HW + p0) * C) * 2;
+    for (int idx = tid; idx < nv; idx += 256) {
+        const int vc = idx % vpr;
         const int c0 = vc * 8;
         float v[8], g[8], bt[8], y[8];
-        unpack8<DT>(*reinterpret_cast<const uint4*>(x + idx * 16), v);
+        unpack8<DT>(*reinterpret_cast<const uint4*>(xb + (int64_t)idx * 16), v);
         unpack8<DT>(*reinterpret_cast<const uint4*>(gamma + c0 * 2), g);
         unpack8<DT>(*reinterpret_cast<const uint4*>(beta + c0 * 2), bt);
         const int g0 = c0 / cg, g1 = (c0 + 4) / cg;
-        const float m0 = ws[(b * G + g0) * 2], r0 = rsqrtf(ws[(b * G + g0) * 2 + 1] + eps);
-        const float m1 = ws[(b * G + g1) * 2], r1 = rsqrtf(ws[(b * G + g1) * 2 + 1] + eps);
+        const float m0 = lm[g0], r0 = lr[g0], m1 = lm[g1], r1 = lr[g1];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float mean = e < 4 ? m0 : m1, rstd = e < 4 ? r0 : r1;
@@ -122,7 +160,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint8_t* x, const f
             }
             y[e] = t;
         }
-        *reinterpret_cast<uint4*>(out + idx * 16) = pack8<DT>(y);
+        *reinterpret_cast<uint4*>(ob + (int64_t)idx * 16) = pack8<DT>(y);
     }
 }
 
@@ -144,18 +182,16 @@ template <int DT> int ln_launch(const void* x, const void* gamma, const void* be
 
 template <int DT> int gn_launch(const void* x, const void* gamma, const void* beta, void* out, float* ws, int B, int HW, int C,
                                 int G, float eps, int silu, hipStream_t s) {
-    hipLaunchKernelGGL((gn_stats_kernel<DT>), dim3(G, B), dim3(256), 0, s, (const uint8_t*)x, ws, HW, C, G);
+    const int nchunk = (HW + GN_CHUNK - 1) / GN_CHUNK;
+    hipLaunchKernelGGL((gn_partial_kernel<DT>), dim3(nchunk, B), dim3(256), 0, s, (const uint8_t*)x, ws, HW, C, G, nchunk);
     int rc = apad_check_launch("apad_groupnorm(stats)");
     if (rc) return rc;
-    const int64_t nvec = (int64_t)B * HW * (C / 8);
-    int64_t blocks = (nvec + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
     if (silu)
-        hipLaunchKernelGGL((gn_apply_kernel<DT, true>), dim3((unsigned)blocks), dim3(256), 0, s, (const uint8_t*)x, ws,
-                           (const uint8_t*)gamma, (const uint8_t*)beta, (uint8_t*)out, nvec, HW, C, G, eps);
+        hipLaunchKernelGGL((gn_apply_kernel<DT, true>), dim3(nchunk, B), dim3(256), 0, s, (const uint8_t*)x, ws,
+                           (const uint8_t*)gamma, (const uint8_t*)beta, (uint8_t*)out, HW, C, G, nchunk, eps);
     else
-        hipLaunchKernelGGL((gn_apply_kernel<DT, false>), dim3((unsigned)blocks), dim3(256), 0, s, (const uint8_t*)x, ws,
-                           (const uint8_t*)gamma, (const uint8_t*)beta, (uint8_t*)out, nvec, HW, C, G, eps);
+        hipLaunchKernelGGL((gn_apply_kernel<DT, false>), dim3(nchunk, B), dim3(256), 0, s, (const uint8_t*)x, ws,
+                           (const uint8_t*)gamma, (const uint8_t*)beta, (uint8_t*)out, HW, C, G, nchunk, eps);
     return apad_check_launch("apad_groupnorm(apply)");
 }
 
@@ -175,14 +211,16 @@ extern "C" int apad_layernorm(const void* x, const void* gamma, const void* beta
                               : ln_launch<APAD_F16>(x, gamma, beta, out, M, C, ldx, ldo, eps, s);
 }
 
-extern "C" int64_t apad_groupnorm_workspace_bytes(int32_t B, int32_t G) { return (int64_t)B * G * 2 * sizeof(float); }
+extern "C" int64_t apad_groupnorm_workspace_bytes(int32_t B, int32_t HW, int32_t G) {
+    return (int64_t)B * ((HW + GN_CHUNK - 1) / GN_CHUNK) * G * 2 * sizeof(float);
+}
 
 extern "C" int apad_groupnorm(const void* x, const void* gamma, const void* beta, void* out, void* workspace, int32_t B,
                               int32_t HW, int32_t C, int32_t G, float eps, int32_t silu, int32_t dtype, void* stream) {
     APAD_CHECK(x && gamma && beta && out && workspace, "apad_groupnorm: null operand");
     APAD_CHECK(dtype == APAD_BF16 || dtype == APAD_F16, "apad_groupnorm: dtype %d not supported", dtype);
-    APAD_CHECK(B > 0 && HW > 0 && G > 0 && C % G == 0 && (C / G) % 4 == 0 && C % 8 == 0,
-               "apad_groupnorm: need C%%G==0, (C/G)%%4==0, C%%8==0 (B=%d HW=%d C=%d G=%d)", B, HW, C, G);
+    APAD_CHECK(B > 0 && HW > 0 && G > 0 && G <= 64 && C % G == 0 && (C / G) % 4 == 0 && C % 8 == 0 && C <= 1280,
+               "apad_groupnorm: need G<=64, C%%G==0, (C/G)%%4==0, C%%8==0, C<=1280 (B=%d HW=%d C=%d G=%d)", B, HW, C, G);
     APAD_CHECK(al16(x) && al16(out) && al16(gamma) && al16(beta), "apad_groupnorm: pointers must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     return dtype == APAD_BF16 ? gn_launch<APAD_BF16>(x, gamma, beta, out, (float*)workspace, B, HW, C, G, eps, silu, s)

@@ -209,10 +209,10 @@ def group_norm(x, gamma, beta, groups, eps, silu=False, out=None):
     """x [B, HW, C] (NHWC)."""
     _req(x, "group_norm.x", gamma.dtype)
     B, HW, Cc = x.shape
-    key = (x.device, B, groups)
+    key = (x.device, B, HW, groups)
     ws = _gn_ws.get(key)
     if ws is None:
-        ws = torch.empty(B * groups * 2, dtype=torch.float32, device=x.device)
+        ws = torch.empty(L.lib().apad_groupnorm_workspace_bytes(B, HW, groups) // 4, dtype=torch.float32, device=x.device)
         _gn_ws[key] = ws
     if out is None:
         out = torch.empty_like(x)

@@ -154,8 +154,8 @@ int apad_layernorm(const void* x, const void* gamma, const void* beta, void* out
                    int64_t ldx, int64_t ldo, float eps, int32_t dtype, void* stream);
 
 /* GroupNorm over NHWC x[B][HW][C] with G groups, optional fused SiLU.  workspace: fp32, at least
-   apad_groupnorm_workspace_bytes(B, G) bytes. */
-int64_t apad_groupnorm_workspace_bytes(int32_t B, int32_t G);
+   apad_groupnorm_workspace_bytes(B, HW, G) bytes. */
+int64_t apad_groupnorm_workspace_bytes(int32_t B, int32_t HW, int32_t G);
 int apad_groupnorm(const void* x, const void* gamma, const void* beta, void* out, void* workspace, int32_t B,
                    int32_t HW, int32_t C, int32_t G, float eps, int32_t silu, int32_t dtype, void* stream);
 
