@@ -15,168 +15,10 @@
 //
 // LDS: weight tile rows are padded by 16 B (row stride = K*2+16 bytes, an odd number of 16-byte slots), which makes
 // the 32-row ds_read_b128 fragment reads bank-conflict free without an XOR swizzle.
-#include "common.h"
-
-#ifndef RP_EXPERIMENT
-#define RP_EXPERIMENT 0  // A/B builds only: 1 = skip global stores, 2 = skip GELU, 3 = both, 4 = skip MFMAs
-#endif
+#include <stdlib.h>
+#include "rp_shared.h"
 
 namespace {
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-struct Seg {
-    uint8_t* out;
-    const uint8_t* bias;
-    int64_t ldo;
-    int32_t n_begin, n_cols, mode;
-};
-
-struct RpP {
-    const uint8_t* x;
-    const uint8_t* w;
-    const uint8_t* gamma;
-    const uint8_t* beta;
-    const uint8_t* res;
-    int64_t M, lda, ldw, ldr;
-    int32_t epi, nseg, n_total, n_tiles, tiles_per_block, nsplit;
-    float eps;
-    int32_t heads, hd, L, Lpad;
-    Seg seg[3];
-};
-
-template <int KC> struct Cfg {
-    static constexpr int BNT = 32;                     // weight rows per LDS tile (one MFMA tile)
-    static constexpr int NT = BNT / 32;               // MFMA tiles per LDS tile
-    static constexpr int CPR = KC * 2;                // 16-byte chunks per weight row
-    static constexpr int ROWB = KC * 32 + 16;         // padded LDS row stride (bytes)
-    static constexpr int TILE_BYTES = BNT * ROWB;
-    static constexpr int NCH = BNT * CPR / 256;       // staging chunks per thread
-};
-
-constexpr int SCR_ROWB = 72;             // per-wave output scratch: 32 rows x 32 columns, 9 eight-byte slots per row
-constexpr int SCR_BYTES = 32 * SCR_ROWB;
-
-// scratch (32 rows x `width` columns, this wave's rows mw0..mw0+31) -> out[:, col0 : col0+width] with 16-byte lanes;
-// the optional residual is read with the same coalescing and added after rounding to the storage type (as the
-// un-fused reference does).
-template <int DT>
-__device__ __forceinline__ void scratch_flush(const uint8_t* scr, int width, uint8_t* out, int64_t ldo, int col0,
-                                              const uint8_t* res, int64_t ldr, int64_t mw0, int64_t M, int lane) {
-    const int cpr = width >> 3;  // 16-byte chunks per row (2 or 4)
-    for (int idx = lane; idx < 32 * cpr; idx += 64) {
-        const int row = idx / cpr, ch = idx - row * cpr;
-        const int64_t m = mw0 + row;
-        if (m >= M) continue;
-        const uint2 lo = *reinterpret_cast<const uint2*>(scr + row * SCR_ROWB + ch * 16);
-        const uint2 hi = *reinterpret_cast<const uint2*>(scr + row * SCR_ROWB + ch * 16 + 8);
-        uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        if (res) {
-            float f[8], r[8];
-            unpack8<DT>(v, f);
-            unpack8<DT>(*reinterpret_cast<const uint4*>(res + (m * ldr + col0 + ch * 8) * 2), r);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] += r[e];
-            v = pack8<DT>(f);
-        }
-        if (!(RP_EXPERIMENT & 1) || v.x == 0x12345678u) *reinterpret_cast<uint4*>(out + (m * ldo + col0 + ch * 8) * 2) = v;
-    }
-}
-
-// V^T flavour: scratch rows are CHANNELS (nl0 + row), columns are this wave's 32 consecutive tokens (mw0..mw0+31).
-// Each 16-byte chunk = 8 consecutive tokens of one (head, dd) row of out[B][heads][hd][Lpad]; chunks that straddle a
-// batch boundary or are not 8-aligned inside it fall back to element stores.
-template <int DT>
-__device__ __forceinline__ void scratch_flush_vt(const uint8_t* scr, uint8_t* out, int nl0, int heads, int hd, int L, int Lpad,
-                                                 int64_t b0, int l0, int64_t mw0, int64_t M, int lane) {
-    using elem = typename ET<DT>::elem;
-    elem* o = reinterpret_cast<elem*>(out);
-    for (int idx = lane; idx < 128; idx += 64) {
-        const int row = idx >> 2, ch = idx & 3;
-        const int nl = nl0 + row;
-        const int h = nl / hd, dd = nl - h * hd;
-        const int64_t m0 = mw0 + ch * 8;
-        if (m0 >= M) continue;
-        int64_t b = b0;
-        int l = l0 + ch * 8;
-        while (l >= L) {
-            l -= L;
-            ++b;
-        }
-        const uint2 lo = *reinterpret_cast<const uint2*>(scr + row * SCR_ROWB + ch * 16);
-        const uint2 hi = *reinterpret_cast<const uint2*>(scr + row * SCR_ROWB + ch * 16 + 8);
-        const int64_t rowoff = ((b * heads + h) * hd + dd) * (int64_t)Lpad;
-        if ((l & 7) == 0 && l + 7 < L && m0 + 7 < M) {
-            *reinterpret_cast<uint4*>(o + rowoff + l) = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        } else {
-            const uint32_t w[4] = {lo.x, lo.y, hi.x, hi.y};
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (m0 + j >= M) break;
-                int64_t bj = b;
-                int lj = l + j;
-                if (lj >= L) {
-                    lj -= L;
-                    ++bj;
-                }
-                const uint16_t bits = (uint16_t)(w[j >> 1] >> ((j & 1) * 16));
-                reinterpret_cast<uint16_t*>(o)[((bj * heads + h) * hd + dd) * (int64_t)Lpad + lj] = bits;
-            }
-        }
-    }
-}
-
-template <int DT, int KC>
-__device__ __forceinline__ void rp_load_group(typename ET<DT>::v8 (&wf)[4][Cfg<KC>::NT], const uint8_t* wt, int c0) {
-    using C = Cfg<KC>;
-#pragma unroll
-    for (int cc = 0; cc < 4; ++cc)
-#pragma unroll
-        for (int s = 0; s < C::NT; ++s)
-            wf[cc][s] = as_v8<DT>(*reinterpret_cast<const uint4*>(wt + s * 32 * C::ROWB + (c0 + cc) * 32));
-}
-
-template <int DT, int KC> __device__ __forceinline__ void rp_pin(typename ET<DT>::v8 (&wf)[4][Cfg<KC>::NT]) {
-    using C = Cfg<KC>;
-#pragma unroll
-    for (int cc = 0; cc < 4; ++cc)
-#pragma unroll
-        for (int s = 0; s < C::NT; ++s) asm volatile("" : "+v"(wf[cc][s]) : : "memory");
-}
-
-// K loop of one weight tile, software-pipelined by hand: the 4*NT weight fragments of chunk group g+1 are requested
-// from LDS before the MFMAs of group g issue ("pin" = empty asm that makes the compiler wait for exactly that group's
-// reads and forbids sinking the next group's reads below it).  Left alone, hipcc emitted read / wait / MFMA one at a
-// time, exposing the LDS latency on every MFMA.  SWAP = false: D^T[n][m] (A = weights, B = x); true: D[m][n].
-template <int DT, int KC, bool SWAP>
-__device__ __forceinline__ void rp_mainloop(f32x16 (&acc)[Cfg<KC>::NT], const uint8_t* wt, const typename ET<DT>::v8 (&xf)[KC]) {
-    using E = ET<DT>;
-    using C = Cfg<KC>;
-    constexpr int NG = KC / 4;
-    typename E::v8 wfa[4][C::NT], wfb[4][C::NT];
-    rp_load_group<DT, KC>(wfa, wt, 0);
-#pragma unroll
-    for (int g = 0; g < NG; g += 2) {
-        if (g + 1 < NG) rp_load_group<DT, KC>(wfb, wt, (g + 1) * 4);
-        rp_pin<DT, KC>(wfa);
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc)
-#pragma unroll
-            for (int s = 0; s < C::NT; ++s) {
-                if (RP_EXPERIMENT & 4) acc[s][0] += (float)wfa[cc][s][0] * (float)xf[g * 4 + cc][0];
-                else acc[s] = SWAP ? E::mfma32(xf[g * 4 + cc], wfa[cc][s], acc[s]) : E::mfma32(wfa[cc][s], xf[g * 4 + cc], acc[s]);
-            }
-        if (g + 1 < NG) {
-            if (g + 2 < NG) rp_load_group<DT, KC>(wfa, wt, (g + 2) * 4);
-            rp_pin<DT, KC>(wfb);
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc)
-#pragma unroll
-                for (int s = 0; s < C::NT; ++s)
-                    acc[s] = SWAP ? E::mfma32(xf[(g + 1) * 4 + cc], wfb[cc][s], acc[s]) : E::mfma32(wfb[cc][s], xf[(g + 1) * 4 + cc], acc[s]);
-        }
-    }
-}
 
 template <int KC, bool GEGLU>
 __device__ __forceinline__ void stage_load(u32x4 (&st)[Cfg<KC>::NCH], const uint8_t* w, int64_t ldw, int n_total, int tile, int tid) {
@@ -455,6 +297,8 @@ inline bool al8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 
 
 }  // namespace
 
+int apad_ws_dispatch(void* rp_params, int K, int dtype, bool ln, bool geglu, void* stream);  // wsgemm.hip
+
 extern "C" int apad_rowpanel_gemm(const apad_rp_desc* d, void* stream) {
     APAD_CHECK(d != nullptr, "apad_rowpanel_gemm: null descriptor");
     APAD_CHECK(d->dtype == APAD_BF16 || d->dtype == APAD_F16, "apad_rowpanel_gemm: dtype %d not supported", d->dtype);
@@ -501,5 +345,16 @@ extern "C" int apad_rowpanel_gemm(const apad_rp_desc* d, void* stream) {
         APAD_CHECK(d->n_segments == 1 && d->seg[0].mode == APAD_OUT_ROWMAJOR && d->ldr % 8 == 0 && al16(d->residual),
                    "apad_rowpanel_gemm: residual needs a single row-major segment and 8-byte aligned rows");
     hipStream_t s = (hipStream_t)stream;
+    // weight-stationary schedule first; APAD_RP_IMPL=stream forces the x-stationary kernel (A/B tests)
+    static const bool force_stream = [] { const char* e = getenv("APAD_RP_IMPL"); return e && e[0] == 's'; }();
+    static const bool force_ws = [] { const char* e = getenv("APAD_RP_IMPL"); return e && e[0] == 'w'; }();
+    // measured on MI355X (tools/microbench.py): the weight-stationary schedule wins when all weight rows fit one or a
+    // few resident slices (q / to_out / proj_in / proj_out, N = C); fused q|k|v and the 8C-wide GEGLU re-read x once
+    // per slice and are faster on the streamed-tile kernel.
+    const bool narrow = !geglu && p.n_total <= 512;
+    if (!force_stream && (narrow || force_ws)) {
+        const int rc = apad_ws_dispatch(&p, d->K, d->dtype, ln, geglu, stream);
+        if (rc != -3) return rc;
+    }
     return d->dtype == APAD_BF16 ? dispatch<APAD_BF16>(p, d->K, ln, geglu, s) : dispatch<APAD_F16>(p, d->K, ln, geglu, s);
 }

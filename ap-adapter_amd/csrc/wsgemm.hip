@@ -1,0 +1,263 @@
+// Weight-stationary row-panel GEMM (the fast path of apad_rowpanel_gemm).
+//
+// Same contract as rpgemm.hip (LayerNorm? -> x . W^T -> bias / activation / GEGLU / residual, up to 3 column segments,
+// V^T output), different schedule: the projection matrices of the transformer blocks are SMALL (K = 256/384, at most
+// 2048 rows), the activation is HUGE (64 samples x 1000 tokens).  So a workgroup (8 waves, one per CU) loads a slice of
+// NS weight rows into LDS ONCE (132 KB at K=256: 256 rows; 98 KB at K=384: 128 rows) and then every wave streams 32-row
+// panels of x through it on its own: x fragments in registers (LayerNorm in registers), KC MFMAs per 32-column tile with
+// the A operand read straight from the resident slice, epilogue through the wave's private LDS scratch.  There is NO
+// workgroup barrier in the main loop and no per-tile global->LDS staging (in the x-stationary kernel a tile's 16-24
+// MFMAs could not cover the latency of the next tile's weight loads); the next panel's x is prefetched into registers
+// while the current one is multiplied (K=256).
+#include "rp_shared.h"
+
+namespace {
+
+template <int KC> struct WsCfg {
+    static constexpr int NS = (KC <= 16) ? 256 : 128;  // weight rows resident in LDS per workgroup
+    static constexpr int NTILES = NS / 32;             // MFMA tiles per slice
+    static constexpr int ROWB = Cfg<KC>::ROWB;         // same padded row stride as the streamed tiles
+    static constexpr int CPR = KC * 2;
+    static constexpr int W_BYTES = NS * ROWB;
+    static constexpr int WAVES = 8;
+    static constexpr bool PREFETCH = (KC <= 16);       // second x panel in registers only fits at K=256
+};
+
+template <int DT, int KC>
+__device__ __forceinline__ void load_panel(typename ET<DT>::v8 (&xf)[KC], const uint8_t* x, int64_t lda, int64_t M, int64_t mw0,
+                                           int l31, int half) {
+    int64_t mrow = mw0 + l31;
+    mrow = mrow < M ? mrow : M - 1;
+    const uint8_t* xp = x + (mrow * lda + half * 8) * 2;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) xf[c] = as_v8<DT>(*reinterpret_cast<const uint4*>(xp + c * 32));
+}
+
+template <int DT, int KC>
+__device__ __forceinline__ void layernorm_panel(typename ET<DT>::v8 (&xf)[KC], const uint8_t* gamma, const uint8_t* beta, float eps,
+                                                int l31, int half) {
+    using E = ET<DT>;
+    // single statistics pass, shifted by the row's first element (both halves of the row use the same shift)
+    const float shift = __shfl((float)xf[0][0], l31, 64);
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d = (float)xf[c][j] - shift;
+            s += d;
+            q += d * d;
+        }
+        asm volatile("" : "+v"(s), "+v"(q));  // evaluate chunk by chunk: bounds the live converted values
+    }
+    s += __shfl_xor(s, 32, 64);
+    q += __shfl_xor(q, 32, 64);
+    const float md = s * (1.0f / (KC * 16));
+    const float mean = shift + md;
+    const float var = fmaxf(q * (1.0f / (KC * 16)) - md * md, 0.f);
+    const float rstd = rsqrtf(var + eps);
+    const float nmr = -mean * rstd;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        typename E::v8 g = as_v8<DT>(*reinterpret_cast<const uint4*>(gamma + (c * 16 + half * 8) * 2));
+        typename E::v8 b = as_v8<DT>(*reinterpret_cast<const uint4*>(beta + (c * 16 + half * 8) * 2));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xf[c][j] = (typename E::elem)(((float)xf[c][j] * rstd + nmr) * (float)g[j] + (float)b[j]);
+        asm volatile("" : "+v"(xf[c]) : : "memory");
+    }
+}
+
+template <int DT, int KC, bool LN, bool GEGLU>
+__global__ __launch_bounds__(512) void wsgemm_kernel(RpP p) {
+    using E = ET<DT>;
+    using W = WsCfg<KC>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    constexpr int COLS_PER_TILE = GEGLU ? 16 : 32;
+    const int nslices = p.nsplit;
+    const int slice = blockIdx.x % nslices, rgrp = blockIdx.x / nslices, ngrp = gridDim.x / nslices;
+    const int t0 = slice * W::NTILES;  // first MFMA tile (global tile index) of this slice
+
+    // ---- weight slice + bias -> LDS, once ----
+    for (int idx = tid; idx < W::NS * W::CPR; idx += 512) {
+        const int j = idx / W::CPR, ch = idx - j * W::CPR;
+        const int tile = t0 + (j >> 5), jj = j & 31;
+        int64_t row;
+        if (GEGLU) {  // per 32-row MFMA tile: 16 value rows then the 16 matching gate rows
+            const int64_t base = (int64_t)tile * 16;
+            row = jj < 16 ? base + jj : (int64_t)p.n_total + base + (jj - 16);
+        } else {
+            row = (int64_t)tile * 32 + jj;
+        }
+        *reinterpret_cast<u32x4*>(smem + j * W::ROWB + ch * 16) = *reinterpret_cast<const u32x4*>(p.w + (row * p.ldw + ch * 8) * 2);
+    }
+    uint8_t* const scr = smem + W::W_BYTES + wave * SCR_BYTES;
+    float* const lbias = reinterpret_cast<float*>(smem + W::W_BYTES + W::WAVES * SCR_BYTES);
+    const int bias_cols = W::NTILES * COLS_PER_TILE;
+    const int bias_c0 = t0 * COLS_PER_TILE;
+    {
+        const int reps = GEGLU ? 2 : 1;
+        for (int i = tid; i < bias_cols * reps; i += 512) {
+            const int part = i / bias_cols, c = i - part * bias_cols;
+            const int n = bias_c0 + c;
+            float v = 0.f;
+            if (GEGLU) {
+                if (p.seg[0].bias) v = ld_elem<DT>(p.seg[0].bias, (int64_t)part * p.n_total + n);
+            } else {
+                const bool b1 = p.nseg > 1 && n >= p.seg[1].n_begin, b2 = p.nseg > 2 && n >= p.seg[2].n_begin;
+                const uint8_t* bp = b2 ? p.seg[2].bias : (b1 ? p.seg[1].bias : p.seg[0].bias);
+                const int nb = b2 ? p.seg[2].n_begin : (b1 ? p.seg[1].n_begin : 0);
+                if (bp) v = ld_elem<DT>(bp, n - nb);
+            }
+            lbias[i] = v;
+        }
+    }
+    __syncthreads();  // the only workgroup barrier
+
+    const int64_t npanels = (p.M + 31) >> 5;
+    const int64_t pstride = (int64_t)ngrp * W::WAVES;
+    int64_t pi = (int64_t)rgrp * W::WAVES + wave;
+    typename E::v8 xf[KC];
+    typename E::v8 xn[W::PREFETCH ? KC : 1];
+    if (pi < npanels) load_panel<DT, KC>(xf, p.x, p.lda, p.M, pi * 32, l31, half);
+
+    for (; pi < npanels; pi += pstride) {
+        const int64_t mw0 = pi * 32;
+        if (LN) layernorm_panel<DT, KC>(xf, p.gamma, p.beta, p.eps, l31, half);
+        if constexpr (W::PREFETCH) {
+            if (pi + pstride < npanels) load_panel<DT, KC>(xn, p.x, p.lda, p.M, (pi + pstride) * 32, l31, half);
+        }
+        int64_t vt_b0 = 0;
+        int vt_l0 = 0;
+        if (!GEGLU && p.L > 0) {
+            vt_b0 = mw0 / p.L;
+            vt_l0 = (int)(mw0 - vt_b0 * p.L);
+        }
+        int cursor = 0, win_col0 = 0;
+
+        for (int ti = 0; ti < W::NTILES; ++ti) {
+            const int n0 = (t0 + ti) * COLS_PER_TILE;
+            const bool s1 = p.nseg > 1 && n0 >= p.seg[1].n_begin, s2 = p.nseg > 2 && n0 >= p.seg[2].n_begin;
+            uint8_t* sg_out = s2 ? p.seg[2].out : (s1 ? p.seg[1].out : p.seg[0].out);
+            const int64_t sg_ldo = s2 ? p.seg[2].ldo : (s1 ? p.seg[1].ldo : p.seg[0].ldo);
+            const int sg_nb = s2 ? p.seg[2].n_begin : (s1 ? p.seg[1].n_begin : p.seg[0].n_begin);
+            const int sg_mode = s2 ? p.seg[2].mode : (s1 ? p.seg[1].mode : p.seg[0].mode);
+            const bool vt = (!GEGLU) && sg_mode == APAD_OUT_VT;
+            const uint8_t* wt = smem + (ti * 32 + l31) * W::ROWB + half * 16;
+
+            f32x16 acc[1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+            if (!vt)
+                rp_mainloop<DT, KC, false>(acc, wt, xf);
+            else
+                rp_mainloop<DT, KC, true>(acc, wt, xf);
+
+            if (GEGLU) {
+                // acc[4g+j] = value, acc[8+4g+j] = gate of output column o = n0 + 8g + 4half + j
+                if (cursor == 0) win_col0 = n0;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const int o = n0 + 8 * g + 4 * half;
+                    const float4 bv4 = *reinterpret_cast<const float4*>(lbias + (o - bias_c0));
+                    const float4 bg4 = *reinterpret_cast<const float4*>(lbias + bias_cols + (o - bias_c0));
+                    const float bv[4] = {bv4.x, bv4.y, bv4.z, bv4.w}, bg[4] = {bg4.x, bg4.y, bg4.z, bg4.w};
+                    typename E::v4 y;
+#pragma unroll
+                    for (int j = 0; j < 4; j += 2) {
+                        const apad_f32x2 gt = {acc[0][8 + 4 * g + j] + bg[j], acc[0][8 + 4 * g + j + 1] + bg[j + 1]};
+                        const apad_f32x2 ge = gelu_erf_2(gt);
+                        y[j] = (typename E::elem)((acc[0][4 * g + j] + bv[j]) * ge[0]);
+                        y[j + 1] = (typename E::elem)((acc[0][4 * g + j + 1] + bv[j + 1]) * ge[1]);
+                    }
+                    *reinterpret_cast<uint2*>(scr + l31 * SCR_ROWB + (cursor + 8 * g + 4 * half) * 2) = __builtin_bit_cast(uint2, y);
+                }
+                cursor += 16;
+                if (cursor == 32) {
+                    scratch_flush<DT>(scr, 32, sg_out, sg_ldo, win_col0, nullptr, 0, mw0, p.M, lane);
+                    cursor = 0;
+                }
+            } else if (!vt) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float f[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) f[j] = acc[0][4 * g + j];
+                    const float4 b4 = *reinterpret_cast<const float4*>(lbias + (n0 + 8 * g + 4 * half - bias_c0));
+                    f[0] += b4.x; f[1] += b4.y; f[2] += b4.z; f[3] += b4.w;
+                    if (p.epi == APAD_EPI_SILU) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) f[j] = silu_f(f[j]);
+                    } else if (p.epi == APAD_EPI_GELU) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) f[j] = gelu_erf_f(f[j]);
+                    }
+                    typename E::v4 y;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) y[j] = (typename E::elem)f[j];
+                    *reinterpret_cast<uint2*>(scr + l31 * SCR_ROWB + (8 * g + 4 * half) * 2) = __builtin_bit_cast(uint2, y);
+                }
+                scratch_flush<DT>(scr, 32, sg_out, sg_ldo, n0 - sg_nb, p.res, p.ldr, mw0, p.M, lane);
+            } else {
+                const float bvv = lbias[n0 + l31 - bias_c0];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    typename E::v4 y;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) y[j] = (typename E::elem)(acc[0][4 * g + j] + bvv);
+                    *reinterpret_cast<uint2*>(scr + l31 * SCR_ROWB + (8 * g + 4 * half) * 2) = __builtin_bit_cast(uint2, y);
+                }
+                scratch_flush_vt<DT>(scr, sg_out, n0 - sg_nb, p.heads, p.hd, p.L, p.Lpad, vt_b0, vt_l0, mw0, p.M, lane);
+            }
+        }
+        if (GEGLU && cursor > 0) scratch_flush<DT>(scr, cursor, p.seg[0].out, p.seg[0].ldo, win_col0, nullptr, 0, mw0, p.M, lane);
+
+        if constexpr (W::PREFETCH) {
+#pragma unroll
+            for (int c = 0; c < KC; ++c) xf[c] = xn[c];
+        } else {
+            if (pi + pstride < npanels) load_panel<DT, KC>(xf, p.x, p.lda, p.M, (pi + pstride) * 32, l31, half);
+        }
+    }
+}
+
+template <int DT, int KC, bool LN, bool GEGLU> int ws_launch(RpP& p, hipStream_t s) {
+    using W = WsCfg<KC>;
+    constexpr int COLS_PER_TILE = GEGLU ? 16 : 32;
+    const int cols_per_slice = W::NTILES * COLS_PER_TILE;
+    if (p.n_total % cols_per_slice != 0) return -3;
+    for (int i = 0; i < p.nseg; ++i)
+        if (p.seg[i].n_begin % COLS_PER_TILE != 0) return -3;
+    p.nsplit = p.n_total / cols_per_slice;  // slices
+    const int64_t npanels = (p.M + 31) >> 5;
+    int ngrp = 256 / p.nsplit;  // one workgroup per CU
+    if (ngrp < 1) ngrp = 1;
+    const int64_t max_grp = (npanels + W::WAVES - 1) / W::WAVES;
+    if (ngrp > max_grp) ngrp = (int)max_grp;
+    const size_t lds = W::W_BYTES + W::WAVES * SCR_BYTES + (size_t)cols_per_slice * (GEGLU ? 2 : 1) * sizeof(float);
+    auto kern = wsgemm_kernel<DT, KC, LN, GEGLU>;
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_lds = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ngrp * p.nsplit)), dim3(512), lds, s, p);
+    return apad_check_launch("apad_rowpanel_gemm(ws)");
+}
+
+template <int DT, int KC> int ws_dispatch2(RpP& p, bool ln, bool geglu, hipStream_t s) {
+    if (ln) return geglu ? ws_launch<DT, KC, true, true>(p, s) : ws_launch<DT, KC, true, false>(p, s);
+    return geglu ? ws_launch<DT, KC, false, true>(p, s) : ws_launch<DT, KC, false, false>(p, s);
+}
+
+}  // namespace
+
+// returns -3 when the shape does not fit the weight-stationary schedule (caller falls back to the streamed kernel)
+int apad_ws_dispatch(void* rp_params, int K, int dtype, bool ln, bool geglu, void* stream) {
+    RpP& p = *reinterpret_cast<RpP*>(rp_params);
+    hipStream_t s = (hipStream_t)stream;
+    if (K == 256) return dtype == APAD_BF16 ? ws_dispatch2<APAD_BF16, 16>(p, ln, geglu, s) : ws_dispatch2<APAD_F16, 16>(p, ln, geglu, s);
+    if (K == 384) return dtype == APAD_BF16 ? ws_dispatch2<APAD_BF16, 24>(p, ln, geglu, s) : ws_dispatch2<APAD_F16, 24>(p, ln, geglu, s);
+    return -3;
+}
