@@ -78,3 +78,38 @@ def test_audiomae_vs_oracle(dev):
     out, ones = m.to(dev)(mel, time_pool=4, freq_pool=4)
     assert out.shape == ref.shape == (2, 32, 768) and ones.shape == (2, 32)
     assert rel_err(out, ref) < 5e-2
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 4e-2), (torch.float16, 6e-3)])
+def test_full_geometry_noise_pred_vs_oracle(dev, dtype, tol):
+    """AudioLDM2-large geometry (718 M parameters, 256 attention sites, 32 AP processors), one CFG pair of a 10 s clip
+    (latents 8x250x16), La = 32 audio tokens: noise_pred of the HIP path vs the fp32 oracle chain on the same
+    storage-rounded weights.  This is the tensor the north-star tolerance is stated on; the bound asserted here is the
+    measured error with ~2x margin (see DESIGN.md 'Tolerance statement')."""
+    import ap_adapter_amd as A
+    from ap_adapter_amd.synthetic import init_synthetic_, synthetic_inputs
+    from oracle import unet as OU
+    u = A.AudioLDM2UNet2DConditionModel()
+    A.install_ap_adapter(u, None, scale=0.55)
+    init_synthetic_(u, 100, bias_std=0.01)
+    u = u.to(dtype)
+    sd = {k: v.detach().float() for k, v in u.state_dict().items()}
+    procs = {n: dict(scale=p.scale, num_tokens=p.num_tokens) for n, p in u.attn_processors.items() if hasattr(p, "to_k_ip")}
+    inp = synthetic_inputs(1, 32)
+    pipe = A.AudioLDM2Pipeline(u)
+    ehs = pipe.assemble_condition(inp["generated_prompt_embeds"], inp["audio_tokens"], inp["uncond_audio_tokens"], dtype)
+    ehs1 = inp["prompt_embeds"].to(dtype)
+    x = torch.cat([inp["latents"]] * 2).to(dtype)
+    t = torch.tensor(501)
+    with torch.no_grad():
+        ref = OU.unet_forward(sd, u.config.geometry_dict(), x.float(), t, ehs.float(), ehs1.float(), None,
+                              inp["attention_mask"].float(), procs)
+        u = u.to(dev)
+        out = u(x.to(dev), t, encoder_hidden_states=ehs.to(dev), encoder_hidden_states_1=ehs1.to(dev),
+                encoder_attention_mask_1=inp["attention_mask"].to(dev), return_dict=False)[0]
+    assert out.shape == ref.shape == (2, 8, 250, 16)
+    err = (out.float().cpu() - ref).abs()
+    rel = float(err.max() / ref.abs().max())
+    print(f"\\n[full-geometry noise_pred, {dtype}] max|ref|={float(ref.abs().max()):.4f} max-abs err={float(err.max()):.3e} "
+          f"mean-abs err={float(err.mean()):.3e} rel-max={rel:.3e}")
+    assert rel < tol
