@@ -262,9 +262,25 @@ template <int DT, int KC, bool LN, bool GEGLU> int launch(RpP& p, hipStream_t s)
     constexpr int COLS_PER_TILE = GEGLU ? C::NT * 16 : C::BNT;
     p.n_tiles = p.n_total / COLS_PER_TILE;
     const int m_tiles = (int)((p.M + 127) / 128);
-    int nsplit = (768 + m_tiles - 1) / m_tiles;  // aim at >= 3 workgroups per CU
-    if (nsplit < 1) nsplit = 1;
-    if (nsplit > p.n_tiles) nsplit = p.n_tiles;
+    // Split the column tiles over `nsplit` workgroups per row panel so that the grid is a near-integer number of
+    // "rounds" of the workgroups the chip can hold at once (256 CUs x wgs/CU): 1000 workgroups on a 768-slot chip run
+    // two rounds for 1.3 rounds of work.  Candidates 1..8, fewest wasted slots wins (ties -> fewer splits).
+    const int wg_per_cu = (GEGLU && KC <= 16) ? 3 : 2;  // from the kernels' VGPR / LDS footprints
+    const int cap = 256 * wg_per_cu;
+    int nsplit = 1;
+    double best = 1e30;
+    for (int c = 1; c <= 8 && c <= p.n_tiles; ++c) {
+        const int tpb = (p.n_tiles + c - 1) / c;
+        const int ns = (p.n_tiles + tpb - 1) / tpb;
+        const long blocks = (long)m_tiles * ns;
+        const long rounds = (blocks + cap - 1) / cap;
+        // time ~ rounds * tiles per block (+ a fixed per-workgroup cost of ~2 tiles for the x panel / LayerNorm)
+        const double cost = (double)rounds * (tpb + 2);
+        if (cost < best - 1e-9) {
+            best = cost;
+            nsplit = c;
+        }
+    }
     p.tiles_per_block = (p.n_tiles + nsplit - 1) / nsplit;
     p.nsplit = (p.n_tiles + p.tiles_per_block - 1) / p.tiles_per_block;
     const size_t lds = 2 * C::TILE_BYTES + 4 * SCR_BYTES + (size_t)p.tiles_per_block * COLS_PER_TILE * (GEGLU ? 2 : 1) * sizeof(float);

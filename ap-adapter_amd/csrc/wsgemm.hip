@@ -79,18 +79,40 @@ __global__ __launch_bounds__(512) void wsgemm_kernel(RpP p) {
     const int slice = blockIdx.x % nslices, rgrp = blockIdx.x / nslices, ngrp = gridDim.x / nslices;
     const int t0 = slice * W::NTILES;  // first MFMA tile (global tile index) of this slice
 
-    // ---- weight slice + bias -> LDS, once ----
-    for (int idx = tid; idx < W::NS * W::CPR; idx += 512) {
-        const int j = idx / W::CPR, ch = idx - j * W::CPR;
-        const int tile = t0 + (j >> 5), jj = j & 31;
-        int64_t row;
-        if (GEGLU) {  // per 32-row MFMA tile: 16 value rows then the 16 matching gate rows
-            const int64_t base = (int64_t)tile * 16;
-            row = jj < 16 ? base + jj : (int64_t)p.n_total + base + (jj - 16);
-        } else {
-            row = (int64_t)tile * 32 + jj;
+    // ---- weight slice + bias -> LDS, once.  Batches of 8 loads are issued back to back before their LDS stores: a plain
+    //      load/store loop exposed one full memory latency per 16 bytes per thread (measured: ~20 us of fixed cost). ----
+    {
+        constexpr int NIT = W::NS * W::CPR / 512;  // chunks per thread (16 at K=256, 12 at K=384)
+        static_assert(W::NS * W::CPR % 512 == 0, "slice must split evenly over the workgroup");
+        constexpr int UB = 8;
+#pragma unroll
+        for (int i0 = 0; i0 < NIT; i0 += UB) {
+            u32x4 v[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                if (i0 + u < NIT) {
+                    const int idx = tid + 512 * (i0 + u);
+                    const int j = idx / W::CPR, ch = idx - j * W::CPR;
+                    const int tile = t0 + (j >> 5), jj = j & 31;
+                    int64_t row;
+                    if (GEGLU) {  // per 32-row MFMA tile: 16 value rows then the 16 matching gate rows
+                        const int64_t base = (int64_t)tile * 16;
+                        row = jj < 16 ? base + jj : (int64_t)p.n_total + base + (jj - 16);
+                    } else {
+                        row = (int64_t)tile * 32 + jj;
+                    }
+                    v[u] = *reinterpret_cast<const u32x4*>(p.w + (row * p.ldw + ch * 8) * 2);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                if (i0 + u < NIT) {
+                    const int idx = tid + 512 * (i0 + u);
+                    const int j = idx / W::CPR, ch = idx - j * W::CPR;
+                    *reinterpret_cast<u32x4*>(smem + j * W::ROWB + ch * 16) = v[u];
+                }
+            }
         }
-        *reinterpret_cast<u32x4*>(smem + j * W::ROWB + ch * 16) = *reinterpret_cast<const u32x4*>(p.w + (row * p.ldw + ch * 8) * 2);
     }
     uint8_t* const scr = smem + W::W_BYTES + wave * SCR_BYTES;
     float* const lbias = reinterpret_cast<float*>(smem + W::W_BYTES + W::WAVES * SCR_BYTES);

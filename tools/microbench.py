@@ -13,13 +13,23 @@ B2 = int(os.environ.get("B2", "64"))
 
 
 def timeit(fn, iters=20):
+    """average kernel time per call: `iters` calls captured into one hipGraph (no host launch overhead), replayed 5x"""
     fn(); torch.cuda.synchronize()
+    s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        fn()
+    torch.cuda.current_stream().wait_stream(s); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            fn()
+    g.replay(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(iters):
-        fn()
+    for _ in range(5):
+        g.replay()
     e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters
+    return e0.elapsed_time(e1) / (5 * iters)
 
 
 def report(name, ms, flops, bytes_):
