@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 BF16, F16, F32 = 0, 1, 2
 A_PLAIN, A_CONV3X3, A_PATCH16 = 0, 1, 2
 EPI_NONE, EPI_SILU, EPI_GELU, EPI_GEGLU = 0, 1, 2, 3
-OUT_ROWMAJOR, OUT_VT = 0, 1
+OUT_ROWMAJOR, OUT_VT, OUT_QKV = 0, 1, 2
 
 _vp, _i64, _i32, _f32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float
 
@@ -27,7 +27,8 @@ class GemmDesc(C.Structure):
     _fields_ = [(n, _vp) for n in ("a", "w", "out", "bias", "residual", "rowgroup_bias", "step_ptr")] + \
                [(n, _i64) for n in ("M", "N", "K", "lda", "ldw", "ldo", "ldr", "ld_rg", "rows_per_group")] + \
                [(n, _i32) for n in ("a_mode", "epilogue", "out_mode", "dtype", "Hin", "Win", "Cin", "Hout", "Wout",
-                                    "stride", "Hup", "Wup", "src_batch_mod", "residual_row_mod", "heads", "head_dim", "L", "Lpad")]
+                                    "stride", "Hup", "Wup", "src_batch_mod", "residual_row_mod", "heads", "head_dim", "L", "Lpad")] + \
+               [("out2", _vp), ("out3", _vp)]
 
 
 class AttnDesc(C.Structure):

@@ -32,6 +32,8 @@ struct GemmP {
     const uint8_t* a;
     const uint8_t* w;
     uint8_t* out;
+    uint8_t* out2;
+    uint8_t* out3;
     const uint8_t* bias;
     const uint8_t* residual;
     const uint8_t* rg;
@@ -241,7 +243,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     }
     __syncthreads();
 
-    if (OUTMODE == APAD_OUT_ROWMAJOR) {
+    // fused q|k|v: the tile lies in exactly one third of the columns (C % tile == 0, checked on the host)
+    const int Cq = (int)(p.N / 3);
+    const int qseg = (OUTMODE == APAD_OUT_QKV) ? (int)(n0 / Cq) : 0;
+    if (OUTMODE == APAD_OUT_ROWMAJOR || (OUTMODE == APAD_OUT_QKV && qseg < 2)) {
+        uint8_t* const obase = (OUTMODE == APAD_OUT_QKV && qseg == 1) ? p.out2 : p.out;
+        const int64_t ncol0 = (OUTMODE == APAD_OUT_QKV) ? (int64_t)qseg * Cq : 0;
         constexpr int VPR = BN_OUT / 8;  // 16-byte vectors per output row
         for (int idx = tid; idx < BM * VPR; idx += 256) {
             const int rl = idx / VPR, vc = idx - rl * VPR;
@@ -267,14 +274,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] = (float)(typename E::elem)f[e] + rr[e];
             }
-            *reinterpret_cast<uint4*>(p.out + (m * p.ldo + n) * 2) = pack8<DT>(f);
+            *reinterpret_cast<uint4*>(obase + (m * p.ldo + (n - ncol0)) * 2) = pack8<DT>(f);
         }
-    } else {  // APAD_OUT_VT: consecutive lanes -> consecutive tokens of one (head, dd) row
-        typename E::elem* o = reinterpret_cast<typename E::elem*>(p.out);
+    } else {  // APAD_OUT_VT (or the v third of APAD_OUT_QKV): consecutive lanes -> consecutive tokens of one (head, dd) row
+        typename E::elem* o = reinterpret_cast<typename E::elem*>(OUTMODE == APAD_OUT_QKV ? p.out3 : p.out);
+        const int64_t nsub = (OUTMODE == APAD_OUT_QKV) ? 2 * (int64_t)Cq : 0;
         for (int idx = tid; idx < BM * BN; idx += 256) {
             const int nl = idx / BM, rl = idx % BM;
-            const int64_t m = m0 + rl, n = n0 + nl;
+            const int64_t m = m0 + rl;
+            int64_t n = n0 + nl;
             if (m >= p.M || n >= p.N) continue;
+            n -= nsub;
             const int64_t b = m / p.L;
             const int l = (int)(m - b * p.L);
             const int h = (int)(n / p.head_dim), dd = (int)(n - (int64_t)h * p.head_dim);
@@ -507,6 +517,10 @@ int dispatch_epi(const GemmP& p, int epi, int outmode, hipStream_t s) {
         APAD_CHECK(epi == APAD_EPI_NONE, "apad_gemm: APAD_OUT_VT supports epilogue NONE only");
         return launch<DT, AMODE, APAD_EPI_NONE, APAD_OUT_VT>(p, s);
     }
+    if (outmode == APAD_OUT_QKV) {
+        APAD_CHECK(epi == APAD_EPI_NONE && AMODE == APAD_A_PLAIN, "apad_gemm: APAD_OUT_QKV supports plain A / epilogue NONE only");
+        if constexpr (AMODE == APAD_A_PLAIN) return launch<DT, AMODE, APAD_EPI_NONE, APAD_OUT_QKV>(p, s);
+    }
     switch (epi) {
         case APAD_EPI_NONE: return launch<DT, AMODE, APAD_EPI_NONE, APAD_OUT_ROWMAJOR>(p, s);
         case APAD_EPI_SILU: return launch<DT, AMODE, APAD_EPI_SILU, APAD_OUT_ROWMAJOR>(p, s);
@@ -550,6 +564,8 @@ extern "C" int apad_gemm(const apad_gemm_desc* d, void* stream) {
     p.a = (const uint8_t*)d->a;
     p.w = (const uint8_t*)d->w;
     p.out = (uint8_t*)d->out;
+    p.out2 = (uint8_t*)d->out2;
+    p.out3 = (uint8_t*)d->out3;
     p.bias = (const uint8_t*)d->bias;
     p.residual = (const uint8_t*)d->residual;
     p.rg = (const uint8_t*)d->rowgroup_bias;
@@ -577,6 +593,12 @@ extern "C" int apad_gemm(const apad_gemm_desc* d, void* stream) {
         APAD_CHECK(d->N % 8 == 0 && d->ldo % 8 == 0, "apad_gemm: N and ldo must be multiples of 8");
         if (d->residual) APAD_CHECK(d->ldr % 8 == 0, "apad_gemm: ldr must be a multiple of 8");
         if (d->epilogue == APAD_EPI_GEGLU) APAD_CHECK(d->N % 64 == 0, "apad_gemm: GEGLU needs N %% 64 == 0");
+    } else if (d->out_mode == APAD_OUT_QKV) {
+        APAD_CHECK(d->out2 && d->out3 && al16(d->out2) && al16(d->out3), "apad_gemm: APAD_OUT_QKV needs 16-byte aligned out2 / out3");
+        APAD_CHECK(d->heads > 0 && d->head_dim > 0 && d->L > 0 && d->Lpad >= d->L && d->N == 3LL * d->heads * d->head_dim &&
+                       d->M % d->L == 0 && (d->N / 3) % 128 == 0 && d->ldo % 8 == 0,
+                   "apad_gemm: fused q|k|v geometry inconsistent (needs C %% 128 == 0)");
+        APAD_CHECK(!d->residual, "apad_gemm: fused q|k|v takes no residual");
     } else if (d->out_mode == APAD_OUT_VT) {
         APAD_CHECK(d->heads > 0 && d->head_dim > 0 && d->L > 0 && d->Lpad >= d->L && d->N == (int64_t)d->heads * d->head_dim &&
                        d->M % d->L == 0,

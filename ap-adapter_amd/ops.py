@@ -128,6 +128,24 @@ def linear_vt(x, w, B, Lk, heads, out_vt, bias=None):
     return out_vt
 
 
+def linear_qkv(x, w_qkv, B, Lk, heads, q, k, vt, bias=None):
+    """Fused q|k|v projection on the tiled kernel (any K): x [B*Lk, K] @ w_qkv[3C, K]^T -> q, k [B*Lk, C] row-major and
+    vt [B, heads, d, Lpad] per-head transposed, one launch."""
+    _req(x, "linear_qkv.x", w_qkv.dtype)
+    K = x.shape[-1]
+    C3 = w_qkv.shape[0]
+    Cc = C3 // 3
+    x2 = x.reshape(B * Lk, K)
+    d = L.GemmDesc()
+    d.a, d.w, d.out, d.out2, d.out3 = x2.data_ptr(), w_qkv.data_ptr(), q.data_ptr(), k.data_ptr(), vt.data_ptr()
+    d.bias = _ptr(bias)
+    d.M, d.N, d.K, d.lda, d.ldw, d.ldo = B * Lk, C3, K, x2.stride(0), w_qkv.stride(0), Cc
+    d.a_mode, d.epilogue, d.out_mode, d.dtype = L.A_PLAIN, L.EPI_NONE, L.OUT_QKV, _DT[w_qkv.dtype]
+    d.heads, d.head_dim, d.L, d.Lpad = heads, Cc // heads, Lk, vt.shape[-1]
+    L.check(L.lib().apad_gemm(C.byref(d), _stream()), "apad_gemm(qkv)")
+    return q, k, vt
+
+
 def conv3x3(x, w_packed, bias, B, Hin, Win, stride=1, up=None, residual=None, rowgroup_bias=None, rows_per_group=0,
             step_ptr=None, src_batch_mod=0, out=None):
     """NHWC implicit-GEMM 3x3 convolution, padding 1.  x [Bsrc, Hin*Win, Cin]; w_packed [Cout, 9*Cin] in
@@ -209,7 +227,7 @@ def group_norm(x, gamma, beta, groups, eps, silu=False, out=None):
     """x [B, HW, C] (NHWC)."""
     _req(x, "group_norm.x", gamma.dtype)
     B, HW, Cc = x.shape
-    key = (x.device, B, HW, groups)
+    key = (x.device, B, HW, groups, torch.cuda.current_stream().cuda_stream)
     ws = _gn_ws.get(key)
     if ws is None:
         ws = torch.empty(L.lib().apad_groupnorm_workspace_bytes(B, HW, groups) // 4, dtype=torch.float32, device=x.device)

@@ -25,7 +25,8 @@ def vt_buffer(slot, B, heads, d, Lk, dtype, device):
     """Zero-padded V^T scratch [B, heads, d, round_up(Lk,32)].  The pad columns are never written (apad_gemm
     APAD_OUT_VT stores l < Lk only), so buffers are shared by shape across attention sites."""
     Lpad = ops.round_up(Lk, 32)
-    key = (slot, B, heads, d, Lpad, dtype, device)
+    # per stream: the denoise step may run the two CFG halves concurrently on two streams
+    key = (slot, B, heads, d, Lpad, dtype, device, torch.cuda.current_stream().cuda_stream)
     buf = _vt_pool.get(key)
     if buf is None:
         buf = torch.zeros(B, heads, d, Lpad, dtype=dtype, device=device)
@@ -100,6 +101,13 @@ class AttnProcessor2_0(nn.Module):
                 vt = vt_buffer("self", B, heads, C_ // heads, N, hidden_states.dtype, hidden_states.device)
                 ops.rowpanel(hidden_states, self._qkv_weight(attn), [(q, None, C_, "row"), (k, None, C_, "row"), (vt, None, C_, "vt")],
                              ln=_ln, vt_geom=(heads, C_ // heads, N, vt.shape[-1]))
+            elif attn.to_q.weight.shape[0] == C_ and C_ % 128 == 0:
+                # widths outside the row-panel envelope (the 640-wide level): LayerNorm, then q|k|v in ONE tiled launch
+                hs = hidden_states if _ln is None else ops.layer_norm(hidden_states, *_ln)
+                q = torch.empty(B, N, C_, dtype=hidden_states.dtype, device=hidden_states.device)
+                k = torch.empty_like(q)
+                vt = vt_buffer("self", B, heads, C_ // heads, N, hidden_states.dtype, hidden_states.device)
+                ops.linear_qkv(hs, self._qkv_weight(attn), B, N, heads, q, k, vt)
             else:
                 hs = hidden_states if _ln is None else ops.layer_norm(hidden_states, *_ln)
                 q = ops.linear(hs, attn.to_q.weight)
@@ -110,12 +118,15 @@ class AttnProcessor2_0(nn.Module):
             if ehs.dim() < 3:
                 ehs = ehs.unsqueeze(0)
             Lk = ehs.shape[1]
-            if self.kv_cache_enabled and self._kv_cache is not None:
-                k, vt = self._kv_cache
+            ck = (ehs.data_ptr(), tuple(ehs.shape))
+            if self.kv_cache_enabled and self._kv_cache is not None and ck in self._kv_cache:
+                k, vt = self._kv_cache[ck]
             else:
                 k, vt = self._project_kv(attn, ehs, None if self.kv_cache_enabled else "cross")
                 if self.kv_cache_enabled:
-                    self._kv_cache = (k, vt)
+                    if self._kv_cache is None:
+                        self._kv_cache = {}
+                    self._kv_cache[ck] = (k, vt)
         bias = _key_bias(attention_mask, B, Lk)
         o = ops.attention(q, k, vt, Lk, heads, key_bias=bias)
         out = ops.fused_linear(o, attn.to_out[0].weight, attn.to_out[0].bias, residual=_residual)
@@ -193,12 +204,15 @@ class IPAttnProcessor2_0(nn.Module):
             ehs = ehs.unsqueeze(0)
         B, N, _ = hidden_states.shape
         q = ops.fused_linear(hidden_states, attn.to_q.weight, ln=_ln)
-        if self.kv_cache_enabled and self._kv_cache is not None:
-            kv = self._kv_cache
+        ck = (ehs.data_ptr(), tuple(ehs.shape))
+        if self.kv_cache_enabled and self._kv_cache is not None and ck in self._kv_cache:
+            kv = self._kv_cache[ck]
         else:
             kv = self._project(attn, ehs)
             if self.kv_cache_enabled:
-                self._kv_cache = kv
+                if self._kv_cache is None:
+                    self._kv_cache = {}
+                self._kv_cache[ck] = kv
         k_t, vt_t, Lt, k_a, vt_a, La = kv
         bias = None
         if attention_mask is not None:

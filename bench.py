@@ -141,6 +141,7 @@ def main():
     ap.add_argument("--la", type=int, default=32, help="audio tokens (32 = style_transfer preset, pooling 4x4)")
     ap.add_argument("--guidance", type=float, default=9.5)
     ap.add_argument("--ap-scale", type=float, default=0.55)
+    ap.add_argument("--streams", type=int, default=1, help="2 = run the two CFG halves on concurrent streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=1)
     args = ap.parse_args()
@@ -177,8 +178,25 @@ def main():
     unet.set_kv_cache(True)
     unet.precompute_time_tables(sched.timesteps.to(dev), step_ptr)
 
+    side = [torch.cuda.Stream() for _ in range(2)] if args.streams == 2 else None
+    eps_buf = torch.empty(2 * B, H * W, Cc, dtype=dtype, device=dev)
+    ge_h, pe_h, am_h = ge.chunk(2), pe.chunk(2), am.chunk(2)
+
     def step():
-        eps2 = unet.forward_nhwc(unet_in, H, W, None, ge, pe, None, am, batch_repeat=2)
+        if side is None:
+            eps2 = unet.forward_nhwc(unet_in, H, W, None, ge, pe, None, am, batch_repeat=2)
+        else:
+            # the unconditional and the conditional half of the CFG batch are independent until the combine: run them
+            # as two concurrent streams (forked / joined inside the captured graph) so that one half's latency-bound
+            # phases overlap the other half's compute
+            cur = torch.cuda.current_stream()
+            for i, s in enumerate(side):
+                s.wait_stream(cur)
+                with torch.cuda.stream(s):
+                    eps_buf[i * B:(i + 1) * B].copy_(unet.forward_nhwc(unet_in, H, W, None, ge_h[i], pe_h[i], None, am_h[i]))
+            for s in side:
+                cur.wait_stream(s)
+            eps2 = eps_buf
         ops.cfg_ddim_step(eps2, lat, unet_in, coef, step_ptr, args.guidance)
         ops.step_advance(step_ptr)
 

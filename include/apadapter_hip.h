@@ -53,8 +53,10 @@ enum { APAD_EPI_NONE = 0, APAD_EPI_SILU = 1, APAD_EPI_GELU = 2, APAD_EPI_GEGLU =
 /* apad_gemm_desc.out_mode */
 enum {
     APAD_OUT_ROWMAJOR = 0, /* out[m*ldo + n]                                                          */
-    APAD_OUT_VT = 1        /* per-head transposed values for apad_attention: m=(b,l), n=(h,dd) ->
+    APAD_OUT_VT = 1,       /* per-head transposed values for apad_attention: m=(b,l), n=(h,dd) ->
                               out[((b*heads + h)*head_dim + dd)*Lpad + l]                               */
+    APAD_OUT_QKV = 2       /* fused q|k|v projection (N = 3*heads*head_dim): columns [0,C) -> out (row-major,
+                              ldo), [C,2C) -> out2 (row-major, ldo), [2C,3C) -> out3 as APAD_OUT_VT            */
 };
 
 typedef struct apad_gemm_desc {
@@ -78,8 +80,10 @@ typedef struct apad_gemm_desc {
     int32_t Hup, Wup;          /* 0 = no upsample; else nearest upsample of source to (Hup,Wup)        */
     int32_t src_batch_mod;     /* 0 = off; else source batch = b % src_batch_mod (CFG duplication)     */
     int32_t residual_row_mod;  /* 0 = off; else residual row = m % residual_row_mod (e.g. pos_embed)    */
-    /* APAD_OUT_VT */
+    /* APAD_OUT_VT / APAD_OUT_QKV */
     int32_t heads, head_dim, L, Lpad;
+    void* out2;                /* APAD_OUT_QKV: k output                                                */
+    void* out3;                /* APAD_OUT_QKV: v^T output                                              */
 } apad_gemm_desc;
 
 typedef struct apad_attn_desc {

@@ -361,3 +361,20 @@ def test_rowpanel_fused_qkv_with_vt(dev, dtype, B, L, K, heads):
     assert rel_err(vt[..., :L], ref_vt) < TOL[dtype]
     if Lpad > L:
         assert float(vt[..., L:].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,L,K,heads", [(2, 64, 640, 8), (3, 100, 128, 4), (64, 64, 640, 8)])
+def test_tiled_fused_qkv(dev, dtype, B, L, K, heads):
+    from ap_adapter_amd import ops
+    M, d = B * L, K // heads
+    x, w = q(R(M, K, seed=70), dtype), q(R(3 * K, K, seed=71, std=0.05), dtype)
+    y = F.linear(x, w)
+    qo = torch.empty(M, K, dtype=dtype, device=dev)
+    ko = torch.empty(M, K, dtype=dtype, device=dev)
+    Lpad = ops.round_up(L, 32)
+    vt = torch.zeros(B, heads, d, Lpad, dtype=dtype, device=dev)
+    ops.linear_qkv(x.to(dev, dtype), w.to(dev, dtype), B, L, heads, qo, ko, vt)
+    assert rel_err(qo, y[:, :K]) < TOL[dtype]
+    assert rel_err(ko, y[:, K:2 * K]) < TOL[dtype]
+    assert rel_err(vt[..., :L], y[:, 2 * K:].view(B, L, heads, d).permute(0, 2, 3, 1)) < TOL[dtype]
