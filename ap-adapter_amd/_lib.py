@@ -51,6 +51,11 @@ class RpDesc(C.Structure):
                [(n, _i32) for n in ("heads", "head_dim", "L", "Lpad")] + [("seg", RpSegment * 3)]
 
 
+class MlpDesc(C.Structure):
+    _fields_ = [(n, _vp) for n in ("x", "ln_gamma", "ln_beta", "w1", "b1", "w2", "b2", "out")] + \
+               [("M", _i64), ("C", _i32), ("dtype", _i32), ("ln_eps", _f32), ("reserved", _i32)]
+
+
 # name -> (restype, argtypes); every symbol include/apadapter_hip.h declares
 SYMBOLS = {
     "apad_last_error": (C.c_char_p, []),
@@ -62,6 +67,9 @@ SYMBOLS = {
     "apad_sizeof_rp_desc": (C.c_int, []),
     "apad_echo_rp_desc": (C.c_int, [C.POINTER(RpDesc), C.POINTER(C.c_double), C.c_int]),
     "apad_rowpanel_gemm": (C.c_int, [C.POINTER(RpDesc), _vp]),
+    "apad_sizeof_mlp_desc": (C.c_int, []),
+    "apad_echo_mlp_desc": (C.c_int, [C.POINTER(MlpDesc), C.POINTER(C.c_double), C.c_int]),
+    "apad_geglu_mlp": (C.c_int, [C.POINTER(MlpDesc), _vp]),
     "apad_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "apad_attention": (C.c_int, [C.POINTER(AttnDesc), _vp]),
     "apad_layernorm": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _i64, _f32, _i32, _vp]),
@@ -108,7 +116,8 @@ def lib():
             if h.apad_abi_version() != 1:
                 raise RuntimeError("libapadapter_hip.so ABI version mismatch")
             if h.apad_sizeof_gemm_desc() != C.sizeof(GemmDesc) or h.apad_sizeof_attn_desc() != C.sizeof(AttnDesc) \
-                    or h.apad_sizeof_rp_desc() != C.sizeof(RpDesc):
+                    or h.apad_sizeof_rp_desc() != C.sizeof(RpDesc) \
+                    or h.apad_sizeof_mlp_desc() != C.sizeof(MlpDesc):
                 raise RuntimeError("descriptor layout mismatch between include/apadapter_hip.h and _lib.py")
             _lib = h
     return _lib

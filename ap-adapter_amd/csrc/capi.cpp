@@ -68,3 +68,11 @@ extern "C" int apad_echo_rp_desc(const apad_rp_desc* d, double* out, int cap) {
     }
     return n;
 }
+
+extern "C" int apad_sizeof_mlp_desc(void) { return (int)sizeof(apad_mlp_desc); }
+extern "C" int apad_echo_mlp_desc(const apad_mlp_desc* d, double* out, int cap) {
+    int n = 0;
+    PUTP(d->x); PUTP(d->ln_gamma); PUTP(d->ln_beta); PUTP(d->w1); PUTP(d->b1); PUTP(d->w2); PUTP(d->b2); PUTP(d->out);
+    PUT(d->M); PUT(d->C); PUT(d->dtype); PUT(d->ln_eps); PUT(d->reserved);
+    return n;
+}

@@ -1,0 +1,283 @@
+// apad_geglu_mlp: the whole feed-forward of a BasicTransformerBlock in ONE kernel:
+//     out = x + W2 . ( value * gelu(gate) ) + b2,   [value | gate] = W1 . LayerNorm(x) + b1        (diffusers FeedForward/GEGLU)
+// The 8C-wide projection and the 4C-wide activation never exist in memory: per 16 hidden units the kernel runs the
+// first GEMM (K = C, x fragments resident in registers, LayerNorm applied in registers), forms value*gelu(gate) in
+// registers, and immediately feeds it -- still in registers -- to the second GEMM as its B operand: the C-layout of the
+// first MFMA (lane = token, registers = hidden units (r&3)+8(r>>2)+4*half) IS a valid B-operand layout of the second
+// MFMA as long as the W2 fragment is read with the same hidden-unit permutation (two 8-byte pieces per lane) -- the same
+// trick apad_attention uses for P.V.  Accumulators of the output (C/32 MFMA tiles) stay in registers for the whole pass.
+//
+// Per workgroup: NWV waves x 32 tokens.  W1 (16 value + 16 gate rows) and W2 (C rows x 16 hidden) tiles of the current
+// chunk are staged through double-buffered LDS by all threads, one chunk ahead.  The kernel needs ~330 VGPRs (x panel
+// 64-96 + output accumulators 128-192 + pipeline), so it runs one wave per SIMD by design; what it removes is the
+// 2 x 131 MB (C=256, 64 samples) round trip of the activation through HBM, one launch, and two LayerNorm/GEMM passes.
+#include "rp_shared.h"
+
+// Optional scheduler hint (VALU instructions requested after each first-GEMM MFMA); 0 = leave it to the scheduler,
+// which measured fastest (183 us vs 192 / 196 us at 6 / 10, M = 64000).
+#ifndef MLP_VALU_PER_MFMA
+#define MLP_VALU_PER_MFMA 0
+#endif
+
+namespace {
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+template <int KC> struct MlpCfg {
+    static constexpr int C = KC * 16, CT = C / 32, HID = 4 * C, NCHUNK = HID / 16;
+    static constexpr int ROWB1 = Cfg<KC>::ROWB;        // W1 tile row stride (K*2 + 16 bytes)
+    static constexpr int W1_BYTES = 32 * ROWB1;
+    static constexpr int ROWB2 = 40;                   // W2 tile row: 16 hidden units (32 B) + 8 B pad (conflict-free b64 reads)
+    static constexpr int W2_BYTES = C * ROWB2;
+    static constexpr int STAGE = W1_BYTES + W2_BYTES;
+};
+
+struct MlpP {
+    const uint8_t* x;
+    const uint8_t* gamma;
+    const uint8_t* beta;
+    const uint8_t* w1;
+    const uint8_t* b1;
+    const uint8_t* w2;
+    const uint8_t* b2;
+    uint8_t* out;
+    int64_t M;
+    float eps;
+};
+
+template <int DT, int KC, int NWV, bool LN>
+__global__ __launch_bounds__(NWV * 64, 1) void mlp_kernel(MlpP p) {
+    using E = ET<DT>;
+    using G = MlpCfg<KC>;
+    constexpr int NTH = NWV * 64;
+    constexpr int N1 = 32 * KC * 2 / NTH;  // 16-byte chunks per thread, W1 tile
+    constexpr int N2 = G::C * 2 / NTH;     // W2 tile
+    constexpr int NG = KC / 4;             // fragment groups of the first GEMM
+    static_assert(32 * KC * 2 % NTH == 0 && G::C * 2 % NTH == 0, "tiles must split evenly over the workgroup");
+    static_assert(NG == 4, "the GEGLU steps are interleaved one per fragment group: 4 groups <-> 4 x 2 hidden units");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int64_t mw0 = ((int64_t)blockIdx.x * NWV + wave) * 32;
+
+    uint8_t* const w1s = smem;                    // ring of 2 W1 tiles
+    uint8_t* const w2s = smem + 2 * G::W1_BYTES;  // ring of 2 W2 tiles
+    uint8_t* const scr = smem + 2 * G::STAGE + wave * SCR_BYTES;
+    float* const lb1 = reinterpret_cast<float*>(smem + 2 * G::STAGE + NWV * SCR_BYTES);  // [2*HID]: value | gate biases
+    float* const lb2 = lb1 + 2 * G::HID;                                                 // [C]
+
+    // ---- staging helpers (global -> registers -> LDS) ----
+    u32x4 s1[N1], s2[N2];
+    auto load_w1 = [&](int jc) {
+#pragma unroll
+        for (int i = 0; i < N1; ++i) {
+            const int idx = tid + NTH * i;
+            const int j = idx / (2 * KC), ch = idx - j * (2 * KC);
+            const int64_t row = j < 16 ? (int64_t)jc * 16 + j : (int64_t)G::HID + jc * 16 + (j - 16);
+            s1[i] = *reinterpret_cast<const u32x4*>(p.w1 + (row * G::C + ch * 8) * 2);
+        }
+    };
+    auto load_w2 = [&](int jc) {
+#pragma unroll
+        for (int i = 0; i < N2; ++i) {
+            const int idx = tid + NTH * i;
+            const int c = idx >> 1, piece = idx & 1;
+            s2[i] = *reinterpret_cast<const u32x4*>(p.w2 + ((int64_t)c * G::HID + jc * 16 + piece * 8) * 2);
+        }
+    };
+    auto store_w1 = [&](uint8_t* st) {
+#pragma unroll
+        for (int i = 0; i < N1; ++i) {
+            const int idx = tid + NTH * i;
+            const int j = idx / (2 * KC), ch = idx - j * (2 * KC);
+            *reinterpret_cast<u32x4*>(st + j * G::ROWB1 + ch * 16) = s1[i];
+        }
+    };
+    auto store_w2 = [&](uint8_t* st) {
+#pragma unroll
+        for (int i = 0; i < N2; ++i) {
+            const int idx = tid + NTH * i;
+            const int c = idx >> 1, piece = idx & 1;
+            uint8_t* dst = st + c * G::ROWB2 + piece * 16;  // 8-byte aligned rows: two 8-byte stores
+            const u32x2 lo = {s2[i][0], s2[i][1]}, hi = {s2[i][2], s2[i][3]};
+            *reinterpret_cast<u32x2*>(dst) = lo;
+            *reinterpret_cast<u32x2*>(dst + 8) = hi;
+        }
+    };
+    load_w1(0);
+    load_w2(0);
+
+    // ---- biases -> LDS (fp32), x panel -> registers, LayerNorm ----
+    for (int i = tid; i < 2 * G::HID; i += NTH) lb1[i] = p.b1 ? ld_elem<DT>(p.b1, i) : 0.f;
+    for (int i = tid; i < G::C; i += NTH) lb2[i] = p.b2 ? ld_elem<DT>(p.b2, i) : 0.f;
+    typename E::v8 xf[KC];
+    load_panel<DT, KC>(xf, p.x, G::C, p.M, mw0, l31, half);
+    if (LN) layernorm_panel<DT, KC>(xf, p.gamma, p.beta, p.eps, l31, half);
+
+    f32x16 yacc[G::CT];
+#pragma unroll
+    for (int ct = 0; ct < G::CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yacc[ct][r] = 0.f;
+
+    store_w1(w1s);
+    store_w2(w2s);
+    load_w1(1);
+    store_w1(w1s + G::W1_BYTES);
+    __syncthreads();
+
+    // first GEMM of chunk 0 (not overlapped with anything)
+    f32x16 acur;
+    {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acur[r] = 0.f;
+        const uint8_t* wt = w1s + l31 * G::ROWB1 + half * 16;
+        typename E::v8 wf[4][1];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            rp_load_group<DT, KC>(wf, wt, g * 4);
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) acur = E::mfma32(wf[cc][0], xf[g * 4 + cc], acur);
+        }
+    }
+    __syncthreads();  // W1 stage 0 is overwritten at the end of iteration 0
+
+    // Software pipeline: iteration jc runs the first GEMM of chunk jc+1 (matrix pipe) underneath the GEGLU arithmetic
+    // of chunk jc (VALU) -- independent instruction streams of the same wave -- then the second GEMM of chunk jc.
+    // On entry: W1[jc+1] in w1 stage (jc+1)&1, W2[jc] in w2 stage jc&1, acur = first-GEMM accumulators of chunk jc.
+    for (int jc = 0; jc < G::NCHUNK; ++jc) {
+        // tail iterations re-load a valid chunk and run a dead first GEMM: no divergent code paths
+        load_w1(jc + 2 < G::NCHUNK ? jc + 2 : G::NCHUNK - 1);
+        load_w2(jc + 1 < G::NCHUNK ? jc + 1 : G::NCHUNK - 1);
+
+        u32x2 w2lo[G::CT], w2hi[G::CT];
+        {
+            const uint8_t* w2t = w2s + (jc & 1) * G::W2_BYTES + l31 * G::ROWB2 + half * 8;
+#pragma unroll
+            for (int ct = 0; ct < G::CT; ++ct) {
+                w2lo[ct] = *reinterpret_cast<const u32x2*>(w2t + ct * 32 * G::ROWB2);
+                w2hi[ct] = *reinterpret_cast<const u32x2*>(w2t + ct * 32 * G::ROWB2 + 16);
+            }
+        }
+        const int u0 = jc * 16 + 4 * half;
+        const float4 bv0 = *reinterpret_cast<const float4*>(lb1 + u0), bv1 = *reinterpret_cast<const float4*>(lb1 + u0 + 8);
+        const float4 bg0 = *reinterpret_cast<const float4*>(lb1 + G::HID + u0), bg1 = *reinterpret_cast<const float4*>(lb1 + G::HID + u0 + 8);
+        const float bv[8] = {bv0.x, bv0.y, bv0.z, bv0.w, bv1.x, bv1.y, bv1.z, bv1.w};
+        const float bg[8] = {bg0.x, bg0.y, bg0.z, bg0.w, bg1.x, bg1.y, bg1.z, bg1.w};
+
+        f32x16 anxt;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) anxt[r] = 0.f;
+        typename E::v8 hb;
+        const uint8_t* wt = w1s + ((jc + 1) & 1) * G::W1_BYTES + l31 * G::ROWB1 + half * 16;
+        typename E::v8 wfa[4][1], wfb[4][1];
+        rp_load_group<DT, KC>(wfa, wt, 0);
+        // register r (0..7) of acur = value, r+8 = gate of hidden unit jc*16 + (r&3) + 8(r>>2) + 4half
+        auto geglu_step = [&](int r) {
+            // the un-fused reference rounds the projection to the storage type before value * gelu(gate)
+            const float v0 = (float)(typename E::elem)(acur[r] + bv[r]);
+            const float v1 = (float)(typename E::elem)(acur[r + 1] + bv[r + 1]);
+            const apad_f32x2 gt = {(float)(typename E::elem)(acur[8 + r] + bg[r]), (float)(typename E::elem)(acur[9 + r] + bg[r + 1])};
+#ifdef MLP_NOGELU
+            const apad_f32x2 ge = gt;
+#else
+            const apad_f32x2 ge = gelu_erf_2(gt);
+#endif
+            hb[r] = (typename E::elem)(v0 * ge[0]);
+            hb[r + 1] = (typename E::elem)(v1 * ge[1]);
+        };
+#pragma unroll
+        for (int g = 0; g < NG; g += 2) {
+            rp_load_group<DT, KC>(wfb, wt, (g + 1) * 4);
+            rp_pin<DT, KC>(wfa);
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) anxt = E::mfma32(wfa[cc][0], xf[g * 4 + cc], anxt);
+            geglu_step(2 * g);
+            if (g + 2 < NG) rp_load_group<DT, KC>(wfa, wt, (g + 2) * 4);
+            rp_pin<DT, KC>(wfb);
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) anxt = E::mfma32(wfb[cc][0], xf[(g + 1) * 4 + cc], anxt);
+            geglu_step(2 * g + 2);
+        }
+#if MLP_VALU_PER_MFMA > 0
+#pragma unroll
+        for (int i = 0; i < 4 * NG; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, MLP_VALU_PER_MFMA, 0);
+        }
+#endif
+        // ---- second GEMM: y^T[c][token] += W2[c][hidden chunk] . h^T  (A = W2 rows read with the C-layout permutation) ----
+#pragma unroll
+        for (int ct = 0; ct < G::CT; ++ct) asm volatile("" : "+v"(w2lo[ct]), "+v"(w2hi[ct])::"memory");
+#pragma unroll
+        for (int ct = 0; ct < G::CT; ++ct) {
+            typename E::v8 wf = as_v8<DT>(make_uint4(w2lo[ct][0], w2lo[ct][1], w2hi[ct][0], w2hi[ct][1]));
+            yacc[ct] = E::mfma32(wf, hb, yacc[ct]);
+        }
+        store_w1(w1s + (jc & 1) * G::W1_BYTES);
+        store_w2(w2s + ((jc + 1) & 1) * G::W2_BYTES);
+        __syncthreads();
+        acur = anxt;
+    }
+
+    // ---- epilogue: y + b2 + residual(x) through the per-wave transpose scratch ----
+#pragma unroll
+    for (int ct = 0; ct < G::CT; ++ct) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 b4 = *reinterpret_cast<const float4*>(lb2 + ct * 32 + 8 * g + 4 * half);
+            typename E::v4 y;
+            y[0] = (typename E::elem)(yacc[ct][4 * g + 0] + b4.x);
+            y[1] = (typename E::elem)(yacc[ct][4 * g + 1] + b4.y);
+            y[2] = (typename E::elem)(yacc[ct][4 * g + 2] + b4.z);
+            y[3] = (typename E::elem)(yacc[ct][4 * g + 3] + b4.w);
+            *reinterpret_cast<uint2*>(scr + l31 * SCR_ROWB + (8 * g + 4 * half) * 2) = __builtin_bit_cast(uint2, y);
+        }
+        scratch_flush<DT>(scr, 32, p.out, G::C, ct * 32, p.x, G::C, mw0, p.M, lane);
+    }
+}
+
+template <int DT, int KC, int NWV, bool LN> int mlp_launch(const MlpP& p, hipStream_t s) {
+    using G = MlpCfg<KC>;
+    const size_t lds = 2 * G::STAGE + NWV * SCR_BYTES + (2 * G::HID + G::C) * sizeof(float);
+    auto kern = mlp_kernel<DT, KC, NWV, LN>;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    const int64_t rows_per_wg = NWV * 32;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((p.M + rows_per_wg - 1) / rows_per_wg)), dim3(NWV * 64), lds, s, p);
+    return apad_check_launch("apad_geglu_mlp");
+}
+
+template <int DT, int KC> int mlp_dispatch(const MlpP& p, bool ln, hipStream_t s) {
+    // 4 waves (128 tokens) per workgroup when that still fills the chip, else 2 waves
+    const bool big = (p.M + 127) / 128 >= 256;
+    if (big) return ln ? mlp_launch<DT, KC, 4, true>(p, s) : mlp_launch<DT, KC, 4, false>(p, s);
+    return ln ? mlp_launch<DT, KC, 2, true>(p, s) : mlp_launch<DT, KC, 2, false>(p, s);
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int apad_geglu_mlp(const apad_mlp_desc* d, void* stream) {
+    APAD_CHECK(d != nullptr, "apad_geglu_mlp: null descriptor");
+    APAD_CHECK(d->dtype == APAD_BF16 || d->dtype == APAD_F16, "apad_geglu_mlp: dtype %d not supported", d->dtype);
+    APAD_CHECK(d->x && d->w1 && d->w2 && d->out && d->M > 0, "apad_geglu_mlp: null operand / empty problem");
+    APAD_CHECK(al16(d->x) && al16(d->w1) && al16(d->w2) && al16(d->out) && al16(d->ln_gamma) && al16(d->ln_beta),
+               "apad_geglu_mlp: pointers must be 16-byte aligned");
+    if (d->C != 256) {
+        apad_set_error("apad_geglu_mlp: C=%d outside the kernel envelope (256)", d->C);
+        return -3;
+    }
+    const bool ln = d->ln_gamma != nullptr;
+    if (ln) APAD_CHECK(d->ln_beta != nullptr, "apad_geglu_mlp: LayerNorm needs gamma and beta");
+    MlpP p;
+    p.x = (const uint8_t*)d->x; p.gamma = (const uint8_t*)d->ln_gamma; p.beta = (const uint8_t*)d->ln_beta;
+    p.w1 = (const uint8_t*)d->w1; p.b1 = (const uint8_t*)d->b1; p.w2 = (const uint8_t*)d->w2; p.b2 = (const uint8_t*)d->b2;
+    p.out = (uint8_t*)d->out; p.M = d->M; p.eps = d->ln_eps;
+    hipStream_t s = (hipStream_t)stream;
+    return d->dtype == APAD_BF16 ? mlp_dispatch<APAD_BF16, 16>(p, ln, s) : mlp_dispatch<APAD_F16, 16>(p, ln, s);
+}

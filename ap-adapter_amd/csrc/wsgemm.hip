@@ -23,50 +23,6 @@ template <int KC> struct WsCfg {
     static constexpr bool PREFETCH = (KC <= 16);       // second x panel in registers only fits at K=256
 };
 
-template <int DT, int KC>
-__device__ __forceinline__ void load_panel(typename ET<DT>::v8 (&xf)[KC], const uint8_t* x, int64_t lda, int64_t M, int64_t mw0,
-                                           int l31, int half) {
-    int64_t mrow = mw0 + l31;
-    mrow = mrow < M ? mrow : M - 1;
-    const uint8_t* xp = x + (mrow * lda + half * 8) * 2;
-#pragma unroll
-    for (int c = 0; c < KC; ++c) xf[c] = as_v8<DT>(*reinterpret_cast<const uint4*>(xp + c * 32));
-}
-
-template <int DT, int KC>
-__device__ __forceinline__ void layernorm_panel(typename ET<DT>::v8 (&xf)[KC], const uint8_t* gamma, const uint8_t* beta, float eps,
-                                                int l31, int half) {
-    using E = ET<DT>;
-    // single statistics pass, shifted by the row's first element (both halves of the row use the same shift)
-    const float shift = __shfl((float)xf[0][0], l31, 64);
-    float s = 0.f, q = 0.f;
-#pragma unroll
-    for (int c = 0; c < KC; ++c) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float d = (float)xf[c][j] - shift;
-            s += d;
-            q += d * d;
-        }
-        asm volatile("" : "+v"(s), "+v"(q));  // evaluate chunk by chunk: bounds the live converted values
-    }
-    s += __shfl_xor(s, 32, 64);
-    q += __shfl_xor(q, 32, 64);
-    const float md = s * (1.0f / (KC * 16));
-    const float mean = shift + md;
-    const float var = fmaxf(q * (1.0f / (KC * 16)) - md * md, 0.f);
-    const float rstd = rsqrtf(var + eps);
-    const float nmr = -mean * rstd;
-#pragma unroll
-    for (int c = 0; c < KC; ++c) {
-        typename E::v8 g = as_v8<DT>(*reinterpret_cast<const uint4*>(gamma + (c * 16 + half * 8) * 2));
-        typename E::v8 b = as_v8<DT>(*reinterpret_cast<const uint4*>(beta + (c * 16 + half * 8) * 2));
-#pragma unroll
-        for (int j = 0; j < 8; ++j) xf[c][j] = (typename E::elem)(((float)xf[c][j] * rstd + nmr) * (float)g[j] + (float)b[j]);
-        asm volatile("" : "+v"(xf[c]) : : "memory");
-    }
-}
-
 template <int DT, int KC, bool LN, bool GEGLU>
 __global__ __launch_bounds__(512) void wsgemm_kernel(RpP p) {
     using E = ET<DT>;

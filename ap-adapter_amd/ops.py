@@ -116,6 +116,29 @@ def fused_linear(x, w, bias=None, ln=None, residual=None, act=None, out=None):
     return linear(x, w, bias, residual=residual, act=act, out=out)
 
 
+MLP_C = (256,)  # envelope of apad_geglu_mlp
+
+
+def geglu_mlp(x, w1, b1, w2, b2, ln=None, out=None):
+    """out = x + W2 . (value * gelu(gate)) + b2 with [value|gate] = W1 . LayerNorm(x) + b1 -- the whole FeedForward of a
+    BasicTransformerBlock plus its residual in one launch (C in MLP_C)."""
+    _req(x, "geglu_mlp.x", w1.dtype)
+    Cc = x.shape[-1]
+    if Cc not in MLP_C or w1.shape != (8 * Cc, Cc) or w2.shape != (Cc, 4 * Cc):
+        raise ValueError(f"geglu_mlp: C={Cc}, w1 {tuple(w1.shape)}, w2 {tuple(w2.shape)} outside the kernel envelope")
+    if not (x.is_contiguous() and w1.is_contiguous() and w2.is_contiguous()):
+        raise ValueError("geglu_mlp: operands must be contiguous")
+    if out is None:
+        out = torch.empty_like(x)
+    d = L.MlpDesc()
+    d.x, d.w1, d.b1, d.w2, d.b2, d.out = x.data_ptr(), w1.data_ptr(), _ptr(b1), w2.data_ptr(), _ptr(b2), out.data_ptr()
+    if ln is not None:
+        d.ln_gamma, d.ln_beta, d.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), float(ln[2])
+    d.M, d.C, d.dtype = x.numel() // Cc, Cc, _DT[w1.dtype]
+    L.check(L.lib().apad_geglu_mlp(C.byref(d), _stream()), "apad_geglu_mlp")
+    return out
+
+
 def linear_vt(x, w, B, Lk, heads, out_vt, bias=None):
     """Values projection stored per-head transposed: x [B*Lk, K] @ w[C,K]^T -> out_vt [B, heads, d, Lpad]
     (zero padded by the caller; only l < Lk is written)."""

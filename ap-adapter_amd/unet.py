@@ -7,6 +7,7 @@ modules are used as PARAMETER CONTAINERS only; every forward below calls the C A
 token-major NHWC activations ``[B, H*W, C]`` (so Transformer2DModel's permute/reshape is free and the 3x3
 convolutions run as implicit GEMMs).  There is no PyTorch compute fallback.
 """
+import os
 from dataclasses import dataclass, field
 from typing import Dict, Optional, Tuple
 
@@ -144,7 +145,11 @@ class FeedForward(nn.Module):
         self.net = nn.ModuleList([GEGLU(dim, dim * 4), nn.Dropout(0.0), nn.Linear(dim * 4, dim)])
 
     def forward(self, x, ln):
-        """x un-normalised; ln = norm3.  LayerNorm + GEGLU projection in one launch, then the 4C->C GEMM + residual."""
+        """x un-normalised; ln = norm3.  C in ops.MLP_C: the whole feed-forward + residual in one launch (the 4C-wide
+        activation never reaches HBM); otherwise LayerNorm + GEGLU projection in one launch, then the 4C->C GEMM +
+        residual."""
+        if x.shape[-1] in ops.MLP_C and os.environ.get("APAD_FUSED_MLP", "1") != "0":
+            return ops.geglu_mlp(x, self.net[0].proj.weight, self.net[0].proj.bias, self.net[2].weight, self.net[2].bias, ln=ln)
         h = ops.fused_linear(x, self.net[0].proj.weight, self.net[0].proj.bias, ln=ln, act="geglu")
         return ops.linear(h, self.net[2].weight, self.net[2].bias, residual=x)
 

@@ -137,6 +137,24 @@ typedef struct apad_rp_desc {
     apad_rp_segment seg[3];
 } apad_rp_desc;
 
+/* Fused feed-forward of a BasicTransformerBlock (diffusers FeedForward with GEGLU, dropout 0):
+ *     out = x + W2 . (value * gelu(gate)) + b2,   [value | gate] = W1 . LayerNorm(x) + b1
+ * in one kernel; the 8C projection and the 4C activation never leave registers.  C in {256, 384} (else -3). */
+typedef struct apad_mlp_desc {
+    const void* x;        /* [M][C]: un-normalised hidden states, also the residual                         */
+    const void* ln_gamma; /* [C] or NULL (no LayerNorm)                                                     */
+    const void* ln_beta;
+    const void* w1;       /* [8C][C]: GEGLU.proj weight, value rows then gate rows                          */
+    const void* b1;       /* [8C] or NULL                                                                   */
+    const void* w2;       /* [C][4C]: FeedForward.net[2] weight                                             */
+    const void* b2;       /* [C] or NULL                                                                    */
+    void* out;            /* [M][C]; may alias x                                                            */
+    int64_t M;
+    int32_t C, dtype;
+    float ln_eps;
+    int32_t reserved;
+} apad_mlp_desc;
+
 const char* apad_last_error(void);
 int apad_abi_version(void);
 /* size of the descriptor structs as compiled, for binding self-checks */
@@ -148,11 +166,15 @@ int apad_echo_gemm_desc(const apad_gemm_desc* d, double* out, int cap);
 int apad_echo_attn_desc(const apad_attn_desc* d, double* out, int cap);
 int apad_sizeof_rp_desc(void);
 int apad_echo_rp_desc(const apad_rp_desc* d, double* out, int cap);
+int apad_sizeof_mlp_desc(void);
+int apad_echo_mlp_desc(const apad_mlp_desc* d, double* out, int cap);
 
 int apad_gemm(const apad_gemm_desc* d, void* stream);
 int apad_attention(const apad_attn_desc* d, void* stream);
 /* returns -3 (and sets the error text) when the shape is outside the kernel's envelope; callers then use apad_gemm */
 int apad_rowpanel_gemm(const apad_rp_desc* d, void* stream);
+/* returns -3 when C is outside {256, 384}; callers then use apad_rowpanel_gemm / apad_gemm for the two halves */
+int apad_geglu_mlp(const apad_mlp_desc* d, void* stream);
 
 int apad_layernorm(const void* x, const void* gamma, const void* beta, void* out, int64_t M, int32_t C,
                    int64_t ldx, int64_t ldo, float eps, int32_t dtype, void* stream);

@@ -339,6 +339,37 @@ def test_rowpanel_geglu(dev, dtype, M, K, ln):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,C", [(1000, 256), (300, 256), (33000, 256), (37, 256)])
+@pytest.mark.parametrize("ln", [False, True])
+def test_geglu_mlp(dev, dtype, M, C, ln):
+    """norm3 + GEGLU + FeedForward.net[2] + residual in one launch (both workgroup sizes, ragged last panel)"""
+    from ap_adapter_amd import ops
+    x = q(R(M, C, seed=156), dtype)
+    w1, b1 = q(R(8 * C, C, seed=157, std=0.08), dtype), q(R(8 * C, seed=158, std=0.5), dtype)
+    w2, b2 = q(R(C, 4 * C, seed=159, std=0.04), dtype), q(R(C, seed=160, std=0.5), dtype)
+    g, be = q(1 + 0.1 * R(C, seed=161), dtype), q(0.1 * R(C, seed=162), dtype)
+    xin = q(F.layer_norm(x, (C,), g, be, 1e-5), dtype) if ln else x
+    a, gate = F.linear(xin, w1, b1).chunk(2, dim=-1)
+    ref = x + F.linear(a * F.gelu(gate), w2, b2)
+    lnp = (g.to(dev, dtype), be.to(dev, dtype), 1e-5) if ln else None
+    xd = x.to(dev, dtype)
+    out = ops.geglu_mlp(xd, w1.to(dev, dtype), b1.to(dev, dtype), w2.to(dev, dtype), b2.to(dev, dtype), ln=lnp)
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < TOL[dtype]
+    # in place (out aliases x) gives the same bits
+    out2 = ops.geglu_mlp(xd, w1.to(dev, dtype), b1.to(dev, dtype), w2.to(dev, dtype), b2.to(dev, dtype), ln=lnp, out=xd)
+    assert torch.equal(out2, out)
+
+
+def test_geglu_mlp_outside_envelope_is_an_error(dev):
+    from ap_adapter_amd import ops
+    x = torch.zeros(64, 384, device=dev, dtype=torch.bfloat16)
+    with pytest.raises(ValueError):
+        ops.geglu_mlp(x, torch.zeros(3072, 384, device=dev, dtype=torch.bfloat16), None,
+                      torch.zeros(384, 1536, device=dev, dtype=torch.bfloat16), None)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,L,K,heads", [(2, 1000, 256, 8), (3, 252, 384, 8), (2, 100, 256, 4), (1, 513, 384, 12), (2, 63, 256, 8)])
 def test_rowpanel_fused_qkv_with_vt(dev, dtype, B, L, K, heads):
     """LayerNorm + q|k|v in one launch; V per-head transposed (incl. token counts that are not multiples of 4)"""

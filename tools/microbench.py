@@ -100,3 +100,19 @@ if "conv" in flt or not flt:
         ms = timeit(lambda: ops.conv3x3(x, w, b, B2, H, W, stride=stride))
         Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
         report(f"conv3x3 {H}x{W} {Cin}->{Cout} s{stride}", ms, 2.0 * B2 * Ho * Wo * 9 * Cin * Cout, 2.0 * (B2 * H * W * Cin + B2 * Ho * Wo * Cout))
+
+if "mlp" in flt or not flt:
+    for N, C in LEVELS[:1]:
+        M = B2 * N
+        x = R(M, C)
+        w1 = R(8 * C, C, std=0.02); b1 = R(8 * C, std=0.02); w2 = R(C, 4 * C, std=0.02); b2 = R(C, std=0.02)
+        g = R(C); be = R(C); out = torch.empty(M, C, device=dev, dtype=dt)
+        hbuf = torch.empty(M, 4 * C, device=dev, dtype=dt)
+        ms = timeit(lambda: ops.geglu_mlp(x, w1, b1, w2, b2, ln=(g, be, 1e-5), out=out))
+        report(f"fused mlp LN+GEGLU+FF2+res M={M} C={C}", ms, 2.0 * M * 12 * C * C, 2.0 * (2 * M * C + 12 * C * C))
+
+        def two():
+            ops.fused_linear(x, w1, b1, ln=(g, be, 1e-5), act="geglu", out=hbuf)
+            ops.linear(hbuf, w2, b2, residual=x, out=out)
+        ms = timeit(two)
+        report(f"  two-kernel LN+GEGLU ; FF2+res M={M} C={C}", ms, 2.0 * M * 12 * C * C, 2.0 * (2 * M * C + 12 * C * C + 2 * M * 4 * C))
