@@ -32,7 +32,7 @@ class GemmDesc(C.Structure):
 
 
 class AttnDesc(C.Structure):
-    _fields_ = [(n, _vp) for n in ("q", "k", "vt", "k2", "vt2", "out", "key_bias")] + \
+    _fields_ = [(n, _vp) for n in ("q", "k", "vt", "k2", "vt2", "out", "key_bias", "lse")] + \
                [(n, _i64) for n in ("q_stride_b", "q_stride_n", "k_stride_b", "k_stride_l", "vt_stride_b",
                                     "k2_stride_b", "k2_stride_l", "vt2_stride_b", "o_stride_b", "o_stride_n")] + \
                [(n, _i32) for n in ("B", "N", "H", "D", "L", "Lpad", "L2", "Lpad2", "kv_batch_div", "kv2_batch_div",
@@ -54,6 +54,12 @@ class RpDesc(C.Structure):
 class MlpDesc(C.Structure):
     _fields_ = [(n, _vp) for n in ("x", "ln_gamma", "ln_beta", "w1", "b1", "w2", "b2", "out")] + \
                [("M", _i64), ("C", _i32), ("dtype", _i32), ("ln_eps", _f32), ("reserved", _i32)]
+
+
+class AttnBwdDesc(C.Structure):
+    _fields_ = [(n, _vp) for n in ("q", "k", "v", "qt", "kt", "out", "dout", "doutt", "lse", "key_bias", "delta", "dq", "dk", "dv")] + \
+               [(n, _i32) for n in ("B", "N", "H", "D", "L", "Npad", "Lpad", "dtype")] + \
+               [("softmax_scale", _f32), ("dout_scale", _f32), ("accumulate_dq", _i32), ("reserved", _i32)]
 
 
 # name -> (restype, argtypes); every symbol include/apadapter_hip.h declares
@@ -79,6 +85,22 @@ SYMBOLS = {
     "apad_timestep_embedding": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
     "apad_cfg_ddim_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _i32, _i64, _i32, _vp]),
     "apad_step_advance": (C.c_int, [_vp, _vp]),
+    # training step (a-11)
+    "apad_sizeof_attn_bwd_desc": (C.c_int, []),
+    "apad_echo_attn_bwd_desc": (C.c_int, [C.POINTER(AttnBwdDesc), C.POINTER(C.c_double), C.c_int]),
+    "apad_attention_bwd": (C.c_int, [C.POINTER(AttnBwdDesc), _vp]),
+    "apad_head_transpose": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "apad_layernorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _i32, _vp]),
+    "apad_groupnorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp]),
+    "apad_geglu": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
+    "apad_geglu_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "apad_upsample_nearest_bwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "apad_zero_stuff2": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "apad_transpose_pad": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "apad_reduce_workspace_bytes": (_i64, []),
+    "apad_mse_loss_grad": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "apad_grad_norm": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "apad_adamw_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _vp]),
 }
 
 _lock = threading.Lock()
@@ -113,11 +135,12 @@ def lib():
                 fn = getattr(h, name)  # AttributeError if the ABI lost a symbol
                 fn.restype = res
                 fn.argtypes = args
-            if h.apad_abi_version() != 1:
+            if h.apad_abi_version() != 2:
                 raise RuntimeError("libapadapter_hip.so ABI version mismatch")
             if h.apad_sizeof_gemm_desc() != C.sizeof(GemmDesc) or h.apad_sizeof_attn_desc() != C.sizeof(AttnDesc) \
                     or h.apad_sizeof_rp_desc() != C.sizeof(RpDesc) \
-                    or h.apad_sizeof_mlp_desc() != C.sizeof(MlpDesc):
+                    or h.apad_sizeof_mlp_desc() != C.sizeof(MlpDesc) \
+                    or h.apad_sizeof_attn_bwd_desc() != C.sizeof(AttnBwdDesc):
                 raise RuntimeError("descriptor layout mismatch between include/apadapter_hip.h and _lib.py")
             _lib = h
     return _lib

@@ -34,6 +34,7 @@ struct AttnP {
     const uint8_t* vt2;
     uint8_t* out;
     const float* key_bias;
+    float* lse;
     int64_t q_sb, q_sn, k_sb, k_sl, vt_sb, k2_sb, k2_sl, vt2_sb, o_sb, o_sn;
     int32_t B, N, H, L, Lpad, L2, Lpad2, kvdiv, kvdiv2;
     float scale_log2, scale2;
@@ -283,7 +284,10 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
         segment<DT, D>(smem, kbase, p.k_sl, vbase, p.L, p.Lpad, bias, p.scale_log2, qf, o, osum, m, tid);
     }
     // denominator of query l31 = row 0 of osum = register 0 of the half-0 lane
-    float inv = 1.0f / __shfl(osum[0], l31, 64);
+    const float den = __shfl(osum[0], l31, 64);
+    float inv = 1.0f / den;
+    if (p.lse != nullptr && half == 0 && qvalid)  // log2 sum exp2 of the scaled (+biased) scores: what the backward re-uses
+        p.lse[((int64_t)b * p.H + h) * ((p.N + 31) & ~31) + q0 + l31] = m + __builtin_log2f(den);
 #pragma unroll
     for (int dt = 0; dt < Y::DT_TILES; ++dt)
 #pragma unroll
@@ -396,6 +400,8 @@ extern "C" int apad_attention(const apad_attn_desc* d, void* stream) {
     p.q = (const uint8_t*)d->q; p.k = (const uint8_t*)d->k; p.vt = (const uint8_t*)d->vt;
     p.k2 = (const uint8_t*)d->k2; p.vt2 = (const uint8_t*)d->vt2; p.out = (uint8_t*)d->out;
     p.key_bias = d->key_bias;
+    p.lse = (float*)d->lse;
+    APAD_CHECK(!(dual && d->lse), "apad_attention: lse is only defined for a single softmax segment");
     p.q_sb = d->q_stride_b; p.q_sn = d->q_stride_n; p.k_sb = d->k_stride_b; p.k_sl = d->k_stride_l; p.vt_sb = d->vt_stride_b;
     p.k2_sb = d->k2_stride_b; p.k2_sl = d->k2_stride_l; p.vt2_sb = d->vt2_stride_b; p.o_sb = d->o_stride_b; p.o_sn = d->o_stride_n;
     p.B = d->B; p.N = d->N; p.H = d->H; p.L = d->L; p.Lpad = d->Lpad; p.L2 = d->L2; p.Lpad2 = d->Lpad2;

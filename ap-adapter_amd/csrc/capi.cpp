@@ -48,7 +48,7 @@ extern "C" int apad_echo_gemm_desc(const apad_gemm_desc* d, double* out, int cap
 
 extern "C" int apad_echo_attn_desc(const apad_attn_desc* d, double* out, int cap) {
     int n = 0;
-    PUTP(d->q); PUTP(d->k); PUTP(d->vt); PUTP(d->k2); PUTP(d->vt2); PUTP(d->out); PUTP(d->key_bias);
+    PUTP(d->q); PUTP(d->k); PUTP(d->vt); PUTP(d->k2); PUTP(d->vt2); PUTP(d->out); PUTP(d->key_bias); PUTP(d->lse);
     PUT(d->q_stride_b); PUT(d->q_stride_n); PUT(d->k_stride_b); PUT(d->k_stride_l); PUT(d->vt_stride_b);
     PUT(d->k2_stride_b); PUT(d->k2_stride_l); PUT(d->vt2_stride_b); PUT(d->o_stride_b); PUT(d->o_stride_n);
     PUT(d->B); PUT(d->N); PUT(d->H); PUT(d->D); PUT(d->L); PUT(d->Lpad); PUT(d->L2); PUT(d->Lpad2);
@@ -74,5 +74,15 @@ extern "C" int apad_echo_mlp_desc(const apad_mlp_desc* d, double* out, int cap) 
     int n = 0;
     PUTP(d->x); PUTP(d->ln_gamma); PUTP(d->ln_beta); PUTP(d->w1); PUTP(d->b1); PUTP(d->w2); PUTP(d->b2); PUTP(d->out);
     PUT(d->M); PUT(d->C); PUT(d->dtype); PUT(d->ln_eps); PUT(d->reserved);
+    return n;
+}
+
+extern "C" int apad_sizeof_attn_bwd_desc(void) { return (int)sizeof(apad_attn_bwd_desc); }
+extern "C" int apad_echo_attn_bwd_desc(const apad_attn_bwd_desc* d, double* out, int cap) {
+    int n = 0;
+    PUTP(d->q); PUTP(d->k); PUTP(d->v); PUTP(d->qt); PUTP(d->kt); PUTP(d->out); PUTP(d->dout); PUTP(d->doutt); PUTP(d->lse);
+    PUTP(d->key_bias); PUTP(d->delta); PUTP(d->dq); PUTP(d->dk); PUTP(d->dv);
+    PUT(d->B); PUT(d->N); PUT(d->H); PUT(d->D); PUT(d->L); PUT(d->Npad); PUT(d->Lpad); PUT(d->dtype);
+    PUT(d->softmax_scale); PUT(d->dout_scale); PUT(d->accumulate_dq); PUT(d->reserved);
     return n;
 }

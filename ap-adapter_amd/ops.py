@@ -292,3 +292,170 @@ def cfg_ddim_step(eps2, latents, unet_in, coef, step_ptr, guidance_scale, eps_ou
 
 def step_advance(step_ptr):
     L.check(L.lib().apad_step_advance(step_ptr.data_ptr(), _stream()), "apad_step_advance")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# training step (SURVEY a-11): raw wrappers of the backward / optimizer entry points; autograd.py composes them
+# ---------------------------------------------------------------------------------------------------------------------
+def attention_lse(q, k, vt, Lk, heads, key_bias=None):
+    """single-segment apad_attention that also returns the base-2 log-sum-exp [B, heads, round_up(N, 32)] fp32"""
+    _req(q, "attention_lse.q")
+    B, N, Cc = q.shape
+    out = torch.empty_like(q)
+    lse = torch.zeros(B, heads, round_up(N, 32), dtype=torch.float32, device=q.device)
+    d = L.AttnDesc()
+    d.q, d.k, d.vt, d.out, d.key_bias, d.lse = q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), _ptr(key_bias), lse.data_ptr()
+    d.q_stride_b, d.q_stride_n = q.stride(0), q.stride(1)
+    d.k_stride_b, d.k_stride_l, d.vt_stride_b = k.stride(0), k.stride(1), vt.stride(0)
+    d.o_stride_b, d.o_stride_n = out.stride(0), out.stride(1)
+    d.B, d.N, d.H, d.D = B, N, heads, Cc // heads
+    d.L, d.Lpad, d.L2, d.Lpad2 = Lk, vt.shape[-1], 0, 0
+    d.kv_batch_div, d.kv2_batch_div, d.dtype = 1, 1, _DT[q.dtype]
+    d.softmax_scale, d.scale2 = 1.0 / math.sqrt(Cc // heads), 0.0
+    L.check(L.lib().apad_attention(C.byref(d), _stream()), "apad_attention")
+    return out, lse
+
+
+def head_transpose(x, heads, pad=None):
+    """x [B, N, C] -> [B, heads, C/heads, pad] (zero padded, pad % 32 == 0)"""
+    _req(x, "head_transpose.x")
+    B, N, Cc = x.shape
+    pad = pad or round_up(N, 32)
+    xt = torch.empty(B, heads, Cc // heads, pad, dtype=x.dtype, device=x.device)
+    L.check(L.lib().apad_head_transpose(x.data_ptr(), xt.data_ptr(), B, N, heads, Cc // heads, pad, _DT[x.dtype], _stream()),
+            "apad_head_transpose")
+    return xt
+
+
+def attention_bwd(q, k, v, out, dout, lse, heads, key_bias=None, dout_scale=1.0, need_dkv=True, dq=None):
+    """gradients of one softmax segment; dq given -> accumulated into.  Returns (dq, dk, dv)."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (out, "out"), (dout, "dout")):
+        _req(t, "attention_bwd." + n, q.dtype)
+        if not t.is_contiguous():
+            raise RuntimeError(f"attention_bwd.{n}: must be contiguous")
+    B, N, Cc = q.shape
+    Lk = k.shape[1]
+    Npad, Lpad = round_up(N, 32), round_up(Lk, 32)
+    d = L.AttnBwdDesc()
+    kt = head_transpose(k, heads, Lpad)
+    keep = [kt]
+    d.q, d.k, d.v, d.kt, d.out, d.dout, d.lse = (q.data_ptr(), k.data_ptr(), v.data_ptr(), kt.data_ptr(), out.data_ptr(),
+                                                 dout.data_ptr(), lse.data_ptr())
+    d.key_bias = _ptr(key_bias)
+    delta = torch.zeros(B, heads, Npad, dtype=torch.float32, device=q.device)
+    d.delta = delta.data_ptr()
+    acc = dq is not None
+    if dq is None:
+        dq = torch.empty_like(q)
+    d.dq = dq.data_ptr()
+    dk = dv = None
+    if need_dkv:
+        qt, dot = head_transpose(q, heads, Npad), head_transpose(dout, heads, Npad)
+        dk, dv = torch.empty_like(k), torch.empty_like(v)
+        keep += [qt, dot]
+        d.qt, d.doutt, d.dk, d.dv = qt.data_ptr(), dot.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    d.B, d.N, d.H, d.D, d.L, d.Npad, d.Lpad, d.dtype = B, N, heads, Cc // heads, Lk, Npad, Lpad, _DT[q.dtype]
+    d.softmax_scale, d.dout_scale, d.accumulate_dq = 1.0 / math.sqrt(Cc // heads), float(dout_scale), 1 if acc else 0
+    L.check(L.lib().apad_attention_bwd(C.byref(d), _stream()), "apad_attention_bwd")
+    return dq, dk, dv
+
+
+def layer_norm_bwd(x, gamma, dy, eps):
+    _req(x, "layer_norm_bwd.x", gamma.dtype)
+    Cc = x.shape[-1]
+    dx = torch.empty_like(x)
+    L.check(L.lib().apad_layernorm_bwd(x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel() // Cc, Cc,
+                                       eps, _DT[x.dtype], _stream()), "apad_layernorm_bwd")
+    return dx
+
+
+def group_norm_bwd(x, gamma, beta, dy, groups, eps, silu):
+    _req(x, "group_norm_bwd.x", gamma.dtype)
+    B, HW, Cc = x.shape
+    dx = torch.empty_like(x)
+    L.check(L.lib().apad_groupnorm_bwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), dy.data_ptr(), dx.data_ptr(), B, HW,
+                                       Cc, groups, eps, 1 if silu else 0, _DT[x.dtype], _stream()), "apad_groupnorm_bwd")
+    return dx
+
+
+def geglu(proj):
+    _req(proj, "geglu.proj")
+    N = proj.shape[-1] // 2
+    h = torch.empty(*proj.shape[:-1], N, dtype=proj.dtype, device=proj.device)
+    L.check(L.lib().apad_geglu(proj.data_ptr(), h.data_ptr(), proj.numel() // (2 * N), N, _DT[proj.dtype], _stream()), "apad_geglu")
+    return h
+
+
+def geglu_bwd(proj, dh):
+    N = proj.shape[-1] // 2
+    dproj = torch.empty_like(proj)
+    L.check(L.lib().apad_geglu_bwd(proj.data_ptr(), dh.data_ptr(), dproj.data_ptr(), proj.numel() // (2 * N), N,
+                                   _DT[proj.dtype], _stream()), "apad_geglu_bwd")
+    return dproj
+
+
+def upsample_nearest_bwd(dup, B, H, W, Hup, Wup):
+    Cc = dup.shape[-1]
+    dx = torch.empty(B, H * W, Cc, dtype=dup.dtype, device=dup.device)
+    L.check(L.lib().apad_upsample_nearest_bwd(dup.data_ptr(), dx.data_ptr(), B, H, W, Hup, Wup, Cc, _DT[dup.dtype], _stream()),
+            "apad_upsample_nearest_bwd")
+    return dx
+
+
+def zero_stuff2(dy, B, H, W, Ho, Wo):
+    Cc = dy.shape[-1]
+    z = torch.empty(B, H * W, Cc, dtype=dy.dtype, device=dy.device)
+    L.check(L.lib().apad_zero_stuff2(dy.data_ptr(), z.data_ptr(), B, H, W, Ho, Wo, Cc, _DT[dy.dtype], _stream()), "apad_zero_stuff2")
+    return z
+
+
+def transpose_pad(x, Mpad):
+    """x [M, C] -> [C, Mpad] zero padded"""
+    M, Cc = x.shape
+    xt = torch.empty(Cc, Mpad, dtype=x.dtype, device=x.device)
+    L.check(L.lib().apad_transpose_pad(x.data_ptr(), xt.data_ptr(), M, Cc, Mpad, _DT[x.dtype], _stream()), "apad_transpose_pad")
+    return xt
+
+
+def weight_grad(dy, x):
+    """dW [N, K] = dy[M, N]^T . x[M, K] (the adapter's to_k_ip / to_v_ip gradient), reduction over the M token rows"""
+    M, N = dy.shape
+    K = x.shape[-1]
+    Mpad = round_up(M, 64)
+    dyt, xt = transpose_pad(dy.contiguous(), Mpad), transpose_pad(x.contiguous(), Mpad)
+    out = torch.empty(N, K, dtype=dy.dtype, device=dy.device)
+    gemm(dyt, xt, M=N, N=K, K=Mpad, lda=Mpad, out=out, ldo=K, ldw=Mpad)
+    return out
+
+
+def _reduce_ws(dev):
+    return torch.empty(L.lib().apad_reduce_workspace_bytes() // 4, dtype=torch.float32, device=dev)
+
+
+def mse_loss_grad(pred, target):
+    """(loss fp32 scalar tensor, dpred in pred.dtype) of F.mse_loss(pred.float(), target.float())"""
+    _req(pred, "mse_loss_grad.pred")
+    _req(target, "mse_loss_grad.target", torch.float32)
+    loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+    dpred = torch.empty_like(pred)
+    ws = _reduce_ws(pred.device)
+    L.check(L.lib().apad_mse_loss_grad(pred.data_ptr(), target.data_ptr(), dpred.data_ptr(), loss.data_ptr(), ws.data_ptr(),
+                                       pred.numel(), _DT[pred.dtype], _stream()), "apad_mse_loss_grad")
+    return loss, dpred
+
+
+def grad_norm(grad, out=None, ws=None):
+    _req(grad, "grad_norm.grad", torch.float32)
+    out = out if out is not None else torch.empty(1, dtype=torch.float32, device=grad.device)
+    ws = ws if ws is not None else _reduce_ws(grad.device)
+    L.check(L.lib().apad_grad_norm(grad.data_ptr(), out.data_ptr(), ws.data_ptr(), grad.numel(), _stream()), "apad_grad_norm")
+    return out
+
+
+def adamw_step(param, work, grad, exp_avg, exp_avg_sq, grad_norm_t, step_t, lr, betas, eps, weight_decay, max_grad_norm):
+    for t, n in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _req(t, "adamw_step." + n, torch.float32)
+    L.check(L.lib().apad_adamw_step(param.data_ptr(), _ptr(work), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                                    _ptr(grad_norm_t), step_t.data_ptr(), param.numel(), lr, betas[0], betas[1], eps,
+                                    weight_decay, max_grad_norm if max_grad_norm else 0.0,
+                                    _DT[work.dtype] if work is not None else L.BF16, _stream()), "apad_adamw_step")

@@ -16,6 +16,7 @@ off every call recomputes them exactly like the reference.
 import torch
 import torch.nn as nn
 
+from . import autograd as AG
 from . import ops
 
 _vt_pool = {}
@@ -92,6 +93,8 @@ class AttnProcessor2_0(nn.Module):
             raise ValueError("hidden_states must be [batch, tokens, channels]")
         B, N, C_ = hidden_states.shape
         heads = attn.heads
+        if AG.on(hidden_states, encoder_hidden_states):
+            return self._call_train(attn, hidden_states, encoder_hidden_states, attention_mask, _residual, _ln)
         if encoder_hidden_states is None:
             Lk = N
             if C_ in ops.RP_K and attn.to_q.weight.shape[0] == C_:
@@ -135,6 +138,29 @@ class AttnProcessor2_0(nn.Module):
         if attn.rescale_output_factor != 1.0:
             raise NotImplementedError("rescale_output_factor != 1 is not on the AudioLDM2 path")
         return out
+
+
+def _train_common(attn):
+    if attn.residual_connection or attn.rescale_output_factor != 1.0:
+        raise NotImplementedError("residual_connection / rescale_output_factor are not on the AudioLDM2 path")
+
+
+def _attn_call_train(self, attn, hidden_states, encoder_hidden_states, attention_mask, _residual, _ln):
+    """Training-mode AttnProcessor2_0 (gradients flow to hidden_states; autograd.py): the un-fused chain LayerNorm ->
+    to_q / to_k / to_v -> attention -> to_out (+ residual), every node a HIP forward with a HIP backward."""
+    _train_common(attn)
+    B, N, _ = hidden_states.shape
+    hs = hidden_states if _ln is None else AG.layer_norm(hidden_states, *_ln)
+    src = hs if encoder_hidden_states is None else (encoder_hidden_states if encoder_hidden_states.dim() == 3
+                                                    else encoder_hidden_states.unsqueeze(0))
+    q = AG.linear(hs, attn.to_q.weight)
+    k = AG.linear(src, attn.to_k.weight)
+    v = AG.linear(src, attn.to_v.weight)
+    o = AG.attention(q, k, v, attn.heads, _key_bias(attention_mask, B, src.shape[1]))
+    return AG.linear(o, attn.to_out[0].weight, attn.to_out[0].bias, residual=_residual)
+
+
+AttnProcessor2_0._call_train = _attn_call_train
 
 
 class IPAttnProcessor2_0(nn.Module):
@@ -203,6 +229,8 @@ class IPAttnProcessor2_0(nn.Module):
         if ehs.dim() < 3:
             ehs = ehs.unsqueeze(0)
         B, N, _ = hidden_states.shape
+        if AG.on(hidden_states, ehs, self.to_k_ip.weight, self.to_v_ip.weight):
+            return self._call_train(attn, hidden_states, ehs, attention_mask, _residual, _ln)
         q = ops.fused_linear(hidden_states, attn.to_q.weight, ln=_ln)
         ck = (ehs.data_ptr(), tuple(ehs.shape))
         if self.kv_cache_enabled and self._kv_cache is not None and ck in self._kv_cache:
@@ -225,3 +253,23 @@ class IPAttnProcessor2_0(nn.Module):
         if attn.residual_connection or attn.rescale_output_factor != 1.0:
             raise NotImplementedError("residual_connection / rescale_output_factor are not on the AudioLDM2 path")
         return out
+
+
+    def _call_train(self, attn, hidden_states, ehs, attention_mask, _residual, _ln):
+        """Training mode (reference :347-470 under autograd; train_apadapter_v2.py:941-957): gradients w.r.t.
+        hidden_states, to_k_ip.weight and to_v_ip.weight (and the condition tokens if they require grad)."""
+        _train_common(attn)
+        B = hidden_states.shape[0]
+        nt = self.num_tokens
+        txt, aud = ehs[:, :nt, :].contiguous(), ehs[:, nt:, :].contiguous()
+        if aud.shape[1] == 0:
+            raise ValueError("IPAttnProcessor2_0 training needs audio tokens after the first num_tokens text tokens")
+        hs = hidden_states if _ln is None else AG.layer_norm(hidden_states, *_ln)
+        q = AG.linear(hs, attn.to_q.weight)
+        k_t, v_t = AG.linear(txt, attn.to_k.weight), AG.linear(txt, attn.to_v.weight)
+        k_a, v_a = AG.linear(aud, self.to_k_ip.weight), AG.linear(aud, self.to_v_ip.weight)
+        bias = None
+        if attention_mask is not None:
+            bias = attention_mask.reshape(B, -1)[:, :1].float().expand(B, txt.shape[1]).contiguous()
+        o = AG.ip_attention(q, k_t, v_t, k_a, v_a, attn.heads, bias, float(self.scale))
+        return AG.linear(o, attn.to_out[0].weight, attn.to_out[0].bias, residual=_residual)

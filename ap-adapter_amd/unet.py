@@ -14,6 +14,7 @@ from typing import Dict, Optional, Tuple
 import torch
 import torch.nn as nn
 
+from . import autograd as AG
 from . import ops
 from .processors import AttnProcessor2_0
 
@@ -148,6 +149,9 @@ class FeedForward(nn.Module):
         """x un-normalised; ln = norm3.  C in ops.MLP_C: the whole feed-forward + residual in one launch (the 4C-wide
         activation never reaches HBM); otherwise LayerNorm + GEGLU projection in one launch, then the 4C->C GEMM +
         residual."""
+        if AG.on(x):  # training: un-fused, the GEGLU projection is kept for the backward
+            h = AG.geglu(AG.linear(AG.layer_norm(x, *ln), self.net[0].proj.weight, self.net[0].proj.bias))
+            return AG.linear(h, self.net[2].weight, self.net[2].bias, residual=x)
         if x.shape[-1] in ops.MLP_C and os.environ.get("APAD_FUSED_MLP", "1") != "0":
             return ops.geglu_mlp(x, self.net[0].proj.weight, self.net[0].proj.bias, self.net[2].weight, self.net[2].bias, ln=ln)
         h = ops.fused_linear(x, self.net[0].proj.weight, self.net[0].proj.bias, ln=ln, act="geglu")
@@ -186,10 +190,16 @@ class Transformer2DModel(nn.Module):
         self.proj_out = nn.Conv2d(inner, in_channels, 1)
 
     def forward(self, x, ehs, emask):
-        h = ops.group_norm(x, self.norm.weight, self.norm.bias, self.groups, self.norm.eps, silu=False)
-        h = ops.fused_linear(h, _w2d(self.proj_in), self.proj_in.bias)
+        if AG.on(x):
+            h = AG.group_norm(x, self.norm.weight, self.norm.bias, self.groups, self.norm.eps, False)
+            h = AG.linear(h, self.proj_in.weight, self.proj_in.bias)
+        else:
+            h = ops.group_norm(x, self.norm.weight, self.norm.bias, self.groups, self.norm.eps, silu=False)
+            h = ops.fused_linear(h, _w2d(self.proj_in), self.proj_in.bias)
         for blk in self.transformer_blocks:
             h = blk(h, ehs, emask)
+        if AG.on(h, x):
+            return AG.linear(h, self.proj_out.weight, self.proj_out.bias, residual=x)
         return ops.fused_linear(h, _w2d(self.proj_out), self.proj_out.bias, residual=x)
 
 
@@ -210,6 +220,13 @@ class ResnetBlock2D(nn.Module):
         return ops.linear(emb_act, self.time_emb_proj.weight, self.time_emb_proj.bias)
 
     def forward(self, x, B, H, W, tproj, rows_per_group, step_ptr=None):
+        if AG.on(x):
+            h = AG.group_norm(x, self.norm1.weight, self.norm1.bias, self.groups, self.norm1.eps, True)
+            h, _, _ = AG.conv3x3(h, self.conv1.weight, self.conv1.bias, B, H, W, rowgroup_bias=tproj, rows_per_group=rows_per_group)
+            h = AG.group_norm(h, self.norm2.weight, self.norm2.bias, self.groups, self.norm2.eps, True)
+            sc = x if self.conv_shortcut is None else AG.linear(x, self.conv_shortcut.weight, self.conv_shortcut.bias)
+            out, _, _ = AG.conv3x3(h, self.conv2.weight, self.conv2.bias, B, H, W, residual=sc)
+            return out
         h = ops.group_norm(x, self.norm1.weight, self.norm1.bias, self.groups, self.norm1.eps, silu=True)
         h, _, _ = _conv3x3(self.conv1, self._pk1, h, B, H, W, rowgroup_bias=tproj, rows_per_group=rows_per_group,
                            step_ptr=step_ptr)
@@ -226,6 +243,8 @@ class Downsample2D(nn.Module):
         self._pk = _Packed()
 
     def forward(self, x, B, H, W):
+        if AG.on(x):
+            return AG.conv3x3(x, self.conv.weight, self.conv.bias, B, H, W, stride=2)
         return _conv3x3(self.conv, self._pk, x, B, H, W, stride=2)
 
 
@@ -237,6 +256,8 @@ class Upsample2D(nn.Module):
 
     def forward(self, x, B, H, W, output_size=None):
         up = tuple(output_size) if output_size is not None else (2 * H, 2 * W)
+        if AG.on(x):
+            return AG.conv3x3(x, self.conv.weight, self.conv.bias, B, H, W, up=up)
         return _conv3x3(self.conv, self._pk, x, B, H, W, up=up)
 
 
@@ -472,6 +493,11 @@ class AudioLDM2UNet2DConditionModel(nn.Module):
             if blk.upsamplers is not None:
                 x, H, W = blk.upsamplers[0](x, B, H, W, up_size)
 
+        if AG.on(x):
+            x = AG.group_norm(x, self.conv_norm_out.weight, self.conv_norm_out.bias, cfg.norm_num_groups,
+                              self.conv_norm_out.eps, True)
+            x, _, _ = AG.conv3x3(x, self.conv_out.weight, self.conv_out.bias, B, H, W)
+            return x
         x = ops.group_norm(x, self.conv_norm_out.weight, self.conv_norm_out.bias, cfg.norm_num_groups,
                            self.conv_norm_out.eps, silu=True)
         wp = self._pk_out.get(self.conv_out.weight, lambda w: w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous())

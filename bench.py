@@ -98,9 +98,19 @@ def dominant_kernel_roofline(dev, dtype, B2):
     ms = time_kernel(lambda: ops.attention(q, k, vt, N, heads, out=out))
     flops = 4.0 * N * N * C * B2
     ach = flops / (ms * 1e-3) / 1e12
+    # HBM bytes per launch from the PMC passes (tools/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3
+    # runs, read counter x2 on gfx950 as calibrated by a known-size probe in the same run); the counters cannot be
+    # collected from inside this process, so the committed measurement is reported when it is for this exact launch
+    traffic = None
+    tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    if dtype == torch.bfloat16 and B2 == 64 and os.path.exists(tp):
+        with open(tp) as f:
+            traffic = json.load(f).get("traffic_bytes_per_launch")
+        traffic = None if traffic is None else int(traffic)
     return {"kernel": "attn_kernel<bf16,D=32> self-attention B'=%d heads=8 N=L=1000" % B2, "bound": "mfma",
             "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-            "avg_launch_ms": round(ms, 4), "algorithmic_bytes": 4 * B2 * N * C * 2, "traffic": None}
+            "avg_launch_ms": round(ms, 4), "algorithmic_bytes": 4 * B2 * N * C * 2, "traffic": traffic,
+            "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes)" if traffic else None}
 
 
 def cpu_baseline(La, gs, steps=1):

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define APAD_ABI_VERSION 1
+#define APAD_ABI_VERSION 2
 
 /* element types of activations / weights */
 enum { APAD_BF16 = 0, APAD_F16 = 1, APAD_F32 = 2 };
@@ -94,6 +94,8 @@ typedef struct apad_attn_desc {
     const void* vt2;       /* segment 2 values                                                        */
     void* out;             /* [B][N][H*D] via strides                                                  */
     const float* key_bias; /* additive fp32 bias on segment-1 scores [B][L] (mask -> bias), or NULL    */
+    float* lse;            /* optional out, single segment only: log2 sum_k exp2(log2e*(scale*s + bias)),
+                              fp32 [B][H][round_up(N,32)] -- what apad_attention_bwd recomputes P from   */
     int64_t q_stride_b, q_stride_n;
     int64_t k_stride_b, k_stride_l, vt_stride_b;
     int64_t k2_stride_b, k2_stride_l, vt2_stride_b;
@@ -200,6 +202,73 @@ int apad_cfg_ddim_step(const void* eps2, float* latents, void* unet_in, float* e
                        const int32_t* step_ptr, float guidance_scale, int32_t B, int64_t n, int32_t dtype,
                        void* stream);
 int apad_step_advance(int32_t* step_ptr, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Training step of the adapter (SURVEY a-11; train_apadapter_v2.py:941-979).  The UNet is frozen: only INPUT
+ * gradients flow through its layers, and the only weight gradients are those of to_k_ip / to_v_ip
+ * (attention_processor.py:324-325).  GEMM-shaped gradients reuse apad_gemm:
+ *   linear dgrad     dx = dy . W            -> apad_gemm(a = dy, w = W^T [K][N] contiguous)
+ *   conv3x3 dgrad    stride 1: apad_gemm conv mode on dy with w'[ci][(2-ky,2-kx,co)] = w[co][(ky,kx,ci)];
+ *                    stride 2: apad_zero_stuff2 first; nearest-upsampled source: apad_upsample_nearest_bwd after
+ *   adapter wgrad    dW[C][768] = dK^T . ehs -> apad_transpose_pad both operands, then apad_gemm
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct apad_attn_bwd_desc {
+    const void* q;      /* [B][N][H*D] contiguous                                                       */
+    const void* k;      /* [B][L][H*D]                                                                  */
+    const void* v;      /* [B][L][H*D] row-major values                                                 */
+    const void* qt;     /* Q^T  [B][H][D][Npad] (apad_head_transpose); only read when dk/dv are wanted   */
+    const void* kt;     /* K^T  [B][H][D][Lpad]                                                         */
+    const void* out;    /* forward output of THIS segment [B][N][H*D]                                   */
+    const void* dout;   /* gradient of the blended output [B][N][H*D]                                   */
+    const void* doutt;  /* dout^T [B][H][D][Npad]; only for dk/dv                                       */
+    const float* lse;   /* [B][H][Npad] from apad_attention                                             */
+    const float* key_bias; /* [B][L] fp32 additive bias of the forward, or NULL                         */
+    float* delta;       /* workspace fp32 [B][H][Npad]                                                  */
+    void* dq;           /* [B][N][H*D]                                                                  */
+    void* dk;           /* [B][L][H*D] or NULL (keys / values that come from frozen conditioning)       */
+    void* dv;
+    int32_t B, N, H, D, L, Npad, Lpad, dtype;
+    float softmax_scale;
+    float dout_scale;      /* the segment saw dout_scale * dout (ap_scale for the audio branch, :454)    */
+    int32_t accumulate_dq; /* 1: dq += (second segment of the decoupled cross-attention)                */
+    int32_t reserved;
+} apad_attn_bwd_desc;
+int apad_sizeof_attn_bwd_desc(void);
+int apad_echo_attn_bwd_desc(const apad_attn_bwd_desc* d, double* out, int cap);
+int apad_attention_bwd(const apad_attn_bwd_desc* d, void* stream);
+/* x [B][N][H*D] -> xt [B][H][D][pad], zero-filled for n >= N (pad % 32 == 0) */
+int apad_head_transpose(const void* x, void* xt, int32_t B, int32_t N, int32_t H, int32_t D, int32_t pad, int32_t dtype,
+                        void* stream);
+
+int apad_layernorm_bwd(const void* x, const void* gamma, const void* dy, void* dx, int64_t M, int32_t C, float eps,
+                       int32_t dtype, void* stream);
+int apad_groupnorm_bwd(const void* x, const void* gamma, const void* beta, const void* dy, void* dx, int32_t B, int32_t HW,
+                       int32_t C, int32_t G, float eps, int32_t silu, int32_t dtype, void* stream);
+/* proj [M][2N] (value | gate) -> h [M][N] = value * gelu(gate), and its gradient dproj [M][2N] */
+int apad_geglu(const void* proj, void* h, int64_t M, int32_t N, int32_t dtype, void* stream);
+int apad_geglu_bwd(const void* proj, const void* dh, void* dproj, int64_t M, int32_t N, int32_t dtype, void* stream);
+/* dup [B][Hup*Wup][C] -> dx [B][H*W][C]: adjoint of the nearest-neighbour gather floor(dst*in/out) of apad_gemm */
+int apad_upsample_nearest_bwd(const void* dup, void* dx, int32_t B, int32_t H, int32_t W, int32_t Hup, int32_t Wup,
+                              int32_t C, int32_t dtype, void* stream);
+/* dy [B][Ho*Wo][C] -> z [B][H*W][C], z[2i][2j] = dy[i][j], 0 elsewhere */
+int apad_zero_stuff2(const void* dy, void* z, int32_t B, int32_t H, int32_t W, int32_t Ho, int32_t Wo, int32_t C,
+                     int32_t dtype, void* stream);
+/* x [M][C] -> xt [C][Mpad] zero padded (Mpad % 32 == 0) */
+int apad_transpose_pad(const void* x, void* xt, int32_t M, int32_t C, int32_t Mpad, int32_t dtype, void* stream);
+
+/* fp32 workspace size of the three reductions below */
+int64_t apad_reduce_workspace_bytes(void);
+/* loss[0] = mean((pred - target)^2) in fp32 (train_apadapter_v2.py:954); dpred = 2 (pred - target) / n in dtype */
+int apad_mse_loss_grad(const void* pred, const float* target, void* dpred, float* loss, float* workspace, int64_t n,
+                       int32_t dtype, void* stream);
+/* norm[0] = ||grad||_2 over the flat fp32 gradient buffer (clip_grad_norm_, :975) */
+int apad_grad_norm(const float* grad, float* norm, float* workspace, int64_t n, void* stream);
+/* clip (coefficient min(1, max_norm / (norm + 1e-6)), read from device) + torch.optim.AdamW update (:763-769) of the
+   flat fp32 master parameters; `work` (optional) receives the updated parameters in `dtype` for the forward kernels.
+   step[0] = index of this step (>= 1), device int32. */
+int apad_adamw_step(float* param, void* work, const float* grad, float* exp_avg, float* exp_avg_sq, const float* grad_norm,
+                    const int32_t* step, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                    float max_grad_norm, int32_t dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,292 @@
+"""-m gpu: the training step (SURVEY a-11).  Every backward kernel against fp32 torch autograd of the same op on
+identical storage-rounded operands; then the adapter gradients, the loss and the optimizer step of a small UNet against
+the oracle chain (oracle/train.py = torch autograd through oracle/unet.py).
+Tolerance: gradients are rounded to the storage type once per layer, so the kernel-level bound is TOL[dtype] on
+max-abs error relative to max|ref|; the end-to-end bound (hundreds of rounded layers) is stated per test."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import TOL, q, rel_err
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.bfloat16, torch.float16]
+
+
+def R(*shape, seed=0, std=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * std
+
+
+def _leaf(t):
+    return t.clone().requires_grad_(True)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,C", [(1000, 256), (77, 384), (5, 640)])
+def test_layer_norm_bwd(dev, dtype, M, C):
+    from ap_adapter_amd import ops
+    x, g, b, dy = q(R(M, C, seed=1), dtype), q(1 + 0.1 * R(C, seed=2), dtype), q(0.1 * R(C, seed=3), dtype), q(R(M, C, seed=4), dtype)
+    xl = _leaf(x)
+    F.layer_norm(xl, (C,), g, b, 1e-5).backward(dy)
+    out = ops.layer_norm_bwd(x.to(dev, dtype), g.to(dev, dtype), dy.to(dev, dtype), 1e-5)
+    assert rel_err(out, xl.grad) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,HW,C,G", [(2, 416, 128, 32), (3, 104, 192, 16), (1, 63 * 4, 1280, 32)])
+@pytest.mark.parametrize("silu", [False, True])
+def test_group_norm_bwd(dev, dtype, B, HW, C, G, silu):
+    from ap_adapter_amd import ops
+    x, g, b = q(R(B, HW, C, seed=5), dtype), q(1 + 0.1 * R(C, seed=6), dtype), q(0.1 * R(C, seed=7), dtype)
+    dy = q(R(B, HW, C, seed=8), dtype)
+    xl = _leaf(x)
+    y = F.group_norm(xl.transpose(1, 2), G, g, b, 1e-5)
+    if silu:
+        y = F.silu(y)
+    y.transpose(1, 2).backward(dy)
+    out = ops.group_norm_bwd(x.to(dev, dtype), g.to(dev, dtype), b.to(dev, dtype), dy.to(dev, dtype), G, 1e-5, silu)
+    assert rel_err(out, xl.grad) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_geglu_fwd_bwd(dev, dtype):
+    from ap_adapter_amd import ops
+    M, N = 333, 512
+    proj, dh = q(R(M, 2 * N, seed=9), dtype), q(R(M, N, seed=10), dtype)
+    pl = _leaf(proj)
+    a, g = pl.chunk(2, dim=-1)
+    h = a * F.gelu(g)
+    h.backward(dh)
+    assert rel_err(ops.geglu(proj.to(dev, dtype)), h.detach()) < TOL[dtype]
+    assert rel_err(ops.geglu_bwd(proj.to(dev, dtype), dh.to(dev, dtype)), pl.grad) < TOL[dtype]
+
+
+def _sdpa(qq, k, v, heads, bias=None):
+    B, N, C = qq.shape
+    sp = lambda t: t.reshape(B, t.shape[1], heads, C // heads).transpose(1, 2)
+    m = None if bias is None else bias[:, None, None, :]
+    o = F.scaled_dot_product_attention(sp(qq), sp(k), sp(v), attn_mask=m)
+    return o.transpose(1, 2).reshape(B, N, C)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,N,L,heads,d,bias", [(2, 100, 100, 4, 32, False), (1, 252, 252, 8, 48, False), (2, 64, 64, 8, 80, False),
+                                                (2, 130, 16, 4, 16, True), (1, 1000, 40, 8, 32, False), (2, 33, 7, 2, 64, True)])
+def test_attention_bwd(dev, dtype, B, N, L, heads, d, bias):
+    """dq, dk, dv of one softmax segment (ragged tiles, every head dim of the UNet, additive key bias)"""
+    from ap_adapter_amd import autograd as AG
+    C = heads * d
+    qq, k, v = q(R(B, N, C, seed=11), dtype), q(R(B, L, C, seed=12), dtype), q(R(B, L, C, seed=13), dtype)
+    do = q(R(B, N, C, seed=14), dtype)
+    kb = None
+    if bias:
+        kb = torch.zeros(B, L)
+        kb[:, -3:] = -10000.0
+    ql, kl, vl = _leaf(qq), _leaf(k), _leaf(v)
+    ref = _sdpa(ql, kl, vl, heads, kb)
+    ref.backward(do)
+    qd, kd, vd = (t.to(dev, dtype).requires_grad_(True) for t in (qq, k, v))
+    out = AG.attention(qd, kd, vd, heads, None if kb is None else kb.to(dev))
+    out.backward(do.to(dev, dtype))
+    assert rel_err(out, ref.detach()) < TOL[dtype]
+    for got, want, name in ((qd.grad, ql.grad, "dq"), (kd.grad, kl.grad, "dk"), (vd.grad, vl.grad, "dv")):
+        assert rel_err(got, want) < 1.5 * TOL[dtype], name
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_ip_attention_bwd(dev, dtype):
+    """decoupled cross-attention (attention_processor.py:429-454): gradients of q and of the audio K/V; text K/V frozen"""
+    from ap_adapter_amd import autograd as AG
+    B, N, heads, d, Lt, La, s = 2, 252, 8, 48, 8, 32, 0.55
+    C = heads * d
+    qq, kt, vt = q(R(B, N, C, seed=21), dtype), q(R(B, Lt, C, seed=22), dtype), q(R(B, Lt, C, seed=23), dtype)
+    ka, va, do = q(R(B, La, C, seed=24), dtype), q(R(B, La, C, seed=25), dtype), q(R(B, N, C, seed=26), dtype)
+    ql, kal, val = _leaf(qq), _leaf(ka), _leaf(va)
+    ref = _sdpa(ql, kt, vt, heads) + s * _sdpa(ql, kal, val, heads)
+    ref.backward(do)
+    qd, kad, vad = (t.to(dev, dtype).requires_grad_(True) for t in (qq, ka, va))
+    out = AG.ip_attention(qd, kt.to(dev, dtype), vt.to(dev, dtype), kad, vad, heads, None, s)
+    out.backward(do.to(dev, dtype))
+    assert rel_err(out, ref.detach()) < TOL[dtype]
+    for got, want, name in ((qd.grad, ql.grad, "dq"), (kad.grad, kal.grad, "dk_ip"), (vad.grad, val.grad, "dv_ip")):
+        assert rel_err(got, want) < 1.5 * TOL[dtype], name
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_linear_bwd_and_weight_grad(dev, dtype):
+    """dx through a frozen weight, dW of a trainable one (to_k_ip: [C, 768], reduction over B*La token rows)"""
+    from ap_adapter_amd import autograd as AG
+    M, K, N = 4 * 32, 768, 384
+    x, w, b, dy = q(R(M, K, seed=31), dtype), q(R(N, K, seed=32, std=0.05), dtype), q(R(N, seed=33), dtype), q(R(M, N, seed=34), dtype)
+    xl, wl = _leaf(x), _leaf(w)
+    F.linear(xl, wl, b).backward(dy)
+    xd, wd = x.to(dev, dtype).requires_grad_(True), w.to(dev, dtype).requires_grad_(True)
+    AG.linear(xd, wd, b.to(dev, dtype)).backward(dy.to(dev, dtype))
+    assert rel_err(xd.grad, xl.grad) < TOL[dtype]
+    assert rel_err(wd.grad, wl.grad) < TOL[dtype]
+    # residual branch receives dy unchanged
+    r = torch.zeros(M, N).to(dev, dtype).requires_grad_(True)
+    AG.linear(x.to(dev, dtype), w.to(dev, dtype), None, residual=r).backward(dy.to(dev, dtype))
+    assert torch.equal(r.grad.cpu().float(), dy)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", ["s1", "s2", "s2_odd", "up2", "up_size"])
+def test_conv3x3_bwd(dev, dtype, case):
+    from ap_adapter_amd import autograd as AG
+    B, Cin, Cout = 2, 64, 96
+    H, W, stride, up = {"s1": (26, 16, 1, None), "s2": (26, 16, 2, None), "s2_odd": (25, 7, 2, None), "up2": (13, 8, 1, (26, 16)),
+                        "up_size": (13, 4, 1, (25, 8))}[case]
+    x, w, b = q(R(B, Cin, H, W, seed=41), dtype), q(R(Cout, Cin, 3, 3, seed=42, std=0.05), dtype), q(R(Cout, seed=43), dtype)
+    xl = _leaf(x)
+    src = xl if up is None else F.interpolate(xl, size=up, mode="nearest")
+    ref = F.conv2d(src, w, b, stride=stride, padding=1)
+    dy = q(R(*ref.shape, seed=44), dtype)
+    ref.backward(dy)
+    xd = x.permute(0, 2, 3, 1).reshape(B, H * W, Cin).to(dev, dtype).requires_grad_(True)
+    out, Ho, Wo = AG.conv3x3(xd, w.to(dev, dtype), b.to(dev, dtype), B, H, W, stride=stride, up=up)
+    assert (Ho, Wo) == tuple(ref.shape[2:])
+    out.backward(dy.permute(0, 2, 3, 1).reshape(B, Ho * Wo, Cout).to(dev, dtype))
+    want = xl.grad.permute(0, 2, 3, 1).reshape(B, H * W, Cin)
+    assert rel_err(out, ref.detach().permute(0, 2, 3, 1).reshape(B, Ho * Wo, Cout)) < TOL[dtype]
+    assert rel_err(xd.grad, want) < TOL[dtype]
+
+
+def test_mse_loss_grad(dev):
+    from ap_adapter_amd import autograd as AG
+    pred = q(R(4, 8, 250, 16, seed=51), torch.bfloat16)
+    tgt = R(4, 8, 250, 16, seed=52)
+    pl = _leaf(pred)
+    ref = F.mse_loss(pl.float(), tgt.float(), reduction="mean")
+    ref.backward()
+    pd = pred.to(dev, torch.bfloat16).requires_grad_(True)
+    loss = AG.mse_loss(pd, tgt.to(dev))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) < 1e-5 * float(ref.detach())
+    assert rel_err(pd.grad, pl.grad) < TOL[torch.bfloat16]
+
+
+def test_grad_norm_and_adamw_match_the_oracle(dev):
+    """clip coefficient + AdamW over a flat buffer, 3 steps, against oracle/train.py (itself pinned to torch.optim.AdamW)"""
+    from ap_adapter_amd import ops
+    from oracle import train as OT
+    n = 100003
+    p0, lr, wd, mx = R(n, seed=61, std=0.05), 1e-3, 1e-2, 1.0
+    p, m, v = p0.clone(), torch.zeros(n), torch.zeros(n)
+    P, M_, V = p0.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    work = torch.empty(n, dtype=torch.bfloat16, device=dev)
+    step_t = torch.zeros(1, dtype=torch.int32, device=dev)
+    for step in (1, 2, 3):
+        g = R(n, seed=70 + step, std=0.02 * step)
+        coef, total = OT.clip_coef([g], mx)
+        p, m, v = OT.adamw_update(p, g * coef, m, v, step, lr, weight_decay=wd)
+        G = g.to(dev)
+        ops.step_advance(step_t)
+        gn = ops.grad_norm(G)
+        assert abs(float(gn) - float(total)) < 1e-5 * float(total)
+        ops.adamw_step(P, work, G, M_, V, gn, step_t, lr, (0.9, 0.999), 1e-8, wd, mx)
+        assert rel_err(P, p) < 1e-6
+        assert torch.equal(work.cpu(), P.cpu().to(torch.bfloat16))
+    assert rel_err(M_, m) < 1e-5 and rel_err(V, v) < 1e-4  # v carries the squared fp32 clip coefficient
+
+
+def _small_unet(dev, dtype, seed=100):
+    import ap_adapter_amd as A
+    from ap_adapter_amd.synthetic import init_synthetic_
+    cfg = A.UNetConfig(block_out_channels=(64, 128, 192, 256), attention_head_dim=4, norm_num_groups=16)
+    u = A.AudioLDM2UNet2DConditionModel(cfg)
+    A.install_ap_adapter(u, None, scale=0.5)
+    init_synthetic_(u, seed, w_std=0.05, bias_std=0.02, norm_jitter=0.1)
+    u = u.to(dtype)
+    sd = {k: v.detach().float().cpu() for k, v in u.state_dict().items()}
+    procs = {n: dict(scale=p.scale, num_tokens=p.num_tokens) for n, p in u.attn_processors.items() if hasattr(p, "to_k_ip")}
+    return u.to(dev), cfg, sd, procs
+
+
+def _batch(B, La, dtype):
+    g = torch.Generator().manual_seed(5)
+    lat = torch.randn(B, 8, 26, 16, generator=g)
+    noise = torch.randn(B, 8, 26, 16, generator=g)
+    t = torch.tensor([17, 503, 998, 250][:B])
+    ehs = torch.randn(B, 8 + La, 768, generator=g).to(dtype).float()
+    ehs1 = torch.randn(B, 16, 1024, generator=g).to(dtype).float()
+    m1 = torch.ones(B, 16)
+    m1[1::2, -4:] = 0
+    return lat, noise, t, ehs, ehs1, m1
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 8e-2), (torch.float16, 2e-2)])
+def test_adapter_gradients_small_unet_vs_oracle(dev, dtype, tol):
+    """loss and d loss / d to_{k,v}_ip.weight of all 32 adapted sites after a backward through the whole frozen UNet
+    (per-sample timesteps, masked T5 stream), against torch autograd through the fp32 oracle.  Bound: max-abs error
+    relative to the largest gradient entry of each tensor, `tol`; the flat gradient's direction within 1 - cos < 2e-3."""
+    import ap_adapter_amd as A
+    from oracle import train as OT
+    u, cfg, sd, procs = _small_unet(dev, dtype)
+    B = 3
+    lat, noise, t, ehs, ehs1, m1 = _batch(B, 32, dtype)
+    noisy = q(OT.add_noise(lat, noise, t), dtype)
+    ref_loss, ref_grads, _ = OT.loss_and_grads(sd, cfg.geometry_dict(), procs, noisy, t, ehs, ehs1, m1, noise)
+    tr = A.AdapterTrainer(u, lr=1e-3)
+    loss = tr.micro_step(noisy.to(dev), t.to(dev), ehs.to(dev), ehs1.to(dev), m1.to(dev), noise.to(dev))
+    assert abs(float(loss) - float(ref_loss)) < 2e-2 * float(ref_loss)
+    names = [n for n, p in u.attn_processors.items() if hasattr(p, "to_k_ip")]
+    assert len(names) == 32 and len(tr.params) == 64
+    flat_ref = []
+    for i, n in enumerate(names):
+        for j, which in enumerate(("to_k_ip", "to_v_ip")):
+            p = tr.params[2 * i + j]
+            got = tr.grad[tr.offsets[2 * i + j]: tr.offsets[2 * i + j] + p.numel()].view(p.shape)
+            want = ref_grads[f"{n}.{which}.weight"]
+            assert float(want.abs().max()) > 0
+            assert rel_err(got, want) < tol, (n, which)
+            flat_ref.append(want.reshape(-1))
+    flat_ref = torch.cat(flat_ref)
+    cos = F.cosine_similarity(tr.grad.cpu(), flat_ref, dim=0)
+    assert 1 - float(cos) < 2e-3
+
+
+def test_trainer_steps_track_the_oracle(dev):
+    """two optimizer steps with gradient accumulation 2: parameters after each step against the oracle's
+    loss_and_grads -> mean over micro-batches -> clip -> AdamW"""
+    import ap_adapter_amd as A
+    from oracle import train as OT
+    dtype = torch.bfloat16
+    u, cfg, sd, procs = _small_unet(dev, dtype)
+    lr, wd = 1e-2, 1e-2
+    tr = A.AdapterTrainer(u, lr=lr, weight_decay=wd, gradient_accumulation_steps=2)
+    keys = OT.adapter_keys(sd)
+    names = [n for n, p in u.attn_processors.items() if hasattr(p, "to_k_ip")]
+    order = [f"{n}.{w}.weight" for n in names for w in ("to_k_ip", "to_v_ip")]
+    assert sorted(order) == keys
+    m = {k: torch.zeros_like(sd[k]) for k in keys}
+    v = {k: torch.zeros_like(sd[k]) for k in keys}
+    before = tr.master.clone()
+    for step in (1, 2):
+        acc = {k: torch.zeros_like(sd[k]) for k in keys}
+        for micro in range(2):
+            lat, noise, t, ehs, ehs1, m1 = _batch(2, 8, dtype)
+            lat = lat + step + micro  # different data per micro-batch
+            noisy = q(OT.add_noise(lat, noise, t), dtype)
+            # the oracle forward sees the storage-rounded working weights, like the kernels
+            sdq = {k: (q(val, dtype) if k in keys else val) for k, val in sd.items()}
+            _, g, _ = OT.loss_and_grads(sdq, cfg.geometry_dict(), procs, noisy, t, ehs, ehs1, m1, noise)
+            for k in keys:
+                acc[k] += g[k] / 2
+            tr.micro_step(noisy.to(dev), t.to(dev), ehs.to(dev), ehs1.to(dev), m1.to(dev), noise.to(dev))
+        tr.optimizer_step()
+        coef, _ = OT.clip_coef([acc[k] for k in keys], 1.0)
+        for k in keys:
+            sd[k], m[k], v[k] = OT.adamw_update(sd[k], acc[k] * coef, m[k], v[k], step, lr, weight_decay=wd)
+        want = torch.cat([sd[k].reshape(-1) for k in order])
+        # AdamW moves every weight by ~lr per step whatever the gradient scale: compare the UPDATE, not the weight
+        upd_ref, upd = want - before.cpu(), tr.master.cpu() - before.cpu()
+        assert float((upd - upd_ref).abs().mean() / upd_ref.abs().mean()) < 0.15
+        assert 1 - float(F.cosine_similarity(upd, upd_ref, dim=0)) < 2e-2
+    assert tr.global_step == 2 and int(tr.step_t.item()) == 2
+    # the nn.Parameters the forward reads are views of the updated working copy
+    p0 = tr.params[0]
+    assert torch.equal(p0.detach().reshape(-1), tr.work[: p0.numel()])
+    assert torch.equal(tr.work.float().cpu(), tr.master.cpu().to(dtype).float())

@@ -3,8 +3,8 @@ import torch
 
 def rel_err(out, ref):
     """max-abs error relative to the reference's max magnitude"""
-    ref = ref.float()
-    return float((out.float().cpu() - ref.cpu()).abs().max() / ref.abs().max().clamp_min(1e-12))
+    ref = ref.detach().float()
+    return float((out.detach().float().cpu() - ref.detach().cpu()).abs().max() / ref.abs().max().clamp_min(1e-12))
 
 
 def q(t, dtype):

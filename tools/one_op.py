@@ -29,6 +29,11 @@ elif op == "gemm_ff2":
     M, C = B2 * 1000, 256
     h = R(M, 4 * C); w2 = R(C, 4 * C, std=0.02); b2 = R(C, std=0.02); x = R(M, C); out = torch.empty(M, C, device=dev, dtype=dt)
     fn = lambda: ops.linear(h, w2, b2, residual=x, out=out)
+elif op == "mlp":
+    M, C = B2 * 1000, 256
+    x = R(M, C); g = R(C); be = R(C); w1 = R(8 * C, C, std=0.02); b1 = R(8 * C, std=0.02)
+    w2 = R(C, 4 * C, std=0.02); b2 = R(C, std=0.02); out = torch.empty(M, C, device=dev, dtype=dt)
+    fn = lambda: ops.geglu_mlp(x, w1, b1, w2, b2, ln=(g, be, 1e-5), out=out)
 for _ in range(iters):
     fn()
 torch.cuda.synchronize()
