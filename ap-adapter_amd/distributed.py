@@ -74,3 +74,16 @@ def allreduce_adapter_grads(params, average=True):
     for g in grads:
         g.copy_(flat[off:off + g.numel()].view_as(g))
         off += g.numel()
+
+
+def average_flat_gradient_(flat, micro_batches=1):
+    """The training step's ONE collective: sum the flat fp32 gradient buffer of the 64 adapter tensors over
+    ranks, then divide by world * micro_batches (DDP's mean over ranks x accelerate's loss / accumulation steps).
+    In place; returns the divisor."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    denom = float(world * max(int(micro_batches), 1))
+    if denom != 1.0:
+        flat.mul_(1.0 / denom)
+    return denom

@@ -15,11 +15,9 @@ model dtype that the forward kernels read: every nn.Parameter is a view into the
 kernel writes master + working copy in one pass.
 """
 import torch
-import torch.distributed as dist
-
 from . import autograd as AG
 from . import ops
-from .distributed import adapter_parameters
+from .distributed import adapter_parameters, average_flat_gradient_
 from .scheduler import DDIMScheduler
 
 
@@ -85,12 +83,7 @@ class AdapterTrainer:
 
     # ---- optimizer step on the accumulation boundary ----
     def optimizer_step(self):
-        world = dist.get_world_size() if dist.is_initialized() else 1
-        if world > 1:
-            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)  # the ONE collective of the step (86.5 MB for -large)
-        denom = float(world * max(self._micro, 1))
-        if denom != 1.0:
-            self.grad.mul_(1.0 / denom)  # DDP mean over ranks, accelerate's loss / accumulation steps
+        average_flat_gradient_(self.grad, self._micro)  # the ONE collective of the step (86.5 MB fp32 for -large)
         ops.step_advance(self.step_t)
         gn = None
         if self.max_grad_norm and self.max_grad_norm > 0:

@@ -38,6 +38,9 @@ def _worker(rank, world, port, q):
         p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
     D.allreduce_adapter_grads(params)                # mean over ranks: (1+2)/2 * (i+1)
     ok_grads = all(torch.allclose(p.grad, torch.full_like(p, 1.5 * (i + 1))) for i, p in enumerate(params))
+    flat = torch.arange(10, dtype=torch.float32) * (rank + 1)   # the trainer's flat fp32 gradient buffer
+    denom = D.average_flat_gradient_(flat, micro_batches=4)   # (1+2) * i / (2 ranks * 4 micro-batches)
+    ok_grads = ok_grads and denom == 8.0 and torch.allclose(flat, torch.arange(10, dtype=torch.float32) * 3 / 8)
     clips = D.shard_clips(7, rank, world)
     lat = torch.full((len(clips[:3]), 2), float(rank))
     gathered = D.gather_latents(lat)
@@ -73,3 +76,5 @@ def test_single_process_is_a_noop():
     p.grad = torch.ones(3)
     D.allreduce_adapter_grads([p])
     assert torch.equal(p.grad, torch.ones(3))
+    f = torch.full((4,), 6.0)
+    assert D.average_flat_gradient_(f, micro_batches=3) == 3.0 and torch.allclose(f, torch.full((4,), 2.0))
