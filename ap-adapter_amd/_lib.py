@@ -100,6 +100,9 @@ SYMBOLS = {
     "apad_reduce_workspace_bytes": (_i64, []),
     "apad_mse_loss_grad": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "apad_grad_norm": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    # audio front-end (f-2)
+    "apad_resample_fir": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
+    "apad_kaldi_fbank": (C.c_int, [_vp, _i64, _f32, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _f32, _f32, _vp]),
     "apad_adamw_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _vp]),
 }
 

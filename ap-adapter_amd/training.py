@@ -114,3 +114,90 @@ class AdapterTrainer:
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.step_t.fill_(sd["step"])
         self.global_step = sd["global_step"]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# data side of the trainer ("next" row f-3): condition dropout, per-batch pooling choice, checkpoint rotation
+# ---------------------------------------------------------------------------------------------------------------------
+POOL_LIST = (1, 2, 4, 8)  # train_apadapter_v2.py:443
+
+
+def apply_condition_dropout(prompt_texts, mels, rng):
+    """train_apadapter_v2.py:446-454, one uniform draw per example: < 0.05 drop the text, < 0.10 zero the audio
+    condition, < 0.15 drop both (5 % each).  ``mels`` are the AudioMAE inputs [1024, 128].  Returns new lists."""
+    texts, out = list(prompt_texts), list(mels)
+    for i in range(len(texts)):
+        r = rng.random()
+        if r < 0.05:
+            texts[i] = ""
+        elif r < 0.1:
+            out[i] = torch.zeros_like(out[i])
+        elif r < 0.15:
+            texts[i] = ""
+            out[i] = torch.zeros_like(out[i])
+    return texts, out
+
+
+class CollateFunction:
+    """The reference's CollateFunction (:424-479) on this package's kernels.  ``encode_prompt(list_of_texts)`` must return
+    (prompt_embeds, attention_mask, generated_prompt_embeds) -- the CLAP / T5 / GPT-2 encoders are third-party models
+    outside the hot path (SURVEY f-4); the audio condition (front-end + AudioMAE + pooling) runs here."""
+
+    def __init__(self, audiomae, encode_prompt, rng=None, device=None):
+        import random
+        self.model = audiomae
+        self.encode_prompt = encode_prompt
+        self.rng = rng or random.Random()
+        self.device = device
+
+    def __call__(self, examples):
+        from .frontend import load_mel
+        texts = [e["text"] for e in examples]
+        mel_spect = [e["fbank"] if "fbank" in e else load_mel(e["audio_path"], device=self.device)[0] for e in examples]
+        pooling_rate = self.rng.choice(POOL_LIST)  # ONE rate per batch (:443-444)
+        texts, mel_spect = apply_condition_dropout(texts, mel_spect, self.rng)
+        with torch.no_grad():
+            prompt_embeds, attention_mask, generated = self.encode_prompt(texts)
+            loa = self.model(torch.stack(mel_spect), time_pool=pooling_rate, freq_pool=pooling_rate)[0]
+            generated = torch.cat((generated.to(loa.device), loa.to(generated.dtype)), dim=1)  # text tokens first (:471)
+        batch = {"prompt_embeds": prompt_embeds, "attention_mask": attention_mask, "generated_prompt_embeds": generated,
+                 "pooling_rate": pooling_rate}
+        if all("mel" in e for e in examples):
+            batch["mel"] = torch.stack([e["mel"] for e in examples]).float()
+        return batch
+
+
+def rotate_checkpoints(output_dir, checkpoints_total_limit):
+    """:990-1006 -- before saving, keep at most ``checkpoints_total_limit - 1`` ``checkpoint-<step>`` directories
+    (oldest removed first).  Returns the removed names."""
+    import os
+    import shutil
+    if checkpoints_total_limit is None or not os.path.isdir(output_dir):
+        return []
+    cps = sorted((d for d in os.listdir(output_dir) if d.startswith("checkpoint")), key=lambda x: int(x.split("-")[1]))
+    removed = []
+    if len(cps) >= checkpoints_total_limit:
+        removed = cps[0:len(cps) - checkpoints_total_limit + 1]
+        for d in removed:
+            shutil.rmtree(os.path.join(output_dir, d))
+    return removed
+
+
+def save_checkpoint(trainer, output_dir, checkpoints_total_limit=None):
+    """:1008-1010 ``accelerator.save_state`` equivalent for the trainable state: adapter weights under the reference key
+    scheme (fp32, from the master buffer) + optimizer state, in ``checkpoint-<global_step>``."""
+    import os
+    from .wiring import adapter_state_dict
+    rotate_checkpoints(output_dir, checkpoints_total_limit)
+    path = os.path.join(output_dir, f"checkpoint-{trainer.global_step}")
+    os.makedirs(path, exist_ok=True)
+    sd = adapter_state_dict(trainer.unet)
+    # fp32 master values, not the rounded working copy
+    names = [n for n, pr in trainer.unet.attn_processors.items() if hasattr(pr, "to_k_ip")]
+    for i, n in enumerate(names):
+        for j, which in enumerate(("to_k_ip", "to_v_ip")):
+            p, o = trainer.params[2 * i + j], trainer.offsets[2 * i + j]
+            sd[f"{n}.{which}.weight"] = trainer.master[o:o + p.numel()].view(p.shape).cpu().clone()
+    torch.save(sd, os.path.join(path, "pytorch_model.bin"))
+    torch.save(trainer.state_dict(), os.path.join(path, "optimizer.bin"))
+    return path

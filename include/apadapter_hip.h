@@ -270,6 +270,21 @@ int apad_adamw_step(float* param, void* work, const float* grad, float* exp_avg,
                     const int32_t* step, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                     float max_grad_norm, int32_t dtype, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Audio front-end ("next" row f-2; audio_encoder/AudioMAE.py:356-394).  fp32.
+ * ------------------------------------------------------------------------------------------------------------- */
+/* torchaudio.functional.resample as a polyphase FIR: kernel [newf][2*width + orig] (sinc * hann^2, from the host),
+   out[b*newf + p] = sum_j kernel[p][j] * xpad[b*orig + j], xpad = x zero-padded by `width` on the left */
+int apad_resample_fir(const float* x, const float* kernel, float* out, int64_t n_in, int64_t n_out, int32_t orig,
+                      int32_t newf, int32_t width, void* stream);
+/* Kaldi fbank of x - dc at 16 kHz (25 ms hanning frames, 10 ms shift, snip_edges, per-frame DC removal, pre-emphasis,
+   512-point power spectrum, mel banks [num_mel_bins][257], log) -> out [target_frames][num_mel_bins] =
+   (logmel - norm_mean) / (2 norm_std), rows past the last frame = (0 - norm_mean) / (2 norm_std).
+   window [400], twiddle [256][2] = (cos, -sin)(2 pi k / 512) */
+int apad_kaldi_fbank(const float* x, int64_t n_samples, float dc, const float* window, const float* twiddle,
+                     const float* mel, float* out, int32_t target_frames, int32_t num_mel_bins, float preemphasis,
+                     float norm_mean, float norm_std, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

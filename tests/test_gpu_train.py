@@ -4,6 +4,7 @@ the oracle chain (oracle/train.py = torch autograd through oracle/unet.py).
 Tolerance: gradients are rounded to the storage type once per layer, so the kernel-level bound is TOL[dtype] on
 max-abs error relative to max|ref|; the end-to-end bound (hundreds of rounded layers) is stated per test."""
 import math
+import os
 
 import pytest
 import torch
@@ -290,3 +291,40 @@ def test_trainer_steps_track_the_oracle(dev):
     p0 = tr.params[0]
     assert torch.equal(p0.detach().reshape(-1), tr.work[: p0.numel()])
     assert torch.equal(tr.work.float().cpu(), tr.master.cpu().to(dtype).float())
+
+
+def test_collate_and_checkpoint(dev, tmp_path):
+    """f-3: per-batch pooling choice + condition dropout in front of AudioMAE (text tokens first, :471), and a checkpoint
+    that carries the fp32 master weights under the reference key scheme plus the optimizer state"""
+    import random
+    import ap_adapter_amd as A
+    from ap_adapter_amd import training as T
+    from ap_adapter_amd.synthetic import init_synthetic_
+    dtype = torch.float16
+    mae = A.AudioMAEConditionCTPoolRand(depth=1)
+    init_synthetic_(mae, 7, w_std=0.03, bias_std=0.02, norm_jitter=0.1)
+    mae = mae.to(dev, dtype)
+    enc = lambda texts: (torch.zeros(len(texts), 16, 1024, device=dev, dtype=dtype), torch.ones(len(texts), 16, device=dev),
+                         torch.full((len(texts), 8, 768), 2.0, device=dev, dtype=dtype))
+    col = T.CollateFunction(mae, enc, rng=random.Random(3), device=dev)
+    ex = [{"text": f"a recording of a {i}", "fbank": torch.randn(1024, 128, device=dev) * 0.5} for i in range(3)]
+    b = col(ex)
+    La = (64 // b["pooling_rate"]) * (8 // b["pooling_rate"])
+    assert b["pooling_rate"] in T.POOL_LIST and b["generated_prompt_embeds"].shape == (3, 8 + La, 768)
+    assert bool((b["generated_prompt_embeds"][:, :8] == 2.0).all())
+
+    u, cfg, sd, procs = _small_unet(dev, torch.bfloat16)
+    tr = A.AdapterTrainer(u, lr=1e-3)
+    tr.master.add_(1e-4)                                   # something the bf16 working copy cannot represent
+    tr.global_step = 7
+    path = T.save_checkpoint(tr, str(tmp_path), checkpoints_total_limit=2)
+    assert os.path.basename(path) == "checkpoint-7"
+    ck = A.load_adapter(os.path.join(path, "pytorch_model.bin"))
+    names = [n for n, p in u.attn_processors.items() if hasattr(p, "to_k_ip")]
+    assert sorted(ck) == sorted(f"{n}.{w}.weight" for n in names for w in ("to_k_ip", "to_v_ip"))
+    k0 = f"{names[0]}.to_k_ip.weight"
+    assert ck[k0].dtype == torch.float32 and torch.equal(ck[k0].reshape(-1), tr.master[: ck[k0].numel()].cpu())
+    st = torch.load(os.path.join(path, "optimizer.bin"), weights_only=True)
+    tr2 = A.AdapterTrainer(_small_unet(dev, torch.bfloat16, seed=5)[0])
+    tr2.load_state_dict(st)
+    assert torch.equal(tr2.master, tr.master) and tr2.global_step == 7

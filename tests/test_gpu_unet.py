@@ -64,11 +64,13 @@ def test_small_unet_graph_loop_vs_oracle_loop(dev):
     assert rel_err(a, ref) < 3e-2
 
 
-def test_audiomae_vs_oracle(dev):
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 5e-2), (torch.float16, 8e-3)])
+def test_audiomae_vs_oracle(dev, dtype, tol):
+    """the reference runs AudioMAE in fp32 (pipeline_audioldm2.py:926, never cast); here its storage type is independent
+    of the UNet's: f16 (10-bit mantissa) is the recommended setting, bf16 is covered for completeness"""
     import ap_adapter_amd as A
     from ap_adapter_amd.synthetic import init_synthetic_
     from oracle import audiomae as OA
-    dtype = torch.bfloat16
     m = A.AudioMAEConditionCTPoolRand(depth=3)
     init_synthetic_(m, 7, w_std=0.03, bias_std=0.02, norm_jitter=0.1)
     m = m.to(dtype)
@@ -77,7 +79,7 @@ def test_audiomae_vs_oracle(dev):
     ref = OA.audio_condition(sd, mel.to(dtype).float(), 4, 4, depth=3)
     out, ones = m.to(dev)(mel, time_pool=4, freq_pool=4)
     assert out.shape == ref.shape == (2, 32, 768) and ones.shape == (2, 32)
-    assert rel_err(out, ref) < 5e-2
+    assert rel_err(out, ref) < tol
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 4e-2), (torch.float16, 6e-3)])
