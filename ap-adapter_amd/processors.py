@@ -262,14 +262,15 @@ class IPAttnProcessor2_0(nn.Module):
         B = hidden_states.shape[0]
         nt = self.num_tokens
         txt, aud = ehs[:, :nt, :].contiguous(), ehs[:, nt:, :].contiguous()
-        if aud.shape[1] == 0:
-            raise ValueError("IPAttnProcessor2_0 training needs audio tokens after the first num_tokens text tokens")
         hs = hidden_states if _ln is None else AG.layer_norm(hidden_states, *_ln)
         q = AG.linear(hs, attn.to_q.weight)
         k_t, v_t = AG.linear(txt, attn.to_k.weight), AG.linear(txt, attn.to_v.weight)
-        k_a, v_a = AG.linear(aud, self.to_k_ip.weight), AG.linear(aud, self.to_v_ip.weight)
         bias = None
         if attention_mask is not None:
             bias = attention_mask.reshape(B, -1)[:, :1].float().expand(B, txt.shape[1]).contiguous()
-        o = AG.ip_attention(q, k_t, v_t, k_a, v_a, attn.heads, bias, float(self.scale))
+        if aud.shape[1] == 0:  # no audio tokens: the text branch alone (reference :435-445 on an empty slice contributes 0)
+            o = AG.attention(q, k_t, v_t, attn.heads, bias)
+        else:
+            k_a, v_a = AG.linear(aud, self.to_k_ip.weight), AG.linear(aud, self.to_v_ip.weight)
+            o = AG.ip_attention(q, k_t, v_t, k_a, v_a, attn.heads, bias, float(self.scale))
         return AG.linear(o, attn.to_out[0].weight, attn.to_out[0].bias, residual=_residual)
