@@ -48,6 +48,11 @@ struct GemmP {
 // byte offset of 16-byte chunk `chunk` (0..7) of tile row `row` (128-byte rows)
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+// internal A mode: 3x3 implicit conv whose every 64-wide k-tile lies inside ONE filter tap (Cin % 64 == 0) and whose
+// source is not upsampled: the tap / channel split of k is tracked by scalar counters instead of per-chunk integer
+// divisions, and each row keeps a precomputed element offset (the gather was 25 % of the conv kernel's wave cycles in VALU)
+#define APAD_A_CONV3X3_FAST 3
+
 template <int AMODE> struct RowInfo {
     int64_t base;  // PLAIN: element offset of the row; CONV/PATCH: source batch index
     int oy, ox;
@@ -146,6 +151,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
                 ra[i].oy = rem / p.Wout;
                 ra[i].ox = rem - ra[i].oy * p.Wout;
                 ra[i].base = p.src_batch_mod > 0 ? b % p.src_batch_mod : b;
+            } else if (AMODE == APAD_A_CONV3X3_FAST) {
+                int64_t hw = (int64_t)p.Hout * p.Wout;
+                int64_t b = m / hw;
+                int rem = (int)(m - b * hw);
+                const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+                ra[i].oy = oy * p.stride - 1;  // source row / column of filter tap (0, 0)
+                ra[i].ox = ox * p.stride - 1;
+                const int64_t sb = p.src_batch_mod > 0 ? b % p.src_batch_mod : b;
+                ra[i].base = ((sb * p.Hin + ra[i].oy) * p.Win + ra[i].ox) * p.Cin;  // element offset of that tap, channel 0
             } else {
                 int wp = p.Win >> 4, hp = p.Hin >> 4;
                 int64_t b = m / (hp * wp);
@@ -169,10 +183,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 
     const int nk = (int)((p.K + BK - 1) / BK);
     u32x4 ga[NLD], gb[NLD];  // (native vectors: HIP's uint4 class type kept such arrays in scratch)
+    int ftap = 0, fc0 = 0;  // CONV3X3_FAST: filter tap and first channel of the NEXT k-tile to load (tiles load in order)
     auto gload = [&](int kt) {
         int k = kt * BK + chunk * 8;
+        int fky = 0, fkx = 0;
+        int64_t fkoff = 0;
+        if (AMODE == APAD_A_CONV3X3_FAST) {
+            fky = ftap / 3;
+            fkx = ftap - fky * 3;
+            fkoff = ((int64_t)fky * p.Win + fkx) * p.Cin + fc0 + chunk * 8;
+            fc0 += BK;
+            if (fc0 >= p.Cin) { fc0 = 0; ++ftap; }
+        }
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
+            if (AMODE == APAD_A_CONV3X3_FAST) {
+                const int iy = ra[i].oy + fky, ix = ra[i].ox + fkx;
+                const bool ok = ra[i].valid && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+                const u32x4 z0 = {0u, 0u, 0u, 0u};
+                ga[i] = ok ? *reinterpret_cast<const u32x4*>(p.a + (ra[i].base + fkoff) * 2) : z0;
+            } else
             ga[i] = __builtin_bit_cast(u32x4, load_a<DT, AMODE>(p, ra[i], k));
             const u32x4 z = {0u, 0u, 0u, 0u};
             gb[i] = (wv[i] && k < p.K) ? *reinterpret_cast<const u32x4*>(p.w + (wb[i] + k) * 2) : z;
@@ -537,6 +567,8 @@ template <int DT> int dispatch_amode(const GemmP& p, const apad_gemm_desc* d, hi
         case APAD_A_CONV3X3:
             APAD_CHECK(d->epilogue == APAD_EPI_NONE && d->out_mode == APAD_OUT_ROWMAJOR,
                        "apad_gemm: conv3x3 supports epilogue NONE / row-major output only");
+            if (d->Cin % 64 == 0 && d->Hup == 0 && getenv("APAD_CONV_SLOW") == nullptr)
+                return launch<DT, APAD_A_CONV3X3_FAST, APAD_EPI_NONE, APAD_OUT_ROWMAJOR>(p, s);
             return launch<DT, APAD_A_CONV3X3, APAD_EPI_NONE, APAD_OUT_ROWMAJOR>(p, s);
         case APAD_A_PATCH16:
             APAD_CHECK(d->epilogue == APAD_EPI_NONE && d->out_mode == APAD_OUT_ROWMAJOR,
