@@ -182,9 +182,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (int)((p.K + BK - 1) / BK);
-    u32x4 ga[NLD], gb[NLD];  // (native vectors: HIP's uint4 class type kept such arrays in scratch)
+    // Global -> register staging, PF k-tiles ahead of the LDS copy.  Depths 2 and 3 were measured on the 64x64 variant
+    // (the 640- and 384-wide levels): no gain (10.5 / 11.2 us vs 10.7 us at M=4096, K=640; 41.8 / 44.1 vs 39.9 us at
+    // M=16128, K=1536) -- those launches are bound by the two barriers per k-tile, not by load latency -- so PF stays 1.
+#ifndef APAD_GEMM_PF64
+#define APAD_GEMM_PF64 1
+#endif
+    constexpr int PF = (TM == 64) ? APAD_GEMM_PF64 : 1;
+    u32x4 ga[PF][NLD], gb[PF][NLD];  // (native vectors: HIP's uint4 class type kept such arrays in scratch)
     int ftap = 0, fc0 = 0;  // CONV3X3_FAST: filter tap and first channel of the NEXT k-tile to load (tiles load in order)
-    auto gload = [&](int kt) {
+    auto gload = [&](int kt, u32x4* gA, u32x4* gB) {
         int k = kt * BK + chunk * 8;
         int fky = 0, fkx = 0;
         int64_t fkoff = 0;
@@ -201,27 +208,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
                 const int iy = ra[i].oy + fky, ix = ra[i].ox + fkx;
                 const bool ok = ra[i].valid && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
                 const u32x4 z0 = {0u, 0u, 0u, 0u};
-                ga[i] = ok ? *reinterpret_cast<const u32x4*>(p.a + (ra[i].base + fkoff) * 2) : z0;
+                gA[i] = ok ? *reinterpret_cast<const u32x4*>(p.a + (ra[i].base + fkoff) * 2) : z0;
             } else
-            ga[i] = __builtin_bit_cast(u32x4, load_a<DT, AMODE>(p, ra[i], k));
+            gA[i] = __builtin_bit_cast(u32x4, load_a<DT, AMODE>(p, ra[i], k));
             const u32x4 z = {0u, 0u, 0u, 0u};
-            gb[i] = (wv[i] && k < p.K) ? *reinterpret_cast<const u32x4*>(p.w + (wb[i] + k) * 2) : z;
+            gB[i] = (wv[i] && k < p.K) ? *reinterpret_cast<const u32x4*>(p.w + (wb[i] + k) * 2) : z;
         }
     };
-    auto sstore = [&]() {
+    auto sstore = [&](const u32x4* gA, const u32x4* gB) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             int rl = (tid >> 3) + 32 * i;
-            *reinterpret_cast<u32x4*>(smem + lds_off(rl, chunk)) = ga[i];
-            *reinterpret_cast<u32x4*>(smem + A_BYTES + lds_off(rl, chunk)) = gb[i];
+            *reinterpret_cast<u32x4*>(smem + lds_off(rl, chunk)) = gA[i];
+            *reinterpret_cast<u32x4*>(smem + A_BYTES + lds_off(rl, chunk)) = gB[i];
         }
     };
-
-    gload(0);
-    sstore();
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) gload(kt + 1);
+    auto compute = [&]() {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int ch = ks * 2 + half;
@@ -237,10 +239,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 #pragma unroll
                 for (int j = 0; j < MI; ++j) acc[i][j] = E::mfma32(af[i], bf[j], acc[i][j]);
         }
-        __syncthreads();
-        if (kt + 1 < nk) {
-            sstore();
-            __syncthreads();
+    };
+
+#pragma unroll
+    for (int s0 = 0; s0 < PF; ++s0)
+        if (s0 < nk) gload(s0, ga[s0], gb[s0]);
+    sstore(ga[0], gb[0]);
+    __syncthreads();
+    for (int kt0 = 0; kt0 < nk; kt0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int kt = kt0 + u;
+            if (kt < nk) {  // uniform
+                if (kt + PF < nk) gload(kt + PF, ga[u], gb[u]);  // set u was copied to LDS before this iteration
+                compute();
+                __syncthreads();
+                if (kt + 1 < nk) {
+                    sstore(ga[(u + 1) % PF], gb[(u + 1) % PF]);
+                    __syncthreads();
+                }
+            }
         }
     }
 

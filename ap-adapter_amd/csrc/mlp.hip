@@ -174,10 +174,11 @@ __global__ __launch_bounds__(NWV * 64, 1) void mlp_kernel(MlpP p) {
         rp_load_group<DT, KC>(wfa, wt, 0);
         // register r (0..7) of acur = value, r+8 = gate of hidden unit jc*16 + (r&3) + 8(r>>2) + 4half
         auto geglu_step = [&](int r) {
-            // the un-fused reference rounds the projection to the storage type before value * gelu(gate)
-            const float v0 = (float)(typename E::elem)(acur[r] + bv[r]);
-            const float v1 = (float)(typename E::elem)(acur[r + 1] + bv[r + 1]);
-            const apad_f32x2 gt = {(float)(typename E::elem)(acur[8 + r] + bg[r]), (float)(typename E::elem)(acur[9 + r] + bg[r + 1])};
+            // value and gate stay fp32 here (the un-fused path rounds the 8C projection to the storage type first; skipping
+            // that rounding is closer to the fp32 reference and saves ~50 VALU instructions per chunk)
+            const float v0 = acur[r] + bv[r];
+            const float v1 = acur[r + 1] + bv[r + 1];
+            const apad_f32x2 gt = {acur[8 + r] + bg[r], acur[9 + r] + bg[r + 1]};
 #ifdef MLP_NOGELU
             const apad_f32x2 ge = gt;
 #else
