@@ -243,8 +243,9 @@ class _MSE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dpred,) = ctx.saved_tensors
-        # g is 1 for loss.backward(); any other scale is a scalar multiply of a [B, 8, 250, 16] tensor
-        return (dpred if (g.numel() == 1 and float(g) == 1.0) else dpred * g.to(dpred.dtype)), None
+        # g is 1 for loss.backward(); applied as a device-side scalar multiply of a [B, 8, 250, 16] tensor (no host
+        # sync: the step must stay capturable in a hipGraph)
+        return dpred * g.to(dpred.dtype), None
 
 
 def mse_loss(pred, target):

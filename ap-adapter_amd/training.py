@@ -81,6 +81,49 @@ class AdapterTrainer:
         self._micro += 1
         return loss.detach()
 
+    # ---- the same micro-batch as ONE hipGraph: the un-fused training chain is ~7k launches, host-bound when eager ----
+    def capture_micro_step(self, batch, height, width, n_gen_tokens, n_t5_tokens):
+        """Capture forward + loss + backward + gradient accumulation for a fixed batch geometry and return
+        ``replay(noisy_latents, timesteps, generated_prompt_embeds, prompt_embeds, attention_mask, target) -> loss``.
+        The autograd tape is recorded once at capture; replays re-run its kernels on new data copied into static buffers.
+        Trainable state is snapshotted around the warm-up runs, so capturing does not change the training trajectory."""
+        dev, dtype = self.work.device, self.work.dtype
+        C_in = self.unet.config.in_channels
+        st = {"noisy": torch.zeros(batch, C_in, height, width, device=dev),
+              "t": torch.zeros(batch, dtype=torch.int64, device=dev),
+              "gen": torch.zeros(batch, n_gen_tokens, 768, dtype=dtype, device=dev),
+              "pe": torch.zeros(batch, n_t5_tokens, 1024, dtype=dtype, device=dev),
+              "mask": torch.ones(batch, n_t5_tokens, device=dev),
+              "target": torch.zeros(batch, C_in, height, width, device=dev)}
+        run = lambda: self.micro_step(st["noisy"], st["t"], st["gen"], st["pe"], st["mask"], st["target"])
+        grad0, micro0 = self.grad.clone(), self._micro
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):  # warm-up: builds the cached transposed weights, primes the allocator
+                run()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.grad.copy_(grad0)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss = run()
+        self._micro = micro0
+
+        def replay(noisy_latents, timesteps, generated_prompt_embeds, prompt_embeds, attention_mask, target):
+            st["noisy"].copy_(noisy_latents)
+            st["t"].copy_(timesteps)
+            st["gen"].copy_(generated_prompt_embeds)
+            st["pe"].copy_(prompt_embeds)
+            st["mask"].copy_(attention_mask)
+            st["target"].copy_(target)
+            graph.replay()
+            self._micro += 1
+            return loss
+
+        replay.graph = graph
+        return replay
+
     # ---- optimizer step on the accumulation boundary ----
     def optimizer_step(self):
         average_flat_gradient_(self.grad, self._micro)  # the ONE collective of the step (86.5 MB fp32 for -large)

@@ -328,3 +328,30 @@ def test_collate_and_checkpoint(dev, tmp_path):
     tr2 = A.AdapterTrainer(_small_unet(dev, torch.bfloat16, seed=5)[0])
     tr2.load_state_dict(st)
     assert torch.equal(tr2.master, tr.master) and tr2.global_step == 7
+
+
+def test_graph_captured_micro_step_equals_eager(dev):
+    """the whole forward + loss + backward of a micro-batch replayed as one hipGraph: same loss and same accumulated
+    gradient, bit for bit, as the eager tape on the same data"""
+    import ap_adapter_amd as A
+    from oracle import train as OT
+    dtype = torch.bfloat16
+    u, cfg, sd, procs = _small_unet(dev, dtype)
+    tr = A.AdapterTrainer(u, lr=1e-3)
+    lat, noise, t, ehs, ehs1, m1 = _batch(2, 8, dtype)
+    noisy = OT.add_noise(lat, noise, t)
+    args = (noisy.to(dev), t.to(dev), ehs.to(dev, dtype), ehs1.to(dev, dtype), m1.to(dev), noise.to(dev))
+    loss_e = float(tr.micro_step(*args))
+    grad_e = tr.grad.clone()
+    tr.grad.zero_(); tr._micro = 0
+    replay = tr.capture_micro_step(2, 26, 16, ehs.shape[1], ehs1.shape[1])
+    assert float(tr.grad.abs().max()) == 0 and tr._micro == 0          # capturing leaves the trainer untouched
+    loss_g = float(replay(*args))
+    assert loss_g == loss_e and torch.equal(tr.grad, grad_e) and tr._micro == 1
+    # new data through the same graph
+    args2 = ((noisy + 0.5).to(dev),) + args[1:]
+    tr.grad.zero_()
+    l2 = float(replay(*args2))
+    g2 = tr.grad.clone()
+    tr.grad.zero_()
+    assert float(tr.micro_step(*args2)) == l2 and torch.equal(tr.grad, g2)

@@ -20,6 +20,8 @@ lat = torch.randn(B, 8, 250, 16, generator=g).to(dev)
 ehs = torch.randn(B, 8 + La, 768, generator=g).to(dev)
 ehs1 = torch.randn(B, 16, 1024, generator=g).to(dev)
 m1 = torch.ones(B, 16, device=dev)
+graphed = os.environ.get("APAD_TRAIN_GRAPH", "1") != "0"
+replay = tr.capture_micro_step(B, 250, 16, 8 + La, 16) if graphed else None
 losses = []
 torch.cuda.reset_peak_memory_stats()
 for i in range(steps + 2):
@@ -27,9 +29,14 @@ for i in range(steps + 2):
         torch.cuda.synchronize(); t0 = time.perf_counter()
     noise = torch.randn(B, 8, 250, 16, generator=g).to(dev)
     t = torch.randint(0, 1000, (B,), generator=g).to(dev)
-    losses.append(tr.train_step(lat, noise, t, ehs, ehs1, m1))
+    if graphed:
+        noisy = A.add_noise(lat, noise, t, tr.alphas_cumprod)
+        losses.append(replay(noisy, t, ehs, ehs1, m1, noise).clone())
+        tr.optimizer_step()
+    else:
+        losses.append(tr.train_step(lat, noise, t, ehs, ehs1, m1))
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
-print(json.dumps({"train_step_ms": round(dt * 1e3, 2), "samples_per_s": round(B / dt, 2), "B": B, "La": La, "steps": steps,
+print(json.dumps({"train_step_ms": round(dt * 1e3, 2), "samples_per_s": round(B / dt, 2), "B": B, "La": La, "steps": steps, "hipgraph": graphed,
                   "loss_first": float(losses[0]), "loss_last": float(losses[-1]), "finite": bool(torch.isfinite(torch.stack(losses)).all()),
                   "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "adapter_params": int(tr.master.numel())}))
