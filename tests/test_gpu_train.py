@@ -245,7 +245,7 @@ def test_adapter_gradients_small_unet_vs_oracle(dev, dtype, tol):
             assert rel_err(got, want) < tol, (n, which)
             flat_ref.append(want.reshape(-1))
     flat_ref = torch.cat(flat_ref)
-    cos = F.cosine_similarity(tr.grad.cpu(), flat_ref, dim=0)
+    cos = F.cosine_similarity(tr.grad.cpu().double(), flat_ref.double(), dim=0)
     assert 1 - float(cos) < 2e-3
 
 
@@ -355,3 +355,47 @@ def test_graph_captured_micro_step_equals_eager(dev):
     g2 = tr.grad.clone()
     tr.grad.zero_()
     assert float(tr.micro_step(*args2)) == l2 and torch.equal(tr.grad, g2)
+
+
+def test_full_geometry_adapter_gradients_vs_oracle(dev):
+    """BASELINE config 5 geometry (AudioLDM2-large, 718 M frozen parameters, 64 trainable tensors = 21 626 880 elements),
+    one 10 s sample at a random t: every adapter gradient after a backward through the whole UNet vs torch autograd
+    through the fp32 oracle.  Bound (bf16): the flat gradient's direction within 1 - cos < 5e-3 and its norm within 3 %;
+    per tensor, max-abs error below 0.15 of that tensor's largest entry (the smallest gradients sit deep in the stack)."""
+    import ap_adapter_amd as A
+    from ap_adapter_amd.synthetic import init_synthetic_, synthetic_inputs
+    from oracle import train as OT
+    dtype = torch.bfloat16
+    u = A.AudioLDM2UNet2DConditionModel()
+    A.install_ap_adapter(u, None, scale=0.55)
+    init_synthetic_(u, 100, bias_std=0.01)
+    u = u.to(dtype)
+    sd = {k: v.detach().float() for k, v in u.state_dict().items()}
+    procs = {n: dict(scale=p.scale, num_tokens=p.num_tokens) for n, p in u.attn_processors.items() if hasattr(p, "to_k_ip")}
+    inp = synthetic_inputs(1, 32)
+    pipe = A.AudioLDM2Pipeline(u)
+    ehs = pipe.assemble_condition(inp["generated_prompt_embeds"], inp["audio_tokens"], inp["uncond_audio_tokens"], dtype)[1:]
+    ehs1 = inp["prompt_embeds"].to(dtype)[1:]
+    m1 = inp["attention_mask"].float()[1:]
+    g = torch.Generator().manual_seed(9)
+    noise = torch.randn(1, 8, 250, 16, generator=g)
+    t = torch.tensor([437])
+    noisy = q(OT.add_noise(inp["latents"].float(), noise, t), dtype)
+    ref_loss, ref_grads, _ = OT.loss_and_grads(sd, u.config.geometry_dict(), procs, noisy, t, ehs.float(), ehs1.float(), m1, noise)
+    u = u.to(dev)
+    tr = A.AdapterTrainer(u)
+    loss = tr.micro_step(noisy.to(dev), t.to(dev), ehs.to(dev), ehs1.to(dev), m1.to(dev), noise.to(dev))
+    assert abs(float(loss) - float(ref_loss)) < 2e-2 * float(ref_loss)
+    names = [n for n, p in u.attn_processors.items() if hasattr(p, "to_k_ip")]
+    flat_ref = torch.cat([ref_grads[f"{n}.{w}.weight"].reshape(-1) for n in names for w in ("to_k_ip", "to_v_ip")])
+    got = tr.grad.cpu()
+    assert got.numel() == flat_ref.numel() == 21626880
+    cos = float(F.cosine_similarity(got.double(), flat_ref.double(), dim=0))
+    nr = float(got.double().norm() / flat_ref.double().norm())
+    worst = 0.0
+    for i, (p, off) in enumerate(zip(tr.params, tr.offsets)):
+        a, b = got[off:off + p.numel()], flat_ref[off:off + p.numel()]
+        worst = max(worst, float((a - b).abs().max() / b.abs().max()))
+    print(f"\\n[full-geometry adapter gradients] loss {float(loss):.5f} vs {float(ref_loss):.5f}; cos {cos:.6f}; norm ratio {nr:.4f}; "
+          f"worst per-tensor rel-max {worst:.3e}")
+    assert 1 - cos < 5e-3 and abs(nr - 1) < 3e-2 and worst < 0.15
