@@ -81,6 +81,28 @@ __device__ __forceinline__ void tile_load(u32x4 (&rk)[Lay<D>::NK], u32x4 (&rv)[L
     }
 }
 
+// same for a tile that lies entirely inside the segment: per-thread byte offsets are precomputed once per segment and the
+// tile base is wave-uniform, so a tile costs no address arithmetic and no predicates on the vector ALU (the generic loader
+// spent ~25 VALU instructions per tile on them, in a loop that is VALU-bound)
+template <int D>
+__device__ __forceinline__ void tile_load_full(u32x4 (&rk)[Lay<D>::NK], u32x4 (&rv)[Lay<D>::NV], const uint8_t* ktile,
+                                               const uint8_t* vtile, const uint32_t (&koff)[Lay<D>::NK],
+                                               const uint32_t (&voff)[Lay<D>::NV], int tid) {
+    using Y = Lay<D>;
+#pragma unroll
+    for (int i = 0; i < Y::NK; ++i) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (tid + 256 * i < Y::KCH) v = *reinterpret_cast<const u32x4*>(ktile + koff[i]);
+        rk[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < Y::NV; ++i) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (tid + 256 * i < Y::VCH) v = *reinterpret_cast<const u32x4*>(vtile + voff[i]);
+        rv[i] = v;
+    }
+}
+
 template <int D>
 __device__ __forceinline__ void tile_store(const u32x4 (&rk)[Lay<D>::NK], const u32x4 (&rv)[Lay<D>::NV], uint8_t* buf, int tid) {
     using Y = Lay<D>;
@@ -211,6 +233,18 @@ __device__ __forceinline__ void segment(uint8_t* smem, const uint8_t* kbase, int
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (typename E::elem)(l31 == 0 ? 1.0f : 0.0f);
     u32x4 rk[Y::NK], rv[Y::NV];
+    uint32_t koff[Y::NK], voff[Y::NV];  // per-thread byte offsets inside a tile (rows x k_sl stays far below 4 GB)
+#pragma unroll
+    for (int i = 0; i < Y::NK; ++i) {
+        const int idx = tid + 256 * i;
+        const int row = idx / (D / 8), ch = idx - row * (D / 8);
+        koff[i] = (uint32_t)(((int64_t)row * k_sl + ch * 8) * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < Y::NV; ++i) {
+        const int idx = tid + 256 * i;
+        voff[i] = (uint32_t)((((int64_t)(idx >> 3)) * Lpad + (idx & 7) * 8) * 2);
+    }
     tile_load<D>(rk, rv, kbase, k_sl, vbase, L, Lpad, 0, tid);
     __syncthreads();  // previous users of the LDS buffers (other segment / zero fill) are done
     tile_store<D>(rk, rv, smem, tid);
@@ -220,7 +254,9 @@ __device__ __forceinline__ void segment(uint8_t* smem, const uint8_t* kbase, int
     int t = 0;
     for (; t < nfull; ++t) {
         const uint8_t* buf = smem + (t & 1) * Y::BUF;
-        if (t + 1 < ntiles) tile_load<D>(rk, rv, kbase, k_sl, vbase, L, Lpad, (t + 1) * KT, tid);
+        if (t + 1 < nfull)  // the next tile is a full one too
+            tile_load_full<D>(rk, rv, kbase + (int64_t)(t + 1) * KT * k_sl * 2, vbase + (int64_t)(t + 1) * KT * 2, koff, voff, tid);
+        else if (t + 1 < ntiles) tile_load<D>(rk, rv, kbase, k_sl, vbase, L, Lpad, (t + 1) * KT, tid);
         tile_compute<DT, D, false>(buf, t * KT, L, bias, c, qf, o, osum, m, ones, l31, half);
         if (t + 1 < ntiles) tile_store<D>(rk, rv, smem + ((t + 1) & 1) * Y::BUF, tid);
         __syncthreads();
