@@ -118,6 +118,18 @@ def dominant_kernel_roofline(dev, dtype, B2):
             "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes)" if traffic else None}
 
 
+def audiomae_ms(dev):
+    """AudioMAE ViT-B (12 blocks, 513 tokens) + (avg + max)/2 pooling over 2 mels [1024, 128], random-init weights"""
+    import ap_adapter_amd as A
+    from ap_adapter_amd.synthetic import init_synthetic_
+    m = A.AudioMAEConditionCTPoolRand()
+    init_synthetic_(m, 7, w_std=0.02)
+    m = m.to(dev, torch.float16)
+    mel = torch.randn(2, 1024, 128, device=dev) * 0.5
+    with torch.no_grad():
+        return time_kernel(lambda: m(mel, time_pool=4, freq_pool=4), iters=5)
+
+
 def cpu_baseline(La, gs, steps=1):
     """Oracle (reference-equivalent CPU restatement, fp32) on the host cores: BASELINE config-1 shape (B=1, CFG) for a
     bounded number of DDIM steps."""
@@ -273,6 +285,15 @@ def main():
             "finite": finite,
         }
         line["roofline"] = dominant_kernel_roofline(dev, dtype, 2 * B)
+        # the audio-condition encoder (2 mels per call: clip + zeros) is outside the timed loop; reported
+        # separately and folded into a per-clip "included" figure (one pipeline call of B clips pays it once)
+        try:
+            mae_ms = audiomae_ms(dev)
+            per_call_s = DDIM_STEPS_PER_CLIP * ms_per_step * 1e-3 + mae_ms * 1e-3
+            line["audiomae"] = {"ms_per_call": round(mae_ms, 3), "mels": 2, "dtype": "f16 storage, fp32 accumulate",
+                                "clips_per_s_including_it": round(B * world / per_call_s, 4)}
+        except Exception as e:  # never lose the headline line over the side measurement
+            line["audiomae"] = {"error": repr(e)}
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.la, args.guidance, args.cpu_steps)
         print(json.dumps(line))
