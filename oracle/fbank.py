@@ -12,6 +12,10 @@ published algorithm and anchored on the reference's call site
       :380-391  zero-pad / crop to TARGET_LEN frames BEFORE normalisation
       :393      (fbank - norm_mean) / (norm_std * 2),  norm_mean -4.2677393, norm_std 4.5689974
 
+Cross-check available offline: transformers.audio_utils carries an independent numpy re-implementation of kaldi.fbank
+(for its AST feature extractor, the model AudioMAE inherited this front-end from); tests/test_frontend_oracle.py holds
+this restatement to it (log-mel within 2e-3, mel banks within 1e-4).  The resampler has no such second source.
+
 numpy, float32 where torch computes in float32.  The tables (window, mel banks, resampling kernel) are shared with the
 product path by construction of the same formulas in ap-adapter_amd/frontend.py; this file recomputes them independently.
 """

@@ -71,3 +71,24 @@ def test_wav_reader_matches_the_pcm_it_wrote(tmp_path):
     # the product's host tables are the oracle's formulas
     assert np.array_equal(_mel_banks(128), OF.mel_banks())
     assert np.array_equal(_resample_kernel(44100, 16000)[0], OF.resample_kernel(44100, 16000)[0])
+
+
+def test_fbank_oracle_agrees_with_an_independent_kaldi_fbank_implementation():
+    """transformers.audio_utils re-implements torchaudio.compliance.kaldi.fbank in numpy for its AST feature extractor
+    (same 25 ms hanning / 10 ms / 128 kaldi-mel-bin / pre-emphasis 0.97 / DC-removal configuration AudioMAE inherited
+    from AST).  torchaudio itself is not installable here, so this is the closest available pin of the restatement."""
+    import warnings
+    from transformers.audio_utils import mel_filter_bank, spectrogram, window_function
+    rs = np.random.RandomState(0)
+    x = (0.1 * rs.randn(32000) + 0.3 * np.sin(2 * np.pi * 440 * np.arange(32000) / 16000.0)).astype(np.float32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mel = mel_filter_bank(num_frequency_bins=257, num_mel_filters=128, min_frequency=20, max_frequency=8000,
+                              sampling_rate=16000, norm=None, mel_scale="kaldi", triangularize_in_mel_space=True)
+    assert np.abs(mel.T - OF.mel_banks()).max() < 1e-4
+    ref = spectrogram(x, window_function(400, "hann", periodic=False), frame_length=400, hop_length=160, fft_length=512,
+                      power=2.0, center=False, preemphasis=0.97, mel_filters=mel, log_mel="log",
+                      mel_floor=1.192092955078125e-07, remove_dc_offset=True).T
+    got = OF.kaldi_fbank(x)
+    assert got.shape == ref.shape == (198, 128)
+    assert np.abs(got - ref).max() < 2e-3           # log-mel units (values span ~[-16, 5])
