@@ -94,6 +94,10 @@ class AudioLDM2Pipeline:
 
         unet.set_kv_cache(True)
         unet.precompute_time_tables(sched.timesteps.to(dev), step_ptr)
+        if use_graph and unet.low_res_streams is None and B >= 8:
+            # the 64-token section of the UNet is latency-bound at any batch: its two batch halves run on two streams
+            # inside the captured step (measured -1.1 % per step at batch 32; no effect on the arithmetic of a sample)
+            unet.low_res_streams = (torch.cuda.Stream(), torch.cuda.Stream())
 
         def step():
             eps2 = unet.forward_nhwc(unet_in, H, W, None, gen, pe, None, attention_mask, batch_repeat=2)

@@ -347,6 +347,8 @@ class AudioLDM2UNet2DConditionModel(nn.Module):
         self.conv_out = nn.Conv2d(boc[0], cfg.out_channels, 3, padding=1)
         self._pk_in, self._pk_out = _Packed(), _Packed()
         self._time_tables = None
+        self.low_res_streams = None  # optional (stream, stream): see forward_nhwc
+        self.low_res_levels = 1      # how many of the lowest-resolution levels run on the two streams
 
     # ---- processor plumbing (modeling_audioldm2.py:517-574) ----
     @property
@@ -453,9 +455,11 @@ class AudioLDM2UNet2DConditionModel(nn.Module):
             step_ptr = None
             tp = lambda name, m: (m.time_proj(emb), None)
 
+        B_of = lambda t_: t_.shape[0]
+
         def resnet(name, m, x, H, W):
             tab, rpg = tp(name, m)
-            return m(x, B, H, W, tab, rpg if rpg is not None else H * W, step_ptr)
+            return m(x, B_of(x), H, W, tab, rpg if rpg is not None else H * W, step_ptr)
 
         wp = self._pk_in.get(self.conv_in.weight, lambda w: w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous())
         x, _, _ = ops.conv3x3(x, wp, self.conv_in.bias, B, H, W, src_batch_mod=(Bs if batch_repeat > 1 else 0))
@@ -464,24 +468,29 @@ class AudioLDM2UNet2DConditionModel(nn.Module):
         n_up = nb - 1
         fwd_up = (H % (2 ** n_up) != 0) or (W % (2 ** n_up) != 0)
 
-        for i, blk in enumerate(self.down_blocks):
+        def down(i, x, H, W, skips, ehs, emask, ehs1, emask1):
+            blk = self.down_blocks[i]
             for layer, rn in enumerate(blk.resnets):
                 x = resnet(f"down_blocks.{i}.resnets.{layer}", rn, x, H, W)
                 if blk.has_cross_attention:
                     x = blk._attn_stack(layer, x, ehs, emask, ehs1, emask1)
                 skips.append((x, H, W))
             if blk.downsamplers is not None:
-                x, H, W = blk.downsamplers[0](x, B, H, W)
+                x, H, W = blk.downsamplers[0](x, B_of(x), H, W)
                 skips.append((x, H, W))
+            return x, H, W
 
-        mb = self.mid_block
-        x = resnet("mid_block.resnets.0", mb.resnets[0], x, H, W)
-        x = mb._attn_stack(0, x, ehs, emask, ehs1, emask1)
-        x = resnet("mid_block.resnets.1", mb.resnets[1], x, H, W)
+        def mid(x, H, W, ehs, emask, ehs1, emask1):
+            mb = self.mid_block
+            x = resnet("mid_block.resnets.0", mb.resnets[0], x, H, W)
+            x = mb._attn_stack(0, x, ehs, emask, ehs1, emask1)
+            return resnet("mid_block.resnets.1", mb.resnets[1], x, H, W)
 
-        for i, blk in enumerate(self.up_blocks):
+        def up(i, x, H, W, skips, ehs, emask, ehs1, emask1):
+            blk = self.up_blocks[i]
             n = len(blk.resnets)
-            res, skips = skips[-n:], skips[:-n]
+            res = skips[-n:]
+            del skips[-n:]
             final = i == nb - 1
             up_size = skips[-1][1:] if (not final and fwd_up) else None
             for layer, rn in enumerate(blk.resnets):
@@ -491,7 +500,46 @@ class AudioLDM2UNet2DConditionModel(nn.Module):
                 if blk.has_cross_attention:
                     x = blk._attn_stack(layer, x, ehs, emask, ehs1, emask1)
             if blk.upsamplers is not None:
-                x, H, W = blk.upsamplers[0](x, B, H, W, up_size)
+                x, H, W = blk.upsamplers[0](x, B_of(x), H, W, up_size)
+            return x, H, W
+
+        cond = (ehs, emask, ehs1, emask1)
+        split = self.low_res_streams is not None and timestep is None and B % 2 == 0 and not AG.on(x) and nb >= 2
+        k0 = max(1, nb - self.low_res_levels) if split else nb  # first down block of the two-stream section
+        for i in range(k0):
+            x, H, W = down(i, x, H, W, skips, *cond)
+        if split:
+            # The lowest-resolution section (last down block(s), mid block, first up block(s): 64-token sequences) under-fills
+            # the chip and is latency-bound kernel after kernel; its two batch halves are independent, so they run on two
+            # streams (forked / joined inside the captured graph) and each other's launch tails overlap.
+            cur = torch.cuda.current_stream()
+            hb = B // 2
+            outs = [None, None]
+            shared = list(skips)  # skips of the higher levels, consumed by the first up block
+            for h, st in enumerate(self.low_res_streams):
+                sl = slice(h * hb, (h + 1) * hb)
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    c_h = tuple(None if c is None else c[sl] for c in cond)
+                    sk = [(t_[sl], hh, ww) for (t_, hh, ww) in shared]
+                    xh, Hh, Wh = x[sl], H, W
+                    for i in range(k0, nb):
+                        xh, Hh, Wh = down(i, xh, Hh, Wh, sk, *c_h)
+                    xh = mid(xh, Hh, Wh, *c_h)
+                    for i in range(nb - k0):
+                        xh, Hh, Wh = up(i, xh, Hh, Wh, sk, *c_h)
+                    outs[h] = (xh, Hh, Wh, len(sk))
+            for st in self.low_res_streams:
+                cur.wait_stream(st)
+            x = torch.cat([outs[0][0], outs[1][0]], dim=0)
+            H, W = outs[0][1], outs[0][2]
+            del skips[outs[0][3]:]
+            first_up = nb - k0
+        else:
+            x = mid(x, H, W, *cond)
+            first_up = 0
+        for i in range(first_up, nb):
+            x, H, W = up(i, x, H, W, skips, *cond)
 
         if AG.on(x):
             x = AG.group_norm(x, self.conv_norm_out.weight, self.conv_norm_out.bias, cfg.norm_num_groups,

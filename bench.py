@@ -169,6 +169,7 @@ def main():
     ap.add_argument("--guidance", type=float, default=9.5)
     ap.add_argument("--ap-scale", type=float, default=0.55)
     ap.add_argument("--streams", type=int, default=1, help="2 = run the two CFG halves on concurrent streams")
+    ap.add_argument("--low-res-streams", type=int, default=1, help="n > 0: run the two batch halves of the n lowest-resolution levels on two streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=1)
     args = ap.parse_args()
@@ -205,6 +206,9 @@ def main():
     unet.set_kv_cache(True)
     unet.precompute_time_tables(sched.timesteps.to(dev), step_ptr)
 
+    if args.low_res_streams:
+        unet.low_res_streams = (torch.cuda.Stream(), torch.cuda.Stream())
+        unet.low_res_levels = args.low_res_streams
     side = [torch.cuda.Stream() for _ in range(2)] if args.streams == 2 else None
     eps_buf = torch.empty(2 * B, H * W, Cc, dtype=dtype, device=dev)
     ge_h, pe_h, am_h = ge.chunk(2), pe.chunk(2), am.chunk(2)
