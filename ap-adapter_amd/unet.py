@@ -504,7 +504,8 @@ class AudioLDM2UNet2DConditionModel(nn.Module):
             return x, H, W
 
         cond = (ehs, emask, ehs1, emask1)
-        split = self.low_res_streams is not None and timestep is None and B % 2 == 0 and not AG.on(x) and nb >= 2
+        nsp = len(self.low_res_streams) if self.low_res_streams is not None else 0
+        split = nsp > 1 and timestep is None and B % nsp == 0 and not AG.on(x) and nb >= 2
         k0 = max(1, nb - self.low_res_levels) if split else nb  # first down block of the two-stream section
         for i in range(k0):
             x, H, W = down(i, x, H, W, skips, *cond)
@@ -513,8 +514,8 @@ class AudioLDM2UNet2DConditionModel(nn.Module):
             # the chip and is latency-bound kernel after kernel; its two batch halves are independent, so they run on two
             # streams (forked / joined inside the captured graph) and each other's launch tails overlap.
             cur = torch.cuda.current_stream()
-            hb = B // 2
-            outs = [None, None]
+            hb = B // nsp
+            outs = [None] * nsp
             shared = list(skips)  # skips of the higher levels, consumed by the first up block
             for h, st in enumerate(self.low_res_streams):
                 sl = slice(h * hb, (h + 1) * hb)
@@ -531,7 +532,7 @@ class AudioLDM2UNet2DConditionModel(nn.Module):
                     outs[h] = (xh, Hh, Wh, len(sk))
             for st in self.low_res_streams:
                 cur.wait_stream(st)
-            x = torch.cat([outs[0][0], outs[1][0]], dim=0)
+            x = torch.cat([o_[0] for o_ in outs], dim=0)
             H, W = outs[0][1], outs[0][2]
             del skips[outs[0][3]:]
             first_up = nb - k0

@@ -207,7 +207,7 @@ def main():
     unet.precompute_time_tables(sched.timesteps.to(dev), step_ptr)
 
     if args.low_res_streams:
-        unet.low_res_streams = (torch.cuda.Stream(), torch.cuda.Stream())
+        unet.low_res_streams = tuple(torch.cuda.Stream() for _ in range(int(os.environ.get("APAD_LOW_RES_NSTREAMS", "2"))))
         unet.low_res_levels = args.low_res_streams
     side = [torch.cuda.Stream() for _ in range(2)] if args.streams == 2 else None
     eps_buf = torch.empty(2 * B, H * W, Cc, dtype=dtype, device=dev)
