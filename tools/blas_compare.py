@@ -32,3 +32,18 @@ for M, K, N in [(4096, 640, 640), (4096, 2560, 640), (16128, 384, 384), (16128, 
     t_lib = timeit(lambda: torch.addmm(r, x, w.t(), out=out))
     fl = 2.0 * M * N * K
     print(f"M={M:6d} K={K:5d} N={N:5d}  ours {t_ours:7.1f} us ({fl/t_ours/1e6:6.0f} TF/s)   torch.addmm {t_lib:7.1f} us ({fl/t_lib/1e6:6.0f} TF/s)")
+
+# attention context: torch's fused SDPA on the roofline kernel's problem (64 samples x 8 heads x 1000 x 1000, d = 32)
+for (B, H, N, d) in [(64, 8, 1000, 32), (64, 8, 252, 48), (64, 8, 64, 80)]:
+    q = (torch.randn(B, N, H * d, device=dev) * 0.32).to(dt); k = (torch.randn(B, N, H * d, device=dev) * 0.32).to(dt)
+    v = (torch.randn(B, N, H * d, device=dev) * 0.32).to(dt)
+    vt = ops.head_transpose(v, H) if hasattr(ops, "head_transpose") else None
+    out = torch.empty_like(q)
+    t_ours = timeit(lambda: ops.attention(q, k, vt, N, H, out=out))
+    q4, k4, v4 = (t.reshape(B, N, H, d).transpose(1, 2) for t in (q, k, v))
+    try:
+        t_lib = timeit(lambda: F.scaled_dot_product_attention(q4, k4, v4))
+    except Exception as e:
+        t_lib = float("nan"); print("sdpa failed:", e)
+    fl = 4.0 * B * H * N * N * d
+    print(f"attention B={B} H={H} N={N} d={d}: ours {t_ours:7.1f} us ({fl/t_ours/1e6:6.0f} TF/s)   torch SDPA {t_lib:7.1f} us ({fl/t_lib/1e6:6.0f} TF/s)")
