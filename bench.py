@@ -298,7 +298,7 @@ def main():
                                 "clips_per_s_including_it": round(B * world / per_call_s, 4)}
         except Exception as e:  # never lose the headline line over the side measurement
             line["audiomae"] = {"error": repr(e)}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the host baseline is reported at N = 1 only
             line["cpu_baseline"] = cpu_baseline(args.la, args.guidance, args.cpu_steps)
         print(json.dumps(line))
     if world > 1:
