@@ -138,9 +138,15 @@ __device__ __forceinline__ void tile_compute(const uint8_t* buf, int key0, int L
     constexpr int KC = D / 16;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // ---- S^T (two 32-key sub-tiles) = K . Q^T ----
+    // short segments (8 text tokens, 32 audio tokens, 16 T5 tokens: the decoupled cross-attention of the adapter) fill
+    // at most the first 32-key sub-tile of their only tile: the second sub-tile's MFMAs, exponentials and P.V steps are
+    // skipped (wave-uniform), which is half the work of such a launch
+    const bool one_sub = MASK && (L - key0) <= 32;
     f32x16 s[2];
+    s[1] = zero16;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
+        if (u == 1 && one_sub) break;
         const uint8_t* kp = buf + (u * 32 + l31) * Y::KROW + half * 16;
         s[u] = E::mfma32(as_v8<DT>(*reinterpret_cast<const uint4*>(kp)), qf[0], zero16);
 #pragma unroll
@@ -152,7 +158,8 @@ __device__ __forceinline__ void tile_compute(const uint8_t* buf, int key0, int L
     float tmax = NEG_BIG;
     if (MASK) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && one_sub) break;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = key0 + u * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -162,6 +169,7 @@ __device__ __forceinline__ void tile_compute(const uint8_t* buf, int key0, int L
                 s[u][r] = v;
                 tmax = fmaxf(tmax, v);
             }
+        }
     } else {
 #pragma unroll
         for (int u = 0; u < 2; ++u)
@@ -182,9 +190,11 @@ __device__ __forceinline__ void tile_compute(const uint8_t* buf, int key0, int L
     }
     if (MASK) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && one_sub) break;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[u][r] = __builtin_amdgcn_exp2f(s[u][r] - m);
+        }
     } else {
         const f32x2 c2 = {c, c}, nm2 = {-m, -m};
 #pragma unroll
@@ -201,6 +211,7 @@ __device__ __forceinline__ void tile_compute(const uint8_t* buf, int key0, int L
     const uint8_t* vtile = buf + Y::K_BYTES;
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
+        if (st == 2 && one_sub) break;
         typename E::v8 pf;
 #pragma unroll
         for (int j = 0; j < 8; ++j) pf[j] = (typename E::elem)s[st >> 1][(st & 1) * 8 + j];

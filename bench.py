@@ -118,6 +118,30 @@ def dominant_kernel_roofline(dev, dtype, B2):
             "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes)" if traffic else None}
 
 
+def fused_attn2_roofline(dev, dtype, B2, La, ap_scale):
+    """The adapter's own kernel -- decoupled cross-attention, two softmax segments (8 text + La audio keys) blended in one
+    launch -- at the 1000-token level.  Algorithmic bytes: read Q, write O (2 x B2*N*C*2) + the K/V of both segments;
+    arithmetic intensity 38 F/B at La = 32, far below the 310 F/B ridge: the HBM roofline applies."""
+    from ap_adapter_amd import ops
+    N, C, heads, Lt = 1000, 256, 8, 8
+    std = 0.02 * math.sqrt(C)
+    q = (torch.randn(B2, N, C, device=dev) * std).to(dtype)
+    kt = (torch.randn(B2, Lt, C, device=dev) * std).to(dtype)
+    ka = (torch.randn(B2, La, C, device=dev) * std).to(dtype)
+    vtt = torch.zeros(B2, heads, C // heads, ops.round_up(Lt, 32), device=dev, dtype=dtype)
+    vta = torch.zeros(B2, heads, C // heads, ops.round_up(La, 32), device=dev, dtype=dtype)
+    vtt[..., :Lt].normal_(0, std)
+    vta[..., :La].normal_(0, std)
+    out = torch.empty_like(q)
+    ms = time_kernel(lambda: ops.attention(q, kt, vtt, Lt, heads, k2=ka, vt2=vta, L2=La, scale2=ap_scale, out=out))
+    nbytes = 2 * B2 * N * C * 2 + 2 * B2 * (Lt + La) * C * 2 * 2
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    return {"kernel": "attn_kernel<bf16,D=32,DUAL> decoupled cross-attention B'=%d N=1000 Lt=8 La=%d" % (B2, La), "bound": "hbm",
+            "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
+            "avg_launch_ms": round(ms, 4), "algorithmic_bytes": nbytes,
+            "flops": 4.0 * B2 * N * (Lt + La) * C}
+
+
 def audiomae_ms(dev):
     """AudioMAE ViT-B (12 blocks, 513 tokens) + (avg + max)/2 pooling over 2 mels [1024, 128], random-init weights"""
     import ap_adapter_amd as A
@@ -289,6 +313,7 @@ def main():
             "finite": finite,
         }
         line["roofline"] = dominant_kernel_roofline(dev, dtype, 2 * B)
+        line["fused_attn2"] = fused_attn2_roofline(dev, dtype, 2 * B, args.la, args.ap_scale)
         # the audio-condition encoder (2 mels per call: clip + zeros) is outside the timed loop; reported
         # separately and folded into a per-clip "included" figure (one pipeline call of B clips pays it once)
         try:
