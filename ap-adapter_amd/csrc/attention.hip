@@ -18,6 +18,7 @@
 //     (wave-uniform branch) whenever no lane's running max moved
 // V must be supplied transposed per head, [Bk][H][D][Lpad] with zero padding (apad_gemm / apad_rowpanel_gemm
 // APAD_OUT_VT).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -396,7 +397,180 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Short-segment variant: every softmax segment has at most 64 keys (the adapter's decoupled cross-attention at
+// La <= 64 -- 8 text + 32 audio tokens in the style_transfer preset --, the 16-token T5 cross-attention).  Such a launch
+// is bound by reading Q and writing O; the staged kernel above spends it on LDS staging and four workgroup barriers per
+// 128 queries.  Here a wave is independent: K fragments (A operand rows = keys) and V^T fragments come straight from
+// global memory (a few KB per (batch, head), L2-resident), one masked tile per segment, no online rescale, row sums by a
+// half-wave exchange; only the output transpose goes through a per-wave LDS scratch.
+template <int DT, int D>
+__device__ __forceinline__ void short_segment(const uint8_t* kbase, int64_t k_sl, const uint8_t* vbase, int L, int Lpad, const float* bias,
+                                              float c, const typename ET<DT>::v8* qf, f32x16* o, float& inv_den, int l31, int half) {
+    using E = ET<DT>;
+    using Y = Lay<D>;
+    constexpr int KC = D / 16;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int nsub = L > 32 ? 2 : 1;
+    f32x16 s[2];
+    s[0] = s[1] = zero16;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (u >= nsub) break;
+        const int key = u * 32 + l31;
+        const uint8_t* kp = kbase + ((int64_t)(key < L ? key : L - 1) * k_sl + half * 8) * 2;  // rows past L: masked below
+#pragma unroll
+        for (int cc = 0; cc < KC; ++cc) {
+            typename E::v8 kf = as_v8<DT>(*reinterpret_cast<const uint4*>(kp + cc * 32));
+            s[u] = E::mfma32(kf, qf[cc], cc == 0 ? zero16 : s[u]);
+        }
+    }
+    float tmax = NEG_BIG;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (u >= nsub) break;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = u * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float v = s[u][r] * c;
+            if (bias) v += bias[key < L ? key : L - 1] * LOG2E;
+            v = key < L ? v : NEG_BIG;
+            s[u][r] = v;
+            tmax = fmaxf(tmax, v);
+        }
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (u >= nsub) break;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            // the denominator sums the probabilities as the P.V MFMA sees them (rounded to the storage type), like the
+            // ones-row MFMA of the staged kernel
+            const float e = (float)(typename E::elem)__builtin_amdgcn_exp2f(s[u][r] - tmax);
+            s[u][r] = e;
+            sum += e;
+        }
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    inv_den = 1.0f / sum;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        if (st >= 2 * nsub) break;
+        typename E::v8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (typename E::elem)s[st >> 1][(st & 1) * 8 + j];
+        const int kcol = st * 16 + 4 * half;
+#pragma unroll
+        for (int dt = 0; dt < Y::DT_TILES; ++dt) {
+            const int d = dt * 32 + l31;
+            uint2 v0 = make_uint2(0u, 0u), v1 = make_uint2(0u, 0u);
+            if (d < D) {  // kcol + 11 < Lpad: Lpad is a multiple of 32 covering every sub-tile that is visited
+                const uint8_t* vp = vbase + ((int64_t)d * Lpad + kcol) * 2;
+                v0 = *reinterpret_cast<const uint2*>(vp);
+                v1 = *reinterpret_cast<const uint2*>(vp + 16);
+            }
+            o[dt] = E::mfma32(as_v8<DT>(make_uint4(v0.x, v0.y, v1.x, v1.y)), pf, o[dt]);
+        }
+    }
+}
+
+template <int DT, int D, bool DUAL>
+__global__ __launch_bounds__(256) void attn_short_kernel(AttnP p) {
+    // (a one-workgroup-per-32-queries-x-all-heads shape, meant to consume whole 2*C-byte rows while their lines are hot,
+    //  measured slower: 38 vs 28 us at the 1000-token level -- the heads serialise inside a wave)
+    using E = ET<DT>;
+    using Y = Lay<D>;
+    constexpr int KC = D / 16;
+    constexpr int OROW = D * 2 + 8;
+    __shared__ __attribute__((aligned(16))) uint8_t smem[4 * 32 * OROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int bh = blockIdx.y, h = bh % p.H, b = bh / p.H;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    if (q0 >= p.N) return;  // waves are independent: no barrier below
+    int qi = q0 + l31;
+    qi = qi < p.N ? qi : p.N - 1;
+    typename E::v8 qf[KC];
+    const uint8_t* qp = p.q + ((int64_t)b * p.q_sb + (int64_t)qi * p.q_sn + h * D + half * 8) * 2;
+#pragma unroll
+    for (int cc = 0; cc < KC; ++cc) qf[cc] = as_v8<DT>(*reinterpret_cast<const uint4*>(qp + cc * 32));
+    f32x16 o[Y::DT_TILES];
+#pragma unroll
+    for (int dt = 0; dt < Y::DT_TILES; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float inv = 1.f;
+    {
+        const int bk = b / p.kvdiv;
+        const uint8_t* kbase = p.k + ((int64_t)bk * p.k_sb + h * D) * 2;
+        const uint8_t* vbase = p.vt + ((int64_t)bk * p.vt_sb + (int64_t)h * D * p.Lpad) * 2;
+        const float* bias = p.key_bias ? p.key_bias + (int64_t)b * p.L : nullptr;
+        short_segment<DT, D>(kbase, p.k_sl, vbase, p.L, p.Lpad, bias, p.scale_log2, qf, o, inv, l31, half);
+    }
+#pragma unroll
+    for (int dt = 0; dt < Y::DT_TILES; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= inv;
+    if (DUAL) {
+        f32x16 o2[Y::DT_TILES];
+#pragma unroll
+        for (int dt = 0; dt < Y::DT_TILES; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o2[dt][r] = 0.f;
+        float inv2 = 1.f;
+        const int bk = b / p.kvdiv2;
+        const uint8_t* kbase = p.k2 + ((int64_t)bk * p.k2_sb + h * D) * 2;
+        const uint8_t* vbase = p.vt2 + ((int64_t)bk * p.vt2_sb + (int64_t)h * D * p.Lpad2) * 2;
+        short_segment<DT, D>(kbase, p.k2_sl, vbase, p.L2, p.Lpad2, nullptr, p.scale_log2, qf, o2, inv2, l31, half);
+        // the un-fused reference rounds each branch, and scale * audio, to the storage type before the add
+#pragma unroll
+        for (int dt = 0; dt < Y::DT_TILES; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float t = (float)(typename E::elem)o[dt][r];
+                const float a = (float)(typename E::elem)(o2[dt][r] * inv2);
+                o[dt][r] = t + (float)(typename E::elem)(p.scale2 * a);
+            }
+    }
+    uint8_t* scr = smem + wave * (32 * OROW);
+#pragma unroll
+    for (int dt = 0; dt < Y::DT_TILES; ++dt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int dcol = dt * 32 + 8 * g + 4 * half;
+            if (dcol < D) {
+                typename E::v4 pk;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pk[j] = (typename E::elem)o[dt][g * 4 + j];
+                *reinterpret_cast<uint2*>(scr + l31 * OROW + dcol * 2) = __builtin_bit_cast(uint2, pk);
+            }
+        }
+    }
+    constexpr int CPR = D / 8;
+    uint8_t* ob = p.out + ((int64_t)b * p.o_sb + h * D) * 2;
+    for (int idx = lane; idx < 32 * CPR; idx += 64) {
+        const int row = idx / CPR, ch = idx - row * CPR;
+        const int q = q0 + row;
+        if (q < p.N) {
+            const uint2 lo = *reinterpret_cast<const uint2*>(scr + row * OROW + ch * 16);
+            const uint2 hi = *reinterpret_cast<const uint2*>(scr + row * OROW + ch * 16 + 8);
+            *reinterpret_cast<uint4*>(ob + ((int64_t)q * p.o_sn + ch * 8) * 2) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+    }
+}
+
 template <int DT, int D> int launch_d(const AttnP& p, bool dual, dim3 grid, hipStream_t s) {
+    static const bool no_short = getenv("APAD_ATTN_NO_SHORT") != nullptr;
+    if (!no_short && p.L <= 64 && (!dual || p.L2 <= 64) && p.lse == nullptr) {
+        dim3 g2((unsigned)((p.N + 127) / 128), (unsigned)(p.B * p.H));
+        if (dual)
+            hipLaunchKernelGGL((attn_short_kernel<DT, D, true>), g2, dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL((attn_short_kernel<DT, D, false>), g2, dim3(256), 0, s, p);
+        return apad_check_launch("apad_attention");
+    }
     if (dual)
         hipLaunchKernelGGL((attn_kernel<DT, D, true>), grid, dim3(256), 0, s, p);
     else
