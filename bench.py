@@ -85,22 +85,56 @@ def time_kernel(fn, iters=20):
     return e0.elapsed_time(e1) / iters
 
 
+def time_kernel_graphed(fn, iters=20, reps=3):
+    """average duration (ms) of one launch: `iters` launches captured into one hipGraph, replayed `reps` times, HIP events
+    on the replaying stream"""
+    fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        fn()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (iters * reps)
+
+
 def dominant_kernel_roofline(dev, dtype, B2):
     """Roofline of the kernel with the largest share of the step in the committed rocprof summary
-    (profiles/r01_bench_kernel_stats_v3.txt: attn_kernel<bf16, d=32, single segment>, the self-attention of the
-    1000-token level, 13 % of the step): softmax(Q K^T / sqrt(32)) V over B2 samples x 8 heads x 1000 x 1000.
+    (profiles/r01_bench_kernel_stats_v5.txt: attn_kernel<bf16, d=32, single segment>, the self-attention of the
+    1000-token level; the 64x64-tile GEMM template has a larger total but is spread over ~500 small launches per step): softmax(Q K^T / sqrt(32)) V over B2 samples x 8 heads x 1000 x 1000.
     Algorithmic FLOPs = 4 * N^2 * C * B2 (QK^T + PV); bound = MFMA (AI = 512 F/B > ridge 310)."""
     from ap_adapter_amd import ops
     N, C, heads = 1000, 256, 8
-    # q, k, v with the statistics they have inside the synthetic-weight model (LayerNorm-ed activations through
-    # N(0, 0.02^2) projections of width 256: std 0.02 * sqrt(256) = 0.32), so that the launch timed here behaves like
-    # the in-model launches of the committed rocprof trace (the online-softmax rescale path is data dependent)
-    std = 0.02 * math.sqrt(C)
-    q = (torch.randn(B2, N, C, device=dev) * std).to(dtype)
-    k = (torch.randn(B2, N, C, device=dev) * std).to(dtype)
-    vt = (torch.randn(B2, heads, C // heads, ops.round_up(N, 32), device=dev) * std).to(dtype)
+    # q, k, v produced the way the model produces them -- LayerNorm-ed activations through N(0, 0.02^2) q|k|v weights
+    # (one apad_rowpanel_gemm launch) -- and the launch timed as 20 replays inside a hipGraph, like the captured step:
+    # the launch time depends on the data (online-softmax rescales) and on the context: 20 back-to-back replays here
+    # measure 139-150 us (sustained all-attention load; eager launches 143-162 us depending on the input statistics),
+    # while the same launches inside the captured step take 122-126 us (profiles/r01_bench_kernel_stats_v5.txt, whose
+    # 130 us average mixes both); a producer-consumer pairing with the q|k|v kernel did not reproduce the difference,
+    # so it is not cache residency -- most likely clock headroom between the step's memory-bound kernels
+    x = torch.randn(B2, N, C, device=dev).to(dtype)
+    g_, b_ = torch.ones(C, device=dev, dtype=dtype), torch.zeros(C, device=dev, dtype=dtype)
+    w = (torch.randn(3 * C, C, device=dev) * 0.02).to(dtype)
+    q = torch.empty(B2, N, C, device=dev, dtype=dtype)
+    k = torch.empty_like(q)
+    vt = torch.zeros(B2, heads, C // heads, ops.round_up(N, 32), device=dev, dtype=dtype)
+    ops.rowpanel(x.reshape(-1, C), w, [(q, None, C, "row"), (k, None, C, "row"), (vt, None, C, "vt")], ln=(g_, b_, 1e-5),
+                 vt_geom=(heads, C // heads, N, vt.shape[-1]))
     out = torch.empty_like(q)
-    ms = time_kernel(lambda: ops.attention(q, k, vt, N, heads, out=out))
+    ms = time_kernel_graphed(lambda: ops.attention(q, k, vt, N, heads, out=out))
     flops = 4.0 * N * N * C * B2
     ach = flops / (ms * 1e-3) / 1e12
     # HBM bytes per launch from the PMC passes (tools/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3
