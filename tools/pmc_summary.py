@@ -1,4 +1,4 @@
-"""Print per-kernel PMC counter sums from a rocprofv3 rocpd sqlite database.  usage: python tools_pmc_summary.py <db> [kernel substring]"""
+"""Print per-kernel PMC counter sums from a rocprofv3 rocpd sqlite database.  usage: python tools/pmc_summary.py <db> [kernel substring]"""
 import sqlite3, sys, re
 c = sqlite3.connect(sys.argv[1])
 sub = sys.argv[2] if len(sys.argv) > 2 else ""

@@ -1,5 +1,5 @@
 """Summarise a rocprofv3 rocpd sqlite database (kernel trace) into a per-kernel stats table.
-usage: python tools_prof_summary.py <results.db> <n_steps_in_trace> "<header line>" > profiles/<name>.txt"""
+usage: python tools/prof_summary.py <results.db> <n_steps_in_trace> "<header line>" > profiles/<name>.txt"""
 import re
 import sqlite3
 import sys
