@@ -130,7 +130,17 @@ class AttnProcessor2_0(nn.Module):
                     if self._kv_cache is None:
                         self._kv_cache = {}
                     self._kv_cache[ck] = (k, vt)
-        bias = _key_bias(attention_mask, B, Lk)
+        if attention_mask is not None and self.kv_cache_enabled:
+            # the mask -> fp32 bias conversion is timestep-invariant too: hoisted with the K/V (two tiny torch kernels
+            # per masked site per step otherwise)
+            bk = ("bias", attention_mask.data_ptr(), tuple(attention_mask.shape))
+            if self._kv_cache is None:
+                self._kv_cache = {}
+            bias = self._kv_cache.get(bk)
+            if bias is None:
+                bias = self._kv_cache[bk] = _key_bias(attention_mask, B, Lk)
+        else:
+            bias = _key_bias(attention_mask, B, Lk)
         o = ops.attention(q, k, vt, Lk, heads, key_bias=bias)
         out = ops.fused_linear(o, attn.to_out[0].weight, attn.to_out[0].bias, residual=_residual)
         if attn.residual_connection:
