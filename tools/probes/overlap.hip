@@ -33,6 +33,32 @@ template <int MODE> __global__ __launch_bounds__(256) void k(float* out, int ite
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if (MODE == 5) {  // VALU only, transcendentals clustered: 32 exps back to back, then 32 fma
+#pragma unroll
+            for (int i = 0; i < 32; ++i) v[i] = __builtin_amdgcn_exp2f(v[i]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) v[i] = v[i] * 0.5f + 0.25f;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (MODE == 6) {  // VALU only, pinned 1 exp : 1 fma of ANOTHER element (independent)
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                v[i] = __builtin_amdgcn_exp2f(v[i]);
+                v[(i + 16) & 31] = v[(i + 16) & 31] * 0.5f + 0.25f;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (MODE == 7) {  // VALU only, 1 exp : 3 plain VALU
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                v[i] = __builtin_amdgcn_exp2f(v[i]);
+                v[(i + 16) & 31] = v[(i + 16) & 31] * 0.5f + 0.25f;
+                v[(i + 8) & 31] = v[(i + 8) & 31] * 0.75f + 0.125f;
+                v[(i + 24) & 31] = v[(i + 24) & 31] * 0.25f + 0.5f;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         if (MODE == 4) {  // VALU first, then MFMAs (pinned)
 #pragma unroll
             for (int i = 0; i < 32; ++i) v[i] = __builtin_amdgcn_exp2f(v[i]) * 0.5f + 0.25f;
@@ -69,6 +95,9 @@ int main() {
         printf("  MFMAs then VALU      %7.0f\n", run<2>(d, wpb));
         printf("  interleaved 1:4      %7.0f\n", run<3>(d, wpb));
         printf("  VALU then MFMAs      %7.0f\n", run<4>(d, wpb));
+        printf("  VALU: 32 exp clustered, then 32 fma   %7.0f\n", run<5>(d, wpb));
+        printf("  VALU: exp : fma 1:1 pinned            %7.0f\n", run<6>(d, wpb));
+        printf("  VALU: exp : 3 fma pinned (32 + 96)    %7.0f\n", run<7>(d, wpb));
     }
     return 0;
 }
