@@ -555,7 +555,9 @@ int launch(const GemmP& p, hipStream_t s) {
     if constexpr (AMODE == APAD_A_PLAIN && OUTMODE == APAD_OUT_ROWMAJOR) {
         if (dma_mode && p.K % 64 == 0 && p.K >= 128 && blocks128 >= 256) return launch_dma<DT, EPI>(p, s);
     }
-    if (blocks128 >= 512) return launch_tm<DT, AMODE, EPI, OUTMODE, 128>(p, s);
+    // long reductions amortise the under-fill: with K >= 1024 the 128-tile wins from ~1.25 workgroups per CU (measured:
+    // conv 63x4 384->384 76.5 -> 71.5 us, FF2 M=16128 K=1536 38.5 -> 37.1 us), short-K launches prefer the 64-tile
+    if (blocks128 >= 512 || (blocks128 >= 320 && p.K >= 1024)) return launch_tm<DT, AMODE, EPI, OUTMODE, 128>(p, s);
     return launch_tm<DT, AMODE, EPI, OUTMODE, 64>(p, s);
 }
 
