@@ -56,6 +56,12 @@ class MlpDesc(C.Structure):
                [("M", _i64), ("C", _i32), ("dtype", _i32), ("ln_eps", _f32), ("reserved", _i32)]
 
 
+class XattnDesc(C.Structure):
+    _fields_ = [(n, _vp) for n in ("x", "ln_gamma", "ln_beta", "wq", "wo", "bo", "k1", "v1t", "key_bias", "k2", "v2t", "out")] + \
+               [(n, _i32) for n in ("B", "N", "C", "heads", "L1", "Lpad1", "L2", "Lpad2", "dtype", "reserved")] + \
+               [(n, _f32) for n in ("ln_eps", "softmax_scale", "scale2", "reserved_f")]
+
+
 class AttnBwdDesc(C.Structure):
     _fields_ = [(n, _vp) for n in ("q", "k", "v", "qt", "kt", "out", "dout", "doutt", "lse", "key_bias", "delta", "dq", "dk", "dv")] + \
                [(n, _i32) for n in ("B", "N", "H", "D", "L", "Npad", "Lpad", "dtype")] + \
@@ -76,6 +82,9 @@ SYMBOLS = {
     "apad_sizeof_mlp_desc": (C.c_int, []),
     "apad_echo_mlp_desc": (C.c_int, [C.POINTER(MlpDesc), C.POINTER(C.c_double), C.c_int]),
     "apad_geglu_mlp": (C.c_int, [C.POINTER(MlpDesc), _vp]),
+    "apad_sizeof_xattn_desc": (C.c_int, []),
+    "apad_echo_xattn_desc": (C.c_int, [C.POINTER(XattnDesc), C.POINTER(C.c_double), C.c_int]),
+    "apad_fused_cross_attention": (C.c_int, [C.POINTER(XattnDesc), _vp]),
     "apad_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "apad_attention": (C.c_int, [C.POINTER(AttnDesc), _vp]),
     "apad_layernorm": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _i64, _f32, _i32, _vp]),
@@ -143,7 +152,8 @@ def lib():
             if h.apad_sizeof_gemm_desc() != C.sizeof(GemmDesc) or h.apad_sizeof_attn_desc() != C.sizeof(AttnDesc) \
                     or h.apad_sizeof_rp_desc() != C.sizeof(RpDesc) \
                     or h.apad_sizeof_mlp_desc() != C.sizeof(MlpDesc) \
-                    or h.apad_sizeof_attn_bwd_desc() != C.sizeof(AttnBwdDesc):
+                    or h.apad_sizeof_attn_bwd_desc() != C.sizeof(AttnBwdDesc) \
+                    or h.apad_sizeof_xattn_desc() != C.sizeof(XattnDesc):
                 raise RuntimeError("descriptor layout mismatch between include/apadapter_hip.h and _lib.py")
             _lib = h
     return _lib

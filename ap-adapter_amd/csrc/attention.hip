@@ -178,7 +178,7 @@ __device__ __forceinline__ void tile_compute(const uint8_t* buf, int key0, int L
             for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[u][r]);
         tmax *= c;  // c > 0
     }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    tmax = half_max(tmax);
     const float mnew = fmaxf(m, tmax);
     if (__any(mnew > m)) {  // wave-uniform: the O rescale is skipped whenever no lane's running max moved
         const float alpha = __builtin_amdgcn_exp2f(m - mnew);
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
         segment<DT, D>(smem, kbase, p.k_sl, vbase, p.L, p.Lpad, bias, p.scale_log2, qf, o, osum, m, tid);
     }
     // denominator of query l31 = row 0 of osum = register 0 of the half-0 lane
-    const float den = __shfl(osum[0], l31, 64);
+    const float den = half_lo(osum[0]);
     float inv = 1.0f / den;
     if (p.lse != nullptr && half == 0 && qvalid)  // log2 sum exp2 of the scaled (+biased) scores: what the backward re-uses
         p.lse[((int64_t)b * p.H + h) * ((p.N + 31) & ~31) + q0 + l31] = m + __builtin_log2f(den);
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
             const uint8_t* kbase = p.k2 + ((int64_t)bk * p.k2_sb + h * D) * 2;
             const uint8_t* vbase = p.vt2 + ((int64_t)bk * p.vt2_sb + (int64_t)h * D * p.Lpad2) * 2;
             segment<DT, D>(smem, kbase, p.k2_sl, vbase, p.L2, p.Lpad2, nullptr, p.scale_log2, qf, o2, osum2, m2, tid);
-            const float inv2 = 1.0f / __shfl(osum2[0], l31, 64);
+            const float inv2 = 1.0f / half_lo(osum2[0]);
             // the un-fused reference rounds each branch, and scale * audio, to the storage type before the add
 #pragma unroll
             for (int dt = 0; dt < Y::DT_TILES; ++dt)
@@ -439,7 +439,7 @@ __device__ __forceinline__ void short_segment(const uint8_t* kbase, int64_t k_sl
             tmax = fmaxf(tmax, v);
         }
     }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    tmax = half_max(tmax);
     float sum = 0.f;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -453,7 +453,7 @@ __device__ __forceinline__ void short_segment(const uint8_t* kbase, int64_t k_sl
             sum += e;
         }
     }
-    sum += __shfl_xor(sum, 32, 64);
+    sum = half_sum(sum);
     inv_den = 1.0f / sum;
 #pragma unroll
     for (int st = 0; st < 4; ++st) {

@@ -57,6 +57,19 @@ template <int DT> __device__ __forceinline__ uint4 pack8(const float* f) {
     return as_u4<DT>(v);
 }
 
+// Exchange between the two 32-lane halves of a wave (lane l <-> lane l ^ 32), the only cross-lane traffic of the
+// transposed-score kernels.  gfx950's v_permlane32_swap does it in one VALU instruction; __shfl_xor(v, 32) lowers to
+// ds_bpermute_b32, i.e. an LDS round trip plus an lgkmcnt wait in the middle of the softmax.
+__device__ __forceinline__ void half_pair(float v, float& lo, float& hi) {
+    const unsigned a = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+    lo = __uint_as_float(r[0]);  // the lower half's value, in every lane
+    hi = __uint_as_float(r[1]);  // the upper half's value, in every lane
+}
+__device__ __forceinline__ float half_max(float v) { float lo, hi; half_pair(v, lo, hi); return fmaxf(lo, hi); }
+__device__ __forceinline__ float half_sum(float v) { float lo, hi; half_pair(v, lo, hi); return lo + hi; }
+__device__ __forceinline__ float half_lo(float v) { float lo, hi; half_pair(v, lo, hi); return lo; }
+
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 // erf via Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32-exact for a bf16/f16 result): one rcp, one exp2 and
 // five FMAs instead of libm's erff (~40 VALU instructions) -- the GEGLU epilogue evaluates this for every element of the

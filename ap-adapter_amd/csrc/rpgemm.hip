@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void rpgemm_kernel(RpP p) {
     }
     if (LN) {
         // single statistics pass, shifted by the row's first element (both halves of the row use the same shift)
-        const float shift = __shfl((float)xf[0][0], l31, 64);
+        const float shift = half_lo((float)xf[0][0]);
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int c = 0; c < KC; ++c) {
@@ -101,8 +101,8 @@ __global__ __launch_bounds__(256, 2) void rpgemm_kernel(RpP p) {
             }
             asm volatile("" : "+v"(s), "+v"(q));  // evaluate chunk by chunk: bounds the live converted values
         }
-        s += __shfl_xor(s, 32, 64);
-        q += __shfl_xor(q, 32, 64);
+        s = half_sum(s);
+        q = half_sum(q);
         const float md = s * (1.0f / (KC * 16));
         const float mean = shift + md;
         const float var = fmaxf(q * (1.0f / (KC * 16)) - md * md, 0.f);

@@ -116,6 +116,37 @@ def fused_linear(x, w, bias=None, ln=None, residual=None, act=None, out=None):
     return linear(x, w, bias, residual=residual, act=act, out=out)
 
 
+XATTN_C, XATTN_HEADS, XATTN_MAXL = 256, 8, 64  # envelope of apad_fused_cross_attention
+
+
+def fused_cross_attention(x, wq, wo, bo, k1, v1t, L1, heads, ln=None, key_bias=None, k2=None, v2t=None, L2=0, scale2=0.0, out=None):
+    """out = x + to_out(A(q, k1, v1, bias) [+ scale2 * A(q, k2, v2)]) + bo with q = to_q(LayerNorm(x)): the whole
+    cross-attention sub-layer in one launch.  x [B, N, C]; k [B, L, C]; vt [B, heads, d, Lpad]."""
+    _req(x, "fused_cross_attention.x", wq.dtype)
+    B, N, Cc = x.shape
+    if Cc != XATTN_C or heads != XATTN_HEADS or L1 > XATTN_MAXL or L2 > XATTN_MAXL:
+        raise ValueError(f"fused_cross_attention: C={Cc} heads={heads} L1={L1} L2={L2} outside the kernel envelope")
+    for t, n in ((x, "x"), (wq, "wq"), (wo, "wo"), (k1, "k1"), (v1t, "v1t")):
+        if not t.is_contiguous():
+            raise ValueError(f"fused_cross_attention.{n}: must be contiguous")
+    if out is None:
+        out = torch.empty_like(x)
+    d = L.XattnDesc()
+    d.x, d.wq, d.wo, d.bo, d.k1, d.v1t, d.out = (x.data_ptr(), wq.data_ptr(), wo.data_ptr(), _ptr(bo), k1.data_ptr(),
+                                                 v1t.data_ptr(), out.data_ptr())
+    if ln is not None:
+        d.ln_gamma, d.ln_beta, d.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), float(ln[2])
+    d.key_bias = _ptr(key_bias)
+    d.B, d.N, d.C, d.heads, d.L1, d.Lpad1 = B, N, Cc, heads, L1, v1t.shape[-1]
+    if L2 > 0:
+        if not (k2.is_contiguous() and v2t.is_contiguous()):
+            raise ValueError("fused_cross_attention: k2 / v2t must be contiguous")
+        d.k2, d.v2t, d.L2, d.Lpad2 = k2.data_ptr(), v2t.data_ptr(), L2, v2t.shape[-1]
+    d.dtype, d.softmax_scale, d.scale2 = _DT[x.dtype], 1.0 / math.sqrt(Cc // heads), float(scale2)
+    L.check(L.lib().apad_fused_cross_attention(C.byref(d), _stream()), "apad_fused_cross_attention")
+    return out
+
+
 MLP_C = (256,)  # envelope of apad_geglu_mlp
 
 

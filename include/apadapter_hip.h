@@ -157,6 +157,32 @@ typedef struct apad_mlp_desc {
     int32_t reserved;
 } apad_mlp_desc;
 
+/* Fused cross-attention sub-layer for hoisted, short key / value sets (<= 64 keys per segment):
+ *     out = x + to_out( A(q, K1, V1, key_bias) [+ scale2 * A(q, K2, V2)] ) + bo,   q = to_q(LayerNorm(x))
+ * = IPAttnProcessor2_0.__call__ (attention_processor.py:347-470) / AttnProcessor2_0.__call__ (:214-294) together with
+ * the block's pre-LayerNorm and residual, in ONE launch.  Envelope: C = 256, 8 heads (else -3). */
+typedef struct apad_xattn_desc {
+    const void* x;         /* [B*N][C] un-normalised hidden states (also the residual)                      */
+    const void* ln_gamma;  /* [C] or NULL                                                                   */
+    const void* ln_beta;
+    const void* wq;        /* [C][C] attn.to_q.weight                                                       */
+    const void* wo;        /* [C][C] attn.to_out[0].weight                                                  */
+    const void* bo;        /* [C] attn.to_out[0].bias or NULL                                               */
+    const void* k1;        /* [B][L1][C]   keys of segment 1 (to_k of the text / T5 tokens)                 */
+    const void* v1t;       /* [B][H][D][Lpad1] values of segment 1, per-head transposed, zero padded        */
+    const float* key_bias; /* [B][L1] fp32 additive bias on segment 1, or NULL                              */
+    const void* k2;        /* [B][L2][C]   keys of segment 2 (to_k_ip of the audio tokens) or NULL          */
+    const void* v2t;       /* [B][H][D][Lpad2]                                                              */
+    void* out;             /* [B*N][C]                                                                      */
+    int32_t B, N, C, heads;
+    int32_t L1, Lpad1, L2, Lpad2;   /* L2 = 0: single segment                                               */
+    int32_t dtype, reserved;
+    float ln_eps, softmax_scale, scale2, reserved_f;
+} apad_xattn_desc;
+int apad_sizeof_xattn_desc(void);
+int apad_echo_xattn_desc(const apad_xattn_desc* d, double* out, int cap);
+int apad_fused_cross_attention(const apad_xattn_desc* d, void* stream);
+
 const char* apad_last_error(void);
 int apad_abi_version(void);
 /* size of the descriptor structs as compiled, for binding self-checks */

@@ -409,3 +409,67 @@ def test_tiled_fused_qkv(dev, dtype, B, L, K, heads):
     assert rel_err(qo, y[:, :K]) < TOL[dtype]
     assert rel_err(ko, y[:, K:2 * K]) < TOL[dtype]
     assert rel_err(vt[..., :L], y[:, 2 * K:].view(B, L, heads, d).permute(0, 2, 3, 1)) < TOL[dtype]
+
+
+def _xattn_ref(x, g, be, wq, wo, bo, ehs_t, wk, wv, heads, bias=None, ehs_a=None, wk_ip=None, wv_ip=None, scale=0.0):
+    """fp32 restatement of LayerNorm -> to_q -> (decoupled) attention -> to_out + residual (attention_processor.py:347-470)"""
+    B, N, C = x.shape
+    d = C // heads
+    hs = F.layer_norm(x, (C,), g, be, 1e-5)
+    sp = lambda t: t.reshape(B, t.shape[1], heads, d).transpose(1, 2)
+    qq = sp(F.linear(hs, wq))
+    m = None if bias is None else bias[:, None, None, :]
+    o = F.scaled_dot_product_attention(qq, sp(F.linear(ehs_t, wk)), sp(F.linear(ehs_t, wv)), attn_mask=m)
+    if ehs_a is not None:
+        o = o + scale * F.scaled_dot_product_attention(qq, sp(F.linear(ehs_a, wk_ip)), sp(F.linear(ehs_a, wv_ip)))
+    o = o.transpose(1, 2).reshape(B, N, C)
+    return x + F.linear(o, wo, bo)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,N,Lt,La,masked", [(2, 1000, 8, 32, False), (3, 100, 8, 8, False), (2, 250, 16, 0, True), (1, 33, 8, 64, False),
+                                               (5, 64, 40, 0, False)])
+def test_fused_cross_attention(dev, dtype, B, N, Lt, La, masked):
+    """LayerNorm + to_q + (decoupled) attention + to_out + residual in one launch, incl. panels that end inside a sample,
+    a tail workgroup with idle waves, the masked T5 form and a 2-sub-tile segment"""
+    from ap_adapter_amd import ops
+    C, H = 256, 8
+    x = q(R(B, N, C, seed=201), dtype)
+    g, be = q(1 + 0.1 * R(C, seed=202), dtype), q(0.1 * R(C, seed=203), dtype)
+    wq, wo, bo = q(R(C, C, seed=204, std=0.06), dtype), q(R(C, C, seed=205, std=0.06), dtype), q(R(C, seed=206, std=0.3), dtype)
+    wk, wv = q(R(C, 768, seed=207, std=0.04), dtype), q(R(C, 768, seed=208, std=0.04), dtype)
+    wki, wvi = q(R(C, 768, seed=209, std=0.04), dtype), q(R(C, 768, seed=210, std=0.04), dtype)
+    et = q(R(B, Lt, 768, seed=211), dtype)
+    ea = q(R(B, La, 768, seed=212), dtype) if La else None
+    bias = None
+    if masked:
+        bias = torch.zeros(B, Lt)
+        bias[1::2, -4:] = -10000.0
+    ref = _xattn_ref(x, g, be, wq, wo, bo, et, wk, wv, H, bias, ea, wki, wvi, 0.55)
+    D = lambda t: t.to(dev, dtype)
+    k1 = ops.linear(D(et), D(wk))
+    v1t = torch.zeros(B, H, C // H, ops.round_up(Lt, 32), device=dev, dtype=dtype)
+    ops.linear_vt(D(et), D(wv), B, Lt, H, v1t)
+    k2 = v2t = None
+    if La:
+        k2 = ops.linear(D(ea), D(wki))
+        v2t = torch.zeros(B, H, C // H, ops.round_up(La, 32), device=dev, dtype=dtype)
+        ops.linear_vt(D(ea), D(wvi), B, La, H, v2t)
+    out = ops.fused_cross_attention(D(x), D(wq), D(wo), D(bo), k1, v1t, Lt, H, ln=(D(g), D(be), 1e-5),
+                                    key_bias=None if bias is None else bias.to(dev), k2=k2, v2t=v2t, L2=La, scale2=0.55)
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < 1.5 * TOL[dtype]
+    # and against the three-kernel chain it replaces
+    qd = ops.fused_linear(D(x), D(wq), ln=(D(g), D(be), 1e-5))
+    od = ops.attention(qd, k1, v1t, Lt, H, key_bias=None if bias is None else bias.to(dev), k2=k2, vt2=v2t, L2=La, scale2=0.55)
+    chain = ops.fused_linear(od, D(wo), D(bo), residual=D(x))
+    assert rel_err(out, chain.float().cpu()) < TOL[dtype]
+
+
+def test_fused_cross_attention_outside_envelope(dev):
+    from ap_adapter_amd import ops
+    x = torch.zeros(1, 64, 384, device=dev, dtype=torch.bfloat16)
+    w = torch.zeros(384, 384, device=dev, dtype=torch.bfloat16)
+    with pytest.raises(ValueError):
+        ops.fused_cross_attention(x, w, w, None, torch.zeros(1, 8, 384, device=dev, dtype=torch.bfloat16),
+                                  torch.zeros(1, 8, 48, 32, device=dev, dtype=torch.bfloat16), 8, 8)

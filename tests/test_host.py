@@ -132,7 +132,8 @@ def test_library_exports_every_declared_symbol():
 def test_descriptor_layout_matches_the_header():
     h = A.lib()
     for desc, echo in ((L.GemmDesc, h.apad_echo_gemm_desc), (L.AttnDesc, h.apad_echo_attn_desc),
-                       (L.MlpDesc, h.apad_echo_mlp_desc), (L.AttnBwdDesc, h.apad_echo_attn_bwd_desc)):
+                       (L.MlpDesc, h.apad_echo_mlp_desc), (L.AttnBwdDesc, h.apad_echo_attn_bwd_desc),
+                       (L.XattnDesc, h.apad_echo_xattn_desc)):
         d = desc()
         names = [f[0] for f in desc._fields_]
         for i, n in enumerate(names):
@@ -143,7 +144,7 @@ def test_descriptor_layout_matches_the_header():
     # field order in the header == field order of the ctypes mirror
     header = open(os.path.join(ROOT, "include", "apadapter_hip.h")).read()
     for struct, desc in (("apad_gemm_desc", L.GemmDesc), ("apad_attn_desc", L.AttnDesc), ("apad_mlp_desc", L.MlpDesc),
-                         ("apad_attn_bwd_desc", L.AttnBwdDesc)):
+                         ("apad_attn_bwd_desc", L.AttnBwdDesc), ("apad_xattn_desc", L.XattnDesc)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), header, re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         fields = []

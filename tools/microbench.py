@@ -116,3 +116,22 @@ if "mlp" in flt or not flt:
             ops.linear(hbuf, w2, b2, residual=x, out=out)
         ms = timeit(two)
         report(f"  two-kernel LN+GEGLU ; FF2+res M={M} C={C}", ms, 2.0 * M * 12 * C * C, 2.0 * (2 * M * C + 12 * C * C + 2 * M * 4 * C))
+
+if "xattn" in flt or not flt:
+    N, C, H, Lt, La = 1000, 256, 8, 8, 32
+    x = R(B2, N, C); g = R(C); be = R(C); wq = R(C, C, std=0.02); wo = R(C, C, std=0.02); bo = R(C, std=0.02)
+    k1 = R(B2, Lt, C, std=0.3); k2 = R(B2, La, C, std=0.3)
+    v1t = torch.zeros(B2, H, C // H, 32, device=dev, dtype=dt); v1t[..., :Lt].normal_(0, 0.3)
+    v2t = torch.zeros(B2, H, C // H, 32, device=dev, dtype=dt); v2t[..., :La].normal_(0, 0.3)
+    out = torch.empty_like(x)
+    fl = 2.0 * 2 * B2 * N * C * C + 4.0 * B2 * N * (Lt + La) * C
+    by = 2.0 * (2 * B2 * N * C + 2 * C * C + 2 * B2 * (Lt + La) * C)
+    ms = timeit(lambda: ops.fused_cross_attention(x, wq, wo, bo, k1, v1t, Lt, H, ln=(g, be, 1e-5), k2=k2, v2t=v2t, L2=La, scale2=0.55, out=out))
+    report(f"fused cross-attention sub-layer N={N} C={C} Lt=8 La=32", ms, fl, by)
+
+    def three():
+        qd = ops.fused_linear(x, wq, ln=(g, be, 1e-5))
+        od = ops.attention(qd, k1, v1t, Lt, H, k2=k2, vt2=v2t, L2=La, scale2=0.55)
+        ops.fused_linear(od, wo, bo, residual=x, out=out)
+    ms = timeit(three)
+    report(f"  three kernels: LN+q ; decoupled attn ; to_out+res", ms, fl, by + 2.0 * 4 * B2 * N * C)
