@@ -68,22 +68,29 @@ __global__ __launch_bounds__(NWV * 64, 1) void mlp_kernel(MlpP p) {
 
     // ---- staging helpers (global -> registers -> LDS) ----
     u32x4 s1[N1], s2[N2];
-    auto load_w1 = [&](int jc) {
+    // per-thread byte offsets inside chunk 0's tiles, computed once: a chunk then adds a wave-uniform stride
+    uint32_t o1[N1], o2[N2];
 #pragma unroll
-        for (int i = 0; i < N1; ++i) {
-            const int idx = tid + NTH * i;
-            const int j = idx / (2 * KC), ch = idx - j * (2 * KC);
-            const int64_t row = j < 16 ? (int64_t)jc * 16 + j : (int64_t)G::HID + jc * 16 + (j - 16);
-            s1[i] = *reinterpret_cast<const u32x4*>(p.w1 + (row * G::C + ch * 8) * 2);
-        }
+    for (int i = 0; i < N1; ++i) {
+        const int idx = tid + NTH * i;
+        const int j = idx / (2 * KC), ch = idx - j * (2 * KC);
+        const int64_t row = j < 16 ? j : (int64_t)G::HID + (j - 16);
+        o1[i] = (uint32_t)((row * G::C + ch * 8) * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < N2; ++i) {
+        const int idx = tid + NTH * i;
+        o2[i] = (uint32_t)((((int64_t)(idx >> 1)) * G::HID + (idx & 1) * 8) * 2);
+    }
+    auto load_w1 = [&](int jc) {
+        const uint8_t* base = p.w1 + (int64_t)jc * 16 * G::C * 2;  // value rows jc*16.., gate rows HID + jc*16..
+#pragma unroll
+        for (int i = 0; i < N1; ++i) s1[i] = *reinterpret_cast<const u32x4*>(base + o1[i]);
     };
     auto load_w2 = [&](int jc) {
+        const uint8_t* base = p.w2 + (int64_t)jc * 16 * 2;  // hidden columns jc*16..
 #pragma unroll
-        for (int i = 0; i < N2; ++i) {
-            const int idx = tid + NTH * i;
-            const int c = idx >> 1, piece = idx & 1;
-            s2[i] = *reinterpret_cast<const u32x4*>(p.w2 + ((int64_t)c * G::HID + jc * 16 + piece * 8) * 2);
-        }
+        for (int i = 0; i < N2; ++i) s2[i] = *reinterpret_cast<const u32x4*>(base + o2[i]);
     };
     auto store_w1 = [&](uint8_t* st) {
 #pragma unroll
