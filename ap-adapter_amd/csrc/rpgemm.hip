@@ -20,8 +20,10 @@
 
 namespace {
 
+// per-thread byte offsets of the staging loads inside weight tile 0, computed once per kernel; tile t adds a wave-uniform
+// stride (the per-tile 64-bit address arithmetic otherwise sits on the vector ALU in front of every tile)
 template <int KC, bool GEGLU>
-__device__ __forceinline__ void stage_load(u32x4 (&st)[Cfg<KC>::NCH], const uint8_t* w, int64_t ldw, int n_total, int tile, int tid) {
+__device__ __forceinline__ void stage_offsets(int64_t (&off)[Cfg<KC>::NCH], int64_t ldw, int n_total, int tid) {
     using C = Cfg<KC>;
 #pragma unroll
     for (int i = 0; i < C::NCH; ++i) {
@@ -30,13 +32,22 @@ __device__ __forceinline__ void stage_load(u32x4 (&st)[Cfg<KC>::NCH], const uint
         int64_t row;
         if (GEGLU) {  // LDS tile rows: per 32-row MFMA tile, 16 value rows then the 16 matching gate rows
             const int sub = j >> 5, jj = j & 31;
-            const int64_t base = ((int64_t)tile * C::NT + sub) * 16;
+            const int64_t base = (int64_t)sub * 16;
             row = jj < 16 ? base + jj : (int64_t)n_total + base + (jj - 16);
         } else {
-            row = (int64_t)tile * C::BNT + j;
+            row = j;
         }
-        st[i] = *reinterpret_cast<const u32x4*>(w + (row * ldw + ch * 8) * 2);
+        off[i] = (row * ldw + ch * 8) * 2;
     }
+}
+
+template <int KC, bool GEGLU>
+__device__ __forceinline__ void stage_load(u32x4 (&st)[Cfg<KC>::NCH], const uint8_t* w, int64_t ldw, const int64_t (&off)[Cfg<KC>::NCH],
+                                           int tile) {
+    using C = Cfg<KC>;
+    const uint8_t* base = w + (int64_t)tile * (GEGLU ? C::NT * 16 : C::BNT) * ldw * 2;
+#pragma unroll
+    for (int i = 0; i < C::NCH; ++i) st[i] = *reinterpret_cast<const u32x4*>(base + off[i]);
 }
 
 template <int KC>
@@ -119,7 +130,9 @@ __global__ __launch_bounds__(256, 2) void rpgemm_kernel(RpP p) {
         }
     }
 
-    stage_load<KC, GEGLU>(st, wbase, ldw, n_total, t_begin, tid);
+    int64_t soff[C::NCH];
+    stage_offsets<KC, GEGLU>(soff, ldw, n_total, tid);
+    stage_load<KC, GEGLU>(st, wbase, ldw, soff, t_begin);
     stage_store<KC>(st, smem, tid);
     __syncthreads();
     uint8_t* const scr = smem + 2 * C::TILE_BYTES + wave * SCR_BYTES;  // this wave's output transpose scratch
@@ -150,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void rpgemm_kernel(RpP p) {
 
     for (int t = t_begin; t < t_end; ++t) {
         const int buf = (t - t_begin) & 1;
-        if (t + 1 < t_end) stage_load<KC, GEGLU>(st, wbase, ldw, n_total, t + 1, tid);
+        if (t + 1 < t_end) stage_load<KC, GEGLU>(st, wbase, ldw, soff, t + 1);
         const uint8_t* wt = smem + buf * C::TILE_BYTES + l31 * C::ROWB + half * 16;
 
         // segment of this tile (tiles never straddle segments: host checks n_cols % COLS_PER_TILE == 0)
