@@ -115,3 +115,77 @@ def test_full_geometry_noise_pred_vs_oracle(dev, dtype, tol):
     print(f"\\n[full-geometry noise_pred, {dtype}] max|ref|={float(ref.abs().max()):.4f} max-abs err={float(err.max()):.3e} "
           f"mean-abs err={float(err.mean()):.3e} rel-max={rel:.3e}")
     assert rel < tol
+
+
+# ---- BASELINE full size (batch 32 -> 64 sample-forwards per step, AudioLDM2-large geometry): size-independent properties ----
+@pytest.fixture(scope="module")
+def full_pipe(dev):
+    import ap_adapter_amd as A
+    from ap_adapter_amd.synthetic import init_synthetic_
+    u = A.AudioLDM2UNet2DConditionModel()
+    A.install_ap_adapter(u, None, scale=0.55)
+    init_synthetic_(u, 100, bias_std=0.01)
+    return A.AudioLDM2Pipeline(u.to(dev, torch.bfloat16))
+
+
+def _full_inputs(pipe, B, La, dev, seed=0):
+    from ap_adapter_amd.synthetic import synthetic_inputs
+    inp = synthetic_inputs(B, La, seed=seed)
+    # per-clip audio conditions (the sharded job of cfg 4 runs a different clip on every row)
+    g = torch.Generator().manual_seed(seed + 9)
+    aud, unc = torch.randn(B, La, 768, generator=g), torch.randn(B, La, 768, generator=g)
+    neg, pos = inp["generated_prompt_embeds"].chunk(2)
+    ehs = torch.cat([torch.cat([neg, unc], 1), torch.cat([pos, aud], 1)], 0).to(torch.bfloat16)
+    return dict(lat=inp["latents"].to(dev), ehs=ehs.to(dev), pe=inp["prompt_embeds"].to(dev),
+                mask=inp["attention_mask"].to(dev))
+
+
+def _rows(d, idx):
+    """the clips `idx` of a batch: latents rows idx, condition rows idx (unconditional half) and B + idx (conditional)"""
+    B = d["lat"].shape[0]
+    i2 = torch.cat([idx, idx + B])
+    return dict(lat=d["lat"][idx], ehs=d["ehs"][i2], pe=d["pe"][i2], mask=d["mask"][i2])
+
+
+def _run(pipe, d, steps=2, gs=9.5):
+    with torch.no_grad():
+        return pipe.denoise(d["lat"], d["ehs"], d["pe"], d["mask"], steps, gs, use_graph=True)
+
+
+@pytest.mark.parametrize("La", [8, 128])
+def test_full_size_clips_are_independent_of_their_batch(dev, full_pipe, La):
+    """the job shards over clips with no exchange, so a clip's latents must not depend on which other clips
+    share its batch, on its row, or on the batch size (tile shapes, the two-stream low-resolution section and the
+    short-segment attention route all change with the batch).  Batch 32 vs the same clips permuted vs a batch of 4."""
+    d = _full_inputs(full_pipe, 32, La, dev)
+    full = _run(full_pipe, d)
+    assert torch.isfinite(full).all()
+    perm = torch.randperm(32, generator=torch.Generator().manual_seed(1)).to(dev)
+    permuted = _run(full_pipe, _rows(d, perm))
+    assert torch.equal(permuted, full[perm]), "a clip's result depends on its row in the batch"
+    idx = torch.tensor([3, 17, 30, 8], device=dev)
+    small = _run(full_pipe, _rows(d, idx))
+    err = rel_err(small, full[idx])
+    print(f"\n[batch 4 vs batch 32, La={La}] rel err {err:.3e} (bit-equal: {torch.equal(small, full[idx])})")
+    assert err < 1e-2
+
+
+def test_full_size_scale_zero_ignores_the_audio_tokens(dev, full_pipe):
+    """attention_processor.py:454 o = o_t + scale * o_a: with scale 0 the audio tokens must not reach the result, and a
+    non-zero scale must (the adapter branch is live at every one of the 32 sites)."""
+    d = _full_inputs(full_pipe, 32, 32, dev)
+    d2 = dict(d, ehs=d["ehs"].clone())
+    d2["ehs"][:, 8:] = torch.randn_like(d2["ehs"][:, 8:])
+    procs = [p for p in full_pipe.unet.attn_processors.values() if hasattr(p, "to_k_ip")]
+    assert len(procs) == 32
+    base = _run(full_pipe, d)
+    assert not torch.equal(base, _run(full_pipe, d2))
+    try:
+        for p in procs:
+            p.scale = 0.0
+        a, b = _run(full_pipe, d), _run(full_pipe, d2)
+    finally:
+        for p in procs:
+            p.scale = 0.55
+    assert torch.equal(a, b)
+    assert not torch.equal(a, base)
