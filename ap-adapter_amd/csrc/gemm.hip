@@ -19,12 +19,13 @@ constexpr int BK = 64;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // TM = block tile edge: 128 (4 waves x 64x64) for big problems, 64 (4 waves x 32x32) when a 128-tiling would leave
 // most of the 256 CUs idle (the 64-token / 4096-row level of the UNet, 32x2 convolutions)
-template <int TM> struct Tile {
+template <int TM, int NS = 1> struct Tile {
     static constexpr int BM = TM, BN = TM;
     static constexpr int MI = TM / 64;              // MFMA tiles per wave per dimension
     static constexpr int A_BYTES = TM * BK * 2;
     static constexpr int C_LD = TM + 8;             // epilogue tile row stride (elements)
-    static constexpr int SMEM_BYTES = (TM * C_LD * 2 > 2 * A_BYTES) ? TM * C_LD * 2 : 2 * A_BYTES;
+    static constexpr int STAGE = 2 * A_BYTES;       // one k-tile of A and of W; NS stages
+    static constexpr int SMEM_BYTES = (TM * C_LD * 2 > NS * STAGE) ? TM * C_LD * 2 : NS * STAGE;
     static constexpr int NLD = TM / 32;             // staging vectors per thread per operand
 };
 
@@ -88,9 +89,9 @@ __device__ __forceinline__ uint4 load_a(const GemmP& p, const RowInfo<AMODE>& r,
     }
 }
 
-template <int DT, int AMODE, int EPI, int OUTMODE, int TM>
+template <int DT, int AMODE, int EPI, int OUTMODE, int TM, int NS = 1>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
-    using T = Tile<TM>;
+    using T = Tile<TM, NS>;
     constexpr int BM = T::BM, BN = T::BN, MI = T::MI, A_BYTES = T::A_BYTES, C_LD = T::C_LD, NLD = T::NLD, WT = TM / 2;
     __shared__ __attribute__((aligned(16))) uint8_t smem[T::SMEM_BYTES];
     using E = ET<DT>;
@@ -215,24 +216,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
             gB[i] = (wv[i] && k < p.K) ? *reinterpret_cast<const u32x4*>(p.w + (wb[i] + k) * 2) : z;
         }
     };
-    auto sstore = [&](const u32x4* gA, const u32x4* gB) {
+    auto sstore = [&](const u32x4* gA, const u32x4* gB, int so = 0) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             int rl = (tid >> 3) + 32 * i;
-            *reinterpret_cast<u32x4*>(smem + lds_off(rl, chunk)) = gA[i];
-            *reinterpret_cast<u32x4*>(smem + A_BYTES + lds_off(rl, chunk)) = gB[i];
+            *reinterpret_cast<u32x4*>(smem + so + lds_off(rl, chunk)) = gA[i];
+            *reinterpret_cast<u32x4*>(smem + so + A_BYTES + lds_off(rl, chunk)) = gB[i];
         }
     };
-    auto compute = [&]() {
+    auto compute = [&](int so = 0) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int ch = ks * 2 + half;
             typename E::v8 af[MI], bf[MI];
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                af[i] = as_v8<DT>(*reinterpret_cast<const uint4*>(smem + lds_off(wm * WT + i * 32 + l31, ch)));
+                af[i] = as_v8<DT>(*reinterpret_cast<const uint4*>(smem + so + lds_off(wm * WT + i * 32 + l31, ch)));
                 bf[i] = as_v8<DT>(
-                    *reinterpret_cast<const uint4*>(smem + A_BYTES + lds_off(wn * WT + i * 32 + l31, ch)));
+                    *reinterpret_cast<const uint4*>(smem + so + A_BYTES + lds_off(wn * WT + i * 32 + l31, ch)));
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
@@ -241,6 +242,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         }
     };
 
+    if constexpr (NS == 2) {
+    // Two LDS stages: the next k-tile is written while the current one is being read -> ONE barrier per k-tile.  Pays
+    // on long reductions (3x3 convolutions with K >= 2048: -3..7 %); the doubled LDS footprint halves the resident
+    // workgroups, which costs more than it gains on short-K launches (K = 256, M = 64000: 22.9 -> 25.7 us), so the
+    // launcher selects it per problem.
+    gload(0, ga[0], gb[0]);
+    sstore(ga[0], gb[0], 0);
+    if (nk > 1) gload(1, ga[0], gb[0]);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = (kt & 1) * T::STAGE;
+        if (kt + 1 < nk) sstore(ga[0], gb[0], cur ^ T::STAGE);  // stage last read in iteration kt-1 (barrier since)
+        if (kt + 2 < nk) gload(kt + 2, ga[0], gb[0]);
+        compute(cur);
+        __syncthreads();
+    }
+    } else {
 #pragma unroll
     for (int s0 = 0; s0 < PF; ++s0)
         if (s0 < nk) gload(s0, ga[s0], gb[s0]);
@@ -260,6 +278,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
                 }
             }
         }
+    }
+
     }
 
     // ---- epilogue: acc (+bias, +rowgroup bias, activation) -> LDS tile ----
@@ -535,14 +555,14 @@ template <int DT, int EPI> int launch_dma(const GemmP& p, hipStream_t s) {
     return apad_check_launch("apad_gemm(dma)");
 }
 
-template <int DT, int AMODE, int EPI, int OUTMODE, int TM>
+template <int DT, int AMODE, int EPI, int OUTMODE, int TM, int NS = 1>
 int launch_tm(const GemmP& p, hipStream_t s) {
     constexpr int BN_OUT = (EPI == APAD_EPI_GEGLU) ? TM / 2 : TM;
     GemmP q = p;
     q.n_tiles = (int)((p.N + BN_OUT - 1) / BN_OUT);
     q.m_tiles = (int)((p.M + TM - 1) / TM);
     dim3 grid((unsigned)(q.n_tiles * q.m_tiles));
-    hipLaunchKernelGGL((gemm_kernel<DT, AMODE, EPI, OUTMODE, TM>), grid, dim3(256), 0, s, q);
+    hipLaunchKernelGGL((gemm_kernel<DT, AMODE, EPI, OUTMODE, TM, NS>), grid, dim3(256), 0, s, q);
     return apad_check_launch("apad_gemm");
 }
 
@@ -557,7 +577,15 @@ int launch(const GemmP& p, hipStream_t s) {
     }
     // long reductions amortise the under-fill: with K >= 1024 the 128-tile wins from ~1.25 workgroups per CU (measured:
     // conv 63x4 384->384 76.5 -> 71.5 us, FF2 M=16128 K=1536 38.5 -> 37.1 us), short-K launches prefer the 64-tile
-    if (blocks128 >= 512 || (blocks128 >= 320 && p.K >= 1024)) return launch_tm<DT, AMODE, EPI, OUTMODE, 128>(p, s);
+    const bool t128 = blocks128 >= 512 || (blocks128 >= 320 && p.K >= 1024);
+    if constexpr (AMODE == APAD_A_CONV3X3_FAST || AMODE == APAD_A_CONV3X3) {
+        static const bool one_stage = getenv("APAD_GEMM_ONE_STAGE") != nullptr;
+        // long reductions on launches of <= ~4 workgroups per CU: two LDS stages, one barrier per k-tile (larger grids
+        // lose more from the halved residency than they gain: 250x16 128->128 118.9 -> 132.6 us)
+        if (p.K >= 2048 && blocks128 <= 1024 && !one_stage)
+            return t128 ? launch_tm<DT, AMODE, EPI, OUTMODE, 128, 2>(p, s) : launch_tm<DT, AMODE, EPI, OUTMODE, 64, 2>(p, s);
+    }
+    if (t128) return launch_tm<DT, AMODE, EPI, OUTMODE, 128>(p, s);
     return launch_tm<DT, AMODE, EPI, OUTMODE, 64>(p, s);
 }
 
