@@ -130,6 +130,8 @@ class Attention(nn.Module):
                         attention_mask=attention_mask, _residual=residual, _ln=ln, **kw)
         if ln is not None:
             hidden_states = ops.layer_norm(hidden_states, *ln)
+        if attention_mask is not None:  # the reference hands processors the bias in the hidden dtype (:741-747)
+            attention_mask = attention_mask.to(hidden_states.dtype)
         out = proc(self, hidden_states, encoder_hidden_states=encoder_hidden_states, attention_mask=attention_mask, **kw)
         return out if residual is None else out + residual  # foreign (non-HIP) processor: its own tensors
 
@@ -434,11 +436,13 @@ class AudioLDM2UNet2DConditionModel(nn.Module):
         dtype = self.conv_in.weight.dtype
         Bs = x.shape[0]
         B = Bs * batch_repeat
-        # mask (1 keep / 0 drop) -> additive bias [B,1,L]  (:741-747)
+        # mask (1 keep / 0 drop) -> additive bias [B,1,L]  (:741-747).  Built in fp32, the type apad_attention takes its
+        # key bias in: the reference's cast to the hidden dtype would only add one bf16 -> fp32 conversion launch in
+        # front of every masked attention site (44 per captured step)
         if emask is not None:
-            emask = ((1 - emask.to(dtype)) * -10000.0).unsqueeze(1)
+            emask = ((1 - emask.float()) * -10000.0).unsqueeze(1)
         if emask1 is not None:
-            emask1 = ((1 - emask1.to(dtype)) * -10000.0).unsqueeze(1)
+            emask1 = ((1 - emask1.float()) * -10000.0).unsqueeze(1)
         if ehs1 is None:
             ehs1, emask1 = ehs, emask
 
