@@ -164,6 +164,122 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint8_t* x, const f
     }
 }
 
+// One-pass GroupNorm for the low-resolution levels (HW <= 1024 pixels per sample): workgroup = (4 groups, sample).  The
+// two-pass schedule above launches only HW/64 x B workgroups there (32 at the 64-pixel level) and pays two launches;
+// here a workgroup reads the [HW][4 groups] slab of its sample ONCE into registers (thread (vc, py) keeps the 16-byte
+// vectors of pixels py, py+PY, ...), reduces it in a fixed order through LDS, and normalises from the registers.
+constexpr int GN1_GPB = 4;
+
+template <int DT, bool SILU, int NTH, int MAXP>
+__global__ __launch_bounds__(NTH) void gn_onepass_kernel(const uint8_t* x, const uint8_t* gamma, const uint8_t* beta,
+                                                         uint8_t* out, int HW, int C, int G, float eps) {
+    __shared__ float lh[NTH][4];   // per thread: (sum, sumsq) of the low and of the high 4 channels of its vector
+    __shared__ float lcol[2][48];  // per 4-channel column of the slab (4 groups x cg <= 40 channels / 4)
+    __shared__ float lm[GN1_GPB], lr[GN1_GPB];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int cg = C / G, wc = GN1_GPB * cg, vps = wc >> 3;  // cg % 4 == 0 -> a 4-channel half vector lies in one group
+    const int PY = NTH / vps;
+    const int vc = tid % vps, py = tid / vps;
+    const bool active = py < PY;
+    const int cbase = blockIdx.x * wc + vc * 8;
+    const uint8_t* xb = x + ((int64_t)b * HW * C + cbase) * 2;
+    uint4 keep[MAXP];
+    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+        const int px = py + i * PY;
+        if (active && px < HW) {
+            keep[i] = *reinterpret_cast<const uint4*>(xb + (int64_t)px * C * 2);
+            float v[8];
+            unpack8<DT>(keep[i], v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s0 += v[e];
+                q0 += v[e] * v[e];
+                s1 += v[e + 4];
+                q1 += v[e + 4] * v[e + 4];
+            }
+        }
+    }
+    lh[tid][0] = s0;
+    lh[tid][1] = q0;
+    lh[tid][2] = s1;
+    lh[tid][3] = q1;
+    __syncthreads();
+    if (tid < 2 * vps) {  // fixed-order sum over the pixel lanes of one 4-channel column
+        const int cv = tid >> 1, h = tid & 1;
+        float a = 0.f, q = 0.f;
+        for (int k = 0; k < PY; ++k) {
+            a += lh[k * vps + cv][2 * h];
+            q += lh[k * vps + cv][2 * h + 1];
+        }
+        lcol[0][tid] = a;
+        lcol[1][tid] = q;
+    }
+    __syncthreads();
+    if (tid < GN1_GPB) {
+        const int ncol = cg >> 2;
+        float a = 0.f, q = 0.f;
+        for (int k = tid * ncol; k < (tid + 1) * ncol; ++k) {
+            a += lcol[0][k];
+            q += lcol[1][k];
+        }
+        const float n = (float)HW * (float)cg;
+        const float mean = a / n;
+        const float var = fmaxf(q / n - mean * mean, 0.f);
+        lm[tid] = mean;
+        lr[tid] = rsqrtf(var + eps);
+    }
+    __syncthreads();
+    if (!active) return;
+    float g[8], bt[8];
+    unpack8<DT>(*reinterpret_cast<const uint4*>(gamma + cbase * 2), g);
+    unpack8<DT>(*reinterpret_cast<const uint4*>(beta + cbase * 2), bt);
+    const int g0 = (vc * 8) / cg, g1 = (vc * 8 + 4) / cg;
+    const float m0 = lm[g0], r0 = lr[g0], m1 = lm[g1], r1 = lr[g1];
+    uint8_t* ob = out + ((int64_t)b * HW * C + cbase) * 2;
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+        const int px = py + i * PY;
+        if (px < HW) {
+            float v[8], y[8];
+            unpack8<DT>(keep[i], v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float mean = e < 4 ? m0 : m1, rstd = e < 4 ? r0 : r1;
+                float t = (v[e] - mean) * rstd * g[e] + bt[e];
+                if (SILU) {
+                    t = (float)(typename ET<DT>::elem)t;  // as gn_apply_kernel: storage rounding before SiLU
+                    t = silu_f(t);
+                }
+                y[e] = t;
+            }
+            *reinterpret_cast<uint4*>(ob + (int64_t)px * C * 2) = pack8<DT>(y);
+        }
+    }
+}
+
+template <int DT, bool SILU>
+bool gn_onepass_launch(const void* x, const void* gamma, const void* beta, void* out, int B, int HW, int C, int G, float eps,
+                       hipStream_t s) {
+    static const int max_hw = [] { const char* e = getenv("APAD_GN_ONEPASS_MAXHW"); return e ? atoi(e) : 1024; }();
+    const int cg = C / G;
+    if (HW > max_hw || G % GN1_GPB != 0 || cg % 4 != 0 || cg > 40) return false;
+    const int vps = GN1_GPB * cg / 8;
+    dim3 grid(G / GN1_GPB, B);
+    if ((HW + 256 / vps - 1) / (256 / vps) <= 24) {
+        hipLaunchKernelGGL((gn_onepass_kernel<DT, SILU, 256, 24>), grid, dim3(256), 0, s, (const uint8_t*)x, (const uint8_t*)gamma,
+                           (const uint8_t*)beta, (uint8_t*)out, HW, C, G, eps);
+        return true;
+    }
+    if ((HW + 1024 / vps - 1) / (1024 / vps) <= 12) {
+        hipLaunchKernelGGL((gn_onepass_kernel<DT, SILU, 1024, 12>), grid, dim3(1024), 0, s, (const uint8_t*)x,
+                           (const uint8_t*)gamma, (const uint8_t*)beta, (uint8_t*)out, HW, C, G, eps);
+        return true;
+    }
+    return false;
+}
+
 template <int DT> int ln_launch(const void* x, const void* gamma, const void* beta, void* out, int64_t M, int C, int64_t ldx,
                                 int64_t ldo, float eps, hipStream_t s) {
     dim3 grid((unsigned)((M + 3) / 4));
@@ -182,6 +298,9 @@ template <int DT> int ln_launch(const void* x, const void* gamma, const void* be
 
 template <int DT> int gn_launch(const void* x, const void* gamma, const void* beta, void* out, float* ws, int B, int HW, int C,
                                 int G, float eps, int silu, hipStream_t s) {
+    if (silu ? gn_onepass_launch<DT, true>(x, gamma, beta, out, B, HW, C, G, eps, s)
+             : gn_onepass_launch<DT, false>(x, gamma, beta, out, B, HW, C, G, eps, s))
+        return apad_check_launch("apad_groupnorm(one pass)");
     const int nchunk = (HW + GN_CHUNK - 1) / GN_CHUNK;
     hipLaunchKernelGGL((gn_partial_kernel<DT>), dim3(nchunk, B), dim3(256), 0, s, (const uint8_t*)x, ws, HW, C, G, nchunk);
     int rc = apad_check_launch("apad_groupnorm(stats)");
