@@ -128,12 +128,15 @@ __device__ __forceinline__ void tile_store(const u32x4 (&rk)[Lay<D>::NK], const 
 
 // Scores, softmax and P.V for ONE staged 64-key tile.  MASK = false is the steady-state path (all 64 keys valid, no
 // bias): max on the raw scores, one packed FMA per two scores folds scale and running max into the exp2 argument.
-// MASK = true handles the additive key bias and the ragged last tile.  Softmax denominators ride on the matrix pipe:
-// one extra MFMA per step against a constant "ones" A-fragment makes row 0 of osum = sum_k P[k][query].
+// MASK = true handles the additive key bias and the ragged last tile.  Softmax denominators: every lane owns one query
+// (half of its keys), so they are a per-lane packed-fp32 sum (osum, two partial sums; the halves meet once per segment).
+// An earlier version put them on the matrix pipe (one MFMA per 16-key step against a "ones" fragment); MFMA and vector
+// work do not overlap inside a wave (tools/probes/overlap.hip), so 16 v_pk_add_f32 (64 cycles) beat 4 MFMAs (128):
+// self-attention N=1000 147.5 -> 142.8 us.
 template <int DT, int D, bool MASK>
 __device__ __forceinline__ void tile_compute(const uint8_t* buf, int key0, int L, const float* bias, float c,
-                                             const typename ET<DT>::v8* qf, f32x16* o, f32x16& osum, float& m,
-                                             const typename ET<DT>::v8& ones, int l31, int half) {
+                                             const typename ET<DT>::v8* qf, f32x16* o, f32x2& osum, float& m, int l31,
+                                             int half) {
     using E = ET<DT>;
     using Y = Lay<D>;
     constexpr int KC = D / 16;
@@ -182,7 +185,7 @@ __device__ __forceinline__ void tile_compute(const uint8_t* buf, int key0, int L
     const float mnew = fmaxf(m, tmax);
     if (__any(mnew > m)) {  // wave-uniform: the O rescale is skipped whenever no lane's running max moved
         const float alpha = __builtin_amdgcn_exp2f(m - mnew);
-        osum[0] *= alpha;  // only row 0 of the denominator tile is ever read
+        osum *= alpha;
 #pragma unroll
         for (int dt = 0; dt < Y::DT_TILES; ++dt)
 #pragma unroll
@@ -194,7 +197,10 @@ __device__ __forceinline__ void tile_compute(const uint8_t* buf, int key0, int L
         for (int u = 0; u < 2; ++u) {
             if (u == 1 && one_sub) break;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[u][r] = __builtin_amdgcn_exp2f(s[u][r] - m);
+            for (int r = 0; r < 16; ++r) {
+                s[u][r] = __builtin_amdgcn_exp2f(s[u][r] - m);
+                osum[0] += s[u][r];
+            }
         }
     } else {
         const f32x2 c2 = {c, c}, nm2 = {-m, -m};
@@ -206,6 +212,7 @@ __device__ __forceinline__ void tile_compute(const uint8_t* buf, int key0, int L
                 v = __builtin_elementwise_fma(v, c2, nm2);
                 s[u][r] = __builtin_amdgcn_exp2f(v[0]);
                 s[u][r + 1] = __builtin_amdgcn_exp2f(v[1]);
+                osum += (f32x2){s[u][r], s[u][r + 1]};
             }
     }
     // ---- O^T += V^T . P^T : four K=16 steps; B operand = P^T in its C-layout key order ----
@@ -225,7 +232,6 @@ __device__ __forceinline__ void tile_compute(const uint8_t* buf, int key0, int L
             typename E::v8 vf = as_v8<DT>(make_uint4(v0.x, v0.y, v1.x, v1.y));
             o[dt] = E::mfma32(vf, pf, o[dt]);
         }
-        osum = E::mfma32(ones, pf, osum);
     }
 }
 
@@ -233,17 +239,12 @@ __device__ __forceinline__ void tile_compute(const uint8_t* buf, int key0, int L
 // running max in the scaled log2 domain.  All 256 threads of the workgroup must call it (LDS staging).
 template <int DT, int D>
 __device__ __forceinline__ void segment(uint8_t* smem, const uint8_t* kbase, int64_t k_sl, const uint8_t* vbase, int L, int Lpad,
-                                        const float* bias, float c, const typename ET<DT>::v8* qf, f32x16* o, f32x16& osum,
+                                        const float* bias, float c, const typename ET<DT>::v8* qf, f32x16* o, f32x2& osum,
                                         float& m, int tid) {
-    using E = ET<DT>;
     using Y = Lay<D>;
     const int lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int ntiles = (L + KT - 1) / KT;
     const int nfull = bias ? 0 : L / KT;  // tiles that need neither bias nor tail masking
-    // A-fragment whose row 0 is all ones (lane l31 == 0 of both halves), every other row zero
-    typename E::v8 ones;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ones[j] = (typename E::elem)(l31 == 0 ? 1.0f : 0.0f);
     u32x4 rk[Y::NK], rv[Y::NV];
     uint32_t koff[Y::NK], voff[Y::NV];  // per-thread byte offsets inside a tile (rows x k_sl stays far below 4 GB)
 #pragma unroll
@@ -269,14 +270,14 @@ __device__ __forceinline__ void segment(uint8_t* smem, const uint8_t* kbase, int
         if (t + 1 < nfull)  // the next tile is a full one too
             tile_load_full<D>(rk, rv, kbase + (int64_t)(t + 1) * KT * k_sl * 2, vbase + (int64_t)(t + 1) * KT * 2, koff, voff, tid);
         else if (t + 1 < ntiles) tile_load<D>(rk, rv, kbase, k_sl, vbase, L, Lpad, (t + 1) * KT, tid);
-        tile_compute<DT, D, false>(buf, t * KT, L, bias, c, qf, o, osum, m, ones, l31, half);
+        tile_compute<DT, D, false>(buf, t * KT, L, bias, c, qf, o, osum, m, l31, half);
         if (t + 1 < ntiles) tile_store<D>(rk, rv, smem + ((t + 1) & 1) * Y::BUF, tid);
         __syncthreads();
     }
     for (; t < ntiles; ++t) {
         const uint8_t* buf = smem + (t & 1) * Y::BUF;
         if (t + 1 < ntiles) tile_load<D>(rk, rv, kbase, k_sl, vbase, L, Lpad, (t + 1) * KT, tid);
-        tile_compute<DT, D, true>(buf, t * KT, L, bias, c, qf, o, osum, m, ones, l31, half);
+        tile_compute<DT, D, true>(buf, t * KT, L, bias, c, qf, o, osum, m, l31, half);
         if (t + 1 < ntiles) tile_store<D>(rk, rv, smem + ((t + 1) & 1) * Y::BUF, tid);
         __syncthreads();
     }
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    f32x16 osum = zero16;
+    f32x2 osum = {0.f, 0.f};
     float m = NEG_BIG;
 
     {
@@ -331,8 +332,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
         const float* bias = p.key_bias ? p.key_bias + (int64_t)b * p.L : nullptr;
         segment<DT, D>(smem, kbase, p.k_sl, vbase, p.L, p.Lpad, bias, p.scale_log2, qf, o, osum, m, tid);
     }
-    // denominator of query l31 = row 0 of osum = register 0 of the half-0 lane
-    const float den = half_lo(osum[0]);
+    // denominator of query l31: the two partial sums of both half-wave lanes that own it
+    const float den = half_sum(osum[0] + osum[1]);
     float inv = 1.0f / den;
     if (p.lse != nullptr && half == 0 && qvalid)  // log2 sum exp2 of the scaled (+biased) scores: what the backward re-uses
         p.lse[((int64_t)b * p.H + h) * ((p.N + 31) & ~31) + q0 + l31] = m + __builtin_log2f(den);
@@ -348,13 +349,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
             for (int dt = 0; dt < Y::DT_TILES; ++dt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o2[dt][r] = 0.f;
-            f32x16 osum2 = zero16;
+            f32x2 osum2 = {0.f, 0.f};
             float m2 = NEG_BIG;
             const int bk = b / p.kvdiv2;
             const uint8_t* kbase = p.k2 + ((int64_t)bk * p.k2_sb + h * D) * 2;
             const uint8_t* vbase = p.vt2 + ((int64_t)bk * p.vt2_sb + (int64_t)h * D * p.Lpad2) * 2;
             segment<DT, D>(smem, kbase, p.k2_sl, vbase, p.L2, p.Lpad2, nullptr, p.scale_log2, qf, o2, osum2, m2, tid);
-            const float inv2 = 1.0f / half_lo(osum2[0]);
+            const float inv2 = 1.0f / half_sum(osum2[0] + osum2[1]);
             // the un-fused reference rounds each branch, and scale * audio, to the storage type before the add
 #pragma unroll
             for (int dt = 0; dt < Y::DT_TILES; ++dt)
@@ -446,8 +447,7 @@ __device__ __forceinline__ void short_segment(const uint8_t* kbase, int64_t k_sl
         if (u >= nsub) break;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            // the denominator sums the probabilities as the P.V MFMA sees them (rounded to the storage type), like the
-            // ones-row MFMA of the staged kernel
+            // the denominator sums the probabilities as the P.V MFMA sees them (rounded to the storage type)
             const float e = (float)(typename E::elem)__builtin_amdgcn_exp2f(s[u][r] - tmax);
             s[u][r] = e;
             sum += e;
