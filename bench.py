@@ -113,7 +113,7 @@ def time_kernel_graphed(fn, iters=20, reps=3):
 
 def dominant_kernel_roofline(dev, dtype, B2):
     """Roofline of the kernel with the largest share of the step in the committed rocprof summary
-    (profiles/r01_bench_kernel_stats_v6.txt: attn_kernel<bf16, d=32, single segment>, the self-attention of the
+    (profiles/r01_bench_kernel_stats_v7.txt: attn_kernel<bf16, d=32, single segment>, the self-attention of the
     1000-token level; the 64x64-tile GEMM template has a larger total but is spread over ~500 small launches per step): softmax(Q K^T / sqrt(32)) V over B2 samples x 8 heads x 1000 x 1000.
     Algorithmic FLOPs = 4 * N^2 * C * B2 (QK^T + PV); bound = MFMA (AI = 512 F/B > ridge 310)."""
     from ap_adapter_amd import ops
@@ -122,7 +122,7 @@ def dominant_kernel_roofline(dev, dtype, B2):
     # (one apad_rowpanel_gemm launch) -- and the launch timed as 20 replays inside a hipGraph, like the captured step:
     # the launch time depends on the data (online-softmax rescales) and on the context: 20 back-to-back replays here
     # measure 139-150 us (sustained all-attention load; eager launches 143-162 us depending on the input statistics),
-    # while the same launches inside the captured step take 122-126 us (profiles/r01_bench_kernel_stats_v6.txt, whose
+    # while the same launches inside the captured step take 122-126 us (profiles/r01_bench_kernel_stats_v7.txt, whose
     # 130 us average mixes both); a producer-consumer pairing with the q|k|v kernel did not reproduce the difference,
     # so it is not cache residency -- most likely clock headroom between the step's memory-bound kernels
     x = torch.randn(B2, N, C, device=dev).to(dtype)
