@@ -7,9 +7,9 @@ import torch
 W_STD = 0.05
 
 
-def _case(name, kind, B, N, C, heads, L, X, seed, scale=1.0, num_tokens=8, masked=False, bf16=False):
+def _case(name, kind, B, N, C, heads, L, X, seed, scale=1.0, num_tokens=8, masked=False, bf16=False, ehs2d=False):
     return dict(name=name, kind=kind, B=B, N=N, C=C, heads=heads, L=L, X=X, seed=seed, scale=scale,
-                num_tokens=num_tokens, masked=masked, bf16=bf16)
+                num_tokens=num_tokens, masked=masked, bf16=bf16, ehs2d=ehs2d)
 
 
 # kind "ip": IPAttnProcessor2_0 with L = num_tokens + La keys of width X=768.
@@ -31,6 +31,8 @@ CASES = [
     _case("ip_256_scale0", "ip", 2, 100, 256, 8, 8 + 32, 768, 22, scale=0.0),
     # masked IP call: only mask column 0 survives (attention_processor.py:424-428)
     _case("ip_256_masked", "ip", 2, 100, 256, 8, 8 + 32, 768, 23, scale=0.5, masked=True),
+    # un-batched condition: a 2-D encoder_hidden_states [L, 768] is unsqueezed to batch 1 (attention_processor.py:371-372)
+    _case("ip_256_ehs2d", "ip", 1, 100, 256, 8, 8 + 32, 768, 25, scale=0.5, ehs2d=True),
     # other head widths the kernels must handle (d = 64, 16 heads)
     _case("ip_256_h4", "ip", 2, 100, 256, 4, 8 + 32, 768, 24, scale=0.5),
     # plain processor: self-attention and masked T5 cross-attention
@@ -56,6 +58,8 @@ def make_inputs(case):
     t = {}
     t["hs"] = _randn(rs, B, N, C)
     t["ehs"] = None if case["kind"] == "self" else _randn(rs, B, L, X)
+    if case.get("ehs2d"):
+        t["ehs"] = t["ehs"][0]  # [L, X]
     t["wq"] = _randn(rs, C, C, std=W_STD)
     t["wk"] = _randn(rs, C, X, std=W_STD)
     t["wv"] = _randn(rs, C, X, std=W_STD)
