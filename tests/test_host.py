@@ -198,3 +198,16 @@ def test_processors_reject_what_is_not_on_the_path_before_any_kernel():
         attn.spatial_norm = torch.nn.Identity()
         with pytest.raises(NotImplementedError):
             proc(attn, torch.zeros(1, 16, 256), encoder_hidden_states=ehs)
+
+
+def test_condition_assembly_matches_the_oracle_token_order():
+    """a-9 (pipeline_audioldm2.py:934-956): text tokens first, audio after; the unconditional half first; cast to the UNet
+    dtype.  The product's assembler against the oracle's on the same tensors (data movement only: bit-equal)."""
+    from oracle import audiomae as OA
+    g = torch.Generator().manual_seed(5)
+    gen = torch.randn(6, 8, 768, generator=g)
+    a, u = torch.randn(1, 32, 768, generator=g), torch.randn(1, 32, 768, generator=g)
+    out = A.AudioLDM2Pipeline.assemble_condition(gen, a, u, torch.bfloat16)
+    ref = OA.assemble_condition(gen, a, u).to(torch.bfloat16)
+    assert out.dtype == torch.bfloat16 and out.shape == (6, 40, 768) and out.is_contiguous()
+    assert torch.equal(out, ref)
