@@ -287,7 +287,7 @@ int64_t apad_reduce_workspace_bytes(void);
 /* loss[0] = mean((pred - target)^2) in fp32 (train_apadapter_v2.py:954); dpred = 2 (pred - target) / n in dtype */
 int apad_mse_loss_grad(const void* pred, const float* target, void* dpred, float* loss, float* workspace, int64_t n,
                        int32_t dtype, void* stream);
-/* norm[0] = ||grad||_2 over the flat fp32 gradient buffer (clip_grad_norm_, :975) */
+/* norm[0] = ||grad||_2 over the flat fp32 gradient buffer (clip_grad_norm_, :976) */
 int apad_grad_norm(const float* grad, float* norm, float* workspace, int64_t n, void* stream);
 /* clip (coefficient min(1, max_norm / (norm + 1e-6)), read from device) + torch.optim.AdamW update (:763-769) of the
    flat fp32 master parameters; `work` (optional) receives the updated parameters in `dtype` for the forward kernels.
