@@ -84,10 +84,13 @@ class AudioMAEEncoder(nn.Module):
         n_tok = self.pos_embed.shape[1] - 1
         x = torch.empty(B, n_tok + 1, dim, dtype=dtype, device=mel.device)
         pos = self.pos_embed.detach()[0]
-        for b in range(B):  # patch tokens land directly behind the CLS slot; + pos_embed rides in the GEMM epilogue
-            ops.gemm(mel[b], w, M=n_tok, N=dim, K=256, lda=0, out=x[b, 1:], ldo=dim, bias=self.patch_embed.proj.bias,
-                     residual=pos[1:], ldr=dim, a_mode=ops.L.A_PATCH16,
-                     conv=(mel.shape[1], mel.shape[2], 1, mel.shape[1] // 16, mel.shape[2] // 16, 1, 0, 0, 0))
+        # ONE implicit-GEMM launch for the whole batch (the mel patches are gathered while staging; + pos_embed rides in the
+        # epilogue, row m of the batch reads pos row m % n_tok); the tokens then move behind the CLS slot (data movement)
+        tok = torch.empty(B, n_tok, dim, dtype=dtype, device=mel.device)
+        ops.gemm(mel, w, M=B * n_tok, N=dim, K=256, lda=0, out=tok, ldo=dim, bias=self.patch_embed.proj.bias,
+                 residual=pos[1:], ldr=dim, residual_row_mod=n_tok, a_mode=ops.L.A_PATCH16,
+                 conv=(mel.shape[1], mel.shape[2], 1, mel.shape[1] // 16, mel.shape[2] // 16, 1, 0, 0, 0))
+        x[:, 1:, :] = tok
         x[:, 0, :] = (self.cls_token.detach()[0, 0] + pos[0])  # one 768-vector (parameter-only, data movement)
         for blk in self.blocks:
             x = blk(x)

@@ -20,6 +20,7 @@
 // APAD_OUT_VT).
 #include <stdlib.h>
 #include "common.h"
+#include "f32_ops.h"
 
 namespace {
 
@@ -598,6 +599,7 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 extern "C" int apad_attention(const apad_attn_desc* d, void* stream) {
     APAD_CHECK(d != nullptr, "apad_attention: null descriptor");
+    if (d->dtype == APAD_F32) return apad_f32_attention(d, (hipStream_t)stream);  // fp32 precision mode (f32_ops.hip)
     APAD_CHECK(d->dtype == APAD_BF16 || d->dtype == APAD_F16, "apad_attention: dtype %d not supported", d->dtype);
     APAD_CHECK(d->q && d->k && d->vt && d->out, "apad_attention: null operand");
     APAD_CHECK(d->B > 0 && d->N > 0 && d->H > 0 && d->L > 0, "apad_attention: empty problem B=%d N=%d H=%d L=%d", d->B, d->N,

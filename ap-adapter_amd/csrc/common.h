@@ -32,6 +32,12 @@ template <> struct ET<APAD_F16> {
     }
 };
 
+// fp32 precision mode: only the element type (the element-wise kernels are templated on it); the MFMA kernels of this
+// mode live in f32_ops.hip
+template <> struct ET<APAD_F32> {
+    using elem = float;
+};
+
 template <int DT> __device__ __forceinline__ typename ET<DT>::v8 as_v8(uint4 u) {
     return __builtin_bit_cast(typename ET<DT>::v8, u);
 }

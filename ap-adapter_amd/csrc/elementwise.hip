@@ -1,6 +1,7 @@
 // Small HBM-bound kernels of the path: AudioMAE token pooling, sinusoidal timestep embedding, fused
 // classifier-free-guidance + DDIM update, device-side step counter.
 #include "common.h"
+#include "f32_ops.h"
 
 namespace {
 
@@ -55,7 +56,10 @@ __global__ void timestep_kernel(const float* t, uint8_t* out, int n, int dim, in
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n * half) return;
     const int r = idx / half, i = idx - r * half;
-    const float freq = expf(-9.210340371976184f * (float)i / ((float)half - freq_shift));
+    // fp32 mode: the exponent in f32 exactly as torch forms it, exp correctly rounded (via f64) -- at t ~ 1000 one ulp of the
+    // frequency is 6e-5 in the sin / cos argument
+    const float ex = (-9.210340371976184f * (float)i) / ((float)half - freq_shift);
+    const float freq = DT == APAD_F32 ? (float)exp((double)ex) : expf(ex);
     const float a = t[r] * freq;
     const float sv = sinf(a), cv = cosf(a);
     const int64_t base = (int64_t)r * dim;
@@ -92,6 +96,11 @@ __global__ void step_advance_kernel(int32_t* p) { *p = *p + 1; }
 extern "C" int apad_audiomae_pool(const void* rep, void* out, int32_t B, int32_t tp, int32_t fp, int32_t dtype,
                                   int32_t out_dtype, void* stream) {
     APAD_CHECK(rep && out && B > 0, "apad_audiomae_pool: null operand / empty batch");
+    if (dtype == APAD_F32) {
+        APAD_CHECK(out_dtype == APAD_F32, "apad_audiomae_pool: f32 input needs f32 output");
+        APAD_CHECK(tp > 0 && fp > 0 && 64 % tp == 0 && 8 % fp == 0, "apad_audiomae_pool: pooling (%d,%d) must divide (64,8)", tp, fp);
+        return apad_f32_audiomae_pool(rep, out, B, tp, fp, (hipStream_t)stream);
+    }
     APAD_CHECK(dtype == APAD_BF16 || dtype == APAD_F16, "apad_audiomae_pool: dtype %d not supported", dtype);
     APAD_CHECK(out_dtype == dtype || out_dtype == APAD_F32, "apad_audiomae_pool: out_dtype must equal dtype or be f32");
     APAD_CHECK(tp > 0 && fp > 0 && 64 % tp == 0 && 8 % fp == 0, "apad_audiomae_pool: pooling (%d,%d) must divide (64,8)", tp, fp);
@@ -118,11 +127,13 @@ extern "C" int apad_audiomae_pool(const void* rep, void* out, int32_t B, int32_t
 extern "C" int apad_timestep_embedding(const float* t, void* out, int32_t n, int32_t dim, int32_t flip_sin_to_cos,
                                        float freq_shift, int32_t dtype, void* stream) {
     APAD_CHECK(t && out && n > 0 && dim > 0 && dim % 2 == 0, "apad_timestep_embedding: bad arguments");
-    APAD_CHECK(dtype == APAD_BF16 || dtype == APAD_F16, "apad_timestep_embedding: dtype %d not supported", dtype);
+    APAD_CHECK(dtype == APAD_BF16 || dtype == APAD_F16 || dtype == APAD_F32, "apad_timestep_embedding: dtype %d not supported", dtype);
     const int total = n * (dim / 2);
     dim3 grid((total + 255) / 256);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == APAD_BF16)
+    if (dtype == APAD_F32)
+        hipLaunchKernelGGL((timestep_kernel<APAD_F32>), grid, dim3(256), 0, s, t, (uint8_t*)out, n, dim, flip_sin_to_cos, freq_shift);
+    else if (dtype == APAD_BF16)
         hipLaunchKernelGGL((timestep_kernel<APAD_BF16>), grid, dim3(256), 0, s, t, (uint8_t*)out, n, dim, flip_sin_to_cos, freq_shift);
     else
         hipLaunchKernelGGL((timestep_kernel<APAD_F16>), grid, dim3(256), 0, s, t, (uint8_t*)out, n, dim, flip_sin_to_cos, freq_shift);
@@ -133,13 +144,16 @@ extern "C" int apad_cfg_ddim_step(const void* eps2, float* latents, void* unet_i
                                   const int32_t* step_ptr, float guidance_scale, int32_t B, int64_t n, int32_t dtype,
                                   void* stream) {
     APAD_CHECK(eps2 && latents && unet_in && coef, "apad_cfg_ddim_step: null operand");
-    APAD_CHECK(dtype == APAD_BF16 || dtype == APAD_F16, "apad_cfg_ddim_step: dtype %d not supported", dtype);
+    APAD_CHECK(dtype == APAD_BF16 || dtype == APAD_F16 || dtype == APAD_F32, "apad_cfg_ddim_step: dtype %d not supported", dtype);
     APAD_CHECK(B > 0 && n > 0, "apad_cfg_ddim_step: empty problem");
     const int64_t total = (int64_t)B * n;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == APAD_BF16)
+    if (dtype == APAD_F32)
+        hipLaunchKernelGGL((cfg_ddim_kernel<APAD_F32>), dim3((unsigned)blocks), dim3(256), 0, s, (const uint8_t*)eps2, latents,
+                           (uint8_t*)unet_in, eps_out, coef, step_ptr, guidance_scale, total);
+    else if (dtype == APAD_BF16)
         hipLaunchKernelGGL((cfg_ddim_kernel<APAD_BF16>), dim3((unsigned)blocks), dim3(256), 0, s, (const uint8_t*)eps2, latents,
                            (uint8_t*)unet_in, eps_out, coef, step_ptr, guidance_scale, total);
     else

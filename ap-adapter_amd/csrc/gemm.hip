@@ -12,6 +12,7 @@
 // Epilogue: accumulators -> LDS tile -> full-row 16 B stores (residual read with the same coalescing).
 #include <stdlib.h>
 #include "common.h"
+#include "f32_ops.h"
 
 namespace {
 
@@ -633,7 +634,8 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 extern "C" int apad_gemm(const apad_gemm_desc* d, void* stream) {
     APAD_CHECK(d != nullptr, "apad_gemm: null descriptor");
-    APAD_CHECK(d->dtype == APAD_BF16 || d->dtype == APAD_F16, "apad_gemm: dtype %d not supported (bf16/f16)", d->dtype);
+    if (d->dtype == APAD_F32) return apad_f32_gemm(d, (hipStream_t)stream);  // fp32 precision mode (f32_ops.hip)
+    APAD_CHECK(d->dtype == APAD_BF16 || d->dtype == APAD_F16, "apad_gemm: dtype %d not supported (bf16/f16/f32)", d->dtype);
     APAD_CHECK(d->a && d->w && d->out, "apad_gemm: null operand");
     APAD_CHECK(d->M > 0 && d->N > 0 && d->K > 0, "apad_gemm: empty problem M=%lld N=%lld K=%lld", (long long)d->M,
                (long long)d->N, (long long)d->K);

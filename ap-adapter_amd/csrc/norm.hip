@@ -1,6 +1,7 @@
 // LayerNorm (token-major rows) and GroupNorm(+SiLU) over NHWC activations.  HBM-bound: 16 B/lane loads, fp32
 // statistics, one pass over the data per kernel.
 #include "common.h"
+#include "f32_ops.h"
 
 namespace {
 
@@ -321,6 +322,7 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 extern "C" int apad_layernorm(const void* x, const void* gamma, const void* beta, void* out, int64_t M, int32_t C, int64_t ldx,
                               int64_t ldo, float eps, int32_t dtype, void* stream) {
     APAD_CHECK(x && gamma && beta && out, "apad_layernorm: null operand");
+    if (dtype == APAD_F32) return apad_f32_layernorm(x, gamma, beta, out, M, C, ldx, ldo, eps, (hipStream_t)stream);
     APAD_CHECK(dtype == APAD_BF16 || dtype == APAD_F16, "apad_layernorm: dtype %d not supported", dtype);
     APAD_CHECK(M > 0 && C > 0 && C % 8 == 0 && C <= 2048, "apad_layernorm: need M>0, C%%8==0, C<=2048 (M=%lld C=%d)", (long long)M, C);
     APAD_CHECK(ldx % 8 == 0 && ldo % 8 == 0 && al16(x) && al16(out) && al16(gamma) && al16(beta),
@@ -337,6 +339,7 @@ extern "C" int64_t apad_groupnorm_workspace_bytes(int32_t B, int32_t HW, int32_t
 extern "C" int apad_groupnorm(const void* x, const void* gamma, const void* beta, void* out, void* workspace, int32_t B,
                               int32_t HW, int32_t C, int32_t G, float eps, int32_t silu, int32_t dtype, void* stream) {
     APAD_CHECK(x && gamma && beta && out && workspace, "apad_groupnorm: null operand");
+    if (dtype == APAD_F32) return apad_f32_groupnorm(x, gamma, beta, out, B, HW, C, G, eps, silu, (hipStream_t)stream);
     APAD_CHECK(dtype == APAD_BF16 || dtype == APAD_F16, "apad_groupnorm: dtype %d not supported", dtype);
     APAD_CHECK(B > 0 && HW > 0 && G > 0 && G <= 64 && C % G == 0 && (C / G) % 4 == 0 && C % 8 == 0 && C <= 1280,
                "apad_groupnorm: need G<=64, C%%G==0, (C/G)%%4==0, C%%8==0, C<=1280 (B=%d HW=%d C=%d G=%d)", B, HW, C, G);

@@ -75,6 +75,13 @@ def linear(x, w, bias=None, residual=None, act=None, out=None, rowgroup_bias=Non
 
 
 RP_K = (256, 384)  # reduction dims the row-panel kernel covers
+FUSED_DTYPES = (torch.bfloat16, torch.float16)  # the fused kernels (row-panel, feed-forward, cross-attention) are 16-bit only;
+# the fp32 precision mode (exact-f32 MFMA, csrc/f32_ops.hip) runs the un-fused apad_layernorm / apad_gemm / apad_attention chain
+
+
+def rp_ok(x, K=None):
+    """row-panel envelope: reduction dim in RP_K and a 16-bit storage type"""
+    return (x.shape[-1] if K is None else K) in RP_K and x.dtype in FUSED_DTYPES
 
 
 def rowpanel(x, w, segs, ln=None, residual=None, act=None, vt_geom=None):
@@ -106,7 +113,7 @@ def fused_linear(x, w, bias=None, ln=None, residual=None, act=None, out=None):
     apad_layernorm + apad_gemm."""
     K = x.shape[-1]
     N = w.shape[0] // 2 if act == "geglu" else w.shape[0]
-    if K in RP_K and N % 64 == 0:
+    if rp_ok(x, K) and N % 64 == 0:
         if out is None:
             out = torch.empty(*x.shape[:-1], N, dtype=w.dtype, device=x.device)
         rowpanel(x, w, [(out, bias, N, "row")], ln=ln, residual=residual, act=act)
@@ -124,7 +131,7 @@ def fused_cross_attention(x, wq, wo, bo, k1, v1t, L1, heads, ln=None, key_bias=N
     cross-attention sub-layer in one launch.  x [B, N, C]; k [B, L, C]; vt [B, heads, d, Lpad]."""
     _req(x, "fused_cross_attention.x", wq.dtype)
     B, N, Cc = x.shape
-    if Cc != XATTN_C or heads != XATTN_HEADS or L1 > XATTN_MAXL or L2 > XATTN_MAXL:
+    if Cc != XATTN_C or heads != XATTN_HEADS or L1 > XATTN_MAXL or L2 > XATTN_MAXL or x.dtype not in FUSED_DTYPES:
         raise ValueError(f"fused_cross_attention: C={Cc} heads={heads} L1={L1} L2={L2} outside the kernel envelope")
     for t, n in ((x, "x"), (wq, "wq"), (wo, "wo"), (k1, "k1"), (v1t, "v1t")):
         if not t.is_contiguous():
@@ -155,7 +162,7 @@ def geglu_mlp(x, w1, b1, w2, b2, ln=None, out=None):
     BasicTransformerBlock plus its residual in one launch (C in MLP_C)."""
     _req(x, "geglu_mlp.x", w1.dtype)
     Cc = x.shape[-1]
-    if Cc not in MLP_C or w1.shape != (8 * Cc, Cc) or w2.shape != (Cc, 4 * Cc):
+    if Cc not in MLP_C or w1.shape != (8 * Cc, Cc) or w2.shape != (Cc, 4 * Cc) or x.dtype not in FUSED_DTYPES:
         raise ValueError(f"geglu_mlp: C={Cc}, w1 {tuple(w1.shape)}, w2 {tuple(w2.shape)} outside the kernel envelope")
     if not (x.is_contiguous() and w1.is_contiguous() and w2.is_contiguous()):
         raise ValueError("geglu_mlp: operands must be contiguous")

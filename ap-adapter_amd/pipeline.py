@@ -74,6 +74,7 @@ class AudioLDM2Pipeline:
         return torch.cat([torch.cat([neg, u], dim=1), torch.cat([pos, a], dim=1)], dim=0).contiguous()
 
     # ---- the loop ----
+    @torch.no_grad()
     def denoise(self, latents_nchw, generated_prompt_embeds, prompt_embeds, attention_mask, num_inference_steps,
                 guidance_scale, use_graph=True, callback=None, callback_steps=1, keep_noise_pred=False):
         unet = self.unet

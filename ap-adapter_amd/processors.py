@@ -32,7 +32,7 @@ def _fused_xattn_ok(attn, hidden_states, residual, ln, L1, L2=0):
     C_ = hidden_states.shape[-1]
     return (USE_FUSED_XATTN and residual is hidden_states and ln is not None and C_ == ops.XATTN_C and attn.heads == ops.XATTN_HEADS
             and tuple(attn.to_q.weight.shape) == (C_, C_) and L1 <= ops.XATTN_MAXL and L2 <= ops.XATTN_MAXL
-            and hidden_states.is_contiguous())
+            and hidden_states.is_contiguous() and hidden_states.dtype in ops.FUSED_DTYPES)
 
 
 def vt_buffer(slot, B, heads, d, Lk, dtype, device):
@@ -46,6 +46,18 @@ def vt_buffer(slot, B, heads, d, Lk, dtype, device):
         buf = torch.zeros(B, heads, d, Lpad, dtype=dtype, device=device)
         _vt_pool[key] = buf
     return buf
+
+
+def _pkey(*params):
+    """identity + storage + version of parameters: changes when a weight is re-assigned (inference.py:56-57 re-assigns
+    ``to_k_ip.weight`` / ``to_v_ip.weight``), moved, cast, or updated in place"""
+    return tuple((id(p), p.data_ptr(), p._version, p.dtype) for p in params)
+
+
+def _tkey(t):
+    """identity of a condition tensor's CONTENT as far as it can be known without reading it: storage, shape, dtype and the
+    in-place version counter"""
+    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype, t._version)
 
 
 def _key_bias(attention_mask, B, Lk):
@@ -110,14 +122,14 @@ class AttnProcessor2_0(nn.Module):
             return self._call_train(attn, hidden_states, encoder_hidden_states, attention_mask, _residual, _ln)
         if encoder_hidden_states is None:
             Lk = N
-            if C_ in ops.RP_K and attn.to_q.weight.shape[0] == C_:
+            if ops.rp_ok(hidden_states) and attn.to_q.weight.shape[0] == C_:
                 # LayerNorm + q|k|v in ONE launch: x is read once, V lands per-head transposed
                 q = torch.empty(B, N, C_, dtype=hidden_states.dtype, device=hidden_states.device)
                 k = torch.empty_like(q)
                 vt = vt_buffer("self", B, heads, C_ // heads, N, hidden_states.dtype, hidden_states.device)
                 ops.rowpanel(hidden_states, self._qkv_weight(attn), [(q, None, C_, "row"), (k, None, C_, "row"), (vt, None, C_, "vt")],
                              ln=_ln, vt_geom=(heads, C_ // heads, N, vt.shape[-1]))
-            elif attn.to_q.weight.shape[0] == C_ and C_ % 128 == 0:
+            elif attn.to_q.weight.shape[0] == C_ and C_ % 128 == 0:  # (fp32 mode: every width whose C % 128 == 0)
                 # widths outside the row-panel envelope (the 640-wide level): LayerNorm, then q|k|v in ONE tiled launch
                 hs = hidden_states if _ln is None else ops.layer_norm(hidden_states, *_ln)
                 q = torch.empty(B, N, C_, dtype=hidden_states.dtype, device=hidden_states.device)
@@ -134,7 +146,9 @@ class AttnProcessor2_0(nn.Module):
             if ehs.dim() < 3:
                 ehs = ehs.unsqueeze(0)
             Lk = ehs.shape[1]
-            ck = (ehs.data_ptr(), tuple(ehs.shape))
+            # hoisted K/V are valid for ONE (Attention site, condition tensor content, to_k / to_v weights): a processor
+            # instance may be shared by every site (set_attn_processor(proc)), weights may be re-assigned or stepped
+            ck = (id(attn), _tkey(ehs), _pkey(attn.to_k.weight, attn.to_v.weight))
             if self.kv_cache_enabled and self._kv_cache is not None and ck in self._kv_cache:
                 k, vt = self._kv_cache[ck]
             else:
@@ -146,7 +160,7 @@ class AttnProcessor2_0(nn.Module):
         if attention_mask is not None and self.kv_cache_enabled:
             # the mask -> fp32 bias conversion is timestep-invariant too: hoisted with the K/V (two tiny torch kernels
             # per masked site per step otherwise)
-            bk = ("bias", attention_mask.data_ptr(), tuple(attention_mask.shape))
+            bk = ("bias", _tkey(attention_mask), Lk)
             if self._kv_cache is None:
                 self._kv_cache = {}
             bias = self._kv_cache.get(bk)
@@ -259,7 +273,10 @@ class IPAttnProcessor2_0(nn.Module):
         B, N, _ = hidden_states.shape
         if AG.on(hidden_states, ehs, self.to_k_ip.weight, self.to_v_ip.weight):
             return self._call_train(attn, hidden_states, ehs, attention_mask, _residual, _ln)
-        ck = (ehs.data_ptr(), tuple(ehs.shape))
+        # see AttnProcessor2_0: keyed on the site, the condition content and all four projection weights, so a re-assigned
+        # to_k_ip / to_v_ip (inference.py:56-57) or an optimizer step is never served stale K/V
+        ck = (id(attn), _tkey(ehs), self.num_tokens,
+              _pkey(attn.to_k.weight, attn.to_v.weight, self.to_k_ip.weight, self.to_v_ip.weight))
         if self.kv_cache_enabled and self._kv_cache is not None and ck in self._kv_cache:
             kv = self._kv_cache[ck]
         else:

@@ -154,7 +154,7 @@ class FeedForward(nn.Module):
         if AG.on(x):  # training: un-fused, the GEGLU projection is kept for the backward
             h = AG.geglu(AG.linear(AG.layer_norm(x, *ln), self.net[0].proj.weight, self.net[0].proj.bias))
             return AG.linear(h, self.net[2].weight, self.net[2].bias, residual=x)
-        if x.shape[-1] in ops.MLP_C and os.environ.get("APAD_FUSED_MLP", "1") != "0":
+        if x.shape[-1] in ops.MLP_C and x.dtype in ops.FUSED_DTYPES and os.environ.get("APAD_FUSED_MLP", "1") != "0":
             return ops.geglu_mlp(x, self.net[0].proj.weight, self.net[0].proj.bias, self.net[2].weight, self.net[2].bias, ln=ln)
         h = ops.fused_linear(x, self.net[0].proj.weight, self.net[0].proj.bias, ln=ln, act="geglu")
         return ops.linear(h, self.net[2].weight, self.net[2].bias, residual=x)

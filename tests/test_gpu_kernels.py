@@ -10,7 +10,8 @@ import torch.nn.functional as F
 from util import TOL, q, rel_err
 
 pytestmark = pytest.mark.gpu
-DTYPES = [torch.bfloat16, torch.float16]
+DTYPES16 = [torch.bfloat16, torch.float16]     # the fused kernels (row-panel, feed-forward, cross-attention)
+DTYPES = DTYPES16 + [torch.float32]            # float32: the fp32 precision mode (csrc/f32_ops.hip)
 
 
 def R(*shape, seed=0, std=1.0):
@@ -251,6 +252,9 @@ def test_audiomae_pool(dev, tp, fp):
     assert rel_err(out, ref) < 1e-6
     out = ops.audiomae_pool(rep.to(dev, dtype), tp, fp)
     assert rel_err(out, ref) < TOL[dtype]
+    rep32 = R(2, 513, 768, seed=43)
+    out = ops.audiomae_pool(rep32.to(dev), tp, fp)
+    assert out.dtype == torch.float32 and rel_err(out, pool(rep32, tp, fp)) < 1e-6
 
 
 def test_timestep_embedding(dev):
@@ -262,13 +266,18 @@ def test_timestep_embedding(dev):
     assert rel_err(out, ref) < TOL[torch.bfloat16]
     out = ops.timestep_embedding(t.to(dev), 128, False, 1.0, torch.float16)
     assert rel_err(out, timestep_embedding(t, 128, False, 1.0)) < TOL[torch.float16]
+    # fp32 mode: the frequency exponent is formed like torch's and exp is correctly rounded; torch's vectorised exp is
+    # within 1 ulp, and 1 ulp of a frequency near 1 is 6e-5 in the sin / cos argument at t ~ 1000
+    out = ops.timestep_embedding(t.to(dev), 128, True, 0.0, torch.float32)
+    assert rel_err(out, ref) < 1e-4
 
 
-def test_cfg_ddim_step_matches_oracle(dev):
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_cfg_ddim_step_matches_oracle(dev, dtype):
     from ap_adapter_amd import ops
     from ap_adapter_amd.scheduler import DDIMScheduler
     from oracle import ddim
-    dtype, B, n, steps, gs = torch.bfloat16, 3, 4000 * 8, 10, 7.5
+    B, n, steps, gs = 3, 4000 * 8, 10, 7.5
     s = DDIMScheduler()
     s.set_timesteps(steps)
     coef = s.coef_table().to(dev)
@@ -338,7 +347,7 @@ def test_rowpanel_geglu(dev, dtype, M, K, ln):
     assert rel_err(out, ref) < TOL[dtype]
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("dtype", DTYPES16)
 @pytest.mark.parametrize("M,C", [(1000, 256), (300, 256), (33000, 256), (37, 256)])
 @pytest.mark.parametrize("ln", [False, True])
 def test_geglu_mlp(dev, dtype, M, C, ln):
@@ -369,7 +378,7 @@ def test_geglu_mlp_outside_envelope_is_an_error(dev):
                       torch.zeros(384, 1536, device=dev, dtype=torch.bfloat16), None)
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("dtype", DTYPES16)
 @pytest.mark.parametrize("B,L,K,heads", [(2, 1000, 256, 8), (3, 252, 384, 8), (2, 100, 256, 4), (1, 513, 384, 12), (2, 63, 256, 8)])
 def test_rowpanel_fused_qkv_with_vt(dev, dtype, B, L, K, heads):
     """LayerNorm + q|k|v in one launch; V per-head transposed (incl. token counts that are not multiples of 4)"""
@@ -426,7 +435,7 @@ def _xattn_ref(x, g, be, wq, wo, bo, ehs_t, wk, wv, heads, bias=None, ehs_a=None
     return x + F.linear(o, wo, bo)
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("dtype", DTYPES16)
 @pytest.mark.parametrize("B,N,Lt,La,masked", [(2, 1000, 8, 32, False), (3, 100, 8, 8, False), (2, 250, 16, 0, True), (1, 33, 8, 64, False),
                                                (5, 64, 40, 0, False)])
 def test_fused_cross_attention(dev, dtype, B, N, Lt, La, masked):

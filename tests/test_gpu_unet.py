@@ -82,39 +82,124 @@ def test_audiomae_vs_oracle(dev, dtype, tol):
     assert rel_err(out, ref) < tol
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 4e-2), (torch.float16, 6e-3)])
-def test_full_geometry_noise_pred_vs_oracle(dev, dtype, tol):
+def _full_geometry_case(dev, dtype, La=32, scale=0.55, t=501):
     """AudioLDM2-large geometry (718 M parameters, 256 attention sites, 32 AP processors), one CFG pair of a 10 s clip
-    (latents 8x250x16), La = 32 audio tokens: noise_pred of the HIP path vs the fp32 oracle chain on the same
-    storage-rounded weights.  This is the tensor the north-star tolerance is stated on; the bound asserted here is the
-    measured error with ~2x margin (see DESIGN.md 'Tolerance statement')."""
+    (latents 8x250x16): returns (noise_pred of the HIP path, a closure running the oracle chain on the same
+    storage-rounded weights and inputs).  noise_pred is the tensor the north-star tolerance is stated on."""
     import ap_adapter_amd as A
     from ap_adapter_amd.synthetic import init_synthetic_, synthetic_inputs
     from oracle import unet as OU
     u = A.AudioLDM2UNet2DConditionModel()
-    A.install_ap_adapter(u, None, scale=0.55)
+    A.install_ap_adapter(u, None, scale=scale)
     init_synthetic_(u, 100, bias_std=0.01)
     u = u.to(dtype)
     sd = {k: v.detach().float() for k, v in u.state_dict().items()}
     procs = {n: dict(scale=p.scale, num_tokens=p.num_tokens) for n, p in u.attn_processors.items() if hasattr(p, "to_k_ip")}
-    inp = synthetic_inputs(1, 32)
+    inp = synthetic_inputs(1, La)
     pipe = A.AudioLDM2Pipeline(u)
     ehs = pipe.assemble_condition(inp["generated_prompt_embeds"], inp["audio_tokens"], inp["uncond_audio_tokens"], dtype)
     ehs1 = inp["prompt_embeds"].to(dtype)
     x = torch.cat([inp["latents"]] * 2).to(dtype)
-    t = torch.tensor(501)
+    tt = torch.tensor(t)
+    geo = u.config.geometry_dict()
+
+    def oracle():
+        with torch.no_grad():
+            return OU.unet_forward(sd, geo, x.float(), tt, ehs.float(), ehs1.float(), None, inp["attention_mask"].float(), procs)
+
     with torch.no_grad():
-        ref = OU.unet_forward(sd, u.config.geometry_dict(), x.float(), t, ehs.float(), ehs1.float(), None,
-                              inp["attention_mask"].float(), procs)
         u = u.to(dev)
-        out = u(x.to(dev), t, encoder_hidden_states=ehs.to(dev), encoder_hidden_states_1=ehs1.to(dev),
+        out = u(x.to(dev), tt, encoder_hidden_states=ehs.to(dev), encoder_hidden_states_1=ehs1.to(dev),
                 encoder_attention_mask_1=inp["attention_mask"].to(dev), return_dict=False)[0]
+    return out.float().cpu(), oracle
+
+
+@pytest.mark.parametrize("La,scale", [(32, 0.55), (512, 1.0)])
+def test_full_geometry_noise_pred_fp32_within_north_star(dev, La, scale):
+    """North-star bar: <= 1e-3 max-abs error on noise_pred vs the reference chain.  In the fp32 precision mode (APAD_F32
+    storage, exact-f32 MFMA; the reference's own arithmetic type for cfg 1 / training / AudioMAE) the only difference to
+    the oracle chain is summation order, so the bound is asserted as stated -- absolute, not relative, not calibrated.
+    (La, scale) = the style preset and the La = 512 / ap_scale = 1.0 corner of BASELINE cfg 3."""
+    out, oracle = _full_geometry_case(dev, torch.float32, La, scale)
+    ref = oracle()
     assert out.shape == ref.shape == (2, 8, 250, 16)
-    err = (out.float().cpu() - ref).abs()
-    rel = float(err.max() / ref.abs().max())
-    print(f"\\n[full-geometry noise_pred, {dtype}] max|ref|={float(ref.abs().max()):.4f} max-abs err={float(err.max()):.3e} "
-          f"mean-abs err={float(err.mean()):.3e} rel-max={rel:.3e}")
-    assert rel < tol
+    err = (out - ref).abs()
+    print(f"\n[full-geometry noise_pred, fp32, La={La}] max|ref|={float(ref.abs().max()):.4f} max-abs err={float(err.max()):.3e} "
+          f"mean-abs err={float(err.mean()):.3e}")
+    assert float(err.max()) <= 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_full_geometry_noise_pred_same_precision(dev, dtype):
+    """16-bit storage cannot meet 1e-3 absolute through ~300 stacked layers -- the reference pipeline itself does not at
+    that storage type.  So the 16-bit bound is a SAME-PRECISION one: the HIP path's error vs the fp32 oracle chain must not
+    exceed 1.25x the error of the reference chain run at the same storage type (the oracle under per-op rounding, which
+    is how PyTorch executes it in half / bfloat16).  UNet-level twin of test_processor_bf16_not_worse_than_reference_bf16."""
+    from util import PerOpRounding
+    out, oracle = _full_geometry_case(dev, dtype)
+    ref = oracle()
+    with PerOpRounding(dtype):
+        ref_lp = oracle()
+    e_hip, e_ref = float((out - ref).abs().max()), float((ref_lp - ref).abs().max())
+    m_hip, m_ref = float((out - ref).abs().mean()), float((ref_lp - ref).abs().mean())
+    print(f"\n[full-geometry noise_pred, {dtype}] max|ref|={float(ref.abs().max()):.4f}  HIP: max {e_hip:.3e} mean {m_hip:.3e}   "
+          f"reference chain at {dtype}: max {e_ref:.3e} mean {m_ref:.3e}")
+    assert e_hip <= 1.25 * e_ref
+    assert m_hip <= 1.25 * m_ref
+
+
+def test_audiomae_fp32_depth12_vs_oracle(dev):
+    """the reference runs AudioMAE in fp32 (pipeline_audioldm2.py:926, never cast): all 12 blocks, fp32 precision mode,
+    <= 1e-4 of max against the oracle"""
+    import ap_adapter_amd as A
+    from ap_adapter_amd.synthetic import init_synthetic_
+    from oracle import audiomae as OA
+    m = A.AudioMAEConditionCTPoolRand()
+    init_synthetic_(m, 7, w_std=0.03, bias_std=0.02, norm_jitter=0.1)
+    sd = {k[len("audiomae.model."):]: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    mel = (torch.randn(2, 1024, 128, generator=torch.Generator().manual_seed(3)) * 0.5)
+    with torch.no_grad():
+        ref_rep = OA.encoder(sd, mel.unsqueeze(1))
+        ref = OA.pool(ref_rep, 4, 4)
+        m = m.to(dev)
+        rep = m.audiomae(mel.to(dev), no_mask=True, no_average=True)
+        out, _ = m(mel, time_pool=4, freq_pool=4)
+    assert rep.dtype == torch.float32 and rep.shape == ref_rep.shape == (2, 513, 768)
+    e_rep, e_out = rel_err(rep, ref_rep), rel_err(out, ref)
+    print(f"\n[AudioMAE fp32 depth 12] encoder rel err {e_rep:.3e}, pooled tokens rel err {e_out:.3e}")
+    assert e_rep <= 1e-4 and e_out <= 1e-4
+
+
+def test_cfg1_timbre_fp32_five_steps_vs_oracle_loop(dev):
+    """BASELINE configs[0]: timbre_transfer preset (ap_scale 0.5, pooling 2x2 -> La = 128, guidance 7.5; config.py:8-11),
+    one 10 s clip, fp32, 5 DDIM steps -- the reference's own CPU-runnable case -- on the HIP path (hipGraph loop) against
+    the oracle loop.  The north-star 1e-3 is asserted on the guided noise_pred of the LAST step (whose input already
+    carries four steps of accumulated difference).  The final latents are bounded by the loop's own amplification of that
+    tolerance: guidance 7.5 multiplies a UNet difference, and the five big DDIM jumps (t = 801 ... 1) multiply what is
+    carried by prod sqrt(a_prev / a_t) ~ 10 (measured: 9e-4 for 1e-5 per UNet call)."""
+    import ap_adapter_amd as A
+    from ap_adapter_amd.synthetic import init_synthetic_, synthetic_inputs
+    from oracle import unet as OU, ddim
+    u = A.AudioLDM2UNet2DConditionModel()
+    A.install_ap_adapter(u, None, scale=0.5)
+    init_synthetic_(u, 100, bias_std=0.01)
+    sd = {k: v.detach().float() for k, v in u.state_dict().items()}
+    procs = {n: dict(scale=p.scale, num_tokens=p.num_tokens) for n, p in u.attn_processors.items() if hasattr(p, "to_k_ip")}
+    inp = synthetic_inputs(1, 128)
+    pipe = A.AudioLDM2Pipeline(u)
+    ehs = pipe.assemble_condition(inp["generated_prompt_embeds"], inp["audio_tokens"], inp["uncond_audio_tokens"], torch.float32)
+    geo = u.config.geometry_dict()
+    fn = lambda x, t: OU.unet_forward(sd, geo, x, t, ehs, inp["prompt_embeds"], None, inp["attention_mask"].float(), procs)
+    with torch.no_grad():
+        ref, preds = ddim.denoise_loop(fn, inp["latents"], 5, 7.5)
+        u.to(dev)
+        out = pipe.denoise(inp["latents"].to(dev), ehs.to(dev), inp["prompt_embeds"].to(dev), inp["attention_mask"].to(dev), 5, 7.5,
+                           use_graph=True, keep_noise_pred=True)
+    e_lat = float((out.cpu() - ref).abs().max())
+    e_eps = float((pipe.last_noise_pred.cpu() - preds[-1]).abs().max())
+    print(f"\n[cfg 1, fp32, 5 steps] final latents max-abs err {e_lat:.3e}; last guided noise_pred max-abs err {e_eps:.3e}")
+    assert e_eps <= 1e-3
+    assert e_lat <= 5e-3
 
 
 # ---- BASELINE full size (batch 32 -> 64 sample-forwards per step, AudioLDM2-large geometry): size-independent properties ----
