@@ -57,8 +57,8 @@ class MlpDesc(C.Structure):
 
 
 class XattnDesc(C.Structure):
-    _fields_ = [(n, _vp) for n in ("x", "ln_gamma", "ln_beta", "wq", "wo", "bo", "k1", "v1t", "key_bias", "k2", "v2t", "out")] + \
-               [(n, _i32) for n in ("B", "N", "C", "heads", "L1", "Lpad1", "L2", "Lpad2", "dtype", "reserved")] + \
+    _fields_ = [(n, _vp) for n in ("x", "ln_gamma", "ln_beta", "wq_packed", "wo_packed", "bo", "kv1_packed", "key_bias", "kv2_packed", "out")] + \
+               [(n, _i32) for n in ("B", "N", "C", "heads", "L1", "L2", "dtype", "reserved")] + \
                [(n, _f32) for n in ("ln_eps", "softmax_scale", "scale2", "reserved_f")]
 
 
@@ -85,6 +85,9 @@ SYMBOLS = {
     "apad_sizeof_xattn_desc": (C.c_int, []),
     "apad_echo_xattn_desc": (C.c_int, [C.POINTER(XattnDesc), C.POINTER(C.c_double), C.c_int]),
     "apad_fused_cross_attention": (C.c_int, [C.POINTER(XattnDesc), _vp]),
+    "apad_xattn_pack_weight": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "apad_xattn_packed_kv_bytes": (_i64, [_i32, _i32]),
+    "apad_xattn_pack_kv": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp]),
     "apad_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "apad_attention": (C.c_int, [C.POINTER(AttnDesc), _vp]),
     "apad_layernorm": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _i64, _f32, _i32, _vp]),
@@ -147,7 +150,7 @@ def lib():
                 fn = getattr(h, name)  # AttributeError if the ABI lost a symbol
                 fn.restype = res
                 fn.argtypes = args
-            if h.apad_abi_version() != 2:
+            if h.apad_abi_version() != 3:
                 raise RuntimeError("libapadapter_hip.so ABI version mismatch")
             if h.apad_sizeof_gemm_desc() != C.sizeof(GemmDesc) or h.apad_sizeof_attn_desc() != C.sizeof(AttnDesc) \
                     or h.apad_sizeof_rp_desc() != C.sizeof(RpDesc) \

@@ -90,9 +90,9 @@ extern "C" int apad_echo_attn_bwd_desc(const apad_attn_bwd_desc* d, double* out,
 extern "C" int apad_sizeof_xattn_desc(void) { return (int)sizeof(apad_xattn_desc); }
 extern "C" int apad_echo_xattn_desc(const apad_xattn_desc* d, double* out, int cap) {
     int n = 0;
-    PUTP(d->x); PUTP(d->ln_gamma); PUTP(d->ln_beta); PUTP(d->wq); PUTP(d->wo); PUTP(d->bo); PUTP(d->k1); PUTP(d->v1t);
-    PUTP(d->key_bias); PUTP(d->k2); PUTP(d->v2t); PUTP(d->out);
-    PUT(d->B); PUT(d->N); PUT(d->C); PUT(d->heads); PUT(d->L1); PUT(d->Lpad1); PUT(d->L2); PUT(d->Lpad2);
+    PUTP(d->x); PUTP(d->ln_gamma); PUTP(d->ln_beta); PUTP(d->wq_packed); PUTP(d->wo_packed); PUTP(d->bo); PUTP(d->kv1_packed);
+    PUTP(d->key_bias); PUTP(d->kv2_packed); PUTP(d->out);
+    PUT(d->B); PUT(d->N); PUT(d->C); PUT(d->heads); PUT(d->L1); PUT(d->L2);
     PUT(d->dtype); PUT(d->reserved); PUT(d->ln_eps); PUT(d->softmax_scale); PUT(d->scale2); PUT(d->reserved_f);
     return n;
 }

@@ -1,19 +1,25 @@
 // apad_fused_cross_attention: a whole cross-attention sub-layer of a BasicTransformerBlock in ONE kernel, for key / value
-// sets that were hoisted out of the denoise loop and are short (<= 64 keys per segment) -- the adapter's decoupled
-// cross-attention (IPAttnProcessor2_0, attention_processor.py:347-470: 8 text keys + La <= 64 audio keys blended by
-// ap_scale) and the 16-token T5 cross-attention (AttnProcessor2_0, :214-294):
+// sets that were hoisted out of the denoise loop -- the adapter's decoupled cross-attention (IPAttnProcessor2_0,
+// attention_processor.py:347-470: 8 text keys + La audio keys blended by ap_scale) and the 16-token T5 cross-attention
+// (AttnProcessor2_0, :214-294):
 //     out = x + to_out( A(q, K1, V1, bias) [+ scale2 * A(q, K2, V2)] ) + b_out,   q = to_q(LayerNorm(x))
 // SURVEY 8d's "fused q-proj + attn + blend + out-proj": per sample-forward the launch reads x and writes out once
 // (2 x N x C x 2 bytes) instead of six activation passes through three kernels.
 //
-// One wave owns 32 tokens of ONE sample.  The LayerNorm-ed x panel stays in registers as the B operand; per head the
-// chain  q_h^T = Wq_h . x^T  ->  S^T = K . q_h  ->  softmax  ->  O_h^T = V^T . P^T  ->  out^T += Wo[:, h] . O_h^T
-// never leaves registers: each MFMA's C layout (lane = token, registers = rows (r&3) + 8(r>>2) + 4*half) is the next
-// MFMA's B operand, the other operand being read with the matching permuted k order (two 8-byte pieces per lane) -- the
-// register trick of apad_attention and apad_geglu_mlp applied three times in a row.  The Wq rows of head h and the
-// Wo columns of head h are staged through double-buffered LDS by the whole workgroup, one head ahead; K and V^T
-// fragments (a few KB per sample, L2-resident) are read straight from global memory.
-// Envelope: C = 256, 8 heads (d = 32): the 1000-token level, where the cross-attention sub-layers cost most.
+// Weight-stationary design, C = 256 / 8 heads of 32 (the 1000-token level):
+//   * one 512-thread workgroup (8 waves = two per SIMD, so one wave's softmax overlaps the other's MFMAs) owns a tile of
+//     128 tokens (4 panels of 32; a panel never straddles two samples)
+//   * wave h keeps the 32 rows of Wq of HEAD h in registers (16 A fragments) for the q-projection and the attention of
+//     that head, then the 32 rows of Wo of OUTPUT-CHANNEL slice h for the output projection: weights never pass through
+//     LDS, and they are read from a fragment-major packing (apad_xattn_pack_weight) so that every wave-load is one
+//     contiguous KB
+//   * tokens are what moves through LDS: phase 1 LayerNorm -> x^ tile [128][256]; phase 2 (wave = head)
+//     q_h^T = Wq_h . x^^T -> S^T = K_h . q_h -> softmax (per segment) -> O_h^T = V_h^T . P^T, the three products chained in
+//     registers (each MFMA's C layout is the next one's B operand, the other operand being stored in the matching
+//     permuted k order by apad_xattn_pack_kv) -> O tile [128][256]; phase 3 (wave = channel slice)
+//     out^T = Wo_slice . O^T + bias -> back into the x^ tile; phase 4 adds the residual and streams whole rows out
+//   * K / V of a (sample, head) are a few KB, fragment-packed at hoist time: coalesced 1 KB loads, L2-resident
+#include <type_traits>
 #include "rp_shared.h"
 
 namespace {
@@ -23,292 +29,612 @@ constexpr float XA_LOG2E = 1.4426950408889634f;
 constexpr float XA_NEG_BIG = -1.0e30f;
 
 constexpr int XC = 256, XKC = 16, XH = 8, XD = 32;
-constexpr int WQ_ROWB = Cfg<XKC>::ROWB;      // 528: Wq tile row stride
-constexpr int WQ_BYTES = 32 * WQ_ROWB;       // 32 rows of Wq (one head)
-constexpr int WO_ROWB = 72;                  // Wo head slice: 32 columns (64 B) + 8 B pad: conflict-free 8-byte reads
-constexpr int WO_BYTES = XC * WO_ROWB;
-constexpr int XSTAGE = WQ_BYTES + WO_BYTES;  // 35 328 B per head
+constexpr int XTM = 128;                  // tokens per workgroup
+constexpr int TROWB = XC * 2 + 16;        // tile row stride (bytes): 33 sixteen-byte slots (odd -> conflict-free fragment reads)
+constexpr int TILE_BYTES = XTM * TROWB;   // 67 584
+constexpr int XA_LDS = 2 * TILE_BYTES + XC * 4;
+constexpr int XMAXSUB = 2;                // <= 64 keys per segment
 
 struct XaP {
     const uint8_t* x;
     const uint8_t* gamma;
     const uint8_t* beta;
-    const uint8_t* wq;
-    const uint8_t* wo;
+    const uint8_t* wq;   // packed
+    const uint8_t* wo;   // packed
     const uint8_t* bo;
-    const uint8_t* k1;
-    const uint8_t* v1t;
+    const uint8_t* kv1;  // packed
     const float* bias1;
-    const uint8_t* k2;
-    const uint8_t* v2t;
+    const uint8_t* kv2;  // packed
     uint8_t* out;
-    int32_t B, N, L1, Lpad1, L2, Lpad2;
+    int32_t B, N, L1, L2, ppn, npanels, ntiles;
     float eps, scale_log2, scale2;
 };
 
-// K / V^T fragments of one short segment for one head, straight from global memory (L2-resident).  Issued at the top of a
-// head's iteration so that their latency hides under the q-projection MFMAs: with one wave per SIMD nothing else would.
-template <int DT> struct XaFrags {
-    typename ET<DT>::v8 kf[2][2];  // [32-key sub-tile][K = 16 step over the head dim]
-    typename ET<DT>::v8 vf[4];     // [K = 16 step over the keys]
+// bytes of one (sample, head) block of a packed K/V set: [K fragments: nsub x 2][V^T fragments: nsub x 2], 1 KB each
+__host__ __device__ inline int64_t xa_kv_block(int L) { return (int64_t)((L + 31) / 32) * 4 * 1024; }
+
+// a wave-uniform pointer, pinned to SGPRs: loads through it take the (scalar base + 32-bit lane offset) form instead of a
+// 64-bit per-lane address -- the compiler otherwise hoists one such address per weight fragment out of the tile loop (24
+// registers per weight), which is what spilled in this 256-register kernel
+// (typed as a GLOBAL-address-space pointer: after the integer round trip the compiler no longer infers that, and a generic
+//  pointer turns the loads into flat_load, which also ticks lgkmcnt and makes every later wait a vmcnt(0))
+typedef const __attribute__((address_space(1))) uint8_t* xa_gptr;
+typedef const __attribute__((address_space(1))) u32x4* xa_gptr16;
+__device__ __forceinline__ xa_gptr sgpr_ptr(const uint8_t* p) {
+    const uint64_t a = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return (xa_gptr)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ u32x4 xa_ld16(xa_gptr base, uint32_t off) { return *(xa_gptr16)(base + off); }
+
+__device__ __forceinline__ float oct_sum(float v) {
+    // 8 consecutive lanes own one token row: two DPP quad permutes + one half-row mirror, no LDS
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+    return v;
+}
+
+// NS = number of 32-key sub-tiles of the segment (compile time: the fragment registers of an unused second sub-tile would
+// push the kernel past the 256-register budget of two waves per SIMD)
+template <int DT, int NS> struct XaFrags {
+    typename ET<DT>::v8 kf[NS][2];  // [32-key sub-tile][K = 16 step over the head dim]
+    typename ET<DT>::v8 vf[2 * NS];  // [K = 16 step over the keys]
 };
 
-template <int DT>
-__device__ __forceinline__ void xa_prefetch(XaFrags<DT>& f, const uint8_t* kbase /* K[b] + h*D, row stride XC */,
-                                            const uint8_t* vbase /* V^T[b][h] */, int L, int Lpad, int l31, int half) {
-    const int nsub = L > 32 ? 2 : 1;
+// coalesced: fragment f of the block is 64 lanes x 16 bytes
+template <int DT, int NS> __device__ __forceinline__ void xa_fetch(XaFrags<DT, NS>& f, const uint8_t* blk_, int L, int lane) {
+    const xa_gptr blk = sgpr_ptr(blk_);
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        if (u >= nsub) break;
-        const int key = u * 32 + l31;
-        const uint8_t* kp = kbase + ((int64_t)(key < L ? key : L - 1) * XC + 4 * half) * 2;  // rows past L: masked later
+    for (int u = 0; u < NS; ++u) {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const uint2 lo = *reinterpret_cast<const uint2*>(kp + kk * 32);
-            const uint2 hi = *reinterpret_cast<const uint2*>(kp + kk * 32 + 16);
-            f.kf[u][kk] = as_v8<DT>(make_uint4(lo.x, lo.y, hi.x, hi.y));
-        }
+        for (int kk = 0; kk < 2; ++kk) f.kf[u][kk] = __builtin_bit_cast(typename ET<DT>::v8, xa_ld16(blk + (u * 2 + kk) * 1024, (uint32_t)(lane * 16)));
     }
+    const xa_gptr vb = blk + NS * 2 * 1024;
 #pragma unroll
-    for (int st = 0; st < 4; ++st) {
-        if (st >= 2 * nsub) break;
-        const uint8_t* vp = vbase + ((int64_t)l31 * Lpad + st * 16 + 4 * half) * 2;  // row = head dim l31 (D = 32: one tile)
-        const uint2 v0 = *reinterpret_cast<const uint2*>(vp);
-        const uint2 v1 = *reinterpret_cast<const uint2*>(vp + 16);
-        f.vf[st] = as_v8<DT>(make_uint4(v0.x, v0.y, v1.x, v1.y));
+    for (int st = 0; st < 2 * NS; ++st) {
+        if (st * 16 >= L) break;
+        f.vf[st] = __builtin_bit_cast(typename ET<DT>::v8, xa_ld16(vb + st * 1024, (uint32_t)(lane * 16)));
     }
 }
 
-// one short softmax segment for the current head: scores from qb (B operand, k = head dim in C-layout order), result
-// O^T (un-normalised) accumulated into o, inv_den = 1 / row sum
-template <int DT>
-__device__ __forceinline__ void xa_segment(const XaFrags<DT>& f, int L, const float* bias, float c, const typename ET<DT>::v8 (&qb)[2],
-                                           f32x16& o, float& inv_den, int half) {
+// One softmax segment of the current head: scores from qb (B operand, k = head dim in C-layout order); the probabilities,
+// normalised and scaled by `pscale`, are rounded to the storage type and O^T += V^T . P^T.
+// Steady-state form: exactly G groups of 8 keys (G and the sub-tile count are compile-time, so the wave's instruction stream
+// carries no uniform branches, no masks and no index arithmetic), optional additive key bias (the masked T5 stream).
+template <int DT, int G, bool BIAS>
+__device__ __forceinline__ void xa_segment_exact(const XaFrags<DT, (G + 3) / 4>& f, const float* bias, float c, float pscale,
+                                                 const typename ET<DT>::v8 (&qb)[2], f32x16& o, bool first, int half) {
+    using E = ET<DT>;
+    constexpr int NS = (G + 3) / 4;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 s[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        s[u] = E::mfma32(f.kf[u][0], qb[0], zero16);  // zero accumulator as an inline constant: no register clears
+        s[u] = E::mfma32(f.kf[u][1], qb[1], s[u]);
+    }
+    float tmax = XA_NEG_BIG;
+    if (BIAS) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float4 b4 = *reinterpret_cast<const float4*>(bias + 8 * g + 4 * half);  // keys 8g + 4 half + j
+            const float bj[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = __builtin_fmaf(s[g >> 2][4 * (g & 3) + j], c, bj[j] * XA_LOG2E);
+                s[g >> 2][4 * (g & 3) + j] = v;
+                tmax = fmaxf(tmax, v);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tmax = fmaxf(tmax, s[g >> 2][4 * (g & 3) + j]);
+    }
+    const float nm = BIAS ? -half_max(tmax) : -half_max(tmax) * c;  // c > 0
+    float sum0 = 0.f, sum1 = 0.f;  // two chains: the adds are latency-bound otherwise
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+            const int r = 4 * (g & 3) + j;
+            const float a0 = s[g >> 2][r], a1 = s[g >> 2][r + 1];
+            const float v0 = __builtin_amdgcn_exp2f(BIAS ? a0 + nm : __builtin_fmaf(a0, c, nm));
+            const float v1 = __builtin_amdgcn_exp2f(BIAS ? a1 + nm : __builtin_fmaf(a1, c, nm));
+            s[g >> 2][r] = v0;
+            s[g >> 2][r + 1] = v1;
+            sum0 += v0;
+            sum1 += v1;
+        }
+    const float w = pscale * __builtin_amdgcn_rcpf(half_sum(sum0 + sum1));
+#pragma unroll
+    for (int st = 0; st < (G + 1) / 2; ++st) {
+        typename E::v8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool live = 2 * st + (j >> 2) < G;  // compile time: the second group of an odd last step is all zeros
+            pf[j] = live ? (typename E::elem)(s[st >> 1][(st & 1) * 8 + j] * w) : (typename E::elem)0.f;
+        }
+        // (`first` is a literal at every call site: the first product of a panel takes a constant-zero accumulator)
+        o = (first && st == 0) ? E::mfma32(f.vf[0], pf, zero16) : E::mfma32(f.vf[st], pf, o);
+    }
+}
+
+// General form: run-time length (any L <= 32 NS) and optional bias; groups of 8 keys that lie entirely past the segment are
+// skipped (wave-uniform branches), partial groups masked.
+template <int DT, int NS>
+__device__ __forceinline__ void xa_segment(const XaFrags<DT, NS>& f, int L, const float* bias, float c, float pscale,
+                                           const typename ET<DT>::v8 (&qb)[2], f32x16& o, bool first, int half) {
     using E = ET<DT>;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int nsub = L > 32 ? 2 : 1;
-    f32x16 s[2];
-    s[0] = s[1] = zero16;
+    f32x16 s[NS];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        if (u >= nsub) break;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) s[u] = E::mfma32(f.kf[u][kk], qb[kk], s[u]);
+    for (int u = 0; u < NS; ++u) {
+        s[u] = E::mfma32(f.kf[u][0], qb[0], zero16);
+        s[u] = E::mfma32(f.kf[u][1], qb[1], s[u]);
     }
     float tmax = XA_NEG_BIG;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        if (u >= nsub) break;
+    for (int u = 0; u < NS; ++u) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = u * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            float v = s[u][r] * c;
-            if (bias) v += bias[key < L ? key : L - 1] * XA_LOG2E;
-            v = key < L ? v : XA_NEG_BIG;
-            s[u][r] = v;
-            tmax = fmaxf(tmax, v);
+        for (int g = 0; g < 4; ++g) {
+            if (u * 32 + g * 8 >= L) continue;  // uniform
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = g * 4 + j;
+                const int key = u * 32 + g * 8 + 4 * half + j;
+                float v = s[u][r] * c;
+                if (bias) v += bias[key < L ? key : L - 1] * XA_LOG2E;
+                v = key < L ? v : XA_NEG_BIG;
+                s[u][r] = v;
+                tmax = fmaxf(tmax, v);
+            }
         }
     }
     tmax = half_max(tmax);
     float sum = 0.f;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        if (u >= nsub) break;
+    for (int u = 0; u < NS; ++u) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float e = __builtin_amdgcn_exp2f(s[u][r] - tmax);
-            s[u][r] = e;
-            sum += e;
+        for (int g = 0; g < 4; ++g) {
+            if (u * 32 + g * 8 >= L) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = g * 4 + j;
+                const float e = __builtin_amdgcn_exp2f(s[u][r] - tmax);
+                s[u][r] = e;
+                sum += e;
+            }
         }
     }
-    sum = half_sum(sum);
-    inv_den = 1.0f / sum;
+    const float w = pscale * __builtin_amdgcn_rcpf(half_sum(sum));
 #pragma unroll
-    for (int st = 0; st < 4; ++st) {
-        if (st >= 2 * nsub) break;
+    for (int st = 0; st < 2 * NS; ++st) {
+        if (st * 16 >= L) break;
         typename E::v8 pf;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pf[j] = (typename E::elem)s[st >> 1][(st & 1) * 8 + j];
-        o = E::mfma32(f.vf[st], pf, o);
+        for (int j = 0; j < 8; ++j) pf[j] = (typename E::elem)(s[st >> 1][(st & 1) * 8 + j] * w);  // skipped groups hold 0 (zero K rows)
+        o = (first && st == 0) ? E::mfma32(f.vf[0], pf, zero16) : E::mfma32(f.vf[st], pf, o);
     }
 }
 
-template <int DT, bool DUAL>
-__global__ __launch_bounds__(256, 1) void xattn_kernel(XaP p) {
+#ifdef XATTN_TRACE  // probe build (tools/xattn_trace.py): s_memtime stamps of wave 0 / wave 7 at the phase boundaries
+__device__ unsigned long long g_xa_trace[1024 * 32];
+#define XA_STAMP(i) \
+    do { if (lane == 0 && (wave == 0 || wave == 7)) g_xa_trace[(tile * 2 + (wave == 7)) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define XA_STAMP(i)
+#endif
+
+// NS1 / NS2 = 32-key sub-tiles per segment (NS2 = 0: single segment).  G1 > 0 selects the exact form: L1 = 8 G1 and L2 = 8 G2
+// keys precisely, BIAS1 = segment 1 carries a key bias; G1 = 0: lengths and bias are run-time (any L <= 32 NS).
+template <int DT, int NS1, int NS2, int G1 = 0, int G2 = 0, bool BIAS1 = false>
+__global__ __launch_bounds__(512) void xattn_kernel(XaP p) {
+    constexpr bool DUAL = NS2 > 0;
+    constexpr bool EXACT = G1 > 0;
     using E = ET<DT>;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint8_t* const xt = smem;                 // x^ tile, later the output tile
+    uint8_t* const ot = smem + TILE_BYTES;    // O tile
+    float* const lbo = reinterpret_cast<float*>(smem + 2 * TILE_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: per-wave bases stay in SGPRs (registers are tight)
     const int half = lane >> 5, l31 = lane & 31;
-    // panels never straddle samples: sample b owns ceil(N / 32) panels, 4 consecutive panels per workgroup
-    const int ppn = (p.N + 31) >> 5;
-    const int64_t panel = (int64_t)blockIdx.x * 4 + wave;
-    const int b = (int)(panel / ppn);
-    const int q0 = (int)(panel - (int64_t)b * ppn) * 32;
-    const bool active = b < p.B;  // tail workgroup: inactive waves still take part in staging and barriers
-    const int bb = active ? b : p.B - 1;
-    const int64_t row0 = (int64_t)bb * p.N + q0;    // first global row of the panel
-    const int64_t rowend = (int64_t)bb * p.N + p.N;  // rows of this sample end here
-
-    uint8_t* const scr = smem + 2 * XSTAGE + wave * SCR_BYTES;
-    float* const lbo = reinterpret_cast<float*>(smem + 2 * XSTAGE + 4 * SCR_BYTES);  // [C] output bias
-
-    // ---- staging (global -> registers -> LDS), one head ahead: Wq rows h*32.., Wo columns h*32.. ----
-    u32x4 sq[4], so[4];
-    auto stage_load = [&](int h) {
+    const int oct = lane & 7;
+    // Persistent workgroups (one per CU: the two LDS tiles fill it), each walking virtual ids v = blockIdx.x, + gridDim.x, ...
+    // XCD-aware order: workgroup id w runs on XCD w % 8 (observed, speed only) and gridDim.x is a multiple of 8, so v % 8 is
+    // that XCD; each XCD walks a contiguous range of tiles, i.e. whole samples, whose packed K/V are then fetched into one L2.
+    const int per = (p.ntiles + 7) >> 3;
+    auto tile_of = [&](int v) { return (v & 7) * per + (v >> 3); };
+    auto next_valid = [&](int v) {  // next virtual id of this workgroup that maps to an existing tile, or -1
+        for (v += gridDim.x; v < 8 * per; v += gridDim.x)
+            if (tile_of(v) < p.ntiles) return v;
+        return -1;
+    };
+    // rows of a tile owned by this thread in phases 1 / 4: a wave owns 16 rows; 8 consecutive lanes own one row and move it as
+    // interleaved 16-byte chunks (chunk = 8 i + lane % 8), so every load / store instruction of the wave covers 8 rows x 128
+    // contiguous bytes = whole cache lines
+    int trow[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i;  // 1024 sixteen-byte chunks each
-            const int rq = idx >> 5, cq = idx & 31;
-            sq[i] = *reinterpret_cast<const u32x4*>(p.wq + (((int64_t)h * 32 + rq) * XC + cq * 8) * 2);
-            const int ro = idx >> 2, po = idx & 3;
-            so[i] = *reinterpret_cast<const u32x4*>(p.wo + ((int64_t)ro * XC + h * 32 + po * 8) * 2);
+    for (int j = 0; j < 2; ++j) trow[j] = wave * 16 + j * 8 + (lane >> 3);
+    // (addresses are a uniform base + a 32-bit per-lane byte offset -- B * N * 512 < 4 GB is checked on the host -- so that the
+    //  compiler keeps bases in SGPRs: hoisted 64-bit per-lane pointers were what spilled in this 256-register kernel)
+    constexpr uint32_t NOROW = 0xffffffffu;
+    auto rows_of = [&](int tile, uint32_t (&xoff)[2]) {  // byte offset of the thread's chunk 0 in its two rows, or NOROW
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int panel = tile * 4 + (trow[j] >> 5);
+            const int b = panel / p.ppn, q = (panel - b * p.ppn) * 32 + (trow[j] & 31);
+            xoff[j] = (panel < p.npanels && q < p.N) ? (uint32_t)(b * p.N + q) * (XC * 2) + oct * 16 : NOROW;
         }
     };
-    auto stage_store = [&](uint8_t* st) {
+    auto load_rows = [&](uint4 (&r)[2][4], const uint32_t (&xoff)[2]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i;
-            const int rq = idx >> 5, cq = idx & 31;
-            *reinterpret_cast<u32x4*>(st + rq * WQ_ROWB + cq * 16) = sq[i];
-            const int ro = idx >> 2, po = idx & 3;
-            uint8_t* dst = st + WQ_BYTES + ro * WO_ROWB + po * 16;
-            const u32x2 lo = {so[i][0], so[i][1]}, hi = {so[i][2], so[i][3]};
-            *reinterpret_cast<u32x2*>(dst) = lo;
-            *reinterpret_cast<u32x2*>(dst + 8) = hi;
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t o = xoff[j] != NOROW ? xoff[j] : oct * 16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[j][i] = *reinterpret_cast<const uint4*>(p.x + (o + i * 128));
         }
     };
-    stage_load(0);
-    for (int i = tid; i < XC; i += 256) lbo[i] = p.bo ? ld_elem<DT>(p.bo, i) : 0.f;
 
-    // ---- x panel -> registers, LayerNorm in registers ----
-    typename E::v8 xf[XKC];
-    load_panel<DT, XKC>(xf, p.x, XC, rowend, row0, l31, half);
-    if (p.gamma != nullptr) layernorm_panel<DT, XKC>(xf, p.gamma, p.beta, p.eps, l31, half);
+    int v = blockIdx.x;
+    if (tile_of(v) >= p.ntiles) v = next_valid(v);
+    if (v < 0) return;
+    for (int i = tid; i < XC; i += 512) lbo[i] = p.bo ? ld_elem<DT>(p.bo, i) : 0.f;
+    uint32_t xoff[2];
+    uint4 raw[2][4];  // the tile's un-normalised rows: requested one tile ahead (under phase 3 of the previous tile)
+    rows_of(tile_of(v), xoff);
+    load_rows(raw, xoff);
 
-    f32x16 yacc[XC / 32];
+    while (true) {
+    const int tile = tile_of(v);
+    // next tile and its row offsets, computed here: the stretch between the Wo loads and their first use below must stay
+    // straight-line code (loops / exec-masked branches there make the compiler's wait-count pass fall back to vmcnt(0), i.e.
+    // wait for the NEXT tile's rows before this tile's output projection)
+    const int vnext = next_valid(v);
+    uint32_t xoff_next[2];
+    rows_of(tile_of(vnext >= 0 ? vnext : v), xoff_next);  // the last tile re-requests its own rows: the loads stay unconditional
+    XA_STAMP(0);
+#ifdef XATTN_TRACE
+    if (lane == 0 && wave == 0) g_xa_trace[tile * 32 + 12] = wall_clock64();
+#endif
+    // ---- phase 1: LayerNorm of the tile's rows -> x^ tile ----
+    {
+        if (p.gamma != nullptr) {
+            float g[32], bt[32];  // this lane's 32 channels of gamma / beta, shared by its two rows
 #pragma unroll
-    for (int ct = 0; ct < XC / 32; ++ct)
+            for (int i = 0; i < 4; ++i) {
+                unpack8<DT>(*reinterpret_cast<const uint4*>(p.gamma + (i * 64 + oct * 8) * 2), g + 8 * i);
+                unpack8<DT>(*reinterpret_cast<const uint4*>(p.beta + (i * 64 + oct * 8) * 2), bt + 8 * i);
+            }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) yacc[ct][r] = 0.f;
-
-    stage_store(smem);
+            for (int j = 0; j < 2; ++j) {
+                float f[32];  // unpacked once; two-pass statistics from registers
+#pragma unroll
+                for (int i = 0; i < 4; ++i) unpack8<DT>(raw[j][i], f + 8 * i);
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 32; e += 2) {
+                    s0 += f[e];
+                    s1 += f[e + 1];
+                }
+                const float mean = oct_sum(s0 + s1) * (1.0f / XC);
+                float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 32; e += 2) {
+                    f[e] -= mean;
+                    f[e + 1] -= mean;
+                    q0 = __builtin_fmaf(f[e], f[e], q0);
+                    q1 = __builtin_fmaf(f[e + 1], f[e + 1], q1);
+                }
+                const float rstd = rsqrtf(oct_sum(q0 + q1) * (1.0f / XC) + p.eps);
+                uint8_t* dst = xt + trow[j] * TROWB + oct * 16;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float y[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) y[e] = __builtin_fmaf(f[8 * i + e] * rstd, g[8 * i + e], bt[8 * i + e]);
+                    *reinterpret_cast<uint4*>(dst + i * 128) = pack8<DT>(y);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(xt + trow[j] * TROWB + oct * 16 + i * 128) = raw[j][i];
+        }
+    }
+    // ---- weights of this wave: head `wave` of Wq (A operand of the q-projection); requested here, behind the LayerNorm's
+    //      temporaries, so that its 64 registers are not live (and spilled) during phase 1; the barrier hides the latency ----
+    typename E::v8 wf[XKC];
+    {
+        const xa_gptr wp = sgpr_ptr(p.wq + wave * (XKC * 1024));
+#pragma unroll
+        for (int kk = 0; kk < XKC; ++kk) wf[kk] = __builtin_bit_cast(typename ET<DT>::v8, xa_ld16(wp + kk * 1024, (uint32_t)(lane * 16)));
+    }
+    XA_STAMP(1);
     __syncthreads();
+    XA_STAMP(2);
 
-    const uint8_t* k1b = p.k1 + (int64_t)bb * p.L1 * XC * 2;
-    const uint8_t* v1b = p.v1t + (int64_t)bb * XH * XD * p.Lpad1 * 2;
-    const float* bias1 = p.bias1 ? p.bias1 + (int64_t)bb * p.L1 : nullptr;
-    const uint8_t* k2b = DUAL ? p.k2 + (int64_t)bb * p.L2 * XC * 2 : nullptr;
-    const uint8_t* v2b = DUAL ? p.v2t + (int64_t)bb * XH * XD * p.Lpad2 * 2 : nullptr;
-
-    for (int h = 0; h < XH; ++h) {
-        const uint8_t* st = smem + (h & 1) * XSTAGE;
-        stage_load(h + 1 < XH ? h + 1 : XH - 1);  // the last head re-loads itself: no divergent path
-        XaFrags<DT> f1, f2;
-        xa_prefetch<DT>(f1, k1b + h * XD * 2, v1b + (int64_t)h * XD * p.Lpad1 * 2, p.L1, p.Lpad1, l31, half);
-        if (DUAL) xa_prefetch<DT>(f2, k2b + h * XD * 2, v2b + (int64_t)h * XD * p.Lpad2 * 2, p.L2, p.Lpad2, l31, half);
-
-        // ---- q_h^T [32 dims x 32 tokens] = Wq_h . x^T ----
-        f32x16 qt;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) qt[r] = 0.f;
+    // ---- phase 2: wave = head h.  (a) q-projection of all four panels at once: q_h^T [32 dims x 32 tokens] = Wq_h . x^^T, A =
+    //      stationary registers, B = token fragments from the x^ tile; four independent accumulator chains keep the matrix
+    //      pipe issuing back to back.  q (storage type, already in the B-operand register order of the score product) is
+    //      parked in this wave's own 64-byte-per-token slots of the O tile.  (b) attention, two panels interleaved (two
+    //      independent MFMA -> softmax -> MFMA chains per wave: a single chain is latency-bound and two waves per SIMD do not
+    //      hide it), O_h over the parked q.  No barrier between (a) and (b): the slots are private to the wave. ----
+    {
+        const int h = wave;
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // K / V fragments of this head for the tile's first sample: requested here, so that their L2 latency hides under the
+        // q-projection; the panels of a tile share them unless the tile crosses a sample boundary
+        XaFrags<DT, NS1> f1;
+        XaFrags<DT, DUAL ? NS2 : 1> f2;
+        auto fetch_kv = [&](int b) {
+            xa_fetch<DT, NS1>(f1, p.kv1 + ((int64_t)b * XH + h) * xa_kv_block(p.L1), p.L1, lane);
+            if (DUAL) xa_fetch<DT, DUAL ? NS2 : 1>(f2, p.kv2 + ((int64_t)b * XH + h) * xa_kv_block(p.L2), p.L2, lane);
+        };
+        const int bfirst = (tile * 4) / p.ppn;
+        if constexpr (EXACT) fetch_kv(bfirst < p.B ? bfirst : p.B - 1);  // (general form: after the q-projection -- registers)
         {
-            const uint8_t* wt = st + l31 * WQ_ROWB + half * 16;
-            typename E::v8 wfa[4][1], wfb[4][1];
-            rp_load_group<DT, XKC>(wfa, wt, 0);
+            f32x16 qa[4];
+            const uint8_t* bt = xt + l31 * TROWB + half * 16;
+            typename E::v8 fb[2][4];
+            auto ldk = [&](int buf, int kk) {
 #pragma unroll
-            for (int g = 0; g < XKC / 4; g += 2) {
-                rp_load_group<DT, XKC>(wfb, wt, (g + 1) * 4);
-                rp_pin<DT, XKC>(wfa);
+                for (int pn = 0; pn < 4; ++pn) fb[buf][pn] = as_v8<DT>(*reinterpret_cast<const uint4*>(bt + pn * 32 * TROWB + kk * 32));
+            };
+            ldk(0, 0);
 #pragma unroll
-                for (int cc = 0; cc < 4; ++cc) qt = E::mfma32(wfa[cc][0], xf[g * 4 + cc], qt);
-                if (g + 2 < XKC / 4) rp_load_group<DT, XKC>(wfa, wt, (g + 2) * 4);
-                rp_pin<DT, XKC>(wfb);
+            for (int kk = 0; kk < XKC; ++kk) {
+                const int cur = kk & 1;
+                if (kk + 1 < XKC) ldk(cur ^ 1, kk + 1);
 #pragma unroll
-                for (int cc = 0; cc < 4; ++cc) qt = E::mfma32(wfb[cc][0], xf[(g + 1) * 4 + cc], qt);
+                for (int pn = 0; pn < 4; ++pn) {
+                    asm volatile("" : "+v"(fb[cur][pn]) : : "memory");  // wait for exactly this k-step's reads
+                    qa[pn] = E::mfma32(wf[kk], fb[cur][pn], kk == 0 ? zero16 : qa[pn]);
+                }
+            }
+            // the reference materialises q in the storage type; registers 0..7 / 8..15 are the two K = 16 steps over the head dim
+#pragma unroll
+            for (int pn = 0; pn < 4; ++pn) {
+                typename E::v8 qb[2];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) qb[r >> 3][r & 7] = (typename E::elem)qa[pn][r];
+                uint8_t* qd = ot + (pn * 32 + l31) * TROWB + h * 64 + half * 32;
+                *reinterpret_cast<uint4*>(qd) = as_u4<DT>(qb[0]);
+                *reinterpret_cast<uint4*>(qd + 16) = as_u4<DT>(qb[1]);
             }
         }
-        // the reference materialises q in the storage type; registers 0..7 / 8..15 are the two K = 16 steps over the head dim
-        typename E::v8 qb[2];
+        if constexpr (!EXACT) fetch_kv(bfirst < p.B ? bfirst : p.B - 1);
+        XA_STAMP(3);
+        // attention of `n` panels (pp, pp + 1) of ONE sample, interleaved: the panels share the K / V fragments
+        auto attend = [&](int pp, auto n_tag, int b) {
+            constexpr int NP = decltype(n_tag)::value;
+            typename E::v8 qb[NP][2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) qb[r >> 3][r & 7] = (typename E::elem)qt[r];
-
-        // ---- attention of head h: segment 1 (text / T5), optional segment 2 (audio), blend ----
-        f32x16 o;
+            for (int u = 0; u < NP; ++u) {
+                const uint8_t* qd = ot + ((pp + u) * 32 + l31) * TROWB + h * 64 + half * 32;
+                qb[u][0] = as_v8<DT>(*reinterpret_cast<const uint4*>(qd));
+                qb[u][1] = as_v8<DT>(*reinterpret_cast<const uint4*>(qd + 16));
+            }
+            const float* bias1 = p.bias1 ? p.bias1 + (int64_t)b * p.L1 : nullptr;
+            f32x16 o[NP];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[r] = 0.f;
-        float inv = 1.f;
-        xa_segment<DT>(f1, p.L1, bias1, p.scale_log2, qb, o, inv, half);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[r] *= inv;
-        if (DUAL) {
-            f32x16 o2;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o2[r] = 0.f;
-            float inv2 = 1.f;
-            xa_segment<DT>(f2, p.L2, nullptr, p.scale_log2, qb, o2, inv2, half);
-            // text + ap_scale * audio (:454) in fp32, rounded once when packed for the output projection (the un-fused
-            // path rounds each branch to the storage type first; emulating that cost ~100 VALU instructions per head in a
-            // kernel whose instruction stream is 80 % vector ALU: 84 -> 75 us)
-            const float s2 = p.scale2 * inv2;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] = __builtin_fmaf(s2, o2[r], o[r]);
-        }
-        typename E::v8 ob[2];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ob[r >> 3][r & 7] = (typename E::elem)o[r];
-
-        // ---- out^T [C x 32 tokens] += Wo[:, h*32 .. +32] . O_h^T  (A = Wo rows, k = head dim in the C-layout order) ----
-        {
-            const uint8_t* wo_t = st + WQ_BYTES + l31 * WO_ROWB + half * 8;
-            u32x2 wlo[XC / 32][2], whi[XC / 32][2];
-#pragma unroll
-            for (int ct = 0; ct < XC / 32; ++ct)
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    wlo[ct][kk] = *reinterpret_cast<const u32x2*>(wo_t + ct * 32 * WO_ROWB + kk * 32);
-                    whi[ct][kk] = *reinterpret_cast<const u32x2*>(wo_t + ct * 32 * WO_ROWB + kk * 32 + 16);
+            for (int u = 0; u < NP; ++u) {
+                o[u] = zero16;
+                // probabilities are normalised (and the audio segment scaled by ap_scale, attention_processor.py:454) BEFORE they
+                // are rounded for the P.V product -- as the reference's softmax output is -- so both segments accumulate
+                // into ONE O accumulator
+                if constexpr (EXACT) xa_segment_exact<DT, G1, BIAS1>(f1, bias1, p.scale_log2, 1.0f, qb[u], o[u], true, half);
+                else xa_segment<DT, NS1>(f1, p.L1, bias1, p.scale_log2, 1.0f, qb[u], o[u], true, half);
+                if (DUAL) {
+                    if constexpr (EXACT && DUAL) xa_segment_exact<DT, (G2 > 0 ? G2 : 1), false>(f2, nullptr, p.scale_log2, p.scale2, qb[u], o[u], false, half);
+                    else xa_segment<DT, DUAL ? NS2 : 1>(f2, p.L2, nullptr, p.scale_log2, p.scale2, qb[u], o[u], false, half);
                 }
+            }
+            // O_h^T (lane = token, registers = head dims 8g + 4 half + j) -> O tile [token][h*32 + dim] (over the parked q)
 #pragma unroll
-            for (int ct = 0; ct < XC / 32; ++ct)
+            for (int u = 0; u < NP; ++u) {
+                uint8_t* od = ot + ((pp + u) * 32 + l31) * TROWB + (h * XD + 4 * half) * 2;
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    typename E::v8 wf = as_v8<DT>(make_uint4(wlo[ct][kk][0], wlo[ct][kk][1], whi[ct][kk][0], whi[ct][kk][1]));
-                    yacc[ct] = E::mfma32(wf, ob[kk], yacc[ct]);
+                for (int g = 0; g < 4; ++g) {
+                    typename E::v4 y;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) y[j] = (typename E::elem)o[u][4 * g + j];
+                    *reinterpret_cast<uint2*>(od + g * 16) = __builtin_bit_cast(uint2, y);
                 }
+            }
+        };
+        using One = std::integral_constant<int, 1>;
+        using Two = std::integral_constant<int, EXACT ? 2 : 1>;  // (the general form's fragment sets leave no room for two chains)
+        int bnext = bfirst, rem = tile * 4 - bfirst * p.ppn;  // sample / panel-in-sample walk over the tile's panels
+        int bcur = bfirst < p.B ? bfirst : p.B - 1;           // sample whose fragments are loaded
+#pragma unroll 1
+        for (int pp = 0; pp < 4; pp += 2) {
+            int bs[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                bs[u] = bnext < p.B ? bnext : p.B - 1;  // tail tile: recompute the last sample's rows (never stored)
+                if (++rem == p.ppn) {
+                    rem = 0;
+                    ++bnext;
+                }
+            }
+            if (Two::value == 2 && bs[0] == bcur && bs[1] == bcur) {  // wave-uniform; 7 tiles of 8 at N = 1000
+                attend(pp, Two{}, bcur);
+            } else {
+#pragma unroll 1
+                for (int u = 0; u < 2; ++u) {
+                    if (bs[u] != bcur) {  // the tile crosses into the next sample: its fragments (latency exposed, once)
+                        bcur = bs[u];
+                        fetch_kv(bcur);
+                    }
+                    attend(pp + u, One{}, bcur);
+                }
+            }
+            XA_STAMP(4 + (pp >> 1));
         }
-        stage_store(smem + ((h + 1) & 1) * XSTAGE);
-        __syncthreads();
     }
-
-    // ---- epilogue: out = y + b_out + x (raw) through the per-wave transpose scratch ----
-    if (active) {
+    // ---- weights of this wave for phase 3: rows (output channels) wave*32.. of Wo ----
+    {
+        const xa_gptr wp = sgpr_ptr(p.wo + wave * (XKC * 1024));
 #pragma unroll
-        for (int ct = 0; ct < XC / 32; ++ct) {
+        for (int kk = 0; kk < XKC; ++kk) wf[kk] = __builtin_bit_cast(typename ET<DT>::v8, xa_ld16(wp + kk * 1024, (uint32_t)(lane * 16)));
+    }
+    XA_STAMP(7);
+    __syncthreads();  // O tile complete; the x^ tile is free
+    XA_STAMP(8);
+
+    // the residual rows of phase 4 and the NEXT tile's rows are requested now: their latency (HBM for the latter) hides
+    // under the output projection instead of standing at the head of the next tile
+    uint4 rx[2][4];
+    load_rows(rx, xoff);
+    load_rows(raw, xoff_next);
+
+    // ---- phase 3: wave = output-channel slice.  out^T [32 channels x 32 tokens] = Wo_slice . O^T + bias -> x^ tile ----
+    {
+#pragma unroll  // (a rolled loop makes the wait-count pass emit vmcnt(0) at its header: see the prefetch above)
+        for (int pn = 0; pn < 4; pn += 2) {
+            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            f32x16 ya = zero16, yb = zero16;  // two panels at once: two independent accumulator chains
+            const uint8_t* b0 = ot + (pn * 32 + l31) * TROWB + half * 16;
+            const uint8_t* b1 = b0 + 32 * TROWB;
+            // fragment reads double-buffered in groups of two k-steps per panel (registers: the next tile's rows and this
+            // tile's residual rows are in flight through this phase)
+            typename E::v8 fa[2][2], ga[2][2];
+            auto ldg = [&](int buf, int g) {
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    fa[buf][cc] = as_v8<DT>(*reinterpret_cast<const uint4*>(b0 + (g * 2 + cc) * 32));
+                    ga[buf][cc] = as_v8<DT>(*reinterpret_cast<const uint4*>(b1 + (g * 2 + cc) * 32));
+                }
+            };
+            ldg(0, 0);
+#pragma unroll
+            for (int g = 0; g < XKC / 2; ++g) {
+                const int cur = g & 1;
+                if (g + 1 < XKC / 2) ldg(cur ^ 1, g + 1);
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    asm volatile("" : "+v"(fa[cur][cc]), "+v"(ga[cur][cc]) : : "memory");  // wait for exactly this group's reads
+                    ya = E::mfma32(wf[g * 2 + cc], fa[cur][cc], ya);
+                    yb = E::mfma32(wf[g * 2 + cc], ga[cur][cc], yb);
+                }
+            }
+            uint8_t* d0 = xt + (pn * 32 + l31) * TROWB + (wave * 32 + 4 * half) * 2;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float4 b4 = *reinterpret_cast<const float4*>(lbo + ct * 32 + 8 * g + 4 * half);
-                typename E::v4 y;
-                y[0] = (typename E::elem)(yacc[ct][4 * g + 0] + b4.x);
-                y[1] = (typename E::elem)(yacc[ct][4 * g + 1] + b4.y);
-                y[2] = (typename E::elem)(yacc[ct][4 * g + 2] + b4.z);
-                y[3] = (typename E::elem)(yacc[ct][4 * g + 3] + b4.w);
-                *reinterpret_cast<uint2*>(scr + l31 * SCR_ROWB + (8 * g + 4 * half) * 2) = __builtin_bit_cast(uint2, y);
+                const float4 b4 = *reinterpret_cast<const float4*>(lbo + wave * 32 + 8 * g + 4 * half);  // (short-lived: registers are tight here)
+                const float bo[4] = {b4.x, b4.y, b4.z, b4.w};
+                typename E::v4 y0, y1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    y0[j] = (typename E::elem)(ya[4 * g + j] + bo[j]);
+                    y1[j] = (typename E::elem)(yb[4 * g + j] + bo[j]);
+                }
+                *reinterpret_cast<uint2*>(d0 + g * 16) = __builtin_bit_cast(uint2, y0);
+                *reinterpret_cast<uint2*>(d0 + 32 * TROWB + g * 16) = __builtin_bit_cast(uint2, y1);
             }
-            scratch_flush<DT>(scr, 32, p.out, XC, ct * 32, p.x, XC, row0, rowend, lane);
         }
+    }
+    XA_STAMP(9);
+    __syncthreads();
+    XA_STAMP(10);
+
+    // ---- phase 4: out = y + x (residual), whole cache lines per store instruction ----
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (xoff[j] == NOROW) continue;
+        const uint8_t* src = xt + trow[j] * TROWB + oct * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float f[8], r[8];
+            unpack8<DT>(*reinterpret_cast<const uint4*>(src + i * 128), f);
+            unpack8<DT>(rx[j][i], r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += r[e];
+            *reinterpret_cast<uint4*>(p.out + (xoff[j] + i * 128)) = pack8<DT>(f);
+        }
+    }
+    XA_STAMP(11);
+#ifdef XATTN_TRACE
+    if (lane == 0 && wave == 0) {
+        g_xa_trace[tile * 32 + 13] = wall_clock64();
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_xa_trace[tile * 32 + 14] = xcc & 0xf;
+    }
+#endif
+    if (vnext < 0) break;
+    v = vnext;
+    xoff[0] = xoff_next[0];
+    xoff[1] = xoff_next[1];
+    __syncthreads();  // phase 4 has read the output tile before the next tile's phase 1 overwrites it
     }
 }
 
-template <int DT, bool DUAL> int xa_launch(const XaP& p, hipStream_t s) {
-    const size_t lds = 2 * XSTAGE + 4 * SCR_BYTES + XC * sizeof(float);
-    auto kern = xattn_kernel<DT, DUAL>;
+// ---- packing kernels (one-off per weight / per hoisted K,V set) ----
+// W [256][256] -> [slice s = row / 32][kk][lane][8] = W[s*32 + l31][kk*16 + half*8 + e]
+template <int DT> __global__ void xa_pack_w_kernel(const uint8_t* w, uint8_t* out, int64_t ldw) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;  // one 16-byte chunk each: 8 slices x 16 kk x 64 lanes
+    if (idx >= XH * XKC * 64) return;
+    const int lane = idx & 63, kk = (idx >> 6) & 15, s = idx >> 10;
+    const int l31 = lane & 31, half = lane >> 5;
+    *reinterpret_cast<uint4*>(out + (int64_t)idx * 16) =
+        *reinterpret_cast<const uint4*>(w + ((int64_t)(s * 32 + l31) * ldw + kk * 16 + half * 8) * 2);
+}
+
+// k [B][L][256], vt [B][8][32][Lpad] -> per (b, h): K fragments [sub][kk][lane][8] = K[b][sub*32 + l31][h*32 + kk*16 + perm(half, e)]
+// (rows >= L: 0), V^T fragments [st][lane][8] = vt[b][h][l31][st*16 + perm(half, e)], perm(half, e) = 4 half + e (e < 4),
+// 8 + 4 half + e - 4 (e >= 4): the key / dim order in which an MFMA C layout holds them (see xattn_kernel)
+template <int DT> __global__ void xa_pack_kv_kernel(const uint8_t* k, const uint8_t* vt, uint8_t* out, int B, int L, int Lpad,
+                                                    int64_t k_sb, int64_t k_sl, int64_t vt_sb) {
+    using elem = typename ET<DT>::elem;
+    const int nsub = (L + 31) >> 5;
+    const int bh = blockIdx.x, b = bh / XH, h = bh % XH;
+    uint8_t* blk = out + (int64_t)bh * xa_kv_block(L);
+    const elem* kb = reinterpret_cast<const elem*>(k) + (int64_t)b * k_sb + h * XD;
+    const elem* vb = reinterpret_cast<const elem*>(vt) + (int64_t)b * vt_sb + (int64_t)h * XD * Lpad;
+    for (int idx = threadIdx.x; idx < nsub * 4 * 64; idx += blockDim.x) {
+        const int lane = idx & 63, fr = idx >> 6;
+        const int l31 = lane & 31, half = lane >> 5;
+        elem v[8];
+        if (fr < nsub * 2) {
+            const int sub = fr >> 1, kk = fr & 1, key = sub * 32 + l31;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int d = kk * 16 + (e < 4 ? 4 * half + e : 8 + 4 * half + e - 4);
+                v[e] = key < L ? kb[(int64_t)key * k_sl + d] : (elem)0.f;
+            }
+        } else {
+            const int st = fr - nsub * 2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int key = st * 16 + (e < 4 ? 4 * half + e : 8 + 4 * half + e - 4);
+                v[e] = key < L ? vb[(int64_t)l31 * Lpad + key] : (elem)0.f;
+            }
+        }
+        *reinterpret_cast<uint4*>(blk + (int64_t)idx * 16) = *reinterpret_cast<const uint4*>(v);
+    }
+}
+
+template <int DT, int NS1, int NS2, int G1 = 0, int G2 = 0, bool BIAS1 = false> int xa_launch(const XaP& p, hipStream_t s) {
+    auto kern = xattn_kernel<DT, NS1, NS2, G1, G2, BIAS1>;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS);
         attr = true;
     }
-    const int64_t panels = (int64_t)p.B * ((p.N + 31) / 32);
-    hipLaunchKernelGGL(kern, dim3((unsigned)((panels + 3) / 4)), dim3(256), lds, s, p);
+    // persistent: one workgroup per CU (a multiple of 8 so that virtual id % 8 stays the XCD), fewer when there are fewer tiles
+    static const int ncu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+        return n / 8 * 8;
+    }();
+    const int want = ((p.ntiles + 7) / 8) * 8;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(want < ncu ? want : ncu)), dim3(512), XA_LDS, s, p);
     return apad_check_launch("apad_fused_cross_attention");
 }
 
@@ -316,32 +642,79 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 }  // namespace
 
+#ifdef XATTN_TRACE
+extern "C" int apad_xattn_trace_read(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_xa_trace), (size_t)n * sizeof(unsigned long long));
+}
+#endif
+
+extern "C" int64_t apad_xattn_packed_kv_bytes(int32_t B, int32_t L) { return (int64_t)B * XH * xa_kv_block(L); }
+
+extern "C" int apad_xattn_pack_weight(const void* w, void* packed, int64_t ldw, int32_t dtype, void* stream) {
+    APAD_CHECK(w && packed && al16(w) && al16(packed) && ldw % 8 == 0 && ldw >= XC, "apad_xattn_pack_weight: bad operand");
+    APAD_CHECK(dtype == APAD_BF16 || dtype == APAD_F16, "apad_xattn_pack_weight: dtype %d not supported", dtype);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == APAD_BF16)
+        hipLaunchKernelGGL((xa_pack_w_kernel<APAD_BF16>), dim3(XH * XKC * 64 / 256), dim3(256), 0, s, (const uint8_t*)w, (uint8_t*)packed, ldw);
+    else
+        hipLaunchKernelGGL((xa_pack_w_kernel<APAD_F16>), dim3(XH * XKC * 64 / 256), dim3(256), 0, s, (const uint8_t*)w, (uint8_t*)packed, ldw);
+    return apad_check_launch("apad_xattn_pack_weight");
+}
+
+extern "C" int apad_xattn_pack_kv(const void* k, const void* vt, void* packed, int32_t B, int32_t L, int32_t Lpad, int64_t k_stride_b,
+                                  int64_t k_stride_l, int64_t vt_stride_b, int32_t dtype, void* stream) {
+    APAD_CHECK(k && vt && packed && al16(packed), "apad_xattn_pack_kv: bad operand");
+    APAD_CHECK(dtype == APAD_BF16 || dtype == APAD_F16, "apad_xattn_pack_kv: dtype %d not supported", dtype);
+    APAD_CHECK(B > 0 && L > 0 && L <= 32 * XMAXSUB && Lpad >= L && Lpad % 16 == 0 && Lpad >= ((L + 15) / 16) * 16,
+               "apad_xattn_pack_kv: need 0 < L <= %d and Lpad >= L (B=%d L=%d Lpad=%d)", 32 * XMAXSUB, B, L, Lpad);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == APAD_BF16)
+        hipLaunchKernelGGL((xa_pack_kv_kernel<APAD_BF16>), dim3((unsigned)(B * XH)), dim3(256), 0, s, (const uint8_t*)k, (const uint8_t*)vt,
+                           (uint8_t*)packed, B, L, Lpad, k_stride_b, k_stride_l, vt_stride_b);
+    else
+        hipLaunchKernelGGL((xa_pack_kv_kernel<APAD_F16>), dim3((unsigned)(B * XH)), dim3(256), 0, s, (const uint8_t*)k, (const uint8_t*)vt,
+                           (uint8_t*)packed, B, L, Lpad, k_stride_b, k_stride_l, vt_stride_b);
+    return apad_check_launch("apad_xattn_pack_kv");
+}
+
 extern "C" int apad_fused_cross_attention(const apad_xattn_desc* d, void* stream) {
     APAD_CHECK(d != nullptr, "apad_fused_cross_attention: null descriptor");
     APAD_CHECK(d->dtype == APAD_BF16 || d->dtype == APAD_F16, "apad_fused_cross_attention: dtype %d not supported", d->dtype);
-    if (d->C != XC || d->heads != XH || d->L1 > 64 || d->L2 > 64) {
-        apad_set_error("apad_fused_cross_attention: C=%d heads=%d L1=%d L2=%d outside the kernel envelope (C 256, 8 heads, <= 64 keys)",
-                       d->C, d->heads, d->L1, d->L2);
+    if (d->C != XC || d->heads != XH || d->L1 > 32 * XMAXSUB || d->L2 > 32 * XMAXSUB) {
+        apad_set_error("apad_fused_cross_attention: C=%d heads=%d L1=%d L2=%d outside the kernel envelope (C 256, 8 heads, <= %d keys)",
+                       d->C, d->heads, d->L1, d->L2, 32 * XMAXSUB);
         return -3;
     }
-    APAD_CHECK(d->x && d->wq && d->wo && d->k1 && d->v1t && d->out, "apad_fused_cross_attention: null operand");
-    APAD_CHECK(d->B > 0 && d->N > 0 && d->L1 > 0 && d->Lpad1 >= d->L1 && d->Lpad1 % 32 == 0,
-               "apad_fused_cross_attention: bad geometry B=%d N=%d L1=%d Lpad1=%d", d->B, d->N, d->L1, d->Lpad1);
+    APAD_CHECK(d->x && d->wq_packed && d->wo_packed && d->kv1_packed && d->out, "apad_fused_cross_attention: null operand");
+    APAD_CHECK(d->B > 0 && d->N > 0 && d->L1 > 0, "apad_fused_cross_attention: bad geometry B=%d N=%d L1=%d", d->B, d->N, d->L1);
     const bool dual = d->L2 > 0;
-    if (dual)
-        APAD_CHECK(d->k2 && d->v2t && d->Lpad2 >= d->L2 && d->Lpad2 % 32 == 0, "apad_fused_cross_attention: segment 2 needs k2 / v2t");
+    if (dual) APAD_CHECK(d->kv2_packed != nullptr, "apad_fused_cross_attention: segment 2 needs kv2_packed");
     APAD_CHECK((d->ln_gamma == nullptr) == (d->ln_beta == nullptr), "apad_fused_cross_attention: LayerNorm needs gamma and beta");
-    APAD_CHECK(al16(d->x) && al16(d->wq) && al16(d->wo) && al16(d->k1) && al16(d->v1t) && al16(d->out) && al16(d->k2) && al16(d->v2t) &&
+    APAD_CHECK(al16(d->x) && al16(d->wq_packed) && al16(d->wo_packed) && al16(d->kv1_packed) && al16(d->out) && al16(d->kv2_packed) &&
                    al16(d->ln_gamma) && al16(d->ln_beta),
                "apad_fused_cross_attention: pointers must be 16-byte aligned");
     XaP p;
     p.x = (const uint8_t*)d->x; p.gamma = (const uint8_t*)d->ln_gamma; p.beta = (const uint8_t*)d->ln_beta;
-    p.wq = (const uint8_t*)d->wq; p.wo = (const uint8_t*)d->wo; p.bo = (const uint8_t*)d->bo;
-    p.k1 = (const uint8_t*)d->k1; p.v1t = (const uint8_t*)d->v1t; p.bias1 = d->key_bias;
-    p.k2 = (const uint8_t*)d->k2; p.v2t = (const uint8_t*)d->v2t; p.out = (uint8_t*)d->out;
-    p.B = d->B; p.N = d->N; p.L1 = d->L1; p.Lpad1 = d->Lpad1; p.L2 = d->L2; p.Lpad2 = d->Lpad2;
+    p.wq = (const uint8_t*)d->wq_packed; p.wo = (const uint8_t*)d->wo_packed; p.bo = (const uint8_t*)d->bo;
+    p.kv1 = (const uint8_t*)d->kv1_packed; p.bias1 = d->key_bias; p.kv2 = (const uint8_t*)d->kv2_packed; p.out = (uint8_t*)d->out;
+    p.B = d->B; p.N = d->N; p.L1 = d->L1; p.L2 = d->L2;
+    p.ppn = (d->N + 31) / 32;
+    p.npanels = d->B * p.ppn;
+    p.ntiles = (p.npanels + 3) / 4;
     p.eps = d->ln_eps; p.scale_log2 = d->softmax_scale * XA_LOG2E; p.scale2 = d->scale2;
     hipStream_t s = (hipStream_t)stream;
-    if (d->dtype == APAD_BF16) return dual ? xa_launch<APAD_BF16, true>(p, s) : xa_launch<APAD_BF16, false>(p, s);
-    return dual ? xa_launch<APAD_F16, true>(p, s) : xa_launch<APAD_F16, false>(p, s);
+    const int ns1 = (d->L1 + 31) / 32, ns2 = (d->L2 + 31) / 32;
+    // exact forms: the adapter's presets (8 text tokens + 8 / 32 / 64 audio tokens, no mask) and the masked 16-token T5 stream
+#define XA_EXACT(g1, g2, hasb)                                                                                          \
+    if (d->L1 == 8 * g1 && d->L2 == 8 * g2 && (d->key_bias != nullptr) == hasb)                                        \
+        return d->dtype == APAD_BF16 ? xa_launch<APAD_BF16, (g1 + 3) / 4, (g2 + 3) / 4, g1, g2, hasb>(p, s)              \
+                                     : xa_launch<APAD_F16, (g1 + 3) / 4, (g2 + 3) / 4, g1, g2, hasb>(p, s);
+    XA_EXACT(1, 4, false) XA_EXACT(1, 1, false) XA_EXACT(1, 8, false) XA_EXACT(2, 0, true)
+#undef XA_EXACT
+#define XA_CASE(A, B2) \
+    if (ns1 == A && ns2 == B2) return d->dtype == APAD_BF16 ? xa_launch<APAD_BF16, A, B2>(p, s) : xa_launch<APAD_F16, A, B2>(p, s);
+    XA_CASE(1, 0) XA_CASE(2, 0) XA_CASE(1, 1) XA_CASE(1, 2) XA_CASE(2, 1) XA_CASE(2, 2)
+#undef XA_CASE
+    apad_set_error("apad_fused_cross_attention: no kernel for L1=%d L2=%d", d->L1, d->L2);
+    return -1;
 }

@@ -126,29 +126,51 @@ def fused_linear(x, w, bias=None, ln=None, residual=None, act=None, out=None):
 XATTN_C, XATTN_HEADS, XATTN_MAXL = 256, 8, 64  # envelope of apad_fused_cross_attention
 
 
-def fused_cross_attention(x, wq, wo, bo, k1, v1t, L1, heads, ln=None, key_bias=None, k2=None, v2t=None, L2=0, scale2=0.0, out=None):
+def xattn_pack_weight(w):
+    """[256, 256] nn.Linear weight -> the fragment-major packing apad_fused_cross_attention keeps in registers (128 KB)"""
+    _req(w, "xattn_pack_weight.w")
+    if tuple(w.shape) != (XATTN_C, XATTN_C) or w.dtype not in FUSED_DTYPES:
+        raise ValueError(f"xattn_pack_weight: weight {tuple(w.shape)} {w.dtype} outside the kernel envelope")
+    out = torch.empty(XATTN_C * XATTN_C, dtype=w.dtype, device=w.device)
+    L.check(L.lib().apad_xattn_pack_weight(w.data_ptr(), out.data_ptr(), w.stride(0), _DT[w.dtype], _stream()), "apad_xattn_pack_weight")
+    return out
+
+
+def xattn_pack_kv(k, vt, Lk):
+    """k [B, Lk, 256], vt [B, 8, 32, Lpad] (per-head transposed values) -> fragment-major packing of one key segment"""
+    _req(k, "xattn_pack_kv.k")
+    _req(vt, "xattn_pack_kv.vt", k.dtype)
+    B = k.shape[0]
+    if k.shape[-1] != XATTN_C or Lk > XATTN_MAXL or tuple(vt.shape[:3]) != (B, XATTN_HEADS, XATTN_C // XATTN_HEADS) or not vt.is_contiguous():
+        raise ValueError(f"xattn_pack_kv: k {tuple(k.shape)}, vt {tuple(vt.shape)}, Lk={Lk} outside the kernel envelope")
+    nbytes = L.lib().apad_xattn_packed_kv_bytes(B, Lk)
+    out = torch.empty(nbytes // k.element_size(), dtype=k.dtype, device=k.device)
+    L.check(L.lib().apad_xattn_pack_kv(k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, Lk, vt.shape[-1], k.stride(0), k.stride(1),
+                                       vt.stride(0), _DT[k.dtype], _stream()), "apad_xattn_pack_kv")
+    return out
+
+
+def fused_cross_attention(x, wq_packed, wo_packed, bo, kv1_packed, L1, heads, ln=None, key_bias=None, kv2_packed=None, L2=0,
+                          scale2=0.0, out=None):
     """out = x + to_out(A(q, k1, v1, bias) [+ scale2 * A(q, k2, v2)]) + bo with q = to_q(LayerNorm(x)): the whole
-    cross-attention sub-layer in one launch.  x [B, N, C]; k [B, L, C]; vt [B, heads, d, Lpad]."""
-    _req(x, "fused_cross_attention.x", wq.dtype)
+    cross-attention sub-layer in one launch.  x [B, N, C]; weights from xattn_pack_weight, K/V from xattn_pack_kv."""
+    _req(x, "fused_cross_attention.x", wq_packed.dtype)
     B, N, Cc = x.shape
     if Cc != XATTN_C or heads != XATTN_HEADS or L1 > XATTN_MAXL or L2 > XATTN_MAXL or x.dtype not in FUSED_DTYPES:
         raise ValueError(f"fused_cross_attention: C={Cc} heads={heads} L1={L1} L2={L2} outside the kernel envelope")
-    for t, n in ((x, "x"), (wq, "wq"), (wo, "wo"), (k1, "k1"), (v1t, "v1t")):
-        if not t.is_contiguous():
-            raise ValueError(f"fused_cross_attention.{n}: must be contiguous")
+    if not x.is_contiguous():
+        raise ValueError("fused_cross_attention.x: must be contiguous")
     if out is None:
         out = torch.empty_like(x)
     d = L.XattnDesc()
-    d.x, d.wq, d.wo, d.bo, d.k1, d.v1t, d.out = (x.data_ptr(), wq.data_ptr(), wo.data_ptr(), _ptr(bo), k1.data_ptr(),
-                                                 v1t.data_ptr(), out.data_ptr())
+    d.x, d.wq_packed, d.wo_packed, d.bo, d.kv1_packed, d.out = (x.data_ptr(), wq_packed.data_ptr(), wo_packed.data_ptr(), _ptr(bo),
+                                                                 kv1_packed.data_ptr(), out.data_ptr())
     if ln is not None:
         d.ln_gamma, d.ln_beta, d.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), float(ln[2])
     d.key_bias = _ptr(key_bias)
-    d.B, d.N, d.C, d.heads, d.L1, d.Lpad1 = B, N, Cc, heads, L1, v1t.shape[-1]
+    d.B, d.N, d.C, d.heads, d.L1 = B, N, Cc, heads, L1
     if L2 > 0:
-        if not (k2.is_contiguous() and v2t.is_contiguous()):
-            raise ValueError("fused_cross_attention: k2 / v2t must be contiguous")
-        d.k2, d.v2t, d.L2, d.Lpad2 = k2.data_ptr(), v2t.data_ptr(), L2, v2t.shape[-1]
+        d.kv2_packed, d.L2 = kv2_packed.data_ptr(), L2
     d.dtype, d.softmax_scale, d.scale2 = _DT[x.dtype], 1.0 / math.sqrt(Cc // heads), float(scale2)
     L.check(L.lib().apad_fused_cross_attention(C.byref(d), _stream()), "apad_fused_cross_attention")
     return out

@@ -21,11 +21,11 @@ from . import ops
 
 _vt_pool = {}
 
-# Route the C = 256 / 8-head cross-attention sub-layers (hoisted K/V, <= 64 keys per segment) through the single-launch
-# apad_fused_cross_attention kernel.  Off by default: at the 1000-token level it measures 74.7 us against 73.4 us for the
-# three-kernel chain it replaces (LN+to_q, decoupled attention, to_out+residual); the switch keeps it testable end to end.
+# Route the C = 256 / 8-head cross-attention sub-layers (<= 64 keys per segment) through the single-launch
+# apad_fused_cross_attention kernel (LN + to_q + decoupled attention + to_out + residual).  APAD_FUSED_XATTN=0 selects the
+# three-kernel chain it replaces (A/B measurements, tests).
 import os as _os
-USE_FUSED_XATTN = _os.environ.get("APAD_FUSED_XATTN", "0") == "1"
+USE_FUSED_XATTN = _os.environ.get("APAD_FUSED_XATTN", "1") == "1"
 
 
 def _fused_xattn_ok(attn, hidden_states, residual, ln, L1, L2=0):
@@ -33,6 +33,16 @@ def _fused_xattn_ok(attn, hidden_states, residual, ln, L1, L2=0):
     return (USE_FUSED_XATTN and residual is hidden_states and ln is not None and C_ == ops.XATTN_C and attn.heads == ops.XATTN_HEADS
             and tuple(attn.to_q.weight.shape) == (C_, C_) and L1 <= ops.XATTN_MAXL and L2 <= ops.XATTN_MAXL
             and hidden_states.is_contiguous() and hidden_states.dtype in ops.FUSED_DTYPES)
+
+
+def _xattn_weights(attn):
+    """fragment-packed to_q / to_out[0] weights of the fused kernel, cached on the Attention module and re-packed when a
+    parameter is re-assigned, moved, cast or updated in place"""
+    key = _pkey(attn.to_q.weight, attn.to_out[0].weight)
+    if getattr(attn, "_xattn_key", None) != key:
+        attn._xattn_w = (ops.xattn_pack_weight(attn.to_q.weight.detach()), ops.xattn_pack_weight(attn.to_out[0].weight.detach()))
+        attn._xattn_key = key
+    return attn._xattn_w
 
 
 def vt_buffer(slot, B, heads, d, Lk, dtype, device):
@@ -149,14 +159,16 @@ class AttnProcessor2_0(nn.Module):
             # hoisted K/V are valid for ONE (Attention site, condition tensor content, to_k / to_v weights): a processor
             # instance may be shared by every site (set_attn_processor(proc)), weights may be re-assigned or stepped
             ck = (id(attn), _tkey(ehs), _pkey(attn.to_k.weight, attn.to_v.weight))
+            fused = _fused_xattn_ok(attn, hidden_states, _residual, _ln, Lk)
             if self.kv_cache_enabled and self._kv_cache is not None and ck in self._kv_cache:
-                k, vt = self._kv_cache[ck]
+                k, vt, pk = self._kv_cache[ck]
             else:
                 k, vt = self._project_kv(attn, ehs, None if self.kv_cache_enabled else "cross")
+                pk = ops.xattn_pack_kv(k, vt, Lk) if fused else None  # hoisted with the projection
                 if self.kv_cache_enabled:
                     if self._kv_cache is None:
                         self._kv_cache = {}
-                    self._kv_cache[ck] = (k, vt)
+                    self._kv_cache[ck] = (k, vt, pk)
         if attention_mask is not None and self.kv_cache_enabled:
             # the mask -> fp32 bias conversion is timestep-invariant too: hoisted with the K/V (two tiny torch kernels
             # per masked site per step otherwise)
@@ -168,9 +180,9 @@ class AttnProcessor2_0(nn.Module):
                 bias = self._kv_cache[bk] = _key_bias(attention_mask, B, Lk)
         else:
             bias = _key_bias(attention_mask, B, Lk)
-        if encoder_hidden_states is not None and _fused_xattn_ok(attn, hidden_states, _residual, _ln, Lk):
-            return ops.fused_cross_attention(hidden_states, attn.to_q.weight, attn.to_out[0].weight, attn.to_out[0].bias, k, vt, Lk,
-                                             heads, ln=_ln, key_bias=bias)
+        if encoder_hidden_states is not None and fused and pk is not None:
+            wq_p, wo_p = _xattn_weights(attn)
+            return ops.fused_cross_attention(hidden_states, wq_p, wo_p, attn.to_out[0].bias, pk, Lk, heads, ln=_ln, key_bias=bias)
         if q is None:
             q = ops.fused_linear(hidden_states, attn.to_q.weight, ln=_ln)
         o = ops.attention(q, k, vt, Lk, heads, key_bias=bias)
@@ -254,7 +266,7 @@ class IPAttnProcessor2_0(nn.Module):
             vt_a = (torch.zeros(B, attn.heads, d, ops.round_up(La, 32), dtype=ehs.dtype, device=ehs.device)
                     if persistent else vt_buffer("ip_aud", B, attn.heads, d, La, ehs.dtype, ehs.device))
             ops.linear_vt(aud, self.to_v_ip.weight, B, La, attn.heads, vt_a)
-        return k_t, vt_t, Lt, k_a, vt_a, La
+        return k_t, vt_t, Lt, k_a, vt_a, La, None, None
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale=1.0,
                  _residual=None, _ln=None):
@@ -281,20 +293,24 @@ class IPAttnProcessor2_0(nn.Module):
             kv = self._kv_cache[ck]
         else:
             kv = self._project(attn, ehs)
+            k_t, vt_t, Lt, k_a, vt_a, La = kv[:6]
+            if _fused_xattn_ok(attn, hidden_states, _residual, _ln, Lt, La):  # packed once, with the hoisted projection
+                kv = kv[:6] + (ops.xattn_pack_kv(k_t, vt_t, Lt), ops.xattn_pack_kv(k_a, vt_a, La) if La > 0 else None)
             if self.kv_cache_enabled:
                 if self._kv_cache is None:
                     self._kv_cache = {}
                 self._kv_cache[ck] = kv
-        k_t, vt_t, Lt, k_a, vt_a, La = kv
+        k_t, vt_t, Lt, k_a, vt_a, La, pk_t, pk_a = kv
         bias = None
         if attention_mask is not None:
             # reference :424-428 keeps only mask column 0 (split by the singleton query dim) and broadcasts it
             # over the text keys
             m = attention_mask.reshape(B, -1)[:, :1].float()
             bias = m.expand(B, Lt).contiguous()
-        if _fused_xattn_ok(attn, hidden_states, _residual, _ln, Lt, La):
-            return ops.fused_cross_attention(hidden_states, attn.to_q.weight, attn.to_out[0].weight, attn.to_out[0].bias, k_t, vt_t,
-                                             Lt, attn.heads, ln=_ln, key_bias=bias, k2=k_a, v2t=vt_a, L2=La, scale2=self.scale)
+        if pk_t is not None and _fused_xattn_ok(attn, hidden_states, _residual, _ln, Lt, La):
+            wq_p, wo_p = _xattn_weights(attn)
+            return ops.fused_cross_attention(hidden_states, wq_p, wo_p, attn.to_out[0].bias, pk_t, Lt, attn.heads, ln=_ln,
+                                             key_bias=bias, kv2_packed=pk_a, L2=La, scale2=self.scale)
         q = ops.fused_linear(hidden_states, attn.to_q.weight, ln=_ln)
         o = ops.attention(q, k_t, vt_t, Lt, attn.heads, key_bias=bias, k2=k_a, vt2=vt_a, L2=La, scale2=self.scale)
         out = ops.fused_linear(o, attn.to_out[0].weight, attn.to_out[0].bias, residual=_residual)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define APAD_ABI_VERSION 2
+#define APAD_ABI_VERSION 3
 
 /* element types of activations / weights */
 enum { APAD_BF16 = 0, APAD_F16 = 1, APAD_F32 = 2 };
@@ -160,28 +160,37 @@ typedef struct apad_mlp_desc {
 /* Fused cross-attention sub-layer for hoisted, short key / value sets (<= 64 keys per segment):
  *     out = x + to_out( A(q, K1, V1, key_bias) [+ scale2 * A(q, K2, V2)] ) + bo,   q = to_q(LayerNorm(x))
  * = IPAttnProcessor2_0.__call__ (attention_processor.py:347-470) / AttnProcessor2_0.__call__ (:214-294) together with
- * the block's pre-LayerNorm and residual, in ONE launch.  Envelope: C = 256, 8 heads (else -3). */
+ * the block's pre-LayerNorm and residual, in ONE launch.  Envelope: C = 256, 8 heads (else -3).
+ * The kernel is weight-stationary: every wave keeps its 32 rows of to_q / to_out[0] in registers, so the two weights
+ * and the hoisted K / V are passed FRAGMENT-PACKED (each MFMA operand fragment = one contiguous KB):
+ *   apad_xattn_pack_weight  once per weight (re-pack when the parameter changes)
+ *   apad_xattn_pack_kv      once per hoisted K / V^T set (i.e. per pipeline call, with the K/V projection itself) */
 typedef struct apad_xattn_desc {
-    const void* x;         /* [B*N][C] un-normalised hidden states (also the residual)                      */
-    const void* ln_gamma;  /* [C] or NULL                                                                   */
+    const void* x;          /* [B*N][C] un-normalised hidden states (also the residual)                     */
+    const void* ln_gamma;   /* [C] or NULL                                                                  */
     const void* ln_beta;
-    const void* wq;        /* [C][C] attn.to_q.weight                                                       */
-    const void* wo;        /* [C][C] attn.to_out[0].weight                                                  */
-    const void* bo;        /* [C] attn.to_out[0].bias or NULL                                               */
-    const void* k1;        /* [B][L1][C]   keys of segment 1 (to_k of the text / T5 tokens)                 */
-    const void* v1t;       /* [B][H][D][Lpad1] values of segment 1, per-head transposed, zero padded        */
-    const float* key_bias; /* [B][L1] fp32 additive bias on segment 1, or NULL                              */
-    const void* k2;        /* [B][L2][C]   keys of segment 2 (to_k_ip of the audio tokens) or NULL          */
-    const void* v2t;       /* [B][H][D][Lpad2]                                                              */
-    void* out;             /* [B*N][C]                                                                      */
+    const void* wq_packed;  /* apad_xattn_pack_weight(attn.to_q.weight)                                     */
+    const void* wo_packed;  /* apad_xattn_pack_weight(attn.to_out[0].weight)                                */
+    const void* bo;         /* [C] attn.to_out[0].bias or NULL                                              */
+    const void* kv1_packed; /* apad_xattn_pack_kv(to_k(tokens), to_v(tokens)^T) of segment 1 (text / T5)     */
+    const float* key_bias;  /* [B][L1] fp32 additive bias on segment 1, or NULL                             */
+    const void* kv2_packed; /* segment 2 (to_k_ip / to_v_ip of the audio tokens) or NULL                     */
+    void* out;              /* [B*N][C]                                                                     */
     int32_t B, N, C, heads;
-    int32_t L1, Lpad1, L2, Lpad2;   /* L2 = 0: single segment                                               */
+    int32_t L1, L2;         /* L2 = 0: single segment                                                       */
     int32_t dtype, reserved;
     float ln_eps, softmax_scale, scale2, reserved_f;
 } apad_xattn_desc;
 int apad_sizeof_xattn_desc(void);
 int apad_echo_xattn_desc(const apad_xattn_desc* d, double* out, int cap);
 int apad_fused_cross_attention(const apad_xattn_desc* d, void* stream);
+/* w [256][ldw] (nn.Linear layout) -> packed [8 row slices][16 k-steps][64 lanes][8], 128 KB */
+int apad_xattn_pack_weight(const void* w, void* packed, int64_t ldw, int32_t dtype, void* stream);
+/* bytes of the packed form of one segment's K / V^T: B * 8 heads * ceil(L/32) * 4 KB */
+int64_t apad_xattn_packed_kv_bytes(int32_t B, int32_t L);
+/* k [B][L][256] (strides in elements), vt [B][8][32][Lpad] (apad_gemm APAD_OUT_VT) -> packed; L <= 64 */
+int apad_xattn_pack_kv(const void* k, const void* vt, void* packed, int32_t B, int32_t L, int32_t Lpad, int64_t k_stride_b,
+                       int64_t k_stride_l, int64_t vt_stride_b, int32_t dtype, void* stream);
 
 const char* apad_last_error(void);
 int apad_abi_version(void);

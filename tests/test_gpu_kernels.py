@@ -420,6 +420,29 @@ def test_tiled_fused_qkv(dev, dtype, B, L, K, heads):
     assert rel_err(vt[..., :L], y[:, 2 * K:].view(B, L, heads, d).permute(0, 2, 3, 1)) < TOL[dtype]
 
 
+def test_xattn_packings(dev):
+    """the fragment-major packings the fused kernel reads: weights [slice][kk][lane][8], K / V^T in MFMA C-layout key order"""
+    from ap_adapter_amd import ops
+    dtype = torch.bfloat16
+    w = q(R(256, 256, seed=300), dtype)
+    pw = ops.xattn_pack_weight(w.to(dev, dtype)).float().cpu().view(8, 16, 2, 32, 8)  # [s][kk][half][l31][e]
+    ref = w.view(8, 32, 16, 2, 8).permute(0, 2, 3, 1, 4)                               # W[s*32+l31][kk*16+half*8+e]
+    assert torch.equal(pw, ref)
+    B, L, H, D = 3, 40, 8, 32
+    k, v = q(R(B, L, 256, seed=301), dtype), q(R(B, L, 256, seed=302), dtype)
+    pk = ops.xattn_pack_kv(k.to(dev, dtype), _vt(v, H, dev, dtype), L).float().cpu().view(B, H, 8, 2, 32, 8)  # [b][h][frag][half][l31][e]
+    perm = lambda half, e: 4 * half + e if e < 4 else 8 + 4 * half + e - 4
+    kp = torch.zeros(B, 64, 256)
+    kp[:, :L] = k
+    vp = torch.zeros(B, 64, 256)
+    vp[:, :L] = v
+    for b, h, half, l31, e in [(0, 0, 0, 0, 0), (1, 3, 1, 17, 5), (2, 7, 0, 31, 7), (1, 5, 1, 9, 2)]:
+        for sub_, kk in [(0, 0), (0, 1), (1, 0), (1, 1)]:
+            assert pk[b, h, sub_ * 2 + kk, half, l31, e] == kp[b, sub_ * 32 + l31, h * D + kk * 16 + perm(half, e)]
+        for st in range(3):  # keys < 48 (L = 40 -> 3 steps of 16)
+            assert pk[b, h, 4 + st, half, l31, e] == vp[b, st * 16 + perm(half, e), h * D + l31]
+
+
 def _xattn_ref(x, g, be, wq, wo, bo, ehs_t, wk, wv, heads, bias=None, ehs_a=None, wk_ip=None, wv_ip=None, scale=0.0):
     """fp32 restatement of LayerNorm -> to_q -> (decoupled) attention -> to_out + residual (attention_processor.py:347-470)"""
     B, N, C = x.shape
@@ -437,7 +460,7 @@ def _xattn_ref(x, g, be, wq, wo, bo, ehs_t, wk, wv, heads, bias=None, ehs_a=None
 
 @pytest.mark.parametrize("dtype", DTYPES16)
 @pytest.mark.parametrize("B,N,Lt,La,masked", [(2, 1000, 8, 32, False), (3, 100, 8, 8, False), (2, 250, 16, 0, True), (1, 33, 8, 64, False),
-                                               (5, 64, 40, 0, False)])
+                                               (5, 64, 40, 0, False), (2, 130, 8, 33, False), (9, 1000, 8, 32, False), (2, 31, 40, 50, True)])
 def test_fused_cross_attention(dev, dtype, B, N, Lt, La, masked):
     """LayerNorm + to_q + (decoupled) attention + to_out + residual in one launch, incl. panels that end inside a sample,
     a tail workgroup with idle waves, the masked T5 form and a 2-sub-tile segment"""
@@ -464,8 +487,11 @@ def test_fused_cross_attention(dev, dtype, B, N, Lt, La, masked):
         k2 = ops.linear(D(ea), D(wki))
         v2t = torch.zeros(B, H, C // H, ops.round_up(La, 32), device=dev, dtype=dtype)
         ops.linear_vt(D(ea), D(wvi), B, La, H, v2t)
-    out = ops.fused_cross_attention(D(x), D(wq), D(wo), D(bo), k1, v1t, Lt, H, ln=(D(g), D(be), 1e-5),
-                                    key_bias=None if bias is None else bias.to(dev), k2=k2, v2t=v2t, L2=La, scale2=0.55)
+    wq_p, wo_p = ops.xattn_pack_weight(D(wq)), ops.xattn_pack_weight(D(wo))
+    pk1 = ops.xattn_pack_kv(k1, v1t, Lt)
+    pk2 = ops.xattn_pack_kv(k2, v2t, La) if La else None
+    out = ops.fused_cross_attention(D(x), wq_p, wo_p, D(bo), pk1, Lt, H, ln=(D(g), D(be), 1e-5),
+                                    key_bias=None if bias is None else bias.to(dev), kv2_packed=pk2, L2=La, scale2=0.55)
     assert out.shape == ref.shape
     assert rel_err(out, ref) < 1.5 * TOL[dtype]
     # and against the three-kernel chain it replaces
@@ -480,5 +506,8 @@ def test_fused_cross_attention_outside_envelope(dev):
     x = torch.zeros(1, 64, 384, device=dev, dtype=torch.bfloat16)
     w = torch.zeros(384, 384, device=dev, dtype=torch.bfloat16)
     with pytest.raises(ValueError):
-        ops.fused_cross_attention(x, w, w, None, torch.zeros(1, 8, 384, device=dev, dtype=torch.bfloat16),
-                                  torch.zeros(1, 8, 48, 32, device=dev, dtype=torch.bfloat16), 8, 8)
+        ops.xattn_pack_weight(w)
+    with pytest.raises(ValueError):
+        ops.xattn_pack_kv(torch.zeros(1, 8, 384, device=dev, dtype=torch.bfloat16), torch.zeros(1, 8, 48, 32, device=dev, dtype=torch.bfloat16), 8)
+    with pytest.raises(ValueError):
+        ops.fused_cross_attention(x, w, w, None, w, 8, 8)

@@ -34,6 +34,16 @@ elif op == "mlp":
     x = R(M, C); g = R(C); be = R(C); w1 = R(8 * C, C, std=0.02); b1 = R(8 * C, std=0.02)
     w2 = R(C, 4 * C, std=0.02); b2 = R(C, std=0.02); out = torch.empty(M, C, device=dev, dtype=dt)
     fn = lambda: ops.geglu_mlp(x, w1, b1, w2, b2, ln=(g, be, 1e-5), out=out)
+elif op == "xattn":
+    N, C, H, Lt, La = 1000, 256, 8, 8, int(os.environ.get("LA", "32"))
+    x, g, be, wq, wo, bo = R(B2, N, C), R(C), R(C), R(C, C, std=0.02), R(C, C, std=0.02), R(C, std=0.02)
+    k1, k2 = R(B2, Lt, C, std=0.3), R(B2, La, C, std=0.3)
+    v1t = torch.zeros(B2, H, 32, 32, device=dev, dtype=dt); v1t[..., :Lt].normal_(0, 0.3)
+    v2t = torch.zeros(B2, H, 32, ops.round_up(La, 32), device=dev, dtype=dt); v2t[..., :La].normal_(0, 0.3)
+    wq_p, wo_p = ops.xattn_pack_weight(wq), ops.xattn_pack_weight(wo)
+    pk1, pk2 = ops.xattn_pack_kv(k1, v1t, Lt), ops.xattn_pack_kv(k2, v2t, La)
+    out = torch.empty_like(x)
+    fn = lambda: ops.fused_cross_attention(x, wq_p, wo_p, bo, pk1, Lt, H, ln=(g, be, 1e-5), kv2_packed=pk2, L2=La, scale2=0.55, out=out)
 for _ in range(iters):
     fn()
 torch.cuda.synchronize()
