@@ -23,7 +23,10 @@ _wcache = {}
 
 
 def _cached(w, tag, make):
-    """per-weight derived tensor (transposed / flipped copy), rebuilt when the weight is re-assigned or updated"""
+    """per-weight derived tensor (transposed / flipped copy), rebuilt when the weight is re-assigned or updated.  Only FROZEN
+    weights are cached: the optimizer kernel updates trainable ones through raw pointers, which no version counter sees."""
+    if w.requires_grad:
+        return make(w.detach())
     key = (id(w), tag)
     sig = (w.data_ptr(), w._version, w.dtype, w.device)
     hit = _wcache.get(key)
@@ -59,6 +62,10 @@ class _Linear(torch.autograd.Function):
     def forward(ctx, x, w, b, residual):
         ctx.save_for_backward(x if w.requires_grad else None, w)
         ctx.has_res = residual is not None
+        # a trainer may attach an fp32 accumulator to a trainable weight (AdapterTrainer: a view of its flat gradient buffer
+        # and the loss scale): the weight gradient is then formed and accumulated in fp32, as the reference's fp32 adapter
+        # gradients are, instead of being rounded to the storage type once per micro-batch
+        ctx.sink = getattr(w, "_apad_grad_sink", None)
         w2 = w.reshape(w.shape[0], -1)
         return ops.linear(_c(x), w2, b, residual=None if residual is None else _c(residual))
 
@@ -70,7 +77,12 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.linear(dy, _wt(w))
         if ctx.needs_input_grad[1]:
-            dw = ops.weight_grad(dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])).reshape(w.shape)
+            if ctx.sink is not None:
+                acc, inv_scale = ctx.sink
+                acc.add_(ops.weight_grad(dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1]), fp32=True).reshape(acc.shape),
+                         alpha=inv_scale)
+            else:
+                dw = ops.weight_grad(dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])).reshape(w.shape)
         return dx, dw, None, (dy if ctx.has_res and ctx.needs_input_grad[3] else None)
 
 
@@ -235,8 +247,8 @@ class _MSE(torch.autograd.Function):
     """F.mse_loss(pred.float(), target.float(), reduction="mean") (train_apadapter_v2.py:954)"""
 
     @staticmethod
-    def forward(ctx, pred, target):
-        loss, dpred = ops.mse_loss_grad(_c(pred), _c(target.float()))
+    def forward(ctx, pred, target, grad_scale):
+        loss, dpred = ops.mse_loss_grad(_c(pred), _c(target.float()), grad_scale)  # loss itself is unscaled
         ctx.save_for_backward(dpred)
         return loss.reshape(())
 
@@ -245,8 +257,10 @@ class _MSE(torch.autograd.Function):
         (dpred,) = ctx.saved_tensors
         # g is 1 for loss.backward(); applied as a device-side scalar multiply of a [B, 8, 250, 16] tensor (no host
         # sync: the step must stay capturable in a hipGraph)
-        return dpred * g.to(dpred.dtype), None
+        return dpred * g.to(dpred.dtype), None, None
 
 
-def mse_loss(pred, target):
-    return _MSE.apply(pred, target)
+def mse_loss(pred, target, grad_scale=1.0):
+    """grad_scale: static loss scale -- the backward delivers grad_scale * d loss / d pred (applied in fp32 inside the kernel,
+    before the rounding to the storage type); the returned loss is unscaled"""
+    return _MSE.apply(pred, target, float(grad_scale))

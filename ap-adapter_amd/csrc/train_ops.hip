@@ -234,10 +234,13 @@ template <int DT> __global__ __launch_bounds__(256) void transpose_pad_kernel(co
 
 // ---- loss ------------------------------------------------------------------------------------------------------------
 // partial[blockIdx] = sum (pred - target)^2 over the block's slice; dpred = 2 (pred - target) / n  (F.mse_loss, mean)
-template <int DT> __global__ __launch_bounds__(256) void mse_kernel(const uint8_t* pred, const float* target, uint8_t* dpred, float* partial, int64_t n) {
+// grad_scale: static loss scale, applied in fp32 BEFORE dpred is rounded to the storage type (2 (p - t) / n is ~1e-5 at full
+// geometry: subnormal in f16)
+template <int DT> __global__ __launch_bounds__(256) void mse_kernel(const uint8_t* pred, const float* target, uint8_t* dpred, float* partial, int64_t n,
+                                                                    float grad_scale) {
     __shared__ float sh[8];
     float acc = 0.f, dummy = 0.f;
-    const float k = 2.0f / (float)n;
+    const float k = 2.0f * grad_scale / (float)n;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float d = ld_elem<DT>(pred, i) - target[i];
         acc += d * d;
@@ -267,6 +270,8 @@ template <int DT> __global__ __launch_bounds__(256) void adamw_kernel(float* par
                                                                       float beta1, float beta2, float eps, float wd, float max_norm) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    // a non-finite gradient norm (f16 overflow under loss scaling) skips the update, as accelerate's GradScaler does
+    if (grad_norm != nullptr && !(fabsf(grad_norm[0]) < 3.0e38f)) return;
     // torch.nn.utils.clip_grad_norm_: coefficient = max_norm / (norm + 1e-6), clamped to 1
     float clip = 1.0f;
     if (max_norm > 0.f) clip = fminf(max_norm / (grad_norm[0] + 1e-6f), 1.0f);
@@ -365,14 +370,24 @@ extern "C" int apad_transpose_pad(const void* x, void* xt, int32_t M, int32_t C,
 extern "C" int64_t apad_reduce_workspace_bytes(void) { return (int64_t)REDUCE_BLOCKS * sizeof(float); }
 
 extern "C" int apad_mse_loss_grad(const void* pred, const float* target, void* dpred, float* loss, float* workspace, int64_t n,
-                                  int32_t dtype, void* stream) {
+                                  float grad_scale, int32_t dtype, void* stream) {
     TRAIN_DT_CHECK("apad_mse_loss_grad");
     APAD_CHECK(pred && target && dpred && loss && workspace && n > 0, "apad_mse_loss_grad: bad operands");
     hipStream_t s = (hipStream_t)stream;
     const int blocks = (int)((n + 255) / 256 < REDUCE_BLOCKS ? (n + 255) / 256 : REDUCE_BLOCKS);
-    LAUNCH_DT(mse_kernel, dim3((unsigned)blocks), (const uint8_t*)pred, target, (uint8_t*)dpred, workspace, n);
+    LAUNCH_DT(mse_kernel, dim3((unsigned)blocks), (const uint8_t*)pred, target, (uint8_t*)dpred, workspace, n, grad_scale);
     hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, s, (const float*)workspace, blocks, loss, 1.0f / (float)n, 0);
     return apad_check_launch("apad_mse_loss_grad");
+}
+
+// step[0] += 1 unless the gradient norm is non-finite (the skipped step of a loss-scaled f16 run keeps its bias-correction index)
+__global__ void step_advance_if_finite_kernel(int32_t* step, const float* norm) {
+    if (norm == nullptr || fabsf(norm[0]) < 3.0e38f) step[0] += 1;
+}
+extern "C" int apad_step_advance_if_finite(int32_t* step, const float* grad_norm, void* stream) {
+    APAD_CHECK(step != nullptr, "apad_step_advance_if_finite: null pointer");
+    hipLaunchKernelGGL(step_advance_if_finite_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, grad_norm);
+    return apad_check_launch("apad_step_advance_if_finite");
 }
 
 extern "C" int apad_grad_norm(const float* grad, float* norm, float* workspace, int64_t n, void* stream) {

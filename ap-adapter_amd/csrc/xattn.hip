@@ -34,6 +34,10 @@ constexpr int TROWB = XC * 2 + 16;        // tile row stride (bytes): 33 sixteen
 constexpr int TILE_BYTES = XTM * TROWB;   // 67 584
 constexpr int XA_LDS = 2 * TILE_BYTES + XC * 4;
 constexpr int XMAXSUB = 2;                // <= 64 keys per segment
+#ifndef XA_SPLIT_Q
+#define XA_SPLIT_Q 0
+#endif
+constexpr bool XA_SPLIT = XA_SPLIT_Q != 0;  // A/B: q-projection of all four panels first (q parked in LDS) vs panel pair by panel pair
 
 struct XaP {
     const uint8_t* x;
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(512) void xattn_kernel(XaP p) {
         };
         const int bfirst = (tile * 4) / p.ppn;
         if constexpr (EXACT) fetch_kv(bfirst < p.B ? bfirst : p.B - 1);  // (general form: after the q-projection -- registers)
-        {
+        if constexpr (XA_SPLIT) {
             f32x16 qa[4];
             const uint8_t* bt = xt + l31 * TROWB + half * 16;
             typename E::v8 fb[2][4];
@@ -413,11 +417,37 @@ __global__ __launch_bounds__(512) void xattn_kernel(XaP p) {
         auto attend = [&](int pp, auto n_tag, int b) {
             constexpr int NP = decltype(n_tag)::value;
             typename E::v8 qb[NP][2];
+            if constexpr (XA_SPLIT) {
 #pragma unroll
-            for (int u = 0; u < NP; ++u) {
-                const uint8_t* qd = ot + ((pp + u) * 32 + l31) * TROWB + h * 64 + half * 32;
-                qb[u][0] = as_v8<DT>(*reinterpret_cast<const uint4*>(qd));
-                qb[u][1] = as_v8<DT>(*reinterpret_cast<const uint4*>(qd + 16));
+                for (int u = 0; u < NP; ++u) {
+                    const uint8_t* qd = ot + ((pp + u) * 32 + l31) * TROWB + h * 64 + half * 32;
+                    qb[u][0] = as_v8<DT>(*reinterpret_cast<const uint4*>(qd));
+                    qb[u][1] = as_v8<DT>(*reinterpret_cast<const uint4*>(qd + 16));
+                }
+            } else {
+                // q-projection of these panels right here: NP accumulator chains, fragment reads one k-step ahead
+                f32x16 qa[NP];
+                const uint8_t* bt = xt + (pp * 32 + l31) * TROWB + half * 16;
+                typename E::v8 fb[2][NP];
+                auto ldk = [&](int buf, int kk) {
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) fb[buf][u] = as_v8<DT>(*reinterpret_cast<const uint4*>(bt + u * 32 * TROWB + kk * 32));
+                };
+                ldk(0, 0);
+#pragma unroll
+                for (int kk = 0; kk < XKC; ++kk) {
+                    const int cur = kk & 1;
+                    if (kk + 1 < XKC) ldk(cur ^ 1, kk + 1);
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) {
+                        asm volatile("" : "+v"(fb[cur][u]) : : "memory");
+                        qa[u] = E::mfma32(wf[kk], fb[cur][u], kk == 0 ? zero16 : qa[u]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < NP; ++u)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) qb[u][r >> 3][r & 7] = (typename E::elem)qa[u][r];
             }
             const float* bias1 = p.bias1 ? p.bias1 + (int64_t)b * p.L1 : nullptr;
             f32x16 o[NP];

@@ -477,13 +477,18 @@ def transpose_pad(x, Mpad):
     return xt
 
 
-def weight_grad(dy, x):
-    """dW [N, K] = dy[M, N]^T . x[M, K] (the adapter's to_k_ip / to_v_ip gradient), reduction over the M token rows"""
+def weight_grad(dy, x, fp32=False):
+    """dW [N, K] = dy[M, N]^T . x[M, K] (the adapter's to_k_ip / to_v_ip gradient), reduction over the M token rows.
+    fp32: the product of the (storage-type) operands is formed on the exact-f32 MFMA path and returned in fp32 -- the reference
+    computes the adapter gradients in fp32, and a per-micro-batch rounding of dW to bf16 would sit in front of the fp32
+    accumulation otherwise."""
     M, N = dy.shape
     K = x.shape[-1]
     Mpad = round_up(M, 64)
     dyt, xt = transpose_pad(dy.contiguous(), Mpad), transpose_pad(x.contiguous(), Mpad)
-    out = torch.empty(N, K, dtype=dy.dtype, device=dy.device)
+    if fp32:
+        dyt, xt = dyt.float(), xt.float()  # widening copies (exact)
+    out = torch.empty(N, K, dtype=dyt.dtype, device=dy.device)
     gemm(dyt, xt, M=N, N=K, K=Mpad, lda=Mpad, out=out, ldo=K, ldw=Mpad)
     return out
 
@@ -492,16 +497,20 @@ def _reduce_ws(dev):
     return torch.empty(L.lib().apad_reduce_workspace_bytes() // 4, dtype=torch.float32, device=dev)
 
 
-def mse_loss_grad(pred, target):
-    """(loss fp32 scalar tensor, dpred in pred.dtype) of F.mse_loss(pred.float(), target.float())"""
+def mse_loss_grad(pred, target, grad_scale=1.0):
+    """(loss fp32 scalar tensor, grad_scale * dpred in pred.dtype) of F.mse_loss(pred.float(), target.float())"""
     _req(pred, "mse_loss_grad.pred")
     _req(target, "mse_loss_grad.target", torch.float32)
     loss = torch.empty(1, dtype=torch.float32, device=pred.device)
     dpred = torch.empty_like(pred)
     ws = _reduce_ws(pred.device)
     L.check(L.lib().apad_mse_loss_grad(pred.data_ptr(), target.data_ptr(), dpred.data_ptr(), loss.data_ptr(), ws.data_ptr(),
-                                       pred.numel(), _DT[pred.dtype], _stream()), "apad_mse_loss_grad")
+                                       pred.numel(), float(grad_scale), _DT[pred.dtype], _stream()), "apad_mse_loss_grad")
     return loss, dpred
+
+
+def step_advance_if_finite(step_ptr, grad_norm_t):
+    L.check(L.lib().apad_step_advance_if_finite(step_ptr.data_ptr(), _ptr(grad_norm_t), _stream()), "apad_step_advance_if_finite")
 
 
 def grad_norm(grad, out=None, ws=None):

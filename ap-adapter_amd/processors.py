@@ -64,10 +64,41 @@ def _pkey(*params):
     return tuple((id(p), p.data_ptr(), p._version, p.dtype) for p in params)
 
 
-def _tkey(t):
-    """identity of a condition tensor's CONTENT as far as it can be known without reading it: storage, shape, dtype and the
-    in-place version counter"""
-    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype, t._version)
+class _Hoist:
+    """One hoisted (timestep-invariant) result: K / V^T / packed fragments of one (Attention site, condition tensor), or a
+    mask's fp32 bias.  ``sig`` = what the result was computed from (condition version, weight identities / versions); when it
+    no longer matches, ``make`` recomputes IN PLACE -- same buffers -- so that a captured hipGraph which reads them stays
+    valid across pipeline calls (``refresh`` is what the pipeline runs before replaying a cached graph on new conditions)."""
+    __slots__ = ("sig_fn", "make", "sig", "out", "owner")
+
+    def __init__(self, sig_fn, make):
+        self.sig_fn, self.make = sig_fn, make
+        self.sig, self.out = sig_fn(), make()
+        self.owner = HOIST_OWNER[0]  # who asked for it (a cached hipGraph, an eager pipeline call): dropped with its owner
+
+    def get(self):
+        sig = self.sig_fn()
+        if sig != self.sig:
+            new = self.make()
+            same = len(new) == len(self.out) and all(
+                (a is None and b is None) or (torch.is_tensor(a) and torch.is_tensor(b) and a.shape == b.shape and a.dtype == b.dtype)
+                or (not torch.is_tensor(a) and a == b) for a, b in zip(self.out, new))
+            if same:
+                for a, b in zip(self.out, new):
+                    if torch.is_tensor(a):
+                        a.copy_(b)
+            else:
+                self.out = new
+            self.sig = sig
+        return self.out
+
+
+HOIST_OWNER = [None]  # set by the pipeline around a call (see AudioLDM2Pipeline.denoise)
+
+
+def _loose_key(attn, t):
+    """which (site, condition BUFFER) a hoisted result belongs to; the content is tracked by _Hoist.sig"""
+    return (id(attn), t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype)
 
 
 def _key_bias(attention_mask, B, Lk):
@@ -96,6 +127,27 @@ class AttnProcessor2_0(nn.Module):
 
     def clear_kv_cache(self):
         self._kv_cache = None
+
+    def refresh_kv_cache(self):
+        """recompute, in place, every hoisted result whose inputs changed (new condition content, re-assigned / stepped
+        weights)"""
+        for e in (self._kv_cache or {}).values():
+            e.get()
+
+    def drop_kv_owner(self, owner):
+        if self._kv_cache:
+            self._kv_cache = {k: e for k, e in self._kv_cache.items() if e.owner != owner}
+
+    def _hoisted(self, key, sig_fn, make):
+        if not self.kv_cache_enabled:
+            return make()
+        if self._kv_cache is None:
+            self._kv_cache = {}
+        e = self._kv_cache.get(key)
+        if e is None:
+            e = self._kv_cache[key] = _Hoist(sig_fn, make)
+            return e.out
+        return e.get()
 
     def _project_kv(self, attn, src, slot):
         B, Lk, _ = src.shape
@@ -156,30 +208,24 @@ class AttnProcessor2_0(nn.Module):
             if ehs.dim() < 3:
                 ehs = ehs.unsqueeze(0)
             Lk = ehs.shape[1]
-            # hoisted K/V are valid for ONE (Attention site, condition tensor content, to_k / to_v weights): a processor
-            # instance may be shared by every site (set_attn_processor(proc)), weights may be re-assigned or stepped
-            ck = (id(attn), _tkey(ehs), _pkey(attn.to_k.weight, attn.to_v.weight))
+            # hoisted K/V belong to ONE (Attention site, condition buffer) -- a processor instance may be shared by every site
+            # (set_attn_processor(proc)) -- and are valid for one condition content and one pair of to_k / to_v weights
+            # (re-assigned or stepped weights, an in-place update of the condition -> recomputed, in place)
             fused = _fused_xattn_ok(attn, hidden_states, _residual, _ln, Lk)
-            if self.kv_cache_enabled and self._kv_cache is not None and ck in self._kv_cache:
-                k, vt, pk = self._kv_cache[ck]
-            else:
-                k, vt = self._project_kv(attn, ehs, None if self.kv_cache_enabled else "cross")
-                pk = ops.xattn_pack_kv(k, vt, Lk) if fused else None  # hoisted with the projection
-                if self.kv_cache_enabled:
-                    if self._kv_cache is None:
-                        self._kv_cache = {}
-                    self._kv_cache[ck] = (k, vt, pk)
-        if attention_mask is not None and self.kv_cache_enabled:
+            persistent = self.kv_cache_enabled
+
+            def make(attn=attn, ehs=ehs, fused=fused, persistent=persistent):
+                k_, vt_ = self._project_kv(attn, ehs, None if persistent else "cross")
+                return (k_, vt_, ops.xattn_pack_kv(k_, vt_, ehs.shape[1]) if fused else None)  # packed with the projection
+
+            k, vt, pk = self._hoisted(_loose_key(attn, ehs), lambda attn=attn, ehs=ehs: (ehs._version, _pkey(attn.to_k.weight, attn.to_v.weight)), make)
+        if attention_mask is not None:
             # the mask -> fp32 bias conversion is timestep-invariant too: hoisted with the K/V (two tiny torch kernels
             # per masked site per step otherwise)
-            bk = ("bias", _tkey(attention_mask), Lk)
-            if self._kv_cache is None:
-                self._kv_cache = {}
-            bias = self._kv_cache.get(bk)
-            if bias is None:
-                bias = self._kv_cache[bk] = _key_bias(attention_mask, B, Lk)
+            (bias,) = self._hoisted(("bias",) + _loose_key(None, attention_mask) + (Lk,), lambda m=attention_mask: m._version,
+                                    lambda m=attention_mask: (_key_bias(m, B, Lk),))
         else:
-            bias = _key_bias(attention_mask, B, Lk)
+            bias = None
         if encoder_hidden_states is not None and fused and pk is not None:
             wq_p, wo_p = _xattn_weights(attn)
             return ops.fused_cross_attention(hidden_states, wq_p, wo_p, attn.to_out[0].bias, pk, Lk, heads, ln=_ln, key_bias=bias)
@@ -244,6 +290,10 @@ class IPAttnProcessor2_0(nn.Module):
     def clear_kv_cache(self):
         self._kv_cache = None
 
+    refresh_kv_cache = AttnProcessor2_0.refresh_kv_cache
+    drop_kv_owner = AttnProcessor2_0.drop_kv_owner
+    _hoisted = AttnProcessor2_0._hoisted
+
     def _project(self, attn, ehs):
         B = ehs.shape[0]
         nt = self.num_tokens
@@ -285,22 +335,21 @@ class IPAttnProcessor2_0(nn.Module):
         B, N, _ = hidden_states.shape
         if AG.on(hidden_states, ehs, self.to_k_ip.weight, self.to_v_ip.weight):
             return self._call_train(attn, hidden_states, ehs, attention_mask, _residual, _ln)
-        # see AttnProcessor2_0: keyed on the site, the condition content and all four projection weights, so a re-assigned
-        # to_k_ip / to_v_ip (inference.py:56-57) or an optimizer step is never served stale K/V
-        ck = (id(attn), _tkey(ehs), self.num_tokens,
-              _pkey(attn.to_k.weight, attn.to_v.weight, self.to_k_ip.weight, self.to_v_ip.weight))
-        if self.kv_cache_enabled and self._kv_cache is not None and ck in self._kv_cache:
-            kv = self._kv_cache[ck]
-        else:
-            kv = self._project(attn, ehs)
-            k_t, vt_t, Lt, k_a, vt_a, La = kv[:6]
-            if _fused_xattn_ok(attn, hidden_states, _residual, _ln, Lt, La):  # packed once, with the hoisted projection
-                kv = kv[:6] + (ops.xattn_pack_kv(k_t, vt_t, Lt), ops.xattn_pack_kv(k_a, vt_a, La) if La > 0 else None)
-            if self.kv_cache_enabled:
-                if self._kv_cache is None:
-                    self._kv_cache = {}
-                self._kv_cache[ck] = kv
-        k_t, vt_t, Lt, k_a, vt_a, La, pk_t, pk_a = kv
+        # see AttnProcessor2_0: one entry per (site, condition buffer), valid for one condition content and one set of the four
+        # projection weights, so a re-assigned to_k_ip / to_v_ip (inference.py:56-57) or an optimizer step is never served stale K/V
+        Lt0 = min(self.num_tokens, ehs.shape[1])
+        fused = _fused_xattn_ok(attn, hidden_states, _residual, _ln, Lt0, ehs.shape[1] - Lt0)  # (no activation captured below)
+
+        def make(attn=attn, ehs=ehs, fused=fused):
+            kv_ = self._project(attn, ehs)
+            k_t_, vt_t_, Lt_, k_a_, vt_a_, La_ = kv_[:6]
+            if fused:  # packed once, with the hoisted projection
+                kv_ = kv_[:6] + (ops.xattn_pack_kv(k_t_, vt_t_, Lt_), ops.xattn_pack_kv(k_a_, vt_a_, La_) if La_ > 0 else None)
+            return kv_
+
+        sig = lambda attn=attn, ehs=ehs: (ehs._version, self.num_tokens,
+                                          _pkey(attn.to_k.weight, attn.to_v.weight, self.to_k_ip.weight, self.to_v_ip.weight))
+        k_t, vt_t, Lt, k_a, vt_a, La, pk_t, pk_a = self._hoisted(_loose_key(attn, ehs), sig, make)
         bias = None
         if attention_mask is not None:
             # reference :424-428 keeps only mask column 0 (split by the singleton query dim) and broadcasts it

@@ -5,14 +5,22 @@ import torch
 import torch.nn as nn
 
 
-def init_synthetic_(module: nn.Module, seed=100, w_std=0.02, bias_std=0.0, norm_jitter=0.0):
+def init_synthetic_(module: nn.Module, seed=100, w_std=0.02, bias_std=0.0, norm_jitter=0.0, on_device=False):
     """Linear/Conv weights ~ N(0, w_std^2); biases ~ N(0, bias_std^2) (0 for the benchmark config); norm scales
-    1 (+ N(0, norm_jitter^2)), norm shifts N(0, norm_jitter^2)."""
+    1 (+ N(0, norm_jitter^2)), norm shifts N(0, norm_jitter^2).  ``on_device``: draw on each tensor's own device with a
+    device generator (the benchmark: 718 M parameters in a second instead of a minute; the bits then depend on the device,
+    so parity tests keep the CPU generator)."""
     g = torch.Generator().manual_seed(seed)
+    dev_gens = {}
 
     def rn(t, std):
         if std == 0.0:
             t.zero_()
+        elif on_device and t.device.type != "cpu":
+            dg = dev_gens.get(t.device)
+            if dg is None:
+                dg = dev_gens[t.device] = torch.Generator(device=t.device).manual_seed(seed)
+            t.copy_(torch.randn(t.shape, generator=dg, dtype=torch.float32, device=t.device) * std)
         else:
             t.copy_(torch.randn(t.shape, generator=g, dtype=torch.float32) * std)
 

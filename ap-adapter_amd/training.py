@@ -32,7 +32,7 @@ def add_noise(latents, noise, timesteps, alphas_cumprod):
 
 class AdapterTrainer:
     def __init__(self, unet, lr=1e-4, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8, max_grad_norm=1.0,
-                 gradient_accumulation_steps=1):
+                 gradient_accumulation_steps=1, loss_scale=None):
         self.unet = unet
         unet.requires_grad_(False)  # :604 (processors are submodules of the UNet: re-enabled below)
         self.params = adapter_parameters(unet)
@@ -45,6 +45,11 @@ class AdapterTrainer:
         self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        # f16 needs loss scaling (the reference's fp16 mode gets a GradScaler from accelerate): d loss / d pred is ~1e-5 at full
+        # geometry, subnormal in f16.  Static scale 2^16 by default, applied in fp32 inside the loss kernel and removed when a
+        # gradient enters the fp32 accumulator; an overflowed step (non-finite gradient norm) is skipped on the device.  bf16 has
+        # the fp32 exponent range and runs unscaled.
+        self.loss_scale = float(loss_scale) if loss_scale is not None else (65536.0 if dtype == torch.float16 else 1.0)
         self.offsets = []
         off = 0
         for p in self.params:
@@ -52,6 +57,8 @@ class AdapterTrainer:
             self.work[off:off + p.numel()].copy_(p.detach().reshape(-1))
             p.data = self.work[off:off + p.numel()].view(p.shape)  # the kernels now read the flat working copy
             p.requires_grad_(True)
+            # weight gradients are formed in fp32 and accumulated straight into the flat buffer (autograd._Linear)
+            p._apad_grad_sink = (self.grad[off:off + p.numel()].view(p.shape), 1.0 / self.loss_scale)
             self.offsets.append(off)
             off += p.numel()
         self.step_t = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -72,11 +79,11 @@ class AdapterTrainer:
         pred = self.unet(noisy_latents.to(dtype), timesteps, encoder_hidden_states=generated_prompt_embeds.to(dtype),
                          encoder_hidden_states_1=prompt_embeds.to(dtype), encoder_attention_mask_1=attention_mask,
                          return_dict=False)[0]
-        loss = AG.mse_loss(pred, target)
-        loss.backward()
+        loss = AG.mse_loss(pred, target, self.loss_scale)
+        loss.backward()  # adapter weight gradients land in self.grad (fp32, unscaled) through the parameters' grad sinks
         for p, off in zip(self.params, self.offsets):
-            if p.grad is not None:
-                self.grad[off:off + p.numel()].add_(p.grad.reshape(-1))  # fp32 accumulation across micro-batches
+            if p.grad is not None:  # (a gradient that reached the parameter another way, e.g. a foreign layer)
+                self.grad[off:off + p.numel()].add_(p.grad.reshape(-1).float(), alpha=1.0 / self.loss_scale)
                 p.grad = None
         self._micro += 1
         return loss.detach()
@@ -127,13 +134,15 @@ class AdapterTrainer:
     # ---- optimizer step on the accumulation boundary ----
     def optimizer_step(self):
         average_flat_gradient_(self.grad, self._micro)  # the ONE collective of the step (86.5 MB fp32 for -large)
-        ops.step_advance(self.step_t)
         gn = None
-        if self.max_grad_norm and self.max_grad_norm > 0:
+        if (self.max_grad_norm and self.max_grad_norm > 0) or self.loss_scale != 1.0:
             gn = ops.grad_norm(self.grad, out=self.norm_t, ws=self._ws)
+        ops.step_advance_if_finite(self.step_t, gn)  # an overflowed (loss-scaled f16) step is skipped entirely, on the device
         ops.adamw_step(self.master, self.work, self.grad, self.exp_avg, self.exp_avg_sq, gn, self.step_t, self.lr,
                        self.betas, self.eps, self.weight_decay, self.max_grad_norm)
         self.grad.zero_()
+        for p in self.params:  # the kernel wrote the working copy through raw pointers: tell version-keyed caches (K/V hoist)
+            torch.autograd.graph.increment_version(p)
         self._micro = 0
         self.global_step += 1
 

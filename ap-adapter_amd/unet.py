@@ -383,13 +383,28 @@ class AudioLDM2UNet2DConditionModel(nn.Module):
         for name, module in self.named_children():
             rec(name, module)
 
-    def set_kv_cache(self, enabled: bool):
-        """Hoist the timestep-invariant K/V projections of every cross-attention out of the denoise loop (clears any
-        cached K/V).  The caller must clear again whenever the condition tensors or the weights change."""
+    def set_kv_cache(self, enabled: bool, clear=True):
+        """Hoist the timestep-invariant K/V projections of every cross-attention out of the denoise loop.  Hoisted results
+        track what they were computed from (condition version, weight identities) and recompute themselves when it
+        changes; ``clear`` drops them."""
         for p in self.attn_processors.values():
             if hasattr(p, "kv_cache_enabled"):
                 p.kv_cache_enabled = enabled
-                p.clear_kv_cache()
+                if clear:
+                    p.clear_kv_cache()
+
+    def drop_kv_owner(self, owner):
+        """drop the hoisted results created on behalf of ``owner`` (processors.HOIST_OWNER at their creation)"""
+        for p in set(self.attn_processors.values()):
+            if hasattr(p, "drop_kv_owner"):
+                p.drop_kv_owner(owner)
+
+    def refresh_kv_cache(self):
+        """Recompute IN PLACE every hoisted K/V whose condition tensor or weights changed: what a cached hipGraph needs
+        before it is replayed on new conditions copied into its static buffers."""
+        for p in set(self.attn_processors.values()):
+            if hasattr(p, "refresh_kv_cache"):
+                p.refresh_kv_cache()
 
     # ---- time embedding ----
     def _resnets(self):

@@ -293,12 +293,17 @@ int apad_transpose_pad(const void* x, void* xt, int32_t M, int32_t C, int32_t Mp
 
 /* fp32 workspace size of the three reductions below */
 int64_t apad_reduce_workspace_bytes(void);
-/* loss[0] = mean((pred - target)^2) in fp32 (train_apadapter_v2.py:954); dpred = 2 (pred - target) / n in dtype */
+/* loss[0] = mean((pred - target)^2) in fp32 (train_apadapter_v2.py:954); dpred = grad_scale * 2 (pred - target) / n in dtype.
+   grad_scale = the static loss scale of an f16 run (the reference's fp16 mode gets a GradScaler from accelerate), applied in
+   fp32 before the rounding; 1 for bf16 */
 int apad_mse_loss_grad(const void* pred, const float* target, void* dpred, float* loss, float* workspace, int64_t n,
-                       int32_t dtype, void* stream);
+                       float grad_scale, int32_t dtype, void* stream);
 /* norm[0] = ||grad||_2 over the flat fp32 gradient buffer (clip_grad_norm_, :976) */
 int apad_grad_norm(const float* grad, float* norm, float* workspace, int64_t n, void* stream);
-/* clip (coefficient min(1, max_norm / (norm + 1e-6)), read from device) + torch.optim.AdamW update (:763-769) of the
+/* step[0] += 1 unless grad_norm[0] is non-finite (NULL: always): device-side, so the step stays hipGraph-capturable */
+int apad_step_advance_if_finite(int32_t* step, const float* grad_norm, void* stream);
+/* (a non-finite grad_norm[0] -- f16 overflow under loss scaling -- makes the update a no-op)
+   clip (coefficient min(1, max_norm / (norm + 1e-6)), read from device) + torch.optim.AdamW update (:763-769) of the
    flat fp32 master parameters; `work` (optional) receives the updated parameters in `dtype` for the forward kernels.
    step[0] = index of this step (>= 1), device int32. */
 int apad_adamw_step(float* param, void* work, const float* grad, float* exp_avg, float* exp_avg_sq, const float* grad_norm,

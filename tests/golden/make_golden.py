@@ -111,3 +111,21 @@ def write_copied_cross_attention_index():
 
 if __name__ == "__main__":
     write_copied_cross_attention_index()
+
+
+def make_task_presets(out_path=None):
+    """tests/golden/task_presets.json: the reference's own ``get_config(task)`` outputs (/root/reference/config.py), imported and
+    run in the build container -- what ap_adapter_amd.config.get_config is pinned against."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("refcfg", "/root/reference/config.py")
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    out_path = out_path or os.path.join(os.path.dirname(os.path.abspath(__file__)), "task_presets.json")
+    with open(out_path, "w") as f:
+        json.dump({t: m.get_config(t) for t in ("timbre_transfer", "style_transfer", "accompaniment_generation", "test")}, f,
+                  indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    make_task_presets()

@@ -67,6 +67,49 @@ def test_dp_world2_gloo():
     assert n0 == n1 == 32
 
 
+def _sharded_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import ap_adapter_amd as A
+    from ap_adapter_amd import distributed as D, sharded as S
+    D.init_from_env("gloo")
+    cfg = A.get_config("timbre_transfer")
+    La = A.config.audio_tokens(cfg)
+    clips = S.list_clips([f"a{i}.wav" for i in range(3)], cfg, 7)
+    enc = lambda path, tp, fp: (torch.full((La, 768), float(int(path[1]))), torch.zeros(La, 768))
+    den = lambda lat, gen, t5, mask, gs: lat * 2 + gen[lat.shape[0]:, 8, 0].reshape(-1, 1, 1, 1) + t5[lat.shape[0]:, 0, 0].reshape(-1, 1, 1, 1)
+    local = S.run_sharded(clips, cfg, enc, den, batch=2, rank=rank, world=world, latent_shape=(8, 4, 16))
+    allc = S.gather_clips(local, len(clips), rank, world)
+    q.put((rank, sorted(local), torch.stack(allc)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_job_world2_equals_world1():
+    """cfg 4: clip i -> rank i mod world, per-clip seeds, one gather at the end: the gathered latents of a 2-rank job
+    are, clip for clip, those of the 1-rank job"""
+    import ap_adapter_amd as A
+    from ap_adapter_amd import sharded as S
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=240) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == [0, 2, 4, 6] and res[1][1] == [1, 3, 5]
+    assert torch.equal(res[0][2], res[1][2])
+    cfg = A.get_config("timbre_transfer")
+    La = A.config.audio_tokens(cfg)
+    clips = S.list_clips([f"a{i}.wav" for i in range(3)], cfg, 7)
+    enc = lambda path, tp, fp: (torch.full((La, 768), float(int(path[1]))), torch.zeros(La, 768))
+    den = lambda lat, gen, t5, mask, gs: lat * 2 + gen[lat.shape[0]:, 8, 0].reshape(-1, 1, 1, 1) + t5[lat.shape[0]:, 0, 0].reshape(-1, 1, 1, 1)
+    one = S.gather_clips(S.run_sharded(clips, cfg, enc, den, batch=3, latent_shape=(8, 4, 16)), len(clips))
+    assert torch.equal(torch.stack(one), res[0][2])
+
+
 def test_single_process_is_a_noop():
     from ap_adapter_amd import distributed as D
     assert D.shard_clips(5, 0, 1) == [0, 1, 2, 3, 4]

@@ -169,6 +169,47 @@ def test_mse_loss_grad(dev):
     assert rel_err(pd.grad, pl.grad) < TOL[torch.bfloat16]
 
 
+def test_mse_loss_scaling_keeps_f16_gradients(dev):
+    """at full geometry d loss / d pred = 2 (p - t) / (B*8*250*16) is ~1e-5: subnormal in f16.  The static loss
+    scale is applied in fp32 inside the kernel, before the rounding; unscaled f16 loses most of the gradient's precision"""
+    from ap_adapter_amd import autograd as AG
+    pred = q(R(4, 8, 250, 16, seed=51), torch.float16)
+    tgt = R(4, 8, 250, 16, seed=52)
+    exact = 2.0 * (pred - tgt) / pred.numel()
+    pd = pred.to(dev, torch.float16).requires_grad_(True)
+    AG.mse_loss(pd, tgt.to(dev), 65536.0).backward()
+    scaled = pd.grad.float().cpu() / 65536.0
+    assert rel_err(scaled, exact) < TOL[torch.float16]
+    pd2 = pred.to(dev, torch.float16).requires_grad_(True)
+    AG.mse_loss(pd2, tgt.to(dev)).backward()
+    assert rel_err(pd2.grad, exact) > 10 * rel_err(scaled, exact)  # what the scale is for
+
+
+def test_trainer_f16_loss_scale_and_overflow_skip(dev):
+    """AdapterTrainer in f16: gradients reach the fp32 accumulator unscaled; a step whose gradient norm is not finite (forced
+    here by an absurd scale) changes neither the weights, nor the moments, nor the bias-correction step index"""
+    import ap_adapter_amd as A
+    u, cfg, sd, procs = _small_unet(dev, torch.float16)
+    tr = A.AdapterTrainer(u, lr=1e-3)
+    assert tr.loss_scale == 65536.0
+    lat, noise, t, ehs, ehs1, m1 = _batch(2, 8, torch.float16)
+    D = lambda x: x.to(dev)
+    tr.micro_step(D(lat), D(t), D(ehs), D(ehs1), D(m1), D(noise))
+    g1 = tr.grad.clone()
+    assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0
+    u2, *_ = _small_unet(dev, torch.float16)
+    tr2 = A.AdapterTrainer(u2, lr=1e-3, loss_scale=1.0)  # the same gradient without scaling, up to f16 rounding of the chain
+    tr2.micro_step(D(lat), D(t), D(ehs), D(ehs1), D(m1), D(noise))
+    assert 1 - float(F.cosine_similarity(g1.double(), tr2.grad.double(), dim=0)) < 1e-2
+    tr.optimizer_step()
+    assert int(tr.step_t.item()) == 1
+    before = tr.master.clone()
+    tr.grad.fill_(float("inf"))
+    tr._micro = 1
+    tr.optimizer_step()
+    assert torch.equal(tr.master, before) and int(tr.step_t.item()) == 1 and torch.isfinite(tr.exp_avg).all()
+
+
 def test_grad_norm_and_adamw_match_the_oracle(dev):
     """clip coefficient + AdamW over a flat buffer, 3 steps, against oracle/train.py (itself pinned to torch.optim.AdamW)"""
     from ap_adapter_amd import ops

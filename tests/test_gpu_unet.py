@@ -1,4 +1,6 @@
 """-m gpu: UNet / AudioMAE / pipeline on the HIP path against the oracle chain on the same seeded weights and inputs."""
+import os
+
 import pytest
 import torch
 
@@ -274,3 +276,99 @@ def test_full_size_scale_zero_ignores_the_audio_tokens(dev, full_pipe):
             p.scale = 0.55
     assert torch.equal(a, b)
     assert not torch.equal(a, base)
+
+
+# ---- hipGraph reuse across pipeline calls, and the cfg 4 driver ----
+def test_graph_is_captured_once_and_replayed_on_new_conditions(dev):
+    """a sharded job runs batch after batch through ONE pipeline: the step is captured for the first batch; later batches copy
+    their latents / conditions into the graph's static buffers, the hoisted K/V are recomputed in place, and the result is
+    bit-identical to a fresh, un-cached run on the same inputs.  A changed adapter weight or ap_scale forces a re-capture."""
+    import ap_adapter_amd as A
+    dtype = torch.bfloat16
+    u, cfg, sd, procs = _small_unet(dev, dtype)
+    u.requires_grad_(False)
+    B, H, W, steps, gs = 2, 26, 16, 3, 7.5
+    pipe = A.AudioLDM2Pipeline(u)
+
+    def inputs(seed):
+        lat = torch.randn(B, 8, H, W, generator=torch.Generator().manual_seed(seed)).to(dev)
+        ehs, ehs1, m1 = _cond(2 * B, 32, dtype, seed=seed)
+        if seed % 2:
+            m1 = m1.clone()
+            m1[0, -6:] = 0  # a different mask too
+        return lat, ehs.to(dev), ehs1.to(dev), m1.to(dev)
+
+    a1 = pipe.denoise(*inputs(1), steps, gs)
+    assert (pipe.graph_captures, pipe.graph_hits) == (1, 0)
+    a2 = pipe.denoise(*inputs(2), steps, gs)
+    a3 = pipe.denoise(*inputs(3), steps, gs)
+    a1b = pipe.denoise(*inputs(1), steps, gs)
+    assert (pipe.graph_captures, pipe.graph_hits) == (1, 3)
+    assert torch.equal(a1, a1b) and not torch.equal(a1, a2)
+    fresh = A.AudioLDM2Pipeline(u)
+    assert torch.equal(fresh.denoise(*inputs(2), steps, gs), a2)
+    assert torch.equal(fresh.denoise(*inputs(3), steps, gs, use_graph=False), a3)
+    # weights change -> the cached graph is not reused
+    ip = [p for p in u.attn_processors.values() if hasattr(p, "to_k_ip")]
+    ip[0].to_k_ip.weight = torch.nn.Parameter(ip[0].to_k_ip.weight.detach() * 1.5, requires_grad=False)
+    b1 = pipe.denoise(*inputs(1), steps, gs)
+    assert pipe.graph_captures == 2 and not torch.equal(b1, a1)
+    for p in ip:
+        p.scale = 0.0
+    c1 = pipe.denoise(*inputs(1), steps, gs)
+    assert pipe.graph_captures == 3 and not torch.equal(c1, b1)
+    pipe.clear_graphs()
+    assert all(not p._kv_cache for p in u.attn_processors.values())
+
+
+def test_cfg4_driver_world1_small(dev, tmp_path):
+    """tools/run_sharded.py's path at world size 1 on a small UNet: synthetic wavs -> Kaldi fbank -> AudioMAE (fp32) -> per-clip
+    conditions -> CFG + DDIM, 5 clips in batches of 2 (one capture, two replays on new conditions, last batch padded); a clip's
+    latents do not depend on its batch"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import run_sharded as RS
+    import ap_adapter_amd as A
+    from ap_adapter_amd import sharded as S
+    from ap_adapter_amd.frontend import load_mel
+    cfg = A.get_config("timbre_transfer")
+    files = RS.write_synthetic_wavs(str(tmp_path), n=3, seconds=2.0)
+    clips = S.list_clips(files, cfg, 5)
+    pipe = RS.build_job(dev, torch.bfloat16, cfg, small=True)
+    enc = lambda path, tp, fp: tuple(t[0] for t in pipe.encode_audio(load_mel(path, device=dev), tp, fp))
+    den = lambda lat, gen, t5, mask, gs: pipe.denoise(lat, gen, t5, mask, 3, gs)
+    out = S.run_sharded(clips, cfg, enc, den, batch=2, latent_shape=(8, 24, 16), device=dev)
+    assert sorted(out) == [0, 1, 2, 3, 4] and all(torch.isfinite(v).all() for v in out.values())
+    assert (pipe.graph_captures, pipe.graph_hits) == (1, 2)
+    tok, unc = enc(files[0], 2, 2)
+    assert tok.shape == unc.shape == (128, 768) and tok.dtype == torch.float32 and not torch.equal(tok, unc)
+    solo = S.run_sharded([clips[3]], cfg, enc, den, batch=2, latent_shape=(8, 24, 16), device=dev)
+    assert torch.equal(solo[3], out[3])
+
+
+def test_rccl_world1_flat_gradient_allreduce(dev):
+    """BASELINE cfg 5's one collective on the GPU flat buffer through RCCL (backend "nccl"), world size 1: initialisation, the
+    all-reduce on a device tensor and the mean over micro-batches at least execute on this hardware (the 8-GPU run is the
+    driver's)"""
+    import socket
+    import torch.distributed as dist
+    from ap_adapter_amd import distributed as D
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        flat = torch.full((21_626_880,), 3.0, dtype=torch.float32, device=dev)  # the -large adapter's gradient buffer: 86.5 MB
+        flat[-1] = 7.0
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        assert float(flat[-1]) == 7.0 and float(flat[0]) == 3.0 and float(flat.double().sum()) == 3.0 * 21_626_879 + 7.0
+        small = torch.full((8,), 6.0, device=dev)
+        assert D.average_flat_gradient_(small, micro_batches=3) == 3.0 and torch.allclose(small, torch.full((8,), 2.0, device=dev))
+        lat = torch.ones(2, 3, device=dev)
+        assert D.gather_latents(lat) is lat
+    finally:
+        dist.destroy_process_group()

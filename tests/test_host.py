@@ -47,6 +47,72 @@ def test_reference_wiring_loop_selects_the_same_sites(unet):
     assert picked == A.ip_layer_names(unet)
 
 
+def _tiny_unet():
+    return A.AudioLDM2UNet2DConditionModel(A.UNetConfig(block_out_channels=(32, 64, 96, 128), attention_head_dim=4,
+                                                        transformer_layers_per_block=1))
+
+
+def test_do_copy_warm_start_reads_the_reference_file_format(tmp_path):
+    """f-1: attention_processor.py:328-344 -- ``do_copy=True`` loads ``copied_cross_attention/<name>_{k,v}.bin`` (pickled fp16
+    nn.Parameter, written by copy_weight.py:58-63) as fp32 trainable to_k_ip / to_v_ip.  Through the constructor, through
+    install_ap_adapter, and copy_frozen_kv gives the same warm start without files."""
+    from make_copied_fixture import write_copied_cross_attention
+    u = _tiny_unet()
+    files = write_copied_cross_attention(u, str(tmp_path))
+    names = A.ip_layer_names(u)
+    assert len(files) == 2 * len(names) == 32
+    # the constructor path, exactly as the reference calls it
+    n0 = names[0]
+    C_ = u.get_submodule(n0[: -len(".processor")]).to_q.in_features
+    proc = A.IPAttnProcessor2_0(hidden_size=C_, name=n0, cross_attention_dim=768, num_tokens=8, scale=0.5, do_copy=True,
+                                copy_dir=str(tmp_path))
+    for which, lin in (("k", proc.to_k_ip), ("v", proc.to_v_ip)):
+        assert lin.weight.dtype == torch.float32 and lin.weight.requires_grad and isinstance(lin.weight, torch.nn.Parameter)
+        assert torch.equal(lin.weight.detach(), files[f"{n0}_{which}.bin"].float())
+    # the wiring path: every adapted site
+    procs = A.install_ap_adapter(u, None, scale=0.5, do_copy=True, copy_dir=str(tmp_path))
+    for n in names:
+        assert torch.equal(procs[n].to_k_ip.weight.detach(), files[n + "_k.bin"].float())
+        assert torch.equal(procs[n].to_v_ip.weight.detach(), files[n + "_v.bin"].float())
+    # the environment-variable default directory
+    os.environ["APADAPTER_COPIED_CROSS_ATTENTION"] = str(tmp_path)
+    try:
+        p2 = A.IPAttnProcessor2_0(hidden_size=C_, name=n0, cross_attention_dim=768, do_copy=True)
+        assert torch.equal(p2.to_v_ip.weight.detach(), files[n0 + "_v.bin"].float())
+    finally:
+        del os.environ["APADAPTER_COPIED_CROSS_ATTENTION"]
+    with pytest.raises(FileNotFoundError):
+        A.IPAttnProcessor2_0(hidden_size=C_, name="no.such.layer.processor", cross_attention_dim=768, do_copy=True, copy_dir=str(tmp_path))
+
+
+def test_copy_frozen_kv_equals_what_copy_weight_extracts():
+    """copy_weight.py:44-63 saves each adapted layer's frozen attn2.to_k / to_v; copy_frozen_kv installs the same tensors
+    directly"""
+    from ap_adapter_amd.wiring import copy_frozen_kv
+    u = _tiny_unet()
+    A.install_ap_adapter(u, None, scale=0.5)
+    copy_frozen_kv(u)
+    for n, p in u.attn_processors.items():
+        if hasattr(p, "to_k_ip"):
+            attn = u.get_submodule(n[: -len(".processor")])
+            assert torch.equal(p.to_k_ip.weight, attn.to_k.weight) and torch.equal(p.to_v_ip.weight, attn.to_v.weight)
+            assert p.to_k_ip.weight.data_ptr() != attn.to_k.weight.data_ptr()  # a copy: training must not move the frozen weight
+            assert isinstance(p.to_k_ip.weight, torch.nn.Parameter)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/copied_cross_attention"), reason="the reference tree is only in the build container")
+def test_do_copy_loads_real_reference_files():
+    """build container only: two of the 64 real files (fp16 [C, 768]) through the same loader"""
+    u = A.AudioLDM2UNet2DConditionModel()
+    d = "/root/reference/copied_cross_attention"
+    for n in (A.ip_layer_names(u)[0], A.ip_layer_names(u)[-1]):
+        C_ = u.get_submodule(n[: -len(".processor")]).to_q.in_features
+        p = A.IPAttnProcessor2_0(hidden_size=C_, name=n, cross_attention_dim=768, num_tokens=8, do_copy=True, copy_dir=d)
+        assert list(p.to_k_ip.weight.shape) == INDEX[n + "_k.bin"] == [C_, 768]
+        assert p.to_k_ip.weight.dtype == torch.float32 and p.to_k_ip.weight.requires_grad
+        assert 0.003 < float(p.to_k_ip.weight.detach().std()) < 0.1  # real weights (SURVEY 8c: std 0.007-0.066)
+
+
 def test_install_and_checkpoint_roundtrip(tmp_path):
     cfg = A.UNetConfig(block_out_channels=(32, 64, 96, 128), attention_head_dim=4, transformer_layers_per_block=1)
     u = A.AudioLDM2UNet2DConditionModel(cfg)
@@ -211,3 +277,41 @@ def test_condition_assembly_matches_the_oracle_token_order():
     ref = OA.assemble_condition(gen, a, u).to(torch.bfloat16)
     assert out.dtype == torch.bfloat16 and out.shape == (6, 40, 768) and out.is_contiguous()
     assert torch.equal(out, ref)
+
+
+def test_task_presets_equal_the_reference():
+    """config.py:2-82 -- pinned by the reference's own get_config outputs (tests/golden/task_presets.json, written by
+    tests/golden/make_golden.py::make_task_presets from an import of the reference)"""
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "task_presets.json")))
+    assert set(A.config.TASKS) == set(want)
+    for t in want:
+        assert A.get_config(t) == want[t]
+    assert [A.config.audio_tokens(A.get_config(t)) for t in ("timbre_transfer", "style_transfer")] == [128, 32]
+    with pytest.raises(KeyError):
+        A.get_config("no_such_task")
+
+
+def test_sharded_job_single_rank_order_padding_and_seeds():
+    """cfg 4 driver logic without a GPU (stub encoder / denoiser): clips enumerate (file, prompt) pairs, the last batch is padded
+    to the job's one geometry, conditions are laid out unconditional-half-first / text-tokens-first, latents depend on the clip
+    only"""
+    from ap_adapter_amd import sharded as S
+    cfg = A.get_config("style_transfer")
+    files = [f"a{i}.wav" for i in range(3)]
+    clips = S.list_clips(files, cfg, 7)
+    assert [c["audio"] for c in clips] == ["a0.wav", "a1.wav", "a2.wav"] * 2 + ["a0.wav"]
+    assert [c["prompt"] for c in clips] == ["Jazz style music"] * 3 + ["Rock style music"] * 3 + ["Pop style music"]
+    La, calls = A.config.audio_tokens(cfg), []
+    enc = lambda path, tp, fp: (torch.full((La, 768), float(int(path[1]))), torch.zeros(La, 768))
+
+    def den(lat, gen, t5, mask, gs):
+        calls.append((tuple(lat.shape), tuple(gen.shape), tuple(t5.shape), gs))
+        b = lat.shape[0]
+        assert torch.equal(gen[:b, 8:], torch.zeros(b, La, 768))             # unconditional half first, audio tokens after the text
+        return lat + gen[b:, 8, 0].reshape(b, 1, 1, 1)                        # + the clip's audio id
+
+    out = S.run_sharded(clips, cfg, enc, den, batch=4, latent_shape=(8, 6, 16))
+    assert calls == [((4, 8, 6, 16), (8, 8 + La, 768), (8, 16, 1024), 9.5)] * 2  # 7 clips -> two batches of the SAME geometry
+    for c in clips:
+        assert torch.equal(out[c["index"]], S.clip_latents(c["index"], (8, 6, 16)) + float(int(c["audio"][1])))
+    assert torch.equal(S.gather_clips(out, 7)[5], out[5])
