@@ -113,17 +113,15 @@ def time_kernel_graphed(fn, iters=20, reps=3):
 
 def profile_in_step_avg_us(substr):
     """average in-step duration (us) of the kernel whose name contains `substr`, from the committed rocprofv3 kernel-trace
-    summary of this bench command (profiles/, newest round first), or None"""
+    summary of `bench.py --step-only` (profiles/r*_bench_kernel_stats*.txt: columns pct calls avg_us min_us max_us name; newest
+    first), or (None, None)"""
     import glob
-    import re
     pdir = os.path.join(ROOT, "profiles")
     for path in sorted(glob.glob(os.path.join(pdir, "r*_bench_kernel_stats*.txt")), reverse=True):
         with open(path) as f:
             for line in f:
-                if substr in line:
-                    m = re.search(r"avg\s*([0-9.]+)\s*us", line) or re.search(r"([0-9.]+)\s*us\s*avg", line)
-                    if m:
-                        return float(m.group(1)), os.path.relpath(path, ROOT)
+                if substr in line and not line.startswith("#"):
+                    return float(line.split()[2]), os.path.relpath(path, ROOT)
     return None, None
 
 
@@ -351,6 +349,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="2 = run the two CFG halves on concurrent streams")
     ap.add_argument("--low-res-streams", type=int, default=1, help="n > 0: run the two batch halves of the n lowest-resolution levels on two streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--step-only", action="store_true", help="only the timed step (for rocprofv3 runs: no roofline re-timings, no AudioMAE, no CPU leg)")
     ap.add_argument("--train", action="store_true", help="time BASELINE cfg 5 (the adapter's training step) instead of the denoise step")
     ap.add_argument("--train-batch", type=int, default=4)
     args = ap.parse_args()
@@ -483,6 +482,9 @@ def main():
             # one-off per pipeline call, outside the timed region: time tables, K/V hoist + packing, warm-up step, graph capture
             "setup_ms": round(setup_ms, 1), "model_build_ms": round(build_ms, 1),
         }
+        if args.step_only:
+            print(json.dumps(line))
+            return
         line["roofline"] = dominant_kernel_roofline(dev, dtype, 2 * B)
         line["fused_attn2"] = fused_attn2_roofline(dev, dtype, 2 * B, args.la, args.ap_scale)
         # the audio-condition encoder (2 mels per call: clip + zeros) is outside the timed loop; reported
