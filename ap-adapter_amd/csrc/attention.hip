@@ -45,6 +45,10 @@ struct AttnP {
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float NEG_BIG = -1.0e30f;
 constexpr int KT = 64;  // keys per LDS tile
+#ifndef APAD_ABL
+#define APAD_ABL 0  // ablation probes of the key loop (tools/ab_build.sh builds only): 1 no exp, 2 no score MFMAs, 4 no P.V MFMAs, 8 no staging
+#endif
+
 
 template <int D> struct Lay {
     static constexpr int KROW = (D + 8) * 2;           // K tile row stride (bytes): D/8 + 1 sixteen-byte slots (odd)
@@ -153,11 +157,17 @@ __device__ __forceinline__ void tile_compute(const uint8_t* buf, int key0, int L
     for (int u = 0; u < 2; ++u) {
         if (u == 1 && one_sub) break;
         const uint8_t* kp = buf + (u * 32 + l31) * Y::KROW + half * 16;
+        if (APAD_ABL & 2) {
+            const uint4 kq = *reinterpret_cast<const uint4*>(kp);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[u][r] = __uint_as_float(kq.x + r) * 1e-30f;
+        } else {
         s[u] = E::mfma32(as_v8<DT>(*reinterpret_cast<const uint4*>(kp)), qf[0], zero16);
 #pragma unroll
         for (int cc = 1; cc < KC; ++cc) {
             typename E::v8 kf = as_v8<DT>(*reinterpret_cast<const uint4*>(kp + cc * 32));
             s[u] = E::mfma32(kf, qf[cc], s[u]);
+        }
         }
     }
     float tmax = NEG_BIG;
@@ -211,8 +221,8 @@ __device__ __forceinline__ void tile_compute(const uint8_t* buf, int key0, int L
             for (int r = 0; r < 16; r += 2) {
                 f32x2 v = {s[u][r], s[u][r + 1]};
                 v = __builtin_elementwise_fma(v, c2, nm2);
-                s[u][r] = __builtin_amdgcn_exp2f(v[0]);
-                s[u][r + 1] = __builtin_amdgcn_exp2f(v[1]);
+                s[u][r] = (APAD_ABL & 1) ? v[0] * 0.5f : __builtin_amdgcn_exp2f(v[0]);
+                s[u][r + 1] = (APAD_ABL & 1) ? v[1] * 0.5f : __builtin_amdgcn_exp2f(v[1]);
                 osum += (f32x2){s[u][r], s[u][r + 1]};
             }
     }
@@ -231,7 +241,8 @@ __device__ __forceinline__ void tile_compute(const uint8_t* buf, int key0, int L
             uint2 v0 = *reinterpret_cast<const uint2*>(vp);
             uint2 v1 = *reinterpret_cast<const uint2*>(vp + 16);
             typename E::v8 vf = as_v8<DT>(make_uint4(v0.x, v0.y, v1.x, v1.y));
-            o[dt] = E::mfma32(vf, pf, o[dt]);
+            if (APAD_ABL & 4) o[dt][st] += (float)vf[0] * (float)pf[0];
+            else o[dt] = E::mfma32(vf, pf, o[dt]);
         }
     }
 }
@@ -271,9 +282,11 @@ __device__ __forceinline__ void segment(uint8_t* smem, const uint8_t* kbase, int
         if (t + 1 < nfull)  // the next tile is a full one too
             tile_load_full<D>(rk, rv, kbase + (int64_t)(t + 1) * KT * k_sl * 2, vbase + (int64_t)(t + 1) * KT * 2, koff, voff, tid);
         else if (t + 1 < ntiles) tile_load<D>(rk, rv, kbase, k_sl, vbase, L, Lpad, (t + 1) * KT, tid);
-        tile_compute<DT, D, false>(buf, t * KT, L, bias, c, qf, o, osum, m, l31, half);
+        tile_compute<DT, D, false>((APAD_ABL & 8) ? smem : buf, t * KT, L, bias, c, qf, o, osum, m, l31, half);
+        if (!(APAD_ABL & 8)) {
         if (t + 1 < ntiles) tile_store<D>(rk, rv, smem + ((t + 1) & 1) * Y::BUF, tid);
         __syncthreads();
+        }
     }
     for (; t < ntiles; ++t) {
         const uint8_t* buf = smem + (t & 1) * Y::BUF;
