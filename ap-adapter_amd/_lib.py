@@ -16,8 +16,8 @@ LIB_PATH = os.environ.get("APAD_LIB_PATH") or os.path.join(_HERE, "libapadapter_
 CSRC = os.path.join(_HERE, "csrc")
 
 BF16, F16, F32 = 0, 1, 2
-A_PLAIN, A_CONV3X3, A_PATCH16 = 0, 1, 2
-EPI_NONE, EPI_SILU, EPI_GELU, EPI_GEGLU = 0, 1, 2, 3
+A_PLAIN, A_CONV3X3, A_PATCH16, A_CONV1D = 0, 1, 2, 4
+EPI_NONE, EPI_SILU, EPI_GELU, EPI_GEGLU, EPI_TANH = 0, 1, 2, 3, 4
 OUT_ROWMAJOR, OUT_VT, OUT_QKV = 0, 1, 2
 
 _vp, _i64, _i32, _f32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float
@@ -28,7 +28,8 @@ class GemmDesc(C.Structure):
                [(n, _i64) for n in ("M", "N", "K", "lda", "ldw", "ldo", "ldr", "ld_rg", "rows_per_group")] + \
                [(n, _i32) for n in ("a_mode", "epilogue", "out_mode", "dtype", "Hin", "Win", "Cin", "Hout", "Wout",
                                     "stride", "Hup", "Wup", "src_batch_mod", "residual_row_mod", "heads", "head_dim", "L", "Lpad")] + \
-               [("out2", _vp), ("out3", _vp)]
+               [("out2", _vp), ("out3", _vp)] + \
+               [(n, _i32) for n in ("taps", "dilation", "pad", "transposed", "a_pre_act")] + [("a_pre_slope", _f32)]
 
 
 class AttnDesc(C.Structure):
@@ -97,6 +98,7 @@ SYMBOLS = {
     "apad_timestep_embedding": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
     "apad_cfg_ddim_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _i32, _i64, _i32, _vp]),
     "apad_step_advance": (C.c_int, [_vp, _vp]),
+    "apad_mix3": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _i32, _vp]),
     # training step (a-11)
     "apad_sizeof_attn_bwd_desc": (C.c_int, []),
     "apad_echo_attn_bwd_desc": (C.c_int, [C.POINTER(AttnBwdDesc), C.POINTER(C.c_double), C.c_int]),

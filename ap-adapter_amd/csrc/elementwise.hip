@@ -91,6 +91,12 @@ __global__ __launch_bounds__(256) void cfg_ddim_kernel(const uint8_t* eps2, floa
 
 __global__ void step_advance_kernel(int32_t* p) { *p = *p + 1; }
 
+template <int DT> __global__ __launch_bounds__(256) void mix3_kernel(const uint8_t* a, const uint8_t* b, const uint8_t* c, uint8_t* out, int64_t n,
+                                                                     float scale) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        st_elem<DT>(out, i, (ld_elem<DT>(a, i) + ld_elem<DT>(b, i) + ld_elem<DT>(c, i)) * scale);
+}
+
 }  // namespace
 
 extern "C" int apad_audiomae_pool(const void* rep, void* out, int32_t B, int32_t tp, int32_t fp, int32_t dtype,
@@ -160,6 +166,19 @@ extern "C" int apad_cfg_ddim_step(const void* eps2, float* latents, void* unet_i
         hipLaunchKernelGGL((cfg_ddim_kernel<APAD_F16>), dim3((unsigned)blocks), dim3(256), 0, s, (const uint8_t*)eps2, latents,
                            (uint8_t*)unet_in, eps_out, coef, step_ptr, guidance_scale, total);
     return apad_check_launch("apad_cfg_ddim_step");
+}
+
+extern "C" int apad_mix3(const void* a, const void* b, const void* c, void* out, int64_t n, float scale, int32_t dtype, void* stream) {
+    APAD_CHECK(a && b && c && out && n > 0, "apad_mix3: bad operands");
+    APAD_CHECK(dtype == APAD_BF16 || dtype == APAD_F16 || dtype == APAD_F32, "apad_mix3: dtype %d not supported", dtype);
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipStream_t s = (hipStream_t)stream;
+    const uint8_t *pa = (const uint8_t*)a, *pb = (const uint8_t*)b, *pc = (const uint8_t*)c;
+    if (dtype == APAD_F32) hipLaunchKernelGGL((mix3_kernel<APAD_F32>), dim3((unsigned)blocks), dim3(256), 0, s, pa, pb, pc, (uint8_t*)out, n, scale);
+    else if (dtype == APAD_BF16) hipLaunchKernelGGL((mix3_kernel<APAD_BF16>), dim3((unsigned)blocks), dim3(256), 0, s, pa, pb, pc, (uint8_t*)out, n, scale);
+    else hipLaunchKernelGGL((mix3_kernel<APAD_F16>), dim3((unsigned)blocks), dim3(256), 0, s, pa, pb, pc, (uint8_t*)out, n, scale);
+    return apad_check_launch("apad_mix3");
 }
 
 extern "C" int apad_step_advance(int32_t* step_ptr, void* stream) {

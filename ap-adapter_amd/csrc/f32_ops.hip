@@ -46,6 +46,8 @@ struct G32P {
     int32_t Hin, Win, Cin, Hout, Wout, stride, Hup, Wup, src_batch_mod, res_mod;
     int32_t heads, head_dim, L, Lpad;
     int32_t epi, outmode, n_tiles;
+    int32_t taps, dilation, pad, transposed, pre_act;  // APAD_A_CONV1D
+    float pre_slope;
 };
 
 // float offset of 16-byte chunk `chunk` (0..7) of tile row `row` (the swizzle of gemm.hip's lds_off)
@@ -73,6 +75,23 @@ template <int AMODE> __device__ __forceinline__ f4 load_a32(const G32P& p, const
             ix = (int)(((int64_t)ix * p.Win) / p.Wup);
         }
         return *reinterpret_cast<const f4*>(p.a + ((r.base * p.Hin + iy) * p.Win + ix) * p.Cin + c);
+    } else if (AMODE == APAD_A_CONV1D) {  // channels-last [B][Hin][Cin]; r.base = b, r.oy = t; k = (tap, c)
+        const int tap = k / p.Cin, c = k - tap * p.Cin;
+        int ti;
+        if (p.transposed) {
+            const int num = r.oy + p.pad - tap;
+            ti = num / p.stride;
+            if (num < 0 || ti * p.stride != num) return z;
+        } else {
+            ti = r.oy + tap * p.dilation - p.pad;
+        }
+        if (ti < 0 || ti >= p.Hin) return z;
+        f4 v = *reinterpret_cast<const f4*>(p.a + ((int64_t)r.base * p.Hin + ti) * p.Cin + c);
+        if (p.pre_act) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.pre_slope;
+        }
+        return v;
     } else {  // PATCH16: mel [B][Hin][Win]; k = py * 16 + px
         const int py = k >> 4, px = k & 15;
         return *reinterpret_cast<const f4*>(p.a + (r.base * p.Hin + r.oy * 16 + py) * p.Win + r.ox * 16 + px);
@@ -118,6 +137,10 @@ template <int AMODE> __global__ __launch_bounds__(256) void gemm_f32_kernel(G32P
                 ra[i].oy = rem / p.Wout;
                 ra[i].ox = rem - ra[i].oy * p.Wout;
                 ra[i].base = p.src_batch_mod > 0 ? b % p.src_batch_mod : b;
+            } else if (AMODE == APAD_A_CONV1D) {
+                const int64_t b = m / p.Hout;
+                ra[i].oy = (int)(m - b * p.Hout);
+                ra[i].base = b;
             } else {
                 const int wp = p.Win >> 4, hp = p.Hin >> 4;
                 const int64_t b = m / (hp * wp);
@@ -185,6 +208,7 @@ template <int AMODE> __global__ __launch_bounds__(256) void gemm_f32_kernel(G32P
             }
             if (p.epi == APAD_EPI_SILU) v = silu_p(v);
             if (p.epi == APAD_EPI_GELU) v = gelu_p(v);
+            if (p.epi == APAD_EPI_TANH) v = tanhf(v);
             ct[ml * CLD + nl] = v;
         }
     }
@@ -496,7 +520,9 @@ int apad_f32_gemm(const apad_gemm_desc* d, hipStream_t s) {
     p.stride = d->stride; p.Hup = d->Hup; p.Wup = d->Wup; p.src_batch_mod = d->src_batch_mod; p.res_mod = d->residual_row_mod;
     p.heads = d->heads; p.head_dim = d->head_dim; p.L = d->L; p.Lpad = d->Lpad;
     p.epi = d->epilogue; p.outmode = d->out_mode;
-    APAD_CHECK(d->epilogue >= APAD_EPI_NONE && d->epilogue <= APAD_EPI_GEGLU, "apad_gemm(f32): unknown epilogue %d", d->epilogue);
+    APAD_CHECK(d->epilogue >= APAD_EPI_NONE && d->epilogue <= APAD_EPI_TANH, "apad_gemm(f32): unknown epilogue %d", d->epilogue);
+    p.taps = d->taps; p.dilation = d->dilation; p.pad = d->pad; p.transposed = d->transposed; p.pre_act = d->a_pre_act;
+    p.pre_slope = d->a_pre_slope;
     if (d->a_mode == APAD_A_PLAIN) {
         APAD_CHECK(d->lda % 4 == 0, "apad_gemm(f32): lda must be a multiple of 4");
     } else if (d->a_mode == APAD_A_CONV3X3) {
@@ -512,6 +538,12 @@ int apad_f32_gemm(const apad_gemm_desc* d, hipStream_t s) {
                    "apad_gemm(f32): patch16 supports epilogue NONE / row-major output only");
         APAD_CHECK(d->K == 256 && d->Hin % 16 == 0 && d->Win % 16 == 0, "apad_gemm(f32): patch16 needs K==256 and H,W %% 16 == 0");
         APAD_CHECK(d->M % ((int64_t)(d->Hin / 16) * (d->Win / 16)) == 0, "apad_gemm(f32): patch16 M inconsistent");
+    } else if (d->a_mode == APAD_A_CONV1D) {
+        APAD_CHECK((d->epilogue == APAD_EPI_NONE || d->epilogue == APAD_EPI_TANH) && d->out_mode == APAD_OUT_ROWMAJOR,
+                   "apad_gemm(f32): conv1d supports epilogue NONE / TANH and row-major output only");
+        APAD_CHECK(d->Cin > 0 && d->Cin % 4 == 0 && d->taps > 0 && d->K == (int64_t)d->taps * d->Cin, "apad_gemm(f32): conv1d needs Cin%%4==0 and K==taps*Cin");
+        APAD_CHECK(d->Hin > 0 && d->Hout > 0 && d->M % d->Hout == 0 && d->pad >= 0, "apad_gemm(f32): conv1d geometry inconsistent with M");
+        APAD_CHECK(d->transposed ? d->stride >= 1 : d->dilation >= 1, "apad_gemm(f32): conv1d needs dilation >= 1 (stride >= 1 when transposed)");
     } else {
         apad_set_error("apad_gemm(f32): unknown a_mode %d", d->a_mode);
         return -1;
@@ -545,6 +577,7 @@ int apad_f32_gemm(const apad_gemm_desc* d, hipStream_t s) {
     switch (d->a_mode) {
         case APAD_A_PLAIN: hipLaunchKernelGGL((gemm_f32_kernel<APAD_A_PLAIN>), grid, dim3(256), 0, s, p); break;
         case APAD_A_CONV3X3: hipLaunchKernelGGL((gemm_f32_kernel<APAD_A_CONV3X3>), grid, dim3(256), 0, s, p); break;
+        case APAD_A_CONV1D: hipLaunchKernelGGL((gemm_f32_kernel<APAD_A_CONV1D>), grid, dim3(256), 0, s, p); break;
         default: hipLaunchKernelGGL((gemm_f32_kernel<APAD_A_PATCH16>), grid, dim3(256), 0, s, p); break;
     }
     return apad_check_launch("apad_gemm(f32)");

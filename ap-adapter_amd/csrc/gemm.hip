@@ -45,6 +45,8 @@ struct GemmP {
     int32_t heads, head_dim, L, Lpad;
     int32_t wrows;  // rows of w (N, or 2N for GEGLU)
     int32_t m_tiles, n_tiles;
+    int32_t taps, dilation, pad, transposed, pre_act;  // APAD_A_CONV1D
+    float pre_slope;
 };
 
 // byte offset of 16-byte chunk `chunk` (0..7) of tile row `row` (128-byte rows)
@@ -80,6 +82,26 @@ __device__ __forceinline__ uint4 load_a(const GemmP& p, const RowInfo<AMODE>& r,
         }
         int64_t off = ((r.base * p.Hin + iy) * p.Win + ix) * p.Cin + c;
         return *reinterpret_cast<const uint4*>(p.a + off * 2);
+    } else if (AMODE == APAD_A_CONV1D) {  // channels-last [B][Hin][Cin]; r.base = b, r.oy = t; k = (tap, c)
+        const int tap = k / p.Cin, c = k - tap * p.Cin;
+        int ti;
+        if (p.transposed) {
+            const int num = r.oy + p.pad - tap;
+            ti = num / p.stride;
+            if (num < 0 || ti * p.stride != num) return z;
+        } else {
+            ti = r.oy + tap * p.dilation - p.pad;
+        }
+        if (ti < 0 || ti >= p.Hin) return z;
+        uint4 v = *reinterpret_cast<const uint4*>(p.a + (((int64_t)r.base * p.Hin + ti) * p.Cin + c) * 2);
+        if (p.pre_act) {  // the vocoder's pre-activation, applied while staging
+            float f[8];
+            unpack8<DT>(v, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = f[e] > 0.f ? f[e] : f[e] * p.pre_slope;
+            v = pack8<DT>(f);
+        }
+        return v;
     } else {  // PATCH16: fp32 mel [B][Hin][Win]; k = py*16 + px
         int py = k >> 4, px = k & 15;
         int64_t off = (r.base * p.Hin + r.oy * 16 + py) * p.Win + r.ox * 16 + px;
@@ -153,6 +175,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
                 ra[i].oy = rem / p.Wout;
                 ra[i].ox = rem - ra[i].oy * p.Wout;
                 ra[i].base = p.src_batch_mod > 0 ? b % p.src_batch_mod : b;
+            } else if (AMODE == APAD_A_CONV1D) {
+                const int64_t b = m / p.Hout;
+                ra[i].oy = (int)(m - b * p.Hout);
+                ra[i].base = b;
             } else if (AMODE == APAD_A_CONV3X3_FAST) {
                 int64_t hw = (int64_t)p.Hout * p.Wout;
                 int64_t b = m / hw;
@@ -306,6 +332,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
                 }
                 if (EPI == APAD_EPI_SILU) v = silu_f(v);
                 if (EPI == APAD_EPI_GELU) v = gelu_erf_f(v);
+                if (EPI == APAD_EPI_TANH) v = tanhf(v);
                 ct[ml * C_LD + nl] = (typename E::elem)v;
             }
         }
@@ -507,6 +534,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmP p) {
                 }
                 if (EPI == APAD_EPI_SILU) v = silu_f(v);
                 if (EPI == APAD_EPI_GELU) v = gelu_erf_f(v);
+                if (EPI == APAD_EPI_TANH) v = tanhf(v);
                 ct[ml * C_LD + nl] = (typename E::elem)v;
             }
         }
@@ -579,7 +607,7 @@ int launch(const GemmP& p, hipStream_t s) {
     // long reductions amortise the under-fill: with K >= 1024 the 128-tile wins from ~1.25 workgroups per CU (measured:
     // conv 63x4 384->384 76.5 -> 71.5 us, FF2 M=16128 K=1536 38.5 -> 37.1 us), short-K launches prefer the 64-tile
     const bool t128 = blocks128 >= 512 || (blocks128 >= 320 && p.K >= 1024);
-    if constexpr (AMODE == APAD_A_CONV3X3_FAST || AMODE == APAD_A_CONV3X3) {
+    if constexpr (AMODE == APAD_A_CONV3X3_FAST || AMODE == APAD_A_CONV3X3 || AMODE == APAD_A_CONV1D) {
         static const bool one_stage = getenv("APAD_GEMM_ONE_STAGE") != nullptr;
         // long reductions on launches of <= ~4 workgroups per CU: two LDS stages, one barrier per k-tile (larger grids
         // lose more from the halved residency than they gain: 250x16 128->128 118.9 -> 132.6 us)
@@ -623,6 +651,11 @@ template <int DT> int dispatch_amode(const GemmP& p, const apad_gemm_desc* d, hi
             APAD_CHECK(d->epilogue == APAD_EPI_NONE && d->out_mode == APAD_OUT_ROWMAJOR,
                        "apad_gemm: patch16 supports epilogue NONE / row-major output only");
             return launch<DT, APAD_A_PATCH16, APAD_EPI_NONE, APAD_OUT_ROWMAJOR>(p, s);
+        case APAD_A_CONV1D:
+            APAD_CHECK((d->epilogue == APAD_EPI_NONE || d->epilogue == APAD_EPI_TANH) && d->out_mode == APAD_OUT_ROWMAJOR,
+                       "apad_gemm: conv1d supports epilogue NONE / TANH and row-major output only");
+            if (d->epilogue == APAD_EPI_TANH) return launch<DT, APAD_A_CONV1D, APAD_EPI_TANH, APAD_OUT_ROWMAJOR>(p, s);
+            return launch<DT, APAD_A_CONV1D, APAD_EPI_NONE, APAD_OUT_ROWMAJOR>(p, s);
     }
     apad_set_error("apad_gemm: unknown a_mode %d", d->a_mode);
     return -1;
@@ -670,7 +703,13 @@ extern "C" int apad_gemm(const apad_gemm_desc* d, void* stream) {
     } else if (d->a_mode == APAD_A_PATCH16) {
         APAD_CHECK(d->K == 256 && d->Hin % 16 == 0 && d->Win % 16 == 0, "apad_gemm: patch16 needs K==256 and H,W %% 16 == 0");
         APAD_CHECK(d->M % ((int64_t)(d->Hin / 16) * (d->Win / 16)) == 0, "apad_gemm: patch16 M inconsistent");
+    } else if (d->a_mode == APAD_A_CONV1D) {
+        APAD_CHECK(d->Cin > 0 && d->Cin % 8 == 0 && d->taps > 0 && d->K == (int64_t)d->taps * d->Cin, "apad_gemm: conv1d needs Cin%%8==0 and K==taps*Cin");
+        APAD_CHECK(d->Hin > 0 && d->Hout > 0 && d->M % d->Hout == 0 && d->pad >= 0, "apad_gemm: conv1d geometry inconsistent with M");
+        APAD_CHECK(d->transposed ? d->stride >= 1 : d->dilation >= 1, "apad_gemm: conv1d needs dilation >= 1 (stride >= 1 when transposed)");
     }
+    p.taps = d->taps; p.dilation = d->dilation; p.pad = d->pad; p.transposed = d->transposed; p.pre_act = d->a_pre_act;
+    p.pre_slope = d->a_pre_slope;
     if (d->out_mode == APAD_OUT_ROWMAJOR) {
         APAD_CHECK(d->N % 8 == 0 && d->ldo % 8 == 0, "apad_gemm: N and ldo must be multiples of 8");
         if (d->residual) APAD_CHECK(d->ldr % 8 == 0, "apad_gemm: ldr must be a multiple of 8");

@@ -12,7 +12,7 @@ import torch
 from . import _lib as L
 
 _DT = {torch.bfloat16: L.BF16, torch.float16: L.F16, torch.float32: L.F32}
-_EPI = {None: L.EPI_NONE, "none": L.EPI_NONE, "silu": L.EPI_SILU, "gelu": L.EPI_GELU, "geglu": L.EPI_GEGLU}
+_EPI = {None: L.EPI_NONE, "none": L.EPI_NONE, "silu": L.EPI_SILU, "gelu": L.EPI_GELU, "geglu": L.EPI_GEGLU, "tanh": L.EPI_TANH}
 
 
 def _stream():
@@ -249,6 +249,43 @@ def conv3x3(x, w_packed, bias, B, Hin, Win, stride=1, up=None, residual=None, ro
          step_ptr=step_ptr, a_mode=L.A_CONV3X3,
          conv=(Hin, Win, Cin, Hout, Wout, stride, (up[0] if up else 0), (up[1] if up else 0), src_batch_mod))
     return out, Hout, Wout
+
+
+def conv1d(x, w_packed, bias, taps, dilation=1, transposed_stride=0, pad=None, pre_slope=None, residual=None, act=None, out=None):
+    """HiFi-GAN convolutions over channels-last x [B, T, Cin] as ONE implicit GEMM: nn.Conv1d(k = taps, dilation, "same" padding
+    (k*d - d)/2) or, with ``transposed_stride`` = s, nn.ConvTranspose1d(k = taps, stride s, padding (k - s)/2) -> [B, T*s, Cout].
+    w_packed [Cout, taps*Cin] in (tap, cin) order.  pre_slope: leaky_relu(x, pre_slope) applied while the input is gathered (the
+    vocoder's pre-activations); act: None | "tanh"; residual [B, T_out, Cout] added after."""
+    _req(x, "conv1d.x", w_packed.dtype)
+    B, T, Cin = x.shape
+    Cout = w_packed.shape[0]
+    s_ = int(transposed_stride)
+    if pad is None:
+        pad = (taps - s_) // 2 if s_ else (taps * dilation - dilation) // 2
+    Tout = (T - 1) * s_ - 2 * pad + taps if s_ else T + 2 * pad - dilation * (taps - 1)
+    if out is None:
+        out = torch.empty(B, Tout, Cout, dtype=x.dtype, device=x.device)
+    d = L.GemmDesc()
+    d.a, d.w, d.out, d.bias, d.residual = x.data_ptr(), w_packed.data_ptr(), out.data_ptr(), _ptr(bias), _ptr(residual)
+    d.M, d.N, d.K, d.lda, d.ldw, d.ldo, d.ldr = B * Tout, Cout, taps * Cin, 0, w_packed.stride(0), Cout, Cout
+    d.a_mode, d.epilogue, d.out_mode, d.dtype = L.A_CONV1D, _EPI[act], L.OUT_ROWMAJOR, _DT[w_packed.dtype]
+    d.Hin, d.Hout, d.Cin, d.stride = T, Tout, Cin, max(s_, 1)
+    d.taps, d.dilation, d.pad, d.transposed = taps, dilation, pad, 1 if s_ else 0
+    if pre_slope is not None:
+        d.a_pre_act, d.a_pre_slope = 1, float(pre_slope)
+    d.rows_per_group = 1
+    L.check(L.lib().apad_gemm(C.byref(d), _stream()), "apad_gemm(conv1d)")
+    return out
+
+
+def mix3(a, b, c, scale, out=None):
+    """(a + b + c) * scale, element-wise"""
+    _req(a, "mix3.a")
+    if out is None:
+        out = torch.empty_like(a)
+    L.check(L.lib().apad_mix3(a.data_ptr(), b.data_ptr(), c.data_ptr(), out.data_ptr(), a.numel(), float(scale), _DT[a.dtype], _stream()),
+            "apad_mix3")
+    return out
 
 
 def patch_embed(mel, w, bias, dtype):

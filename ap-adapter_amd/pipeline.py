@@ -30,8 +30,10 @@ class AudioLDM2Pipeline:
     vocoder_model_in_dim = 64      # mel bins
     vocoder_upsample_factor = 0.01  # prod(upsample_rates) / sampling_rate = 160 / 16000
 
-    def __init__(self, unet, scheduler: Optional[DDIMScheduler] = None, audiomae=None):
+    def __init__(self, unet, scheduler: Optional[DDIMScheduler] = None, audiomae=None, vocoder=None, vae=None):
         self.unet = unet
+        self.vocoder = vocoder  # vocoder.SpeechT5HifiGan (HIP) -- mel -> waveform
+        self.vae = vae          # a caller-supplied latents -> mel decoder (the VAE is not rebuilt here)
         self.scheduler = scheduler or DDIMScheduler()
         self.audiomae = audiomae
         self._uncond_cache = {}
@@ -42,6 +44,14 @@ class AudioLDM2Pipeline:
         self.last_noise_pred = None
 
     # ---- pieces ----
+    def mel_spectrogram_to_waveform(self, mel_spectrogram):
+        """pipeline_audioldm2.py:583-590"""
+        if self.vocoder is None:
+            raise RuntimeError("this pipeline was built without a vocoder")
+        if mel_spectrogram.dim() == 4:
+            mel_spectrogram = mel_spectrogram.squeeze(1)
+        return self.vocoder(mel_spectrogram).cpu().float()
+
     def prepare_latents(self, batch_size, num_channels_latents, height, dtype, device, generator, latents=None):
         shape = (batch_size, num_channels_latents, height // self.vae_scale_factor,
                  self.vocoder_model_in_dim // self.vae_scale_factor)
@@ -214,8 +224,10 @@ class AudioLDM2Pipeline:
             raise NotImplementedError(
                 "text prompts need the CLAP/T5/GPT-2 encoders, which are outside the hot path; pass prompt_embeds, "
                 "generated_prompt_embeds, attention_mask and their negative_* twins (the reference accepts them too)")
-        if output_type != "latent":
-            raise NotImplementedError("VAE decode + vocoder are outside the hot path; use output_type='latent'")
+        if output_type != "latent" and (self.vae is None or self.vocoder is None):
+            raise NotImplementedError("waveform output needs latents -> mel (the AutoencoderKL decoder is not rebuilt here: pass "
+                                      "vae=<module with .decode>) and mel -> waveform (vocoder=ap_adapter_amd.SpeechT5HifiGan); "
+                                      "or use output_type='latent'")
         if eta != 0.0:
             raise NotImplementedError("eta != 0 is not used by the reference drivers")
         for n, v in (("prompt_embeds", prompt_embeds), ("negative_prompt_embeds", negative_prompt_embeds),
@@ -247,6 +259,13 @@ class AudioLDM2Pipeline:
                                    dev, generator, latents)
         out = self.denoise(lat, ge, pe, am, num_inference_steps, guidance_scale, use_graph=use_graph, callback=callback,
                            callback_steps=callback_steps)
+        if output_type != "latent":  # :1036-1044
+            scaling = getattr(getattr(self.vae, "config", None), "scaling_factor", 1.0)
+            mel = self.vae.decode(out / scaling)
+            mel = getattr(mel, "sample", mel)
+            out = self.mel_spectrogram_to_waveform(mel)[:, : int(audio_length_in_s * 16000)]
+            if output_type == "np":
+                out = out.numpy()
         if not return_dict:
             return (out,)
         return AudioPipelineOutput(audios=out)

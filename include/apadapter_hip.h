@@ -44,11 +44,15 @@ enum {
     APAD_A_PLAIN = 0,   /* A[m][k] = a[m*lda + k]                                                    */
     APAD_A_CONV3X3 = 1, /* implicit GEMM over NHWC: m=(b,oy,ox), k=(ky,kx,c); zero padding 1; optional
                            nearest-neighbour upsample of the source to (Hup,Wup) before the taps         */
-    APAD_A_PATCH16 = 2  /* AudioMAE patch embed: a = fp32 mel [B,Hin,Win]; m=(b,ty,fx), k=(py,px)       */
+    APAD_A_PATCH16 = 2, /* AudioMAE patch embed: a = fp32 mel [B,Hin,Win]; m=(b,ty,fx), k=(py,px)       */
+    /* 3 is reserved (internal fast form of CONV3X3) */
+    APAD_A_CONV1D = 4   /* HiFi-GAN: implicit GEMM over channels-last [B][Hin = T_in][Cin]; m=(b,t), k=(tap,c):
+                           Conv1d (dilation, zero padding) or ConvTranspose1d (stride = up-sampling rate), with an
+                           optional leaky-ReLU applied to the gathered input (the vocoder's pre-activations)     */
 };
 
 /* apad_gemm_desc.epilogue (applied to acc + bias + rowgroup_bias, before + residual) */
-enum { APAD_EPI_NONE = 0, APAD_EPI_SILU = 1, APAD_EPI_GELU = 2, APAD_EPI_GEGLU = 3 };
+enum { APAD_EPI_NONE = 0, APAD_EPI_SILU = 1, APAD_EPI_GELU = 2, APAD_EPI_GEGLU = 3, APAD_EPI_TANH = 4 };
 
 /* apad_gemm_desc.out_mode */
 enum {
@@ -84,6 +88,12 @@ typedef struct apad_gemm_desc {
     int32_t heads, head_dim, L, Lpad;
     void* out2;                /* APAD_OUT_QKV: k output                                                */
     void* out3;                /* APAD_OUT_QKV: v^T output                                              */
+    /* APAD_A_CONV1D (Hin = T_in, Hout = T_out, Cin; K = taps * Cin; w = [Cout][tap][Cin]):
+         transposed = 0: x[b][t*1 + tap*dilation - pad][c]                              (nn.Conv1d, stride 1)
+         transposed = 1: x[b][(t + pad - tap) / stride][c] where that division is exact  (nn.ConvTranspose1d)   */
+    int32_t taps, dilation, pad, transposed;
+    int32_t a_pre_act;         /* 1: leaky_relu(a, a_pre_slope) on the gathered input                  */
+    float a_pre_slope;
 } apad_gemm_desc;
 
 typedef struct apad_attn_desc {
@@ -237,6 +247,9 @@ int apad_cfg_ddim_step(const void* eps2, float* latents, void* unet_in, float* e
                        const int32_t* step_ptr, float guidance_scale, int32_t B, int64_t n, int32_t dtype,
                        void* stream);
 int apad_step_advance(int32_t* step_ptr, void* stream);
+/* out = (a + b + c) * scale, element-wise over n values of `dtype` (HiFi-GAN: mean of the three residual-block branches,
+   SpeechT5HifiGan.forward) */
+int apad_mix3(const void* a, const void* b, const void* c, void* out, int64_t n, float scale, int32_t dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Training step of the adapter (SURVEY a-11; train_apadapter_v2.py:941-979).  The UNet is frozen: only INPUT

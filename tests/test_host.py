@@ -177,7 +177,7 @@ def test_pipeline_rejects_out_of_scope_stages(unet):
     with pytest.raises(NotImplementedError, match="text prompts"):
         pipe(prompt="jazz")
     e = torch.zeros(1, 16, 1024)
-    with pytest.raises(NotImplementedError, match="VAE"):
+    with pytest.raises(NotImplementedError, match="AutoencoderKL"):
         pipe(prompt_embeds=e, negative_prompt_embeds=e, generated_prompt_embeds=e, negative_generated_prompt_embeds=e,
              attention_mask=e[..., 0], negative_attention_mask=e[..., 0], output_type="np")
     with pytest.raises(ValueError, match="required"):
