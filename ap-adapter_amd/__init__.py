@@ -7,6 +7,7 @@ from .audiomae import AudioMAEConditionCTPoolRand, Vanilla_AudioMAE, AudioMAEEnc
 from .scheduler import DDIMScheduler  # noqa: F401
 from .pipeline import AudioLDM2Pipeline  # noqa: F401
 from .vocoder import SpeechT5HifiGan, HifiGanConfig  # noqa: F401
+from .vae import AutoencoderKL, VaeConfig  # noqa: F401
 from .wiring import install_ap_adapter, build_processors, ip_layer_names, adapter_state_dict, save_adapter, load_adapter  # noqa: F401
 from . import ops, distributed, autograd, config, sharded  # noqa: F401
 from .config import get_config  # noqa: F401

@@ -29,7 +29,8 @@ class GemmDesc(C.Structure):
                [(n, _i32) for n in ("a_mode", "epilogue", "out_mode", "dtype", "Hin", "Win", "Cin", "Hout", "Wout",
                                     "stride", "Hup", "Wup", "src_batch_mod", "residual_row_mod", "heads", "head_dim", "L", "Lpad")] + \
                [("out2", _vp), ("out3", _vp)] + \
-               [(n, _i32) for n in ("taps", "dilation", "pad", "transposed", "a_pre_act")] + [("a_pre_slope", _f32)]
+               [(n, _i32) for n in ("taps", "dilation", "pad", "transposed", "a_pre_act")] + [("a_pre_slope", _f32)] + \
+               [("conv_asym_pad", _i32), ("reserved_conv", _i32)]
 
 
 class AttnDesc(C.Structure):
@@ -99,6 +100,8 @@ SYMBOLS = {
     "apad_cfg_ddim_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _i32, _i64, _i32, _vp]),
     "apad_step_advance": (C.c_int, [_vp, _vp]),
     "apad_mix3": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _i32, _vp]),
+    "apad_softmax_rows": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _i64, _f32, _i32, _vp]),
+    "apad_gaussian_sample": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _i32, _vp]),
     # training step (a-11)
     "apad_sizeof_attn_bwd_desc": (C.c_int, []),
     "apad_echo_attn_bwd_desc": (C.c_int, [C.POINTER(AttnBwdDesc), C.POINTER(C.c_double), C.c_int]),

@@ -44,6 +44,7 @@ extern "C" int apad_echo_gemm_desc(const apad_gemm_desc* d, double* out, int cap
     PUT(d->src_batch_mod); PUT(d->residual_row_mod); PUT(d->heads); PUT(d->head_dim); PUT(d->L); PUT(d->Lpad);
     PUTP(d->out2); PUTP(d->out3);
     PUT(d->taps); PUT(d->dilation); PUT(d->pad); PUT(d->transposed); PUT(d->a_pre_act); PUT(d->a_pre_slope);
+    PUT(d->conv_asym_pad); PUT(d->reserved_conv);
     return n;
 }
 

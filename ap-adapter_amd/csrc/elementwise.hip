@@ -97,6 +97,41 @@ template <int DT> __global__ __launch_bounds__(256) void mix3_kernel(const uint8
         st_elem<DT>(out, i, (ld_elem<DT>(a, i) + ld_elem<DT>(b, i) + ld_elem<DT>(c, i)) * scale);
 }
 
+// out[m][n] = softmax_n(scale * x[m][n]); one wave per row, statistics and exponentials in fp32 (libm expf: the op runs once per
+// decoded clip, not per denoise step).  Serves the VAE mid-block's single-head d = 512 attention, which lies outside
+// apad_attention's head-dim envelope and runs as apad_gemm (Q.K^T) -> this -> apad_gemm (P.V).
+template <int DT> __global__ __launch_bounds__(256) void softmax_rows_kernel(const uint8_t* x, uint8_t* out, int64_t M, int N, int64_t ldx,
+                                                                             int64_t ldo, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int64_t xo = m * ldx, oo = m * ldo;
+    float mx = -INFINITY;
+    for (int n = lane; n < N; n += 64) mx = fmaxf(mx, ld_elem<DT>(x, xo + n) * scale);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int n = lane; n < N; n += 64) sum += expf(ld_elem<DT>(x, xo + n) * scale - mx);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.0f / sum;
+    for (int n = lane; n < N; n += 64) st_elem<DT>(out, oo + n, expf(ld_elem<DT>(x, xo + n) * scale - mx) * inv);
+}
+
+// DiagonalGaussianDistribution.sample() of the VAE encoder: moments [rows][2L] = (mean | logvar) per latent pixel ->
+// out [rows][L] = (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise) * scale  (scale = the pipeline's scaling_factor, or 1)
+template <int DT> __global__ __launch_bounds__(256) void gaussian_sample_kernel(const uint8_t* moments, const uint8_t* noise, uint8_t* out,
+                                                                                int64_t rows, int L, float scale) {
+    const int64_t n = rows * L;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / L;
+        const int c = (int)(i - r * L);
+        const float mean = ld_elem<DT>(moments, r * 2 * L + c);
+        const float logvar = fminf(fmaxf(ld_elem<DT>(moments, r * 2 * L + L + c), -30.0f), 20.0f);
+        st_elem<DT>(out, i, (mean + expf(0.5f * logvar) * ld_elem<DT>(noise, i)) * scale);
+    }
+}
+
 }  // namespace
 
 extern "C" int apad_audiomae_pool(const void* rep, void* out, int32_t B, int32_t tp, int32_t fp, int32_t dtype,
@@ -179,6 +214,34 @@ extern "C" int apad_mix3(const void* a, const void* b, const void* c, void* out,
     else if (dtype == APAD_BF16) hipLaunchKernelGGL((mix3_kernel<APAD_BF16>), dim3((unsigned)blocks), dim3(256), 0, s, pa, pb, pc, (uint8_t*)out, n, scale);
     else hipLaunchKernelGGL((mix3_kernel<APAD_F16>), dim3((unsigned)blocks), dim3(256), 0, s, pa, pb, pc, (uint8_t*)out, n, scale);
     return apad_check_launch("apad_mix3");
+}
+
+extern "C" int apad_softmax_rows(const void* x, void* out, int64_t M, int32_t N, int64_t ldx, int64_t ldo, float scale, int32_t dtype,
+                                 void* stream) {
+    APAD_CHECK(x && out && M > 0 && N > 0 && ldx >= N && ldo >= N, "apad_softmax_rows: bad operands (M=%lld N=%d ldx=%lld ldo=%lld)",
+               (long long)M, N, (long long)ldx, (long long)ldo);
+    APAD_CHECK(dtype == APAD_BF16 || dtype == APAD_F16 || dtype == APAD_F32, "apad_softmax_rows: dtype %d not supported", dtype);
+    const dim3 grid((unsigned)((M + 3) / 4));
+    hipStream_t s = (hipStream_t)stream;
+    const uint8_t* px = (const uint8_t*)x;
+    if (dtype == APAD_F32) hipLaunchKernelGGL((softmax_rows_kernel<APAD_F32>), grid, dim3(256), 0, s, px, (uint8_t*)out, M, N, ldx, ldo, scale);
+    else if (dtype == APAD_BF16) hipLaunchKernelGGL((softmax_rows_kernel<APAD_BF16>), grid, dim3(256), 0, s, px, (uint8_t*)out, M, N, ldx, ldo, scale);
+    else hipLaunchKernelGGL((softmax_rows_kernel<APAD_F16>), grid, dim3(256), 0, s, px, (uint8_t*)out, M, N, ldx, ldo, scale);
+    return apad_check_launch("apad_softmax_rows");
+}
+
+extern "C" int apad_gaussian_sample(const void* moments, const void* noise, void* out, int64_t rows, int32_t latent, float scale,
+                                    int32_t dtype, void* stream) {
+    APAD_CHECK(moments && noise && out && rows > 0 && latent > 0, "apad_gaussian_sample: bad operands");
+    APAD_CHECK(dtype == APAD_BF16 || dtype == APAD_F16 || dtype == APAD_F32, "apad_gaussian_sample: dtype %d not supported", dtype);
+    int64_t blocks = (rows * latent + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipStream_t s = (hipStream_t)stream;
+    const uint8_t *pm = (const uint8_t*)moments, *pn = (const uint8_t*)noise;
+    if (dtype == APAD_F32) hipLaunchKernelGGL((gaussian_sample_kernel<APAD_F32>), dim3((unsigned)blocks), dim3(256), 0, s, pm, pn, (uint8_t*)out, rows, latent, scale);
+    else if (dtype == APAD_BF16) hipLaunchKernelGGL((gaussian_sample_kernel<APAD_BF16>), dim3((unsigned)blocks), dim3(256), 0, s, pm, pn, (uint8_t*)out, rows, latent, scale);
+    else hipLaunchKernelGGL((gaussian_sample_kernel<APAD_F16>), dim3((unsigned)blocks), dim3(256), 0, s, pm, pn, (uint8_t*)out, rows, latent, scale);
+    return apad_check_launch("apad_gaussian_sample");
 }
 
 extern "C" int apad_step_advance(int32_t* step_ptr, void* stream) {

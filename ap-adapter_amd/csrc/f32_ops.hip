@@ -48,6 +48,7 @@ struct G32P {
     int32_t epi, outmode, n_tiles;
     int32_t taps, dilation, pad, transposed, pre_act;  // APAD_A_CONV1D
     float pre_slope;
+    int32_t lead;  // conv3x3: zero rows / columns before the first source row / column (1, or 0 with conv_asym_pad)
 };
 
 // float offset of 16-byte chunk `chunk` (0..7) of tile row `row` (the swizzle of gemm.hip's lds_off)
@@ -67,7 +68,7 @@ template <int AMODE> __device__ __forceinline__ f4 load_a32(const G32P& p, const
     } else if (AMODE == APAD_A_CONV3X3) {
         const int tap = k / p.Cin, c = k - tap * p.Cin;
         const int ky = tap / 3, kx = tap - ky * 3;
-        int iy = r.oy * p.stride + ky - 1, ix = r.ox * p.stride + kx - 1;
+        int iy = r.oy * p.stride + ky - p.lead, ix = r.ox * p.stride + kx - p.lead;
         const int H = p.Hup > 0 ? p.Hup : p.Hin, W = p.Hup > 0 ? p.Wup : p.Win;
         if (iy < 0 || iy >= H || ix < 0 || ix >= W) return z;
         if (p.Hup > 0) {  // nearest-neighbour source index, floor(dst * in / out)
@@ -523,6 +524,7 @@ int apad_f32_gemm(const apad_gemm_desc* d, hipStream_t s) {
     APAD_CHECK(d->epilogue >= APAD_EPI_NONE && d->epilogue <= APAD_EPI_TANH, "apad_gemm(f32): unknown epilogue %d", d->epilogue);
     p.taps = d->taps; p.dilation = d->dilation; p.pad = d->pad; p.transposed = d->transposed; p.pre_act = d->a_pre_act;
     p.pre_slope = d->a_pre_slope;
+    p.lead = d->conv_asym_pad ? 0 : 1;
     if (d->a_mode == APAD_A_PLAIN) {
         APAD_CHECK(d->lda % 4 == 0, "apad_gemm(f32): lda must be a multiple of 4");
     } else if (d->a_mode == APAD_A_CONV3X3) {

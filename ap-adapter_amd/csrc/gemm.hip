@@ -47,6 +47,7 @@ struct GemmP {
     int32_t m_tiles, n_tiles;
     int32_t taps, dilation, pad, transposed, pre_act;  // APAD_A_CONV1D
     float pre_slope;
+    int32_t lead;  // conv3x3: zero rows / columns before the first source row / column (1, or 0 with conv_asym_pad)
 };
 
 // byte offset of 16-byte chunk `chunk` (0..7) of tile row `row` (128-byte rows)
@@ -73,7 +74,7 @@ __device__ __forceinline__ uint4 load_a(const GemmP& p, const RowInfo<AMODE>& r,
         int tap = k / p.Cin;
         int c = k - tap * p.Cin;
         int ky = tap / 3, kx = tap - ky * 3;
-        int iy = r.oy * p.stride + ky - 1, ix = r.ox * p.stride + kx - 1;
+        int iy = r.oy * p.stride + ky - p.lead, ix = r.ox * p.stride + kx - p.lead;
         int H = p.Hup > 0 ? p.Hup : p.Hin, W = p.Hup > 0 ? p.Wup : p.Win;
         if (iy < 0 || iy >= H || ix < 0 || ix >= W) return z;
         if (p.Hup > 0) {  // nearest-neighbour source index, floor(dst * in / out)
@@ -184,8 +185,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
                 int64_t b = m / hw;
                 int rem = (int)(m - b * hw);
                 const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-                ra[i].oy = oy * p.stride - 1;  // source row / column of filter tap (0, 0)
-                ra[i].ox = ox * p.stride - 1;
+                ra[i].oy = oy * p.stride - p.lead;  // source row / column of filter tap (0, 0)
+                ra[i].ox = ox * p.stride - p.lead;
                 const int64_t sb = p.src_batch_mod > 0 ? b % p.src_batch_mod : b;
                 ra[i].base = ((sb * p.Hin + ra[i].oy) * p.Win + ra[i].ox) * p.Cin;  // element offset of that tap, channel 0
             } else {
@@ -710,6 +711,7 @@ extern "C" int apad_gemm(const apad_gemm_desc* d, void* stream) {
     }
     p.taps = d->taps; p.dilation = d->dilation; p.pad = d->pad; p.transposed = d->transposed; p.pre_act = d->a_pre_act;
     p.pre_slope = d->a_pre_slope;
+    p.lead = d->conv_asym_pad ? 0 : 1;
     if (d->out_mode == APAD_OUT_ROWMAJOR) {
         APAD_CHECK(d->N % 8 == 0 && d->ldo % 8 == 0, "apad_gemm: N and ldo must be multiples of 8");
         if (d->residual) APAD_CHECK(d->ldr % 8 == 0, "apad_gemm: ldr must be a multiple of 8");

@@ -39,7 +39,7 @@ def round_up(x, m):
 
 def gemm(a, w, *, M, N, K, lda, out, ldo, bias=None, residual=None, ldr=0, act=None, rowgroup_bias=None, ld_rg=0,
          rows_per_group=0, step_ptr=None, a_mode=L.A_PLAIN, out_mode=L.OUT_ROWMAJOR, conv=None, vt=None, ldw=None,
-         residual_row_mod=0):
+         residual_row_mod=0, asym_pad=False):
     """Raw descriptor call; the typed helpers below are what the model code uses."""
     d = L.GemmDesc()
     d.a, d.w, d.out = a.data_ptr(), w.data_ptr(), out.data_ptr()
@@ -52,6 +52,7 @@ def gemm(a, w, *, M, N, K, lda, out, ldo, bias=None, residual=None, ldr=0, act=N
         (d.Hin, d.Win, d.Cin, d.Hout, d.Wout, d.stride, d.Hup, d.Wup, d.src_batch_mod) = conv
     if vt is not None:
         d.heads, d.head_dim, d.L, d.Lpad = vt
+    d.conv_asym_pad = 1 if asym_pad else 0
     L.check(L.lib().apad_gemm(C.byref(d), _stream()), "apad_gemm")
     return out
 
@@ -230,23 +231,24 @@ def linear_qkv(x, w_qkv, B, Lk, heads, q, k, vt, bias=None):
 
 
 def conv3x3(x, w_packed, bias, B, Hin, Win, stride=1, up=None, residual=None, rowgroup_bias=None, rows_per_group=0,
-            step_ptr=None, src_batch_mod=0, out=None):
+            step_ptr=None, src_batch_mod=0, out=None, asym_pad=False):
     """NHWC implicit-GEMM 3x3 convolution, padding 1.  x [Bsrc, Hin*Win, Cin]; w_packed [Cout, 9*Cin] in
-    (ky, kx, cin) order; up=(Hup, Wup) applies a nearest-neighbour upsample to the source first.
+    (ky, kx, cin) order; up=(Hup, Wup) applies a nearest-neighbour upsample to the source first.  asym_pad: the zero row /
+    column only at the bottom / right (F.pad(x, (0,1,0,1)) + an un-padded conv: the VAE encoder's down-sampler).
     Returns ([B, Hout*Wout, Cout], Hout, Wout)."""
     _req(x, "conv3x3.x", w_packed.dtype)
     Cin = x.shape[-1]
     Cout = w_packed.shape[0]
     Hs, Ws = (up if up is not None else (Hin, Win))
-    Hout = (Hs + 2 - 3) // stride + 1
-    Wout = (Ws + 2 - 3) // stride + 1
+    Hout = (Hs + (1 if asym_pad else 2) - 3) // stride + 1
+    Wout = (Ws + (1 if asym_pad else 2) - 3) // stride + 1
     M = B * Hout * Wout
     if out is None:
         out = torch.empty(B, Hout * Wout, Cout, dtype=x.dtype, device=x.device)
     gemm(x, w_packed, M=M, N=Cout, K=9 * Cin, lda=0, out=out, ldo=Cout, bias=bias,
          residual=residual, ldr=Cout, rowgroup_bias=rowgroup_bias,
          ld_rg=(rowgroup_bias.stride(0) if rowgroup_bias is not None else 0), rows_per_group=rows_per_group,
-         step_ptr=step_ptr, a_mode=L.A_CONV3X3,
+         step_ptr=step_ptr, a_mode=L.A_CONV3X3, asym_pad=asym_pad,
          conv=(Hin, Win, Cin, Hout, Wout, stride, (up[0] if up else 0), (up[1] if up else 0), src_batch_mod))
     return out, Hout, Wout
 
@@ -285,6 +287,31 @@ def mix3(a, b, c, scale, out=None):
         out = torch.empty_like(a)
     L.check(L.lib().apad_mix3(a.data_ptr(), b.data_ptr(), c.data_ptr(), out.data_ptr(), a.numel(), float(scale), _DT[a.dtype], _stream()),
             "apad_mix3")
+    return out
+
+
+def softmax_rows(x, scale=1.0, out=None):
+    """softmax(scale * x) over the last dim of x [..., N] (row-contiguous), fp32 statistics"""
+    _req(x, "softmax_rows.x")
+    N = x.shape[-1]
+    x2 = x.reshape(-1, N)
+    if out is None:
+        out = torch.empty_like(x2)
+    L.check(L.lib().apad_softmax_rows(x2.data_ptr(), out.data_ptr(), x2.shape[0], N, x2.stride(0), out.stride(0), float(scale),
+                                      _DT[x.dtype], _stream()), "apad_softmax_rows")
+    return out.view(x.shape)
+
+
+def gaussian_sample(moments, noise, scale=1.0):
+    """moments [rows, 2L] = (mean | logvar), noise [rows, L] -> (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise) * scale"""
+    _req(moments, "gaussian_sample.moments")
+    _req(noise, "gaussian_sample.noise", moments.dtype)
+    rows, L2 = moments.shape
+    if not (moments.is_contiguous() and noise.is_contiguous() and tuple(noise.shape) == (rows, L2 // 2)):
+        raise ValueError(f"gaussian_sample: moments {tuple(moments.shape)} / noise {tuple(noise.shape)} must be contiguous [rows, 2L] / [rows, L]")
+    out = torch.empty_like(noise)
+    L.check(L.lib().apad_gaussian_sample(moments.data_ptr(), noise.data_ptr(), out.data_ptr(), rows, L2 // 2, float(scale), _DT[moments.dtype],
+                                         _stream()), "apad_gaussian_sample")
     return out
 
 

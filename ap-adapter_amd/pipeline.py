@@ -1,8 +1,8 @@
 """Hot-path half of ``AudioLDM2Pipeline`` (/root/reference/pipeline/pipeline_audioldm2.py:748-1061): audio-condition
 assembly (:919-956), latent preparation (:724-744), the CFG + DDIM denoise loop (:983-1031), ``output_type="latent"``
-exit (:1036-1040).  The keyword surface of ``__call__`` is the reference's; the one-off [3P] stages either side of the
-loop (text encoders, VAE, vocoder -- SURVEY 8 out of scope) are not rebuilt: drive it with the precomputed-embedding
-arguments the reference already accepts.
+exit (:1036-1040), and -- with ``vae=`` / ``vocoder=`` supplied -- the VAE decode and HiFi-GAN stages after it (:1036-1044,
+SURVEY f-4, ``vae.py`` / ``vocoder.py``).  The keyword surface of ``__call__`` is the reference's; the text encoders (CLAP / T5 /
+GPT-2, [3P]) are not rebuilt: drive it with the precomputed-embedding arguments the reference already accepts.
 
 MI355X-first structure of the loop:
   * K/V of all 64 cross-attention sites are projected once per call (timestep-invariant), not once per step
@@ -33,7 +33,7 @@ class AudioLDM2Pipeline:
     def __init__(self, unet, scheduler: Optional[DDIMScheduler] = None, audiomae=None, vocoder=None, vae=None):
         self.unet = unet
         self.vocoder = vocoder  # vocoder.SpeechT5HifiGan (HIP) -- mel -> waveform
-        self.vae = vae          # a caller-supplied latents -> mel decoder (the VAE is not rebuilt here)
+        self.vae = vae          # vae.AutoencoderKL (HIP) -- latents -> mel
         self.scheduler = scheduler or DDIMScheduler()
         self.audiomae = audiomae
         self._uncond_cache = {}
@@ -225,9 +225,8 @@ class AudioLDM2Pipeline:
                 "text prompts need the CLAP/T5/GPT-2 encoders, which are outside the hot path; pass prompt_embeds, "
                 "generated_prompt_embeds, attention_mask and their negative_* twins (the reference accepts them too)")
         if output_type != "latent" and (self.vae is None or self.vocoder is None):
-            raise NotImplementedError("waveform output needs latents -> mel (the AutoencoderKL decoder is not rebuilt here: pass "
-                                      "vae=<module with .decode>) and mel -> waveform (vocoder=ap_adapter_amd.SpeechT5HifiGan); "
-                                      "or use output_type='latent'")
+            raise NotImplementedError("waveform output needs latents -> mel (vae=ap_adapter_amd.AutoencoderKL) and mel -> waveform "
+                                      "(vocoder=ap_adapter_amd.SpeechT5HifiGan); or use output_type='latent'")
         if eta != 0.0:
             raise NotImplementedError("eta != 0 is not used by the reference drivers")
         for n, v in (("prompt_embeds", prompt_embeds), ("negative_prompt_embeds", negative_prompt_embeds),

@@ -154,6 +154,22 @@ class AdapterTrainer:
             self.optimizer_step()
         return loss
 
+    def train_batch(self, batch, vae, generator=None, num_train_timesteps=1000):
+        """One iteration of the reference's loop body (:892-979) from a CollateFunction batch: mel -> VAE posterior draw x
+        scaling_factor (:895-897, vae.AutoencoderKL: encoder + apad_gaussian_sample on the HIP path), noise and ONE uniform timestep
+        per sample (:900-905), then ``train_step``.  ``generator``: a device torch.Generator for the three draws."""
+        dev = self.master.device
+        mel = batch["mel"].to(dev)
+        if mel.dim() == 3:
+            mel = mel.unsqueeze(1)  # [B, T, 64] -> [B, 1, T, 64]
+        latents = vae.encode(mel).latent_dist.sample(generator=generator, scale=vae.config.scaling_factor)
+        noise = torch.randn(latents.shape, generator=generator, device=dev, dtype=latents.dtype)
+        timesteps = torch.randint(0, num_train_timesteps, (latents.shape[0],), generator=generator, device=dev).long()
+        pe = batch["prompt_embeds"]
+        if pe.dim() == 4:
+            pe = pe.squeeze(-3)  # :917
+        return self.train_step(latents, noise, timesteps, batch["generated_prompt_embeds"].to(dev), pe.to(dev), batch["attention_mask"].to(dev))
+
     # ---- checkpoint / resume of the trainable state (reference: accelerator.save_state, :988-1011) ----
     def state_dict(self):
         return {"master": self.master.cpu(), "exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(),

@@ -94,6 +94,10 @@ typedef struct apad_gemm_desc {
     int32_t taps, dilation, pad, transposed;
     int32_t a_pre_act;         /* 1: leaky_relu(a, a_pre_slope) on the gathered input                  */
     float a_pre_slope;
+    int32_t conv_asym_pad;     /* APAD_A_CONV3X3: 0 = one zero row / column on every side (nn.Conv2d padding 1);
+                                  1 = none on the top / left, one at the bottom / right (diffusers
+                                  Downsample2D(padding=0): F.pad(x, (0,1,0,1)) then a stride-2 conv, the VAE encoder) */
+    int32_t reserved_conv;
 } apad_gemm_desc;
 
 typedef struct apad_attn_desc {
@@ -250,6 +254,18 @@ int apad_step_advance(int32_t* step_ptr, void* stream);
 /* out = (a + b + c) * scale, element-wise over n values of `dtype` (HiFi-GAN: mean of the three residual-block branches,
    SpeechT5HifiGan.forward) */
 int apad_mix3(const void* a, const void* b, const void* c, void* out, int64_t n, float scale, int32_t dtype, void* stream);
+
+/* Row softmax: out[m][n] = softmax over n of (scale * x[m][n]), fp32 statistics, one wave per row (x, out: [M][ld] of dtype).
+   The VAE mid-block attention (diffusers AutoencoderKL decoder/encoder, one head of d = 512 over the 4000 latent pixels --
+   outside apad_attention's head-dim envelope) runs as apad_gemm (Q.K^T) -> apad_softmax_rows -> apad_gemm (P.V). */
+int apad_softmax_rows(const void* x, void* out, int64_t M, int32_t N, int64_t ldx, int64_t ldo, float scale, int32_t dtype,
+                      void* stream);
+
+/* The VAE encoder's posterior draw (diffusers DiagonalGaussianDistribution.sample(), train_apadapter_v2.py:895-897):
+   moments [rows][2*latent] = (mean | logvar) per latent pixel, noise [rows][latent] ->
+   out [rows][latent] = (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise) * scale. */
+int apad_gaussian_sample(const void* moments, const void* noise, void* out, int64_t rows, int32_t latent, float scale,
+                         int32_t dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Training step of the adapter (SURVEY a-11; train_apadapter_v2.py:941-979).  The UNet is frozen: only INPUT
