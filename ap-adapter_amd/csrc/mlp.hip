@@ -18,6 +18,14 @@
 #ifndef MLP_VALU_PER_MFMA
 #define MLP_VALU_PER_MFMA 0
 #endif
+#ifndef MLP_PIPE2
+#define MLP_PIPE2 1
+#endif
+// timing ablations of the pipelined loop (results are wrong): 1 = no GELU arithmetic, 2 = no first-GEMM MFMAs,
+// 4 = no second-GEMM MFMAs, 8 = no weight staging (global loads / LDS stores), 16 = no per-chunk barrier
+#ifndef MLP_ABL
+#define MLP_ABL 0
+#endif
 
 namespace {
 
@@ -149,6 +157,142 @@ __global__ __launch_bounds__(NWV * 64, 1) void mlp_kernel(MlpP p) {
     }
     __syncthreads();  // W1 stage 0 is overwritten at the end of iteration 0
 
+#if MLP_PIPE2
+    // Three-stage software pipeline, one iteration = one 16-unit hidden chunk jc:
+    //   matrix pipe: second GEMM of chunk jc-1 (8 MFMAs, operands fetched one iteration ago) + first GEMM of chunk jc+1 (16 MFMAs)
+    //   VALU:        GEGLU arithmetic of chunk jc
+    // The 24 MFMAs depend on nothing the iteration's VALU work produces, so the ~160 VALU instructions can be dealt between
+    // them (a wave's own VALU issues underneath its MFMAs; another wave's does not -- tools/probes/pair.hip); the
+    // sched_group_barrier sequence below asks for exactly that deal.  The former schedule ran the second GEMM of chunk jc in
+    // the same iteration as its GEGLU: half of the VALU stream had no MFMA to hide under and 13 MFMAs ran bare.
+    typename E::v8 hb_prev;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) hb_prev[r] = (typename E::elem)0.f;
+    u32x2 w2lo_p[G::CT], w2hi_p[G::CT];
+#pragma unroll
+    for (int ct = 0; ct < G::CT; ++ct) w2lo_p[ct] = w2hi_p[ct] = (u32x2){0u, 0u};
+    // biases of the chunk whose GEGLU runs this iteration: fetched from LDS one iteration ahead
+    auto load_bias = [&](int jc, float4 (&b)[4]) {
+        const int u0 = jc * 16 + 4 * half;
+        b[0] = *reinterpret_cast<const float4*>(lb1 + u0);
+        b[1] = *reinterpret_cast<const float4*>(lb1 + u0 + 8);
+        b[2] = *reinterpret_cast<const float4*>(lb1 + G::HID + u0);
+        b[3] = *reinterpret_cast<const float4*>(lb1 + G::HID + u0 + 8);
+    };
+    float4 bcur[4];
+    load_bias(0, bcur);
+    for (int jc = 0; jc < G::NCHUNK; ++jc) {
+        if (!(MLP_ABL & 8)) {
+            load_w1(jc + 2 < G::NCHUNK ? jc + 2 : G::NCHUNK - 1);
+            load_w2(jc + 1 < G::NCHUNK ? jc + 1 : G::NCHUNK - 1);
+        }
+        // every LDS read of the iteration is issued here; the second GEMM of chunk jc-1 (register operands) and the first
+        // GEGLU steps run while they are in flight -- one wave per SIMD: nothing else covers that latency
+        const uint8_t* wt = w1s + ((jc + 1) & 1) * G::W1_BYTES + l31 * G::ROWB1 + half * 16;
+        typename E::v8 wf[NG][4][1];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) rp_load_group<DT, KC>(wf[g], wt, g * 4);
+        u32x2 w2lo[G::CT], w2hi[G::CT];  // W2 fragments of chunk jc: consumed next iteration
+        {
+            const uint8_t* w2t = w2s + (jc & 1) * G::W2_BYTES + l31 * G::ROWB2 + half * 8;
+#pragma unroll
+            for (int ct = 0; ct < G::CT; ++ct) {
+                w2lo[ct] = *reinterpret_cast<const u32x2*>(w2t + ct * 32 * G::ROWB2);
+                w2hi[ct] = *reinterpret_cast<const u32x2*>(w2t + ct * 32 * G::ROWB2 + 16);
+            }
+        }
+        float4 bnxt[4];
+        load_bias(jc + 1 < G::NCHUNK ? jc + 1 : jc, bnxt);
+        const float bv[8] = {bcur[0].x, bcur[0].y, bcur[0].z, bcur[0].w, bcur[1].x, bcur[1].y, bcur[1].z, bcur[1].w};
+        const float bg[8] = {bcur[2].x, bcur[2].y, bcur[2].z, bcur[2].w, bcur[3].x, bcur[3].y, bcur[3].z, bcur[3].w};
+
+        f32x16 anxt;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) anxt[r] = 0.f;
+        typename E::v8 hb;
+        auto geglu_step = [&](int r) {
+            const float v0 = acur[r] + bv[r];
+            const float v1 = acur[r + 1] + bv[r + 1];
+            const apad_f32x2 gt = {acur[8 + r] + bg[r], acur[9 + r] + bg[r + 1]};
+            const apad_f32x2 ge = (MLP_ABL & 1) ? gt : gelu_erf_2(gt);
+            hb[r] = (typename E::elem)(v0 * ge[0]);
+            hb[r + 1] = (typename E::elem)(v1 * ge[1]);
+        };
+#ifndef MLP_ORDER
+#define MLP_ORDER 0
+#endif
+#if MLP_ORDER == 1  // second GEMM first, then the first GEMM
+#pragma unroll
+        for (int ct = 0; ct < G::CT; ++ct) {
+            typename E::v8 w2f = as_v8<DT>(make_uint4(w2lo_p[ct][0], w2lo_p[ct][1], w2hi_p[ct][0], w2hi_p[ct][1]));
+            if (MLP_ABL & 4) yacc[ct][ct & 7] += (float)w2f[0] * (float)hb_prev[ct & 7];
+            else yacc[ct] = E::mfma32(w2f, hb_prev, yacc[ct]);
+            if (ct == G::CT / 2 - 1) geglu_step(0);
+        }
+        geglu_step(2);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                if (MLP_ABL & 2) anxt[cc] += (float)wf[g][cc][0][0] * (float)xf[g * 4 + cc][0];
+                else anxt = E::mfma32(wf[g][cc][0], xf[g * 4 + cc], anxt);
+            }
+            if (g == 1) geglu_step(4);
+        }
+        geglu_step(6);
+#else  // per fragment group: 2 second-GEMM MFMAs, 4 first-GEMM MFMAs, one GEGLU step
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+            for (int c2 = 0; c2 < G::CT / NG; ++c2) {
+                const int ct = g * (G::CT / NG) + c2;
+                typename E::v8 w2f = as_v8<DT>(make_uint4(w2lo_p[ct][0], w2lo_p[ct][1], w2hi_p[ct][0], w2hi_p[ct][1]));
+                if (MLP_ABL & 4) yacc[ct][c2] += (float)w2f[0] * (float)hb_prev[c2];
+                else yacc[ct] = E::mfma32(w2f, hb_prev, yacc[ct]);
+            }
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                if (MLP_ABL & 2) anxt[cc] += (float)wf[g][cc][0][0] * (float)xf[g * 4 + cc][0];
+                else anxt = E::mfma32(wf[g][cc][0], xf[g * 4 + cc], anxt);
+            }
+            geglu_step(2 * g);
+        }
+#endif
+#ifndef MLP_PIPE2_VALU
+#define MLP_PIPE2_VALU 7
+#endif
+#if MLP_PIPE2_VALU > 0
+#ifdef MLP_DSFIRST
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 * NG + 2 * G::CT + 4, 0);  // the DS reads first
+#endif
+#pragma unroll
+        for (int i = 0; i < 4 * NG + G::CT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, MLP_PIPE2_VALU, 0);
+        }
+#endif
+        if (!(MLP_ABL & 8)) {
+            store_w1(w1s + (jc & 1) * G::W1_BYTES);
+            store_w2(w2s + ((jc + 1) & 1) * G::W2_BYTES);
+        }
+        if (!(MLP_ABL & 16)) __syncthreads();
+        acur = anxt;
+        hb_prev = hb;
+#pragma unroll
+        for (int ct = 0; ct < G::CT; ++ct) {
+            w2lo_p[ct] = w2lo[ct];
+            w2hi_p[ct] = w2hi[ct];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bcur[i] = bnxt[i];
+    }
+    // drain: second GEMM of the last chunk
+#pragma unroll
+    for (int ct = 0; ct < G::CT; ++ct) {
+        typename E::v8 w2f = as_v8<DT>(make_uint4(w2lo_p[ct][0], w2lo_p[ct][1], w2hi_p[ct][0], w2hi_p[ct][1]));
+        yacc[ct] = E::mfma32(w2f, hb_prev, yacc[ct]);
+    }
+#else
     // Software pipeline: iteration jc runs the first GEMM of chunk jc+1 (matrix pipe) underneath the GEGLU arithmetic
     // of chunk jc (VALU) -- independent instruction streams of the same wave -- then the second GEMM of chunk jc.
     // On entry: W1[jc+1] in w1 stage (jc+1)&1, W2[jc] in w2 stage jc&1, acur = first-GEMM accumulators of chunk jc.
@@ -227,6 +371,8 @@ __global__ __launch_bounds__(NWV * 64, 1) void mlp_kernel(MlpP p) {
         __syncthreads();
         acur = anxt;
     }
+
+#endif
 
     // ---- epilogue: y + b2 + residual(x) through the per-wave transpose scratch ----
 #pragma unroll
