@@ -8,6 +8,8 @@ from .scheduler import DDIMScheduler  # noqa: F401
 from .pipeline import AudioLDM2Pipeline  # noqa: F401
 from .vocoder import SpeechT5HifiGan, HifiGanConfig  # noqa: F401
 from .vae import AutoencoderKL, VaeConfig  # noqa: F401
+from .text_encoders import (PromptEncoder, ClapTextModelWithProjection, T5EncoderModel, GPT2Model,  # noqa: F401
+                            AudioLDM2ProjectionModel)
 from .wiring import install_ap_adapter, build_processors, ip_layer_names, adapter_state_dict, save_adapter, load_adapter  # noqa: F401
 from . import ops, distributed, autograd, config, sharded  # noqa: F401
 from .config import get_config  # noqa: F401

@@ -17,7 +17,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 BF16, F16, F32 = 0, 1, 2
 A_PLAIN, A_CONV3X3, A_PATCH16, A_CONV1D = 0, 1, 2, 4
-EPI_NONE, EPI_SILU, EPI_GELU, EPI_GEGLU, EPI_TANH = 0, 1, 2, 3, 4
+EPI_NONE, EPI_SILU, EPI_GELU, EPI_GEGLU, EPI_TANH, EPI_RELU, EPI_GELU_TANH, EPI_GEGLU_TANH = 0, 1, 2, 3, 4, 5, 6, 7
 OUT_ROWMAJOR, OUT_VT, OUT_QKV = 0, 1, 2
 
 _vp, _i64, _i32, _f32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float
@@ -100,7 +100,9 @@ SYMBOLS = {
     "apad_cfg_ddim_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _i32, _i64, _i32, _vp]),
     "apad_step_advance": (C.c_int, [_vp, _vp]),
     "apad_mix3": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _i32, _vp]),
-    "apad_softmax_rows": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _i64, _f32, _i32, _vp]),
+    "apad_softmax_rows": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i64, _i64, _i64, _f32, _i32, _vp]),
+    "apad_rmsnorm": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i64, _i64, _f32, _i32, _i32, _vp]),
+    "apad_gather_rows": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     "apad_gaussian_sample": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _i32, _vp]),
     # training step (a-11)
     "apad_sizeof_attn_bwd_desc": (C.c_int, []),

@@ -100,22 +100,53 @@ template <int DT> __global__ __launch_bounds__(256) void mix3_kernel(const uint8
 // out[m][n] = softmax_n(scale * x[m][n]); one wave per row, statistics and exponentials in fp32 (libm expf: the op runs once per
 // decoded clip, not per denoise step).  Serves the VAE mid-block's single-head d = 512 attention, which lies outside
 // apad_attention's head-dim envelope and runs as apad_gemm (Q.K^T) -> this -> apad_gemm (P.V).
-template <int DT> __global__ __launch_bounds__(256) void softmax_rows_kernel(const uint8_t* x, uint8_t* out, int64_t M, int N, int64_t ldx,
-                                                                             int64_t ldo, float scale) {
+template <int DT> __global__ __launch_bounds__(256) void softmax_rows_kernel(const uint8_t* x, const float* bias, uint8_t* out, int64_t M, int N,
+                                                                             int64_t ldx, int64_t ldb, int64_t ldo, float scale) {
     const int lane = threadIdx.x & 63;
     const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
     const int64_t xo = m * ldx, oo = m * ldo;
+    const float* bm = bias ? bias + m * ldb : nullptr;
+    auto at = [&](int n) { return ld_elem<DT>(x, xo + n) * scale + (bm ? bm[n] : 0.f); };
     float mx = -INFINITY;
-    for (int n = lane; n < N; n += 64) mx = fmaxf(mx, ld_elem<DT>(x, xo + n) * scale);
+    for (int n = lane; n < N; n += 64) mx = fmaxf(mx, at(n));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (mx == -INFINITY) mx = 0.f;  // a fully masked row: exp(-inf) = 0 everywhere, written as zeros below
     float sum = 0.f;
-    for (int n = lane; n < N; n += 64) sum += expf(ld_elem<DT>(x, xo + n) * scale - mx);
+    for (int n = lane; n < N; n += 64) sum += expf(at(n) - mx);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    const float inv = 1.0f / sum;
-    for (int n = lane; n < N; n += 64) st_elem<DT>(out, oo + n, expf(ld_elem<DT>(x, xo + n) * scale - mx) * inv);
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+    for (int n = lane; n < N; n += 64) st_elem<DT>(out, oo + n, expf(at(n) - mx) * inv);
+}
+
+// T5LayerNorm (mode 0: x * rsqrt(mean(x^2) + eps) * gamma) and F.normalize (mode 1: x / max(||x||, eps)); one wave per row
+template <int DT> __global__ __launch_bounds__(256) void rmsnorm_kernel(const uint8_t* x, const uint8_t* gamma, uint8_t* out, int64_t M, int C,
+                                                                        int64_t ldx, int64_t ldo, float eps, int mode) {
+    const int lane = threadIdx.x & 63;
+    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    float ss = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float v = ld_elem<DT>(x, m * ldx + c);
+        ss = fmaf(v, v, ss);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    const float r = mode == 0 ? 1.0f / sqrtf(ss / (float)C + eps) : 1.0f / fmaxf(sqrtf(ss), eps);
+    for (int c = lane; c < C; c += 64) st_elem<DT>(out, m * ldo + c, ld_elem<DT>(x, m * ldx + c) * r * (mode == 0 ? ld_elem<DT>(gamma, c) : 1.0f));
+}
+
+// nn.Embedding: one wave per output row
+template <int DT> __global__ __launch_bounds__(256) void gather_rows_kernel(const uint8_t* table, const int64_t* ids, uint8_t* out, int64_t n,
+                                                                            int64_t rows, int C) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int64_t id = ids[i];
+    const bool ok = id >= 0 && id < rows;
+    for (int c = lane; c < C; c += 64) st_elem<DT>(out, i * C + c, ok ? ld_elem<DT>(table, id * C + c) : 0.f);
 }
 
 // DiagonalGaussianDistribution.sample() of the VAE encoder: moments [rows][2L] = (mean | logvar) per latent pixel ->
@@ -216,18 +247,43 @@ extern "C" int apad_mix3(const void* a, const void* b, const void* c, void* out,
     return apad_check_launch("apad_mix3");
 }
 
-extern "C" int apad_softmax_rows(const void* x, void* out, int64_t M, int32_t N, int64_t ldx, int64_t ldo, float scale, int32_t dtype,
-                                 void* stream) {
-    APAD_CHECK(x && out && M > 0 && N > 0 && ldx >= N && ldo >= N, "apad_softmax_rows: bad operands (M=%lld N=%d ldx=%lld ldo=%lld)",
-               (long long)M, N, (long long)ldx, (long long)ldo);
+extern "C" int apad_softmax_rows(const void* x, const float* bias, void* out, int64_t M, int32_t N, int64_t ldx, int64_t ldb, int64_t ldo,
+                                 float scale, int32_t dtype, void* stream) {
+    APAD_CHECK(x && out && M > 0 && N > 0 && ldx >= N && ldo >= N && (!bias || ldb >= N),
+               "apad_softmax_rows: bad operands (M=%lld N=%d ldx=%lld ldb=%lld ldo=%lld)", (long long)M, N, (long long)ldx, (long long)ldb, (long long)ldo);
     APAD_CHECK(dtype == APAD_BF16 || dtype == APAD_F16 || dtype == APAD_F32, "apad_softmax_rows: dtype %d not supported", dtype);
     const dim3 grid((unsigned)((M + 3) / 4));
     hipStream_t s = (hipStream_t)stream;
     const uint8_t* px = (const uint8_t*)x;
-    if (dtype == APAD_F32) hipLaunchKernelGGL((softmax_rows_kernel<APAD_F32>), grid, dim3(256), 0, s, px, (uint8_t*)out, M, N, ldx, ldo, scale);
-    else if (dtype == APAD_BF16) hipLaunchKernelGGL((softmax_rows_kernel<APAD_BF16>), grid, dim3(256), 0, s, px, (uint8_t*)out, M, N, ldx, ldo, scale);
-    else hipLaunchKernelGGL((softmax_rows_kernel<APAD_F16>), grid, dim3(256), 0, s, px, (uint8_t*)out, M, N, ldx, ldo, scale);
+    if (dtype == APAD_F32) hipLaunchKernelGGL((softmax_rows_kernel<APAD_F32>), grid, dim3(256), 0, s, px, bias, (uint8_t*)out, M, N, ldx, ldb, ldo, scale);
+    else if (dtype == APAD_BF16) hipLaunchKernelGGL((softmax_rows_kernel<APAD_BF16>), grid, dim3(256), 0, s, px, bias, (uint8_t*)out, M, N, ldx, ldb, ldo, scale);
+    else hipLaunchKernelGGL((softmax_rows_kernel<APAD_F16>), grid, dim3(256), 0, s, px, bias, (uint8_t*)out, M, N, ldx, ldb, ldo, scale);
     return apad_check_launch("apad_softmax_rows");
+}
+
+extern "C" int apad_rmsnorm(const void* x, const void* gamma, void* out, int64_t M, int32_t C, int64_t ldx, int64_t ldo, float eps, int32_t mode,
+                            int32_t dtype, void* stream) {
+    APAD_CHECK(x && out && M > 0 && C > 0 && ldx >= C && ldo >= C && (mode == 0 || mode == 1) && (mode == 1 || gamma), "apad_rmsnorm: bad operands");
+    APAD_CHECK(dtype == APAD_BF16 || dtype == APAD_F16 || dtype == APAD_F32, "apad_rmsnorm: dtype %d not supported", dtype);
+    const dim3 grid((unsigned)((M + 3) / 4));
+    hipStream_t s = (hipStream_t)stream;
+    const uint8_t *px = (const uint8_t*)x, *pg = (const uint8_t*)gamma;
+    if (dtype == APAD_F32) hipLaunchKernelGGL((rmsnorm_kernel<APAD_F32>), grid, dim3(256), 0, s, px, pg, (uint8_t*)out, M, C, ldx, ldo, eps, mode);
+    else if (dtype == APAD_BF16) hipLaunchKernelGGL((rmsnorm_kernel<APAD_BF16>), grid, dim3(256), 0, s, px, pg, (uint8_t*)out, M, C, ldx, ldo, eps, mode);
+    else hipLaunchKernelGGL((rmsnorm_kernel<APAD_F16>), grid, dim3(256), 0, s, px, pg, (uint8_t*)out, M, C, ldx, ldo, eps, mode);
+    return apad_check_launch("apad_rmsnorm");
+}
+
+extern "C" int apad_gather_rows(const void* table, const int64_t* ids, void* out, int64_t n, int64_t rows, int32_t C, int32_t dtype, void* stream) {
+    APAD_CHECK(table && ids && out && n > 0 && rows > 0 && C > 0, "apad_gather_rows: bad operands");
+    APAD_CHECK(dtype == APAD_BF16 || dtype == APAD_F16 || dtype == APAD_F32, "apad_gather_rows: dtype %d not supported", dtype);
+    const dim3 grid((unsigned)((n + 3) / 4));
+    hipStream_t s = (hipStream_t)stream;
+    const uint8_t* pt = (const uint8_t*)table;
+    if (dtype == APAD_F32) hipLaunchKernelGGL((gather_rows_kernel<APAD_F32>), grid, dim3(256), 0, s, pt, ids, (uint8_t*)out, n, rows, C);
+    else if (dtype == APAD_BF16) hipLaunchKernelGGL((gather_rows_kernel<APAD_BF16>), grid, dim3(256), 0, s, pt, ids, (uint8_t*)out, n, rows, C);
+    else hipLaunchKernelGGL((gather_rows_kernel<APAD_F16>), grid, dim3(256), 0, s, pt, ids, (uint8_t*)out, n, rows, C);
+    return apad_check_launch("apad_gather_rows");
 }
 
 extern "C" int apad_gaussian_sample(const void* moments, const void* noise, void* out, int64_t rows, int32_t latent, float scale,

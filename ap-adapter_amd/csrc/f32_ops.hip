@@ -23,6 +23,8 @@ __device__ __forceinline__ f32x16 mfma2(float a, float b, f32x16 c) {
 }
 __device__ __forceinline__ float silu_p(float x) { return x / (1.0f + expf(-x)); }
 __device__ __forceinline__ float gelu_p(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// "gelu_new" of GPT-2 / T5's gated-gelu (transformers NewGELUActivation)
+__device__ __forceinline__ float gelu_tanh_p(float x) { return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x))); }
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -105,7 +107,7 @@ template <int AMODE> __global__ __launch_bounds__(256) void gemm_f32_kernel(G32P
     float* const sB = smem + TB * BKF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
-    const bool geglu = p.epi == APAD_EPI_GEGLU;
+    const bool geglu = p.epi == APAD_EPI_GEGLU || p.epi == APAD_EPI_GEGLU_TANH;
     const int bn_out = geglu ? TB / 2 : TB;  // GEGLU: first half of the tile columns = value rows, second half = gate rows
     const int nt = blockIdx.x % p.n_tiles, mt = blockIdx.x / p.n_tiles;
     const int64_t m0 = (int64_t)mt * TB, n0 = (int64_t)nt * bn_out;
@@ -210,6 +212,8 @@ template <int AMODE> __global__ __launch_bounds__(256) void gemm_f32_kernel(G32P
             if (p.epi == APAD_EPI_SILU) v = silu_p(v);
             if (p.epi == APAD_EPI_GELU) v = gelu_p(v);
             if (p.epi == APAD_EPI_TANH) v = tanhf(v);
+            if (p.epi == APAD_EPI_RELU) v = fmaxf(v, 0.f);
+            if (p.epi == APAD_EPI_GELU_TANH) v = gelu_tanh_p(v);
             ct[ml * CLD + nl] = v;
         }
     }
@@ -229,7 +233,7 @@ template <int AMODE> __global__ __launch_bounds__(256) void gemm_f32_kernel(G32P
             if (geglu) {
                 const f4 g = *reinterpret_cast<const f4*>(&ct[rl * CLD + TB / 2 + vc * 4]);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) f[e] *= gelu_p(g[e]);
+                for (int e = 0; e < 4; ++e) f[e] *= p.epi == APAD_EPI_GEGLU_TANH ? gelu_tanh_p(g[e]) : gelu_p(g[e]);
             }
             if (p.residual) {
                 const int64_t rm = p.res_mod > 0 ? m % p.res_mod : m;
@@ -521,7 +525,7 @@ int apad_f32_gemm(const apad_gemm_desc* d, hipStream_t s) {
     p.stride = d->stride; p.Hup = d->Hup; p.Wup = d->Wup; p.src_batch_mod = d->src_batch_mod; p.res_mod = d->residual_row_mod;
     p.heads = d->heads; p.head_dim = d->head_dim; p.L = d->L; p.Lpad = d->Lpad;
     p.epi = d->epilogue; p.outmode = d->out_mode;
-    APAD_CHECK(d->epilogue >= APAD_EPI_NONE && d->epilogue <= APAD_EPI_TANH, "apad_gemm(f32): unknown epilogue %d", d->epilogue);
+    APAD_CHECK(d->epilogue >= APAD_EPI_NONE && d->epilogue <= APAD_EPI_GEGLU_TANH, "apad_gemm(f32): unknown epilogue %d", d->epilogue);
     p.taps = d->taps; p.dilation = d->dilation; p.pad = d->pad; p.transposed = d->transposed; p.pre_act = d->a_pre_act;
     p.pre_slope = d->a_pre_slope;
     p.lead = d->conv_asym_pad ? 0 : 1;
@@ -553,7 +557,7 @@ int apad_f32_gemm(const apad_gemm_desc* d, hipStream_t s) {
     if (d->out_mode == APAD_OUT_ROWMAJOR) {
         APAD_CHECK(d->N % 4 == 0 && d->ldo % 4 == 0, "apad_gemm(f32): N and ldo must be multiples of 4");
         if (d->residual) APAD_CHECK(d->ldr % 4 == 0, "apad_gemm(f32): ldr must be a multiple of 4");
-        if (d->epilogue == APAD_EPI_GEGLU) APAD_CHECK(d->N % 32 == 0, "apad_gemm(f32): GEGLU needs N %% 32 == 0");
+        if (d->epilogue == APAD_EPI_GEGLU || d->epilogue == APAD_EPI_GEGLU_TANH) APAD_CHECK(d->N % 32 == 0, "apad_gemm(f32): GEGLU needs N %% 32 == 0");
     } else if (d->out_mode == APAD_OUT_QKV) {
         APAD_CHECK(d->epilogue == APAD_EPI_NONE && d->a_mode == APAD_A_PLAIN, "apad_gemm(f32): APAD_OUT_QKV supports plain A / epilogue NONE only");
         APAD_CHECK(d->out2 && d->out3 && al16(d->out2) && al16(d->out3), "apad_gemm(f32): APAD_OUT_QKV needs 16-byte aligned out2 / out3");
@@ -572,7 +576,7 @@ int apad_f32_gemm(const apad_gemm_desc* d, hipStream_t s) {
         return -1;
     }
     if (d->rowgroup_bias) APAD_CHECK(d->ld_rg > 0, "apad_gemm(f32): rowgroup_bias needs ld_rg");
-    const int bn_out = d->epilogue == APAD_EPI_GEGLU ? TB / 2 : TB;
+    const int bn_out = (d->epilogue == APAD_EPI_GEGLU || d->epilogue == APAD_EPI_GEGLU_TANH) ? TB / 2 : TB;
     p.n_tiles = (int)((d->N + bn_out - 1) / bn_out);
     const int64_t m_tiles = (d->M + TB - 1) / TB;
     dim3 grid((unsigned)(p.n_tiles * m_tiles));

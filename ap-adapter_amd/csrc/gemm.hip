@@ -635,6 +635,10 @@ int dispatch_epi(const GemmP& p, int epi, int outmode, hipStream_t s) {
         case APAD_EPI_GELU: return launch<DT, AMODE, APAD_EPI_GELU, APAD_OUT_ROWMAJOR>(p, s);
         case APAD_EPI_GEGLU: return launch<DT, AMODE, APAD_EPI_GEGLU, APAD_OUT_ROWMAJOR>(p, s);
     }
+    if (epi == APAD_EPI_TANH || epi == APAD_EPI_RELU || epi == APAD_EPI_GELU_TANH || epi == APAD_EPI_GEGLU_TANH) {
+        apad_set_error("apad_gemm: epilogue %d is an fp32-mode epilogue (dtype APAD_F32; 16-bit: tanh in conv1d mode only)", epi);
+        return -1;
+    }
     apad_set_error("apad_gemm: unknown epilogue %d", epi);
     return -1;
 }

@@ -12,7 +12,8 @@ import torch
 from . import _lib as L
 
 _DT = {torch.bfloat16: L.BF16, torch.float16: L.F16, torch.float32: L.F32}
-_EPI = {None: L.EPI_NONE, "none": L.EPI_NONE, "silu": L.EPI_SILU, "gelu": L.EPI_GELU, "geglu": L.EPI_GEGLU, "tanh": L.EPI_TANH}
+_EPI = {None: L.EPI_NONE, "none": L.EPI_NONE, "silu": L.EPI_SILU, "gelu": L.EPI_GELU, "geglu": L.EPI_GEGLU, "tanh": L.EPI_TANH,
+        "relu": L.EPI_RELU, "gelu_tanh": L.EPI_GELU_TANH, "geglu_tanh": L.EPI_GEGLU_TANH}  # the last three: fp32 mode only
 
 
 def _stream():
@@ -64,7 +65,7 @@ def linear(x, w, bias=None, residual=None, act=None, out=None, rowgroup_bias=Non
     _req(w, "linear.w")
     K = x.shape[-1]
     M = x.numel() // K
-    N = w.shape[0] // 2 if act == "geglu" else w.shape[0]
+    N = w.shape[0] // 2 if act in ("geglu", "geglu_tanh") else w.shape[0]
     x2 = x.reshape(M, K)
     if out is None:
         out = torch.empty(*x.shape[:-1], N, dtype=w.dtype, device=x.device)
@@ -290,16 +291,55 @@ def mix3(a, b, c, scale, out=None):
     return out
 
 
-def softmax_rows(x, scale=1.0, out=None):
-    """softmax(scale * x) over the last dim of x [..., N] (row-contiguous), fp32 statistics"""
+def softmax_rows(x, scale=1.0, out=None, bias=None):
+    """softmax(scale * x + bias) over the last dim of x [..., N] (row-contiguous), fp32 statistics; bias: fp32, same shape"""
     _req(x, "softmax_rows.x")
     N = x.shape[-1]
     x2 = x.reshape(-1, N)
     if out is None:
         out = torch.empty_like(x2)
-    L.check(L.lib().apad_softmax_rows(x2.data_ptr(), out.data_ptr(), x2.shape[0], N, x2.stride(0), out.stride(0), float(scale),
-                                      _DT[x.dtype], _stream()), "apad_softmax_rows")
+    b2 = None
+    if bias is not None:
+        b2 = _req(bias, "softmax_rows.bias", torch.float32).reshape(-1, N)
+        if b2.shape[0] != x2.shape[0]:
+            raise ValueError(f"softmax_rows: bias {tuple(bias.shape)} does not match x {tuple(x.shape)}")
+    L.check(L.lib().apad_softmax_rows(x2.data_ptr(), _ptr(b2), out.data_ptr(), x2.shape[0], N, x2.stride(0), b2.stride(0) if b2 is not None else 0,
+                                      out.stride(0), float(scale), _DT[x.dtype], _stream()), "apad_softmax_rows")
     return out.view(x.shape)
+
+
+def rms_norm(x, gamma, eps):
+    """T5LayerNorm: x * rsqrt(mean(x^2) + eps) * gamma over the last dim"""
+    _req(x, "rms_norm.x", gamma.dtype)
+    Cc = x.shape[-1]
+    x2 = x.reshape(-1, Cc)
+    out = torch.empty_like(x2)
+    L.check(L.lib().apad_rmsnorm(x2.data_ptr(), gamma.data_ptr(), out.data_ptr(), x2.shape[0], Cc, x2.stride(0), Cc, float(eps), 0, _DT[x.dtype],
+                                 _stream()), "apad_rmsnorm")
+    return out.view(x.shape)
+
+
+def l2_normalize(x, eps=1e-12):
+    """F.normalize(x, dim=-1)"""
+    _req(x, "l2_normalize.x")
+    Cc = x.shape[-1]
+    x2 = x.reshape(-1, Cc)
+    out = torch.empty_like(x2)
+    L.check(L.lib().apad_rmsnorm(x2.data_ptr(), None, out.data_ptr(), x2.shape[0], Cc, x2.stride(0), Cc, float(eps), 1, _DT[x.dtype], _stream()),
+            "apad_rmsnorm")
+    return out.view(x.shape)
+
+
+def embedding(table, ids):
+    """nn.Embedding lookup on the device: table [rows, C], ids int64 [...] -> [..., C]"""
+    _req(table, "embedding.table")
+    if ids.dtype != torch.int64 or not ids.is_cuda:
+        raise RuntimeError("embedding.ids: expected an int64 GPU tensor")
+    ids = ids.contiguous()
+    out = torch.empty(*ids.shape, table.shape[1], dtype=table.dtype, device=table.device)
+    L.check(L.lib().apad_gather_rows(table.data_ptr(), ids.data_ptr(), out.data_ptr(), ids.numel(), table.shape[0], table.shape[1],
+                                     _DT[table.dtype], _stream()), "apad_gather_rows")
+    return out
 
 
 def gaussian_sample(moments, noise, scale=1.0):

@@ -1,8 +1,9 @@
 """Hot-path half of ``AudioLDM2Pipeline`` (/root/reference/pipeline/pipeline_audioldm2.py:748-1061): audio-condition
 assembly (:919-956), latent preparation (:724-744), the CFG + DDIM denoise loop (:983-1031), ``output_type="latent"``
 exit (:1036-1040), and -- with ``vae=`` / ``vocoder=`` supplied -- the VAE decode and HiFi-GAN stages after it (:1036-1044,
-SURVEY f-4, ``vae.py`` / ``vocoder.py``).  The keyword surface of ``__call__`` is the reference's; the text encoders (CLAP / T5 /
-GPT-2, [3P]) are not rebuilt: drive it with the precomputed-embedding arguments the reference already accepts.
+SURVEY f-4, ``vae.py`` / ``vocoder.py``) and, with ``prompt_encoder=`` and the two tokenizers, ``encode_prompt`` for text prompts
+(:272-580, ``text_encoders.py``).  The keyword surface of ``__call__`` is the reference's; without a prompt encoder, drive it with the
+precomputed-embedding arguments the reference already accepts.
 
 MI355X-first structure of the loop:
   * K/V of all 64 cross-attention sites are projected once per call (timestep-invariant), not once per step
@@ -30,10 +31,13 @@ class AudioLDM2Pipeline:
     vocoder_model_in_dim = 64      # mel bins
     vocoder_upsample_factor = 0.01  # prod(upsample_rates) / sampling_rate = 160 / 16000
 
-    def __init__(self, unet, scheduler: Optional[DDIMScheduler] = None, audiomae=None, vocoder=None, vae=None):
+    def __init__(self, unet, scheduler: Optional[DDIMScheduler] = None, audiomae=None, vocoder=None, vae=None, prompt_encoder=None,
+                 tokenizer=None, tokenizer_2=None):
         self.unet = unet
         self.vocoder = vocoder  # vocoder.SpeechT5HifiGan (HIP) -- mel -> waveform
         self.vae = vae          # vae.AutoencoderKL (HIP) -- latents -> mel
+        self.prompt_encoder = prompt_encoder  # text_encoders.PromptEncoder (HIP): CLAP text + T5 + projection + GPT-2
+        self.tokenizer, self.tokenizer_2 = tokenizer, tokenizer_2  # the caller's CLAP (RoBERTa) / T5 tokenizers (host-side, vocab files)
         self.scheduler = scheduler or DDIMScheduler()
         self.audiomae = audiomae
         self._uncond_cache = {}
@@ -51,6 +55,61 @@ class AudioLDM2Pipeline:
         if mel_spectrogram.dim() == 4:
             mel_spectrogram = mel_spectrogram.squeeze(1)
         return self.vocoder(mel_spectrogram).cpu().float()
+
+    def _encode_text(self, texts, t5_max_length=None):
+        """tokenise as encode_prompt does (:381-392 positive, :485-496 negative) and run the HIP prompt encoder on one CFG half"""
+        if self.prompt_encoder is None or self.tokenizer is None or self.tokenizer_2 is None:
+            raise NotImplementedError("text prompts need prompt_encoder=ap_adapter_amd.PromptEncoder(...) and the CLAP / T5 tokenizers "
+                                      "(tokenizer=, tokenizer_2=); or pass prompt_embeds, generated_prompt_embeds, attention_mask and their "
+                                      "negative_* twins (the reference accepts them too)")
+        dev = next(self.prompt_encoder.parameters()).device
+        # the first tokenizer is CLAP's RoBERTa tokenizer: always padded to its model_max_length; the second (T5) to the longest prompt,
+        # or -- for the negative prompts -- to the positive prompts' length
+        ct = self.tokenizer(texts, padding="max_length", max_length=self.tokenizer.model_max_length, truncation=True, return_tensors="pt")
+        if t5_max_length is None:
+            tt = self.tokenizer_2(texts, padding=True, max_length=self.tokenizer_2.model_max_length, truncation=True, return_tensors="pt")
+        else:
+            tt = self.tokenizer_2(texts, padding="max_length", max_length=t5_max_length, truncation=True, return_tensors="pt")
+        return self.prompt_encoder.encode(ct.input_ids.to(dev), ct.attention_mask.to(dev), tt.input_ids.to(dev), tt.attention_mask.to(dev),
+                                          max_new_tokens=self._max_new_tokens)
+
+    def encode_prompt(self, prompt, device, num_waveforms_per_prompt, do_classifier_free_guidance, negative_prompt=None, prompt_embeds=None,
+                      negative_prompt_embeds=None, generated_prompt_embeds=None, negative_generated_prompt_embeds=None, attention_mask=None,
+                      negative_attention_mask=None, max_new_tokens=None):
+        """pipeline_audioldm2.py:272-580, same arguments and return value: (prompt_embeds = T5 states, attention_mask,
+        generated_prompt_embeds = GPT-2 vectors), each repeated per waveform and -- under guidance -- stacked [negative; positive]."""
+        self._max_new_tokens = max_new_tokens
+        if prompt is not None and isinstance(prompt, str):
+            batch_size = 1
+            prompt = [prompt]
+        elif prompt is not None and isinstance(prompt, list):
+            batch_size = len(prompt)
+        else:
+            batch_size = prompt_embeds.shape[0]
+        if prompt_embeds is None:
+            prompt_embeds, attention_mask, generated_prompt_embeds = self._encode_text(prompt)
+        if attention_mask is None:
+            attention_mask = torch.ones(prompt_embeds.shape[:2], dtype=torch.long)
+        rep = lambda t: t.to(device).repeat_interleave(num_waveforms_per_prompt, dim=0)  # == repeat(1, n, 1).view(b * n, ...) (:427-443)
+        prompt_embeds, attention_mask, generated_prompt_embeds = rep(prompt_embeds), rep(attention_mask), rep(generated_prompt_embeds)
+        if do_classifier_free_guidance and negative_prompt_embeds is None:
+            if negative_prompt is None:
+                uncond_tokens = [""] * batch_size
+            elif isinstance(negative_prompt, str):
+                uncond_tokens = [negative_prompt]
+            elif batch_size != len(negative_prompt):
+                raise ValueError(f"`negative_prompt` has batch size {len(negative_prompt)}, but `prompt` has batch size {batch_size}")
+            else:
+                uncond_tokens = negative_prompt
+            negative_prompt_embeds, negative_attention_mask, negative_generated_prompt_embeds = self._encode_text(
+                uncond_tokens, t5_max_length=prompt_embeds.shape[1])
+        if do_classifier_free_guidance:
+            if negative_attention_mask is None:
+                negative_attention_mask = torch.ones(negative_prompt_embeds.shape[:2], dtype=torch.long)
+            prompt_embeds = torch.cat([rep(negative_prompt_embeds), prompt_embeds])
+            attention_mask = torch.cat([rep(negative_attention_mask), attention_mask])
+            generated_prompt_embeds = torch.cat([rep(negative_generated_prompt_embeds), generated_prompt_embeds])
+        return prompt_embeds, attention_mask, generated_prompt_embeds
 
     def prepare_latents(self, batch_size, num_channels_latents, height, dtype, device, generator, latents=None):
         shape = (batch_size, num_channels_latents, height // self.vae_scale_factor,
@@ -220,21 +279,18 @@ class AudioLDM2Pipeline:
                  attention_mask=None, negative_attention_mask=None, max_new_tokens=None, return_dict=True,
                  callback=None, callback_steps=1, cross_attention_kwargs=None, output_type="latent", mel=None,
                  use_graph=True):
-        if prompt is not None or negative_prompt is not None:
-            raise NotImplementedError(
-                "text prompts need the CLAP/T5/GPT-2 encoders, which are outside the hot path; pass prompt_embeds, "
-                "generated_prompt_embeds, attention_mask and their negative_* twins (the reference accepts them too)")
         if output_type != "latent" and (self.vae is None or self.vocoder is None):
             raise NotImplementedError("waveform output needs latents -> mel (vae=ap_adapter_amd.AutoencoderKL) and mel -> waveform "
                                       "(vocoder=ap_adapter_amd.SpeechT5HifiGan); or use output_type='latent'")
         if eta != 0.0:
             raise NotImplementedError("eta != 0 is not used by the reference drivers")
-        for n, v in (("prompt_embeds", prompt_embeds), ("negative_prompt_embeds", negative_prompt_embeds),
-                     ("generated_prompt_embeds", generated_prompt_embeds),
-                     ("negative_generated_prompt_embeds", negative_generated_prompt_embeds),
-                     ("attention_mask", attention_mask), ("negative_attention_mask", negative_attention_mask)):
-            if v is None:
-                raise ValueError(f"{n} is required when no text prompt is given")
+        if prompt is None:
+            for n, v in (("prompt_embeds", prompt_embeds), ("negative_prompt_embeds", negative_prompt_embeds),
+                         ("generated_prompt_embeds", generated_prompt_embeds),
+                         ("negative_generated_prompt_embeds", negative_generated_prompt_embeds),
+                         ("attention_mask", attention_mask), ("negative_attention_mask", negative_attention_mask)):
+                if v is None:
+                    raise ValueError(f"{n} is required when no text prompt is given")
         if audio_file is not None and mel is None:
             from .frontend import load_mel  # "next" row f-2
             mel = load_mel(audio_file)
@@ -245,12 +301,15 @@ class AudioLDM2Pipeline:
             height = -(-height // self.vae_scale_factor) * self.vae_scale_factor
         dev = self.unet.conv_in.weight.device
         dtype = self.unet.conv_in.weight.dtype
-        batch_size = prompt_embeds.shape[0]
-        rep = lambda t: t.to(dev).repeat_interleave(num_waveforms_per_prompt, dim=0)
-        # encode_prompt with precomputed embeddings (:547-580): [negative; positive]
-        pe = torch.cat([rep(negative_prompt_embeds), rep(prompt_embeds)])
-        am = torch.cat([rep(negative_attention_mask), rep(attention_mask)])
-        ge = torch.cat([rep(negative_generated_prompt_embeds), rep(generated_prompt_embeds)])
+        if prompt is not None:
+            batch_size = 1 if isinstance(prompt, str) else len(prompt)
+        else:
+            batch_size = prompt_embeds.shape[0]
+        # encode_prompt (:272-580): text prompts through the HIP prompt encoder, or the precomputed embeddings; [negative; positive]
+        pe, am, ge = self.encode_prompt(prompt, dev, num_waveforms_per_prompt, True, negative_prompt, prompt_embeds=prompt_embeds,
+                                        negative_prompt_embeds=negative_prompt_embeds, generated_prompt_embeds=generated_prompt_embeds,
+                                        negative_generated_prompt_embeds=negative_generated_prompt_embeds, attention_mask=attention_mask,
+                                        negative_attention_mask=negative_attention_mask, max_new_tokens=max_new_tokens)
         if mel is not None:
             tokens, uncond = self.encode_audio(mel.to(dev), time_pooling, freq_pooling)
             ge = self.assemble_condition(ge, tokens, uncond, dtype)

@@ -52,7 +52,13 @@ enum {
 };
 
 /* apad_gemm_desc.epilogue (applied to acc + bias + rowgroup_bias, before + residual) */
-enum { APAD_EPI_NONE = 0, APAD_EPI_SILU = 1, APAD_EPI_GELU = 2, APAD_EPI_GEGLU = 3, APAD_EPI_TANH = 4 };
+enum {
+    APAD_EPI_NONE = 0, APAD_EPI_SILU = 1, APAD_EPI_GELU = 2, APAD_EPI_GEGLU = 3, APAD_EPI_TANH = 4,
+    /* fp32 precision mode only (the prompt encoders, which run once per prompt): */
+    APAD_EPI_RELU = 5,       /* CLAP's text projection                                                 */
+    APAD_EPI_GELU_TANH = 6,  /* "gelu_new": 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))) -- GPT-2    */
+    APAD_EPI_GEGLU_TANH = 7  /* value * gelu_new(gate), weight rows value|gate -- T5's gated-gelu FF   */
+};
 
 /* apad_gemm_desc.out_mode */
 enum {
@@ -255,11 +261,22 @@ int apad_step_advance(int32_t* step_ptr, void* stream);
    SpeechT5HifiGan.forward) */
 int apad_mix3(const void* a, const void* b, const void* c, void* out, int64_t n, float scale, int32_t dtype, void* stream);
 
-/* Row softmax: out[m][n] = softmax over n of (scale * x[m][n]), fp32 statistics, one wave per row (x, out: [M][ld] of dtype).
+/* Row softmax: out[m][n] = softmax over n of (scale * x[m][n] + bias[m][n]), fp32 statistics, one wave per row (x, out: [M][ld]
+   of dtype; bias: optional fp32 [M][ldb] -- T5's relative-position bias, causal / padding masks as -inf).
    The VAE mid-block attention (diffusers AutoencoderKL decoder/encoder, one head of d = 512 over the 4000 latent pixels --
    outside apad_attention's head-dim envelope) runs as apad_gemm (Q.K^T) -> apad_softmax_rows -> apad_gemm (P.V). */
-int apad_softmax_rows(const void* x, void* out, int64_t M, int32_t N, int64_t ldx, int64_t ldo, float scale, int32_t dtype,
-                      void* stream);
+int apad_softmax_rows(const void* x, const float* bias, void* out, int64_t M, int32_t N, int64_t ldx, int64_t ldb, int64_t ldo,
+                      float scale, int32_t dtype, void* stream);
+
+/* T5LayerNorm / RMS norm (mode 0): out = x * rsqrt(mean(x^2) + eps) * gamma; F.normalize (mode 1, gamma ignored):
+   out = x / max(||x||_2, eps).  x, out [M][ld] of dtype, one wave per row, fp32 statistics. */
+int apad_rmsnorm(const void* x, const void* gamma, void* out, int64_t M, int32_t C, int64_t ldx, int64_t ldo, float eps,
+                 int32_t mode, int32_t dtype, void* stream);
+
+/* nn.Embedding lookup: out[i][:] = table[ids[i]][:] (ids int64 on the device, rows of C elements of dtype); an id outside
+   [0, rows) writes zeros. */
+int apad_gather_rows(const void* table, const int64_t* ids, void* out, int64_t n, int64_t rows, int32_t C, int32_t dtype,
+                     void* stream);
 
 /* The VAE encoder's posterior draw (diffusers DiagonalGaussianDistribution.sample(), train_apadapter_v2.py:895-897):
    moments [rows][2*latent] = (mean | logvar) per latent pixel, noise [rows][latent] ->

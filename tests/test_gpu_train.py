@@ -182,7 +182,11 @@ def test_mse_loss_scaling_keeps_f16_gradients(dev):
     assert rel_err(scaled, exact) < TOL[torch.float16]
     pd2 = pred.to(dev, torch.float16).requires_grad_(True)
     AG.mse_loss(pd2, tgt.to(dev)).backward()
-    assert rel_err(pd2.grad, exact) > 10 * rel_err(scaled, exact)  # what the scale is for
+    # what the scale is for: every gradient here is an f16 subnormal (spacing 6e-8, i.e. ~0.5 % of a 1e-5 value); max-normalised error
+    # hides that, the mean element-wise relative error shows it
+    sel = exact.abs() > 1e-6
+    mean_rel = lambda g: float(((g.float().cpu() - exact).abs() / exact.abs())[sel].mean())
+    assert mean_rel(pd2.grad) > 5 * mean_rel(scaled)
 
 
 def test_trainer_f16_loss_scale_and_overflow_skip(dev):

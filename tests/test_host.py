@@ -174,7 +174,7 @@ def test_scheduler_matches_oracle():
 
 def test_pipeline_rejects_out_of_scope_stages(unet):
     pipe = A.AudioLDM2Pipeline(unet)
-    with pytest.raises(NotImplementedError, match="text prompts"):
+    with pytest.raises(NotImplementedError, match="text prompts need prompt_encoder"):
         pipe(prompt="jazz")
     e = torch.zeros(1, 16, 1024)
     with pytest.raises(NotImplementedError, match="AutoencoderKL"):

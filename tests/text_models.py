@@ -1,0 +1,56 @@
+"""Tiny seeded transformers models (the reference's own dependency for CLAP / T5 / GPT-2) shared by the CPU and GPU prompt-encoding tests."""
+import torch
+
+
+def tiny_clap(heads=4, hidden=64, seed=0):
+    from transformers import ClapAudioConfig, ClapConfig, ClapModel, ClapTextConfig
+    torch.manual_seed(seed)
+    tc = ClapTextConfig(vocab_size=120, hidden_size=hidden, num_hidden_layers=2, num_attention_heads=heads, intermediate_size=128,
+                        max_position_embeddings=80, projection_dim=32)
+    ac = ClapAudioConfig(patch_embeds_hidden_size=8, depths=[1, 1], num_attention_heads=[1, 1], hidden_size=16, num_mel_bins=16, spec_size=32,
+                         patch_size=4, patch_stride=[4, 4], window_size=2, projection_dim=32)
+    m = ClapModel(ClapConfig(text_config=tc.to_dict(), audio_config=ac.to_dict(), projection_dim=32)).eval()
+    return m, tc
+
+
+def tiny_t5(seed=1):
+    from transformers import T5Config, T5EncoderModel
+    torch.manual_seed(seed)
+    c = T5Config(vocab_size=100, d_model=64, d_kv=16, d_ff=96, num_layers=2, num_heads=4, feed_forward_proj="gated-gelu")
+    m = T5EncoderModel(c).eval()
+    with torch.no_grad():  # default init leaves the relative bias tiny: make it matter
+        m.encoder.block[0].layer[0].SelfAttention.relative_attention_bias.weight.normal_(std=1.0)
+    return m, c
+
+
+def tiny_gpt2(seed=2):
+    from transformers import GPT2Config, GPT2Model
+    torch.manual_seed(seed)
+    c = GPT2Config(vocab_size=100, n_positions=64, n_embd=64, n_layer=2, n_head=4)
+    m = GPT2Model(c).eval()
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() > 1:
+                p.mul_(3.0)  # default std 0.02 makes attention nearly uniform
+    return m, c
+
+
+def ours_from(tm, tc, kind, dev=None):
+    """the HIP module with the transformers module's weights"""
+    import ap_adapter_amd.text_encoders as TE
+    if kind == "clap":
+        o = TE.ClapTextModelWithProjection(TE.ClapTextConfig(vocab_size=tc.vocab_size, hidden_size=tc.hidden_size, num_hidden_layers=tc.num_hidden_layers,
+                                                             num_attention_heads=tc.num_attention_heads, intermediate_size=tc.intermediate_size,
+                                                             max_position_embeddings=tc.max_position_embeddings, projection_dim=tc.projection_dim,
+                                                             pad_token_id=tc.pad_token_id, layer_norm_eps=tc.layer_norm_eps))
+    elif kind == "t5":
+        o = TE.T5EncoderModel(TE.T5Config(vocab_size=tc.vocab_size, d_model=tc.d_model, d_kv=tc.d_kv, d_ff=tc.d_ff, num_layers=tc.num_layers,
+                                          num_heads=tc.num_heads, relative_attention_num_buckets=tc.relative_attention_num_buckets,
+                                          relative_attention_max_distance=tc.relative_attention_max_distance, layer_norm_epsilon=tc.layer_norm_epsilon))
+    else:
+        o = TE.GPT2Model(TE.GPT2Config(n_positions=tc.n_positions, n_embd=tc.n_embd, n_layer=tc.n_layer, n_head=tc.n_head,
+                                       layer_norm_epsilon=tc.layer_norm_epsilon, vocab_size=tc.vocab_size))
+    sd = tm.state_dict()
+    missing, unexpected = o.load_state_dict(sd, strict=False)
+    assert not missing, missing  # every parameter of the HIP module exists under the same name in the transformers module
+    return (o.to(dev) if dev is not None else o), unexpected
