@@ -413,6 +413,233 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Long self-attention variant: a wave owns TWO 32-query tiles (64 queries; 256 per workgroup).  Inside one wave MFMAs
+// only hide under VALU work of the SAME wave that does not depend on them (tools/probes/pair.hip), and with one query
+// tile the key loop is one dependency chain (scores -> softmax -> P.V).  Two tiles give the instruction stream independent
+// work: tile B's score MFMAs run under tile A's softmax, tile A's P.V MFMAs under tile B's softmax; each K fragment read
+// from LDS feeds two MFMAs and the staging / barrier cost per query halves.  No key bias, one segment (the UNet's attn1).
+template <int DT, int D, bool MASK>
+__device__ __forceinline__ void tile_compute2(const uint8_t* buf, int key0, int L, float c, const typename ET<DT>::v8 (&qf)[2][D / 16],
+                                              f32x16 (&o)[2][Lay<D>::DT_TILES], f32x2 (&osum)[2], float (&m)[2], int l31, int half) {
+    using E = ET<DT>;
+    using Y = Lay<D>;
+    constexpr int KC = D / 16;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 s[2][2];  // [query tile][32-key sub-tile]
+    // every fragment of the tile is requested from LDS up front, in one batch: K (A operand of both tiles' score MFMAs) and V^T
+    // (A operand of both tiles' P.V MFMAs).  Left inline, each read was waited for right before its MFMA (4 exposed LDS round
+    // trips per tile).
+    typename E::v8 kf[2][KC], vf[4][Y::DT_TILES];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int cc = 0; cc < KC; ++cc)
+            kf[u][cc] = as_v8<DT>(*reinterpret_cast<const uint4*>(buf + (u * 32 + l31) * Y::KROW + half * 16 + cc * 32));
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+        for (int dt = 0; dt < Y::DT_TILES; ++dt) {
+            const uint8_t* vp = buf + Y::K_BYTES + (dt * 32 + l31) * Y::VROW + (st * 16 + 4 * half) * 2;
+            const uint2 v0 = *reinterpret_cast<const uint2*>(vp);
+            const uint2 v1 = *reinterpret_cast<const uint2*>(vp + 16);
+            vf[st][dt] = as_v8<DT>(make_uint4(v0.x, v0.y, v1.x, v1.y));
+        }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            s[qt][u] = E::mfma32(kf[u][0], qf[qt][0], zero16);
+#pragma unroll
+            for (int cc = 1; cc < KC; ++cc) s[qt][u] = E::mfma32(kf[u][cc], qf[qt][cc], s[qt][u]);
+        }
+    // pin: the V^T fragments are complete HERE (behind the score MFMAs, where the wait is free) -- without it the compiler sinks
+    // each read to just before its P.V MFMA and waits for it there
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+        for (int dt = 0; dt < Y::DT_TILES; ++dt) asm volatile("" : "+v"(vf[st][dt]));
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float tmax = NEG_BIG;
+        if (MASK) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + u * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const float v = key < L ? s[qt][u][r] * c : NEG_BIG;
+                    s[qt][u][r] = v;
+                    tmax = fmaxf(tmax, v);
+                }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[qt][u][r]);
+            tmax *= c;  // c > 0
+        }
+        tmax = half_max(tmax);
+        const float mnew = fmaxf(m[qt], tmax);
+        // unconditional rescale (17 multiplies): a wave-uniform branch here would end the scheduling region and with it the
+        // interleave of this tile's VALU work with the other tile's MFMAs
+        const float alpha = __builtin_amdgcn_exp2f(m[qt] - mnew);
+        osum[qt] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < Y::DT_TILES; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qt][dt][r] *= alpha;
+        m[qt] = mnew;
+        if (MASK) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s[qt][u][r] = __builtin_amdgcn_exp2f(s[qt][u][r] - mnew);
+                    osum[qt][0] += s[qt][u][r];
+                }
+        } else {
+            const f32x2 c2 = {c, c}, nm2 = {-mnew, -mnew};
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    f32x2 v = {s[qt][u][r], s[qt][u][r + 1]};
+                    v = __builtin_elementwise_fma(v, c2, nm2);
+                    s[qt][u][r] = __builtin_amdgcn_exp2f(v[0]);
+                    s[qt][u][r + 1] = __builtin_amdgcn_exp2f(v[1]);
+                    osum[qt] += (f32x2){s[qt][u][r], s[qt][u][r + 1]};
+                }
+        }
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            typename E::v8 pf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[j] = (typename E::elem)s[qt][st >> 1][(st & 1) * 8 + j];
+#pragma unroll
+            for (int dt = 0; dt < Y::DT_TILES; ++dt) o[qt][dt] = E::mfma32(vf[st][dt], pf, o[qt][dt]);
+        }
+    }
+}
+
+template <int DT, int D>
+__global__ __launch_bounds__(256) void attn2q_kernel(AttnP p) {
+    using E = ET<DT>;
+    using Y = Lay<D>;
+    constexpr int KC = D / 16;
+    __shared__ __attribute__((aligned(16))) uint8_t smem[2 * Y::BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int nbh = p.B * p.H;
+    const int nqt = (p.N + 255) >> 8;
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;  // XCD-aware order as in attn_kernel
+    const int bh = (seq / nqt) * 8 + xcd, qtile = seq % nqt;
+    if (bh >= nbh) return;
+    const int h = bh % p.H, b = bh / p.H;
+    const int q0 = qtile * 256 + wave * 64;
+    if (Y::VROWS > D) {
+        for (int i = tid; i < 2 * Y::BUF / 4; i += 256) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
+    }
+    typename E::v8 qf[2][KC];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        int qi = q0 + qt * 32 + l31;
+        qi = qi < p.N ? qi : p.N - 1;
+        const uint8_t* qp = p.q + ((int64_t)b * p.q_sb + (int64_t)qi * p.q_sn + h * D + half * 8) * 2;
+#pragma unroll
+        for (int cc = 0; cc < KC; ++cc) qf[qt][cc] = as_v8<DT>(*reinterpret_cast<const uint4*>(qp + cc * 32));
+    }
+    f32x16 o[2][Y::DT_TILES];
+    f32x2 osum[2];
+    float m[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        osum[qt] = (f32x2){0.f, 0.f};
+        m[qt] = NEG_BIG;
+#pragma unroll
+        for (int dt = 0; dt < Y::DT_TILES; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qt][dt][r] = 0.f;
+    }
+    const int bk = b / p.kvdiv;
+    const uint8_t* kbase = p.k + ((int64_t)bk * p.k_sb + h * D) * 2;
+    const uint8_t* vbase = p.vt + ((int64_t)bk * p.vt_sb + (int64_t)h * D * p.Lpad) * 2;
+    const int L = p.L, Lpad = p.Lpad;
+    const int64_t k_sl = p.k_sl;
+    const float c = p.scale_log2;
+    {   // key loop: the staging of segment(), two query tiles per wave
+        const int ntiles = (L + KT - 1) / KT, nfull = L / KT;
+        u32x4 rk[Y::NK], rv[Y::NV];
+        uint32_t koff[Y::NK], voff[Y::NV];
+#pragma unroll
+        for (int i = 0; i < Y::NK; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / (D / 8), ch = idx - row * (D / 8);
+            koff[i] = (uint32_t)(((int64_t)row * k_sl + ch * 8) * 2);
+        }
+#pragma unroll
+        for (int i = 0; i < Y::NV; ++i) {
+            const int idx = tid + 256 * i;
+            voff[i] = (uint32_t)((((int64_t)(idx >> 3)) * Lpad + (idx & 7) * 8) * 2);
+        }
+        tile_load<D>(rk, rv, kbase, k_sl, vbase, L, Lpad, 0, tid);
+        __syncthreads();
+        tile_store<D>(rk, rv, smem, tid);
+        __syncthreads();
+        int t = 0;
+        for (; t < nfull; ++t) {
+            const uint8_t* buf = smem + (t & 1) * Y::BUF;
+            if (t + 1 < nfull)
+                tile_load_full<D>(rk, rv, kbase + (int64_t)(t + 1) * KT * k_sl * 2, vbase + (int64_t)(t + 1) * KT * 2, koff, voff, tid);
+            else if (t + 1 < ntiles) tile_load<D>(rk, rv, kbase, k_sl, vbase, L, Lpad, (t + 1) * KT, tid);
+            tile_compute2<DT, D, false>(buf, t * KT, L, c, qf, o, osum, m, l31, half);
+            if (t + 1 < ntiles) tile_store<D>(rk, rv, smem + ((t + 1) & 1) * Y::BUF, tid);
+            __syncthreads();
+        }
+        for (; t < ntiles; ++t) {
+            const uint8_t* buf = smem + (t & 1) * Y::BUF;
+            if (t + 1 < ntiles) tile_load<D>(rk, rv, kbase, k_sl, vbase, L, Lpad, (t + 1) * KT, tid);
+            tile_compute2<DT, D, true>(buf, t * KT, L, c, qf, o, osum, m, l31, half);
+            if (t + 1 < ntiles) tile_store<D>(rk, rv, smem + ((t + 1) & 1) * Y::BUF, tid);
+            __syncthreads();
+        }
+    }
+    constexpr int OROW = D * 2 + 8;
+    constexpr int CPR = D / 8;
+    uint8_t* scr = smem + wave * (32 * OROW);
+    uint8_t* ob = p.out + ((int64_t)b * p.o_sb + h * D) * 2;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const float den = half_sum(osum[qt][0] + osum[qt][1]);
+        const float inv = 1.0f / den;
+        const int qb = q0 + qt * 32;
+        if (p.lse != nullptr && half == 0 && qb + l31 < p.N)
+            p.lse[((int64_t)b * p.H + h) * ((p.N + 31) & ~31) + qb + l31] = m[qt] + __builtin_log2f(den);
+#pragma unroll
+        for (int dt = 0; dt < Y::DT_TILES; ++dt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int dcol = dt * 32 + 8 * g + 4 * half;
+                if (dcol < D) {
+                    typename E::v4 pk;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pk[j] = (typename E::elem)(o[qt][dt][g * 4 + j] * inv);
+                    *reinterpret_cast<uint2*>(scr + l31 * OROW + dcol * 2) = __builtin_bit_cast(uint2, pk);
+                }
+            }
+        }
+        for (int idx = lane; idx < 32 * CPR; idx += 64) {
+            const int row = idx / CPR, ch = idx - row * CPR;
+            const int q = qb + row;
+            if (q < p.N) {
+                const uint2 lo = *reinterpret_cast<const uint2*>(scr + row * OROW + ch * 16);
+                const uint2 hi = *reinterpret_cast<const uint2*>(scr + row * OROW + ch * 16 + 8);
+                *reinterpret_cast<uint4*>(ob + ((int64_t)q * p.o_sn + ch * 8) * 2) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Short-segment variant: every softmax segment has at most 64 keys (the adapter's decoupled cross-attention at
 // La <= 64 -- 8 text + 32 audio tokens in the style_transfer preset --, the 16-token T5 cross-attention).  Such a launch
 // is bound by reading Q and writing O; the staged kernel above spends it on LDS staging and four workgroup barriers per
@@ -584,6 +811,15 @@ template <int DT, int D> int launch_d(const AttnP& p, bool dual, dim3 grid, hipS
         else
             hipLaunchKernelGGL((attn_short_kernel<DT, D, false>), g2, dim3(256), 0, s, p);
         return apad_check_launch("apad_attention");
+    }
+    if constexpr (D == 32 || D == 48 || D == 64) {
+        // long single-segment launches without a key bias (the UNet's self-attention): two query tiles per wave
+        static const int two_q = [] { const char* e = getenv("APAD_ATTN_2Q"); return e ? atoi(e) : 1; }();
+        if (two_q && !dual && p.key_bias == nullptr && p.N >= 512 && p.L >= 256 && (D == 32 || two_q > 1)) {
+            dim3 g2((unsigned)(((p.N + 255) / 256) * (((p.H * p.B) + 7) / 8 * 8)));
+            hipLaunchKernelGGL((attn2q_kernel<DT, D>), g2, dim3(256), 0, s, p);
+            return apad_check_launch("apad_attention");
+        }
     }
     if (dual)
         hipLaunchKernelGGL((attn_kernel<DT, D, true>), grid, dim3(256), 0, s, p);

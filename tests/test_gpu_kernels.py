@@ -151,7 +151,9 @@ def _vt(v, heads, dev, dtype):
 @pytest.mark.parametrize("B,N,L,heads,d,masked", [
     (2, 100, 100, 8, 32, False), (1, 1000, 1000, 8, 32, False), (2, 252, 252, 8, 48, False), (2, 64, 64, 8, 80, False),
     (2, 64, 16, 8, 80, True), (1, 513, 513, 12, 64, False), (2, 130, 33, 4, 64, True), (1, 40, 7, 2, 16, False),
-    (1, 33, 70, 2, 128, False), (1, 64, 45, 2, 96, False)])
+    (1, 33, 70, 2, 128, False), (1, 64, 45, 2, 96, False),
+    # the two-query-tile kernel of long self-attention (N >= 512, L >= 256, d = 32): ragged query and key tails, key sharing across a CFG pair
+    (3, 1000, 1000, 8, 32, False), (2, 600, 300, 4, 32, False), (1, 777, 1029, 2, 32, False)])
 def test_attention_single_segment(dev, dtype, B, N, L, heads, d, masked):
     from ap_adapter_amd import ops
     C_ = heads * d
@@ -165,6 +167,26 @@ def test_attention_single_segment(dev, dtype, B, N, L, heads, d, masked):
     out = ops.attention(qq.to(dev, dtype), kk.to(dev, dtype), _vt(vv, heads, dev, dtype), L, heads,
                         key_bias=None if bias is None else bias.to(dev))
     assert rel_err(out, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES16)
+def test_attention_two_query_tile_kernel_lse_and_equality(dev, dtype):
+    """long self-attention runs two query tiles per wave: the output, and the log-sum-exp the backward re-uses"""
+    from ap_adapter_amd import ops
+    B, N, heads, d = 2, 1000, 8, 32
+    C_ = heads * d
+    qq, kk, vv = q(R(B, N, C_, seed=26), dtype), q(R(B, N, C_, seed=27), dtype), q(R(B, N, C_, seed=28), dtype)
+    qd, kd, vt = qq.to(dev, dtype), kk.to(dev, dtype), _vt(vv, heads, dev, dtype)
+    out = ops.attention(qd, kd, vt, N, heads)
+    o2, lse = ops.attention_lse(qd, kd, vt, N, heads)  # the training forward: same kernel, plus log2-sum-exp2 per query
+    qh, kh = _heads(qq, heads), _heads(kk, heads)
+    sc = (qh @ kh.transpose(-1, -2)) / math.sqrt(d)
+    ref = (torch.softmax(sc, -1) @ _heads(vv, heads)).transpose(1, 2).reshape(B, N, C_)
+    assert rel_err(out, ref) < TOL[dtype]
+    assert torch.equal(o2, out)
+    ref_lse = torch.logsumexp(sc, -1) * math.log2(math.e)
+    assert rel_err(lse.view(B, heads, -1)[..., :N], ref_lse) < 1e-3
+
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
