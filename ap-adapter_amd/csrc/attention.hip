@@ -214,7 +214,9 @@ __device__ __forceinline__ void tile_compute(const uint8_t* buf, int key0, int L
             }
         }
     } else {
+        // four independent partial sums: one accumulator chained 16 dependent v_pk_add_f32, each followed by a hazard s_nop
         const f32x2 c2 = {c, c}, nm2 = {-m, -m};
+        f32x2 part[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -223,8 +225,9 @@ __device__ __forceinline__ void tile_compute(const uint8_t* buf, int key0, int L
                 v = __builtin_elementwise_fma(v, c2, nm2);
                 s[u][r] = (APAD_ABL & 1) ? v[0] * 0.5f : __builtin_amdgcn_exp2f(v[0]);
                 s[u][r + 1] = (APAD_ABL & 1) ? v[1] * 0.5f : __builtin_amdgcn_exp2f(v[1]);
-                osum += (f32x2){s[u][r], s[u][r + 1]};
+                part[(r >> 1) & 3] += (f32x2){s[u][r], s[u][r + 1]};
             }
+        osum += (part[0] + part[1]) + (part[2] + part[3]);
     }
     // ---- O^T += V^T . P^T : four K=16 steps; B operand = P^T in its C-layout key order ----
     const uint8_t* vtile = buf + Y::K_BYTES;
@@ -480,15 +483,17 @@ __device__ __forceinline__ void tile_compute2(const uint8_t* buf, int key0, int 
         }
         tmax = half_max(tmax);
         const float mnew = fmaxf(m[qt], tmax);
-        // unconditional rescale (17 multiplies): a wave-uniform branch here would end the scheduling region and with it the
-        // interleave of this tile's VALU work with the other tile's MFMAs
-        const float alpha = __builtin_amdgcn_exp2f(m[qt] - mnew);
-        osum[qt] *= alpha;
+        // rescale only when some lane's running max moved (wave-uniform; rare after the first tiles).  MFMA and VALU time add up
+        // on this part whatever the interleave, so the branch costs nothing and the skipped multiplies are a net gain
+        if (__any(mnew > m[qt])) {
+            const float alpha = __builtin_amdgcn_exp2f(m[qt] - mnew);
+            osum[qt] *= alpha;
 #pragma unroll
-        for (int dt = 0; dt < Y::DT_TILES; ++dt)
+            for (int dt = 0; dt < Y::DT_TILES; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[qt][dt][r] *= alpha;
-        m[qt] = mnew;
+                for (int r = 0; r < 16; ++r) o[qt][dt][r] *= alpha;
+            m[qt] = mnew;
+        }
         if (MASK) {
 #pragma unroll
             for (int u = 0; u < 2; ++u)
@@ -498,7 +503,10 @@ __device__ __forceinline__ void tile_compute2(const uint8_t* buf, int key0, int 
                     osum[qt][0] += s[qt][u][r];
                 }
         } else {
+            // four independent partial sums per sub-tile pair: a single accumulator made every v_pk_add_f32 wait on the previous
+            // one (each pair cost a hazard s_nop on top of its issue slot)
             const f32x2 c2 = {c, c}, nm2 = {-mnew, -mnew};
+            f32x2 part[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -507,8 +515,9 @@ __device__ __forceinline__ void tile_compute2(const uint8_t* buf, int key0, int 
                     v = __builtin_elementwise_fma(v, c2, nm2);
                     s[qt][u][r] = __builtin_amdgcn_exp2f(v[0]);
                     s[qt][u][r + 1] = __builtin_amdgcn_exp2f(v[1]);
-                    osum[qt] += (f32x2){s[qt][u][r], s[qt][u][r + 1]};
+                    part[(r >> 1) & 3] += (f32x2){s[qt][u][r], s[qt][u][r + 1]};
                 }
+            osum[qt] += (part[0] + part[1]) + (part[2] + part[3]);
         }
 #pragma unroll
         for (int st = 0; st < 4; ++st) {

@@ -127,7 +127,7 @@ def profile_in_step_avg_us(substr):
 
 def dominant_kernel_roofline(dev, dtype, B2):
     """Roofline of the kernel with the largest share of the step in the committed rocprof summary: the self-attention of the
-    1000-token level (attn_kernel<bf16, d=32, single segment>), softmax(Q K^T / sqrt(32)) V over B2 samples x 8 heads x
+    1000-token level (attn2q_kernel<bf16, d=32>: single segment, two query tiles per wave), softmax(Q K^T / sqrt(32)) V over B2 samples x 8 heads x
     1000 x 1000.  Algorithmic FLOPs = 4 * N^2 * C * B2 (QK^T + PV); bound = MFMA (AI = 512 F/B > ridge 310).
     `avg_launch_ms` is an ISOLATED re-timing (20 back-to-back launches inside one hipGraph, HIP events on the replaying
     stream, q / k / v produced the way the model produces them); `in_step_avg_us` is the same kernel's average inside the
@@ -157,8 +157,8 @@ def dominant_kernel_roofline(dev, dtype, B2):
                 traffic = json.load(f).get("traffic_bytes_per_launch")
             traffic, tsrc = (None if traffic is None else int(traffic)), os.path.relpath(tp, ROOT)
             break
-    in_step, psrc = profile_in_step_avg_us("attn_kernel<0, 32, false>")
-    return {"kernel": "attn_kernel<bf16,D=32> self-attention B'=%d heads=8 N=L=1000" % B2, "bound": "mfma",
+    in_step, psrc = profile_in_step_avg_us("attn2q_kernel<0, 32>")
+    return {"kernel": "attn2q_kernel<bf16,D=32> self-attention B'=%d heads=8 N=L=1000" % B2, "bound": "mfma",
             "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
             "avg_launch_ms": round(ms, 4), "avg_launch_is": "isolated re-timing (20 launches in one hipGraph, HIP events)",
             "in_step_avg_us": in_step, "in_step_source": psrc,

@@ -2,7 +2,7 @@
 # HBM traffic of the roofline kernel from the PMC counters (run on the GPU box through gpurun):
 #   FETCH_SIZE and WRITE_SIZE in SEPARATE passes (TCC slots), each also over a read / write probe of KNOWN byte count
 #   so the gfx950 unit corrections (MI355X_MICROARCH.md, HBM section) are calibrated in the same run.
-# Result: gpurun_out/traffic/*.db -> tools/pmc_traffic_summary.py -> profiles/r01_pmc_traffic.json
+# Result: gpurun_out/traffic/*.db -> tools/pmc_traffic_summary.py -> profiles/rNN_pmc_traffic.json
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/traffic

@@ -30,12 +30,13 @@ if wr:
     out["calibration"]["write_probe_bytes"] = 131072000
     out["calibration"]["write_probe_WRITE_SIZE_KB"] = w
     out["calibration"]["write_factor"] = 131072000 / (w * 1024.0)
-fa = per_dispatch("FETCH_SIZE_attn", "FETCH_SIZE", "attn_kernel")
-wa = per_dispatch("WRITE_SIZE_attn", "WRITE_SIZE", "attn_kernel")
+KERNEL = "attn2q_kernel"  # the self-attention kernel of the 1000-token level (two query tiles per wave since round 2)
+fa = per_dispatch("FETCH_SIZE_attn", "FETCH_SIZE", KERNEL)
+wa = per_dispatch("WRITE_SIZE_attn", "WRITE_SIZE", KERNEL)
 if fa and wa and rd and wr:
     f = sorted(fa)[len(fa) // 2] * 1024.0 * out["calibration"]["read_factor"]
     w = sorted(wa)[len(wa) // 2] * 1024.0 * out["calibration"]["write_factor"]
-    out["kernel"] = "attn_kernel<bf16,D=32> self-attention B'=64 heads=8 N=L=1000"
+    out["kernel"] = KERNEL + "<bf16,D=32> self-attention B'=64 heads=8 N=L=1000"
     out["raw_FETCH_SIZE_KB"] = sorted(fa)[len(fa) // 2]
     out["raw_WRITE_SIZE_KB"] = sorted(wa)[len(wa) // 2]
     out["read_bytes_per_launch"] = f
