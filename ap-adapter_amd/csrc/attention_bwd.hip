@@ -12,6 +12,7 @@
 // apad_head_transpose, so every fragment is a 16- or 8-byte vector load.  Fragments are loaded straight from global
 // memory (L2-resident at training batch sizes); there is no LDS staging and no barrier.
 #include "common.h"
+#include "f32_ops.h"
 
 namespace {
 
@@ -287,10 +288,12 @@ extern "C" int apad_head_transpose(const void* x, void* xt, int32_t B, int32_t N
                                    int32_t dtype, void* stream) {
     APAD_CHECK(x && xt && B > 0 && N > 0 && H > 0 && D > 0, "apad_head_transpose: null operand / empty problem");
     APAD_CHECK(pad >= N && pad % 32 == 0, "apad_head_transpose: pad must be >= N and a multiple of 32");
-    APAD_CHECK(dtype == APAD_BF16 || dtype == APAD_F16, "apad_head_transpose: dtype %d not supported", dtype);
+    APAD_CHECK(dtype == APAD_BF16 || dtype == APAD_F16 || dtype == APAD_F32, "apad_head_transpose: dtype %d not supported", dtype);
     dim3 grid((unsigned)(pad / 32), (unsigned)((H * D + 31) / 32), (unsigned)B);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == APAD_BF16)
+    if (dtype == APAD_F32)
+        hipLaunchKernelGGL(head_transpose_kernel<APAD_F32>, grid, dim3(256), 0, s, (const uint8_t*)x, (uint8_t*)xt, N, H, D, pad);
+    else if (dtype == APAD_BF16)
         hipLaunchKernelGGL(head_transpose_kernel<APAD_BF16>, grid, dim3(256), 0, s, (const uint8_t*)x, (uint8_t*)xt, N, H, D, pad);
     else
         hipLaunchKernelGGL(head_transpose_kernel<APAD_F16>, grid, dim3(256), 0, s, (const uint8_t*)x, (uint8_t*)xt, N, H, D, pad);
@@ -299,6 +302,7 @@ extern "C" int apad_head_transpose(const void* x, void* xt, int32_t B, int32_t N
 
 extern "C" int apad_attention_bwd(const apad_attn_bwd_desc* d, void* stream) {
     APAD_CHECK(d != nullptr, "apad_attention_bwd: null descriptor");
+    if (d->dtype == APAD_F32) return apad_f32_attention_bwd(d, (hipStream_t)stream);  // fp32 training mode (f32_ops.hip): no transposed operands
     APAD_CHECK(d->dtype == APAD_BF16 || d->dtype == APAD_F16, "apad_attention_bwd: dtype %d not supported", d->dtype);
     APAD_CHECK(d->q && d->k && d->v && d->kt && d->out && d->dout && d->lse && d->delta && d->dq,
                "apad_attention_bwd: null operand");

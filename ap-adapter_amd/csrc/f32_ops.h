@@ -11,3 +11,4 @@ int apad_f32_layernorm(const void* x, const void* gamma, const void* beta, void*
 int apad_f32_groupnorm(const void* x, const void* gamma, const void* beta, void* out, int32_t B, int32_t HW, int32_t C,
                        int32_t G, float eps, int32_t silu, hipStream_t s);
 int apad_f32_audiomae_pool(const void* rep, void* out, int32_t B, int32_t tp, int32_t fp, hipStream_t s);
+int apad_f32_attention_bwd(const apad_attn_bwd_desc* d, hipStream_t s);

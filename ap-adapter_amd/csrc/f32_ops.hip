@@ -505,6 +505,145 @@ __global__ __launch_bounds__(256) void pool_f32_kernel(const float* rep, float* 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fp32 attention backward (the reference's default training precision: train.sh leaves --mixed_precision unset).  Plain fp32
+// FMAs, no MFMA: P is rebuilt from q, k and the forward's log-sum-exp; one wave owns one query row (dq) or one key row (dk, dv),
+// its lanes walk the other sequence, head-dim accumulators are reduced across the wave at the end.  The head dimension is
+// processed in chunks of 32 accumulators per lane (scores are recomputed per chunk).  A precision mode: ~3 N L D scalar MACs per
+// (sample, head), two launches per attention.
+struct BwdF {
+    const float *q, *k, *v, *out, *dout, *lse, *key_bias;
+    float *delta, *dq, *dk, *dv;
+    int B, N, H, L, D, Npad;
+    float scale, scale_log2, dout_scale;
+    int accumulate_dq;
+};
+// (LOG2E_F: defined above)
+
+__global__ __launch_bounds__(256) void delta_f32_kernel(BwdF p) {  // delta[b][h][n] = dout_scale * sum_d dO . O
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)p.B * p.N * p.H) return;
+    const int h = (int)(idx % p.H);
+    const int64_t bn = idx / p.H;
+    const int n = (int)(bn % p.N), b = (int)(bn / p.N);
+    const int C = p.H * p.D;
+    const float* o = p.out + bn * C + h * p.D;
+    const float* g = p.dout + bn * C + h * p.D;
+    float acc = 0.f;
+    for (int d = 0; d < p.D; ++d) acc = fmaf(o[d], g[d], acc);
+    p.delta[((int64_t)b * p.H + h) * p.Npad + n] = acc * p.dout_scale;
+}
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// dq[b][i][h] = scale * sum_j P_ij (dP_ij - delta_i) k_j ; wave = one (b, h, i)
+__global__ __launch_bounds__(256) void attn_bwd_dq_f32_kernel(BwdF p) {
+    __shared__ float sh[4][2 * 128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;  // (b, h, i)
+    if (row >= (int64_t)p.B * p.H * p.N) return;
+    const int i = (int)(row % p.N);
+    const int64_t bh = row / p.N;
+    const int h = (int)(bh % p.H), b = (int)(bh / p.H);
+    const int C = p.H * p.D, D = p.D;
+    float* qs = sh[wave];
+    float* gs = sh[wave] + 128;
+    for (int d = lane; d < D; d += 64) {
+        qs[d] = p.q[((int64_t)b * p.N + i) * C + h * D + d];
+        gs[d] = p.dout[((int64_t)b * p.N + i) * C + h * D + d];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const float lse = p.lse[bh * p.Npad + i], delta = p.delta[bh * p.Npad + i];
+    const float* kb = p.k + (int64_t)b * p.L * C + h * D;
+    const float* vb = p.v + (int64_t)b * p.L * C + h * D;
+    const float* bias = p.key_bias ? p.key_bias + (int64_t)b * p.L : nullptr;
+    float* dst = p.dq + ((int64_t)b * p.N + i) * C + h * D;
+    for (int c0 = 0; c0 < D; c0 += 32) {
+        float acc[32];
+#pragma unroll
+        for (int t = 0; t < 32; ++t) acc[t] = 0.f;
+        for (int j = lane; j < p.L; j += 64) {
+            const float* kr = kb + (int64_t)j * C;
+            const float* vr = vb + (int64_t)j * C;
+            float sc = 0.f, dp = 0.f;
+            for (int d = 0; d < D; ++d) {
+                sc = fmaf(qs[d], kr[d], sc);
+                dp = fmaf(gs[d], vr[d], dp);
+            }
+            const float pij = exp2f(sc * p.scale_log2 + (bias ? bias[j] * LOG2E_F : 0.f) - lse);
+            const float ds = pij * (dp * p.dout_scale - delta) * p.scale;
+#pragma unroll
+            for (int t = 0; t < 32; ++t)
+                if (c0 + t < D) acc[t] = fmaf(ds, kr[c0 + t], acc[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < 32; ++t) {
+            const float v = wave_sum_f(acc[t]);
+            if (lane == 0 && c0 + t < D) dst[c0 + t] = p.accumulate_dq ? dst[c0 + t] + v : v;
+        }
+    }
+}
+
+// dk[b][j][h] = scale * sum_i P_ij (dP_ij - delta_i) q_i ; dv[b][j][h] = dout_scale * sum_i P_ij dO_i ; wave = one (b, h, j)
+__global__ __launch_bounds__(256) void attn_bwd_dkv_f32_kernel(BwdF p) {
+    __shared__ float sh[4][2 * 128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;  // (b, h, j)
+    if (row >= (int64_t)p.B * p.H * p.L) return;
+    const int j = (int)(row % p.L);
+    const int64_t bh = row / p.L;
+    const int h = (int)(bh % p.H), b = (int)(bh / p.H);
+    const int C = p.H * p.D, D = p.D;
+    float* ks = sh[wave];
+    float* vs = sh[wave] + 128;
+    for (int d = lane; d < D; d += 64) {
+        ks[d] = p.k[((int64_t)b * p.L + j) * C + h * D + d];
+        vs[d] = p.v[((int64_t)b * p.L + j) * C + h * D + d];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const float bj = p.key_bias ? p.key_bias[(int64_t)b * p.L + j] * LOG2E_F : 0.f;
+    const float* qb = p.q + (int64_t)b * p.N * C + h * D;
+    const float* gb = p.dout + (int64_t)b * p.N * C + h * D;
+    float* dkd = p.dk + ((int64_t)b * p.L + j) * C + h * D;
+    float* dvd = p.dv + ((int64_t)b * p.L + j) * C + h * D;
+    for (int c0 = 0; c0 < D; c0 += 32) {
+        float ak[32], av[32];
+#pragma unroll
+        for (int t = 0; t < 32; ++t) ak[t] = av[t] = 0.f;
+        for (int i = lane; i < p.N; i += 64) {
+            const float* qr = qb + (int64_t)i * C;
+            const float* gr = gb + (int64_t)i * C;
+            float sc = 0.f, dp = 0.f;
+            for (int d = 0; d < D; ++d) {
+                sc = fmaf(qr[d], ks[d], sc);
+                dp = fmaf(gr[d], vs[d], dp);
+            }
+            const float pij = exp2f(sc * p.scale_log2 + bj - p.lse[bh * p.Npad + i]);
+            const float ds = pij * (dp * p.dout_scale - p.delta[bh * p.Npad + i]) * p.scale;
+            const float pv = pij * p.dout_scale;
+#pragma unroll
+            for (int t = 0; t < 32; ++t)
+                if (c0 + t < D) {
+                    ak[t] = fmaf(ds, qr[c0 + t], ak[t]);
+                    av[t] = fmaf(pv, gr[c0 + t], av[t]);
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < 32; ++t) {
+            const float a = wave_sum_f(ak[t]), c = wave_sum_f(av[t]);
+            if (lane == 0 && c0 + t < D) {
+                dkd[c0 + t] = a;
+                dvd[c0 + t] = c;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 int apad_f32_gemm(const apad_gemm_desc* d, hipStream_t s) {
@@ -658,4 +797,26 @@ int apad_f32_audiomae_pool(const void* rep, void* out, int32_t B, int32_t tp, in
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(pool_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)rep, (float*)out, B, tp, fp);
     return apad_check_launch("apad_audiomae_pool(f32)");
+}
+
+int apad_f32_attention_bwd(const apad_attn_bwd_desc* d, hipStream_t s) {
+    APAD_CHECK(d->q && d->k && d->v && d->out && d->dout && d->lse && d->delta && d->dq, "apad_attention_bwd(f32): null operand");
+    APAD_CHECK(d->B > 0 && d->N > 0 && d->H > 0 && d->L > 0 && d->D > 0 && d->D <= 128, "apad_attention_bwd(f32): empty problem / head dim > 128");
+    APAD_CHECK(d->Npad >= d->N, "apad_attention_bwd(f32): Npad must cover N");
+    APAD_CHECK((d->dk == nullptr) == (d->dv == nullptr), "apad_attention_bwd(f32): dk and dv are requested together");
+    BwdF p;
+    p.q = (const float*)d->q; p.k = (const float*)d->k; p.v = (const float*)d->v; p.out = (const float*)d->out;
+    p.dout = (const float*)d->dout; p.lse = d->lse; p.key_bias = d->key_bias; p.delta = d->delta;
+    p.dq = (float*)d->dq; p.dk = (float*)d->dk; p.dv = (float*)d->dv;
+    p.B = d->B; p.N = d->N; p.H = d->H; p.L = d->L; p.D = d->D; p.Npad = d->Npad;
+    p.scale = d->softmax_scale; p.scale_log2 = d->softmax_scale * LOG2E_F; p.dout_scale = d->dout_scale;
+    p.accumulate_dq = d->accumulate_dq;
+    const int64_t nd = (int64_t)p.B * p.N * p.H;
+    hipLaunchKernelGGL(delta_f32_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(attn_bwd_dq_f32_kernel, dim3((unsigned)((nd + 3) / 4)), dim3(256), 0, s, p);
+    if (p.dk) {
+        const int64_t nk = (int64_t)p.B * p.L * p.H;
+        hipLaunchKernelGGL(attn_bwd_dkv_f32_kernel, dim3((unsigned)((nk + 3) / 4)), dim3(256), 0, s, p);
+    }
+    return apad_check_launch("apad_attention_bwd(f32)");
 }

@@ -8,16 +8,45 @@
 
 namespace {
 
-template <int DT> __device__ __forceinline__ void ld4(const uint8_t* p, float* f) {
-    typename ET<DT>::v4 v = __builtin_bit_cast(typename ET<DT>::v4, *reinterpret_cast<const uint2*>(p));
+// element-typed vector accessors: `e` is an ELEMENT offset from `base` (16-bit storage types and, for the fp32 training mode --
+// the reference's default, train.sh leaves --mixed_precision unset -- float)
+template <int DT> struct ESZ { static constexpr int v = 2; };
+template <> struct ESZ<APAD_F32> { static constexpr int v = 4; };
+template <int DT> __device__ __forceinline__ void ld4(const uint8_t* base, int64_t e, float* f) {
+    if constexpr (DT == APAD_F32) {
+        const float4 v = *reinterpret_cast<const float4*>(base + e * 4);
+        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+    } else {
+        typename ET<DT>::v4 v = __builtin_bit_cast(typename ET<DT>::v4, *reinterpret_cast<const uint2*>(base + e * 2));
 #pragma unroll
-    for (int j = 0; j < 4; ++j) f[j] = (float)v[j];
+        for (int j = 0; j < 4; ++j) f[j] = (float)v[j];
+    }
 }
-template <int DT> __device__ __forceinline__ void st4(uint8_t* p, const float* f) {
-    typename ET<DT>::v4 v;
+template <int DT> __device__ __forceinline__ void st4(uint8_t* base, int64_t e, const float* f) {
+    if constexpr (DT == APAD_F32) {
+        *reinterpret_cast<float4*>(base + e * 4) = make_float4(f[0], f[1], f[2], f[3]);
+    } else {
+        typename ET<DT>::v4 v;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = (typename ET<DT>::elem)f[j];
-    *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, v);
+        for (int j = 0; j < 4; ++j) v[j] = (typename ET<DT>::elem)f[j];
+        *reinterpret_cast<uint2*>(base + e * 2) = __builtin_bit_cast(uint2, v);
+    }
+}
+template <int DT> __device__ __forceinline__ void ld8(const uint8_t* base, int64_t e, float* f) {
+    if constexpr (DT == APAD_F32) {
+        ld4<DT>(base, e, f);
+        ld4<DT>(base, e + 4, f + 4);
+    } else {
+        unpack8<DT>(*reinterpret_cast<const uint4*>(base + e * 2), f);
+    }
+}
+template <int DT> __device__ __forceinline__ void st8(uint8_t* base, int64_t e, const float* f) {
+    if constexpr (DT == APAD_F32) {
+        st4<DT>(base, e, f);
+        st4<DT>(base, e + 4, f + 4);
+    } else {
+        *reinterpret_cast<uint4*>(base + e * 2) = pack8<DT>(f);
+    }
 }
 
 // block-wide sum of two values in a fixed order (256 threads); result broadcast to every thread
@@ -38,13 +67,12 @@ template <int DT> __global__ __launch_bounds__(256) void ln_bwd_kernel(const uin
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    const uint8_t* xr = x + row * C * 2;
-    const uint8_t* gr = dy + row * C * 2;
+    const int64_t r0 = row * C;  // element offset of the row
     const int nch = C / 8;
     float s = 0.f, ss = 0.f;
     for (int c = lane; c < nch; c += 64) {
         float v[8];
-        unpack8<DT>(*reinterpret_cast<const uint4*>(xr + c * 16), v);
+        ld8<DT>(x, r0 + c * 8, v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s += v[j]; ss += v[j] * v[j]; }
     }
@@ -54,21 +82,21 @@ template <int DT> __global__ __launch_bounds__(256) void ln_bwd_kernel(const uin
     float sg = 0.f, sgx = 0.f;
     for (int c = lane; c < nch; c += 64) {
         float v[8], g[8], w[8];
-        unpack8<DT>(*reinterpret_cast<const uint4*>(xr + c * 16), v);
-        unpack8<DT>(*reinterpret_cast<const uint4*>(gr + c * 16), g);
-        unpack8<DT>(*reinterpret_cast<const uint4*>(gamma + c * 16), w);
+        ld8<DT>(x, r0 + c * 8, v);
+        ld8<DT>(dy, r0 + c * 8, g);
+        ld8<DT>(gamma, c * 8, w);
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const float gg = g[j] * w[j]; sg += gg; sgx += gg * (v[j] - mean) * rstd; }
     }
     sg = wave_sum(sg) / C; sgx = wave_sum(sgx) / C;
     for (int c = lane; c < nch; c += 64) {
         float v[8], g[8], w[8], o[8];
-        unpack8<DT>(*reinterpret_cast<const uint4*>(xr + c * 16), v);
-        unpack8<DT>(*reinterpret_cast<const uint4*>(gr + c * 16), g);
-        unpack8<DT>(*reinterpret_cast<const uint4*>(gamma + c * 16), w);
+        ld8<DT>(x, r0 + c * 8, v);
+        ld8<DT>(dy, r0 + c * 8, g);
+        ld8<DT>(gamma, c * 8, w);
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = rstd * (g[j] * w[j] - sg - (v[j] - mean) * rstd * sgx);
-        *reinterpret_cast<uint4*>(dx + row * C * 2 + c * 16) = pack8<DT>(o);
+        st8<DT>(dx, r0 + c * 8, o);
     }
 }
 
@@ -79,14 +107,14 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const uint8_t* x, const uin
     __shared__ float sh[8];
     const int g = blockIdx.x, b = blockIdx.y;
     const int cg = C / G, q4 = cg / 4;  // 4-channel pieces per pixel of this group
-    const int64_t base = ((int64_t)b * HW * C + g * cg) * 2;
+    const int64_t base = (int64_t)b * HW * C + g * cg;  // element offset of the (sample, group) slab
     const int items = HW * q4;
     const float n = (float)HW * cg;
     float s = 0.f, ss = 0.f;
     for (int i = threadIdx.x; i < items; i += 256) {
         const int pix = i / q4, c4 = i - pix * q4;
         float v[4];
-        ld4<DT>(x + base + ((int64_t)pix * C + c4 * 4) * 2, v);
+        ld4<DT>(x, base + (int64_t)pix * C + c4 * 4, v);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { s += v[j]; ss += v[j] * v[j]; }
     }
@@ -97,17 +125,17 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const uint8_t* x, const uin
     for (int i = threadIdx.x; i < items; i += 256) {
         const int pix = i / q4, c4 = i - pix * q4;
         float v[4], d[4], w[4], bb[4];
-        ld4<DT>(x + base + ((int64_t)pix * C + c4 * 4) * 2, v);
-        ld4<DT>(dy + base + ((int64_t)pix * C + c4 * 4) * 2, d);
-        ld4<DT>(gamma + (g * cg + c4 * 4) * 2, w);
-        ld4<DT>(beta + (g * cg + c4 * 4) * 2, bb);
+        ld4<DT>(x, base + (int64_t)pix * C + c4 * 4, v);
+        ld4<DT>(dy, base + (int64_t)pix * C + c4 * 4, d);
+        ld4<DT>(gamma, g * cg + c4 * 4, w);
+        ld4<DT>(beta, g * cg + c4 * 4, bb);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float xh = (v[j] - mean) * rstd;
             float dz = d[j];
             if (SILU) {
                 const float z = xh * w[j] + bb[j];
-                const float sig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
+                const float sig = DT == APAD_F32 ? 1.0f / (1.0f + expf(-z)) : __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
                 dz *= sig * (1.0f + z * (1.0f - sig));
             }
             const float gg = dz * w[j];
@@ -119,22 +147,22 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const uint8_t* x, const uin
     for (int i = threadIdx.x; i < items; i += 256) {
         const int pix = i / q4, c4 = i - pix * q4;
         float v[4], d[4], w[4], bb[4], o[4];
-        ld4<DT>(x + base + ((int64_t)pix * C + c4 * 4) * 2, v);
-        ld4<DT>(dy + base + ((int64_t)pix * C + c4 * 4) * 2, d);
-        ld4<DT>(gamma + (g * cg + c4 * 4) * 2, w);
-        ld4<DT>(beta + (g * cg + c4 * 4) * 2, bb);
+        ld4<DT>(x, base + (int64_t)pix * C + c4 * 4, v);
+        ld4<DT>(dy, base + (int64_t)pix * C + c4 * 4, d);
+        ld4<DT>(gamma, g * cg + c4 * 4, w);
+        ld4<DT>(beta, g * cg + c4 * 4, bb);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float xh = (v[j] - mean) * rstd;
             float dz = d[j];
             if (SILU) {
                 const float z = xh * w[j] + bb[j];
-                const float sig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
+                const float sig = DT == APAD_F32 ? 1.0f / (1.0f + expf(-z)) : __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
                 dz *= sig * (1.0f + z * (1.0f - sig));
             }
             o[j] = rstd * (dz * w[j] - sg - xh * sgx);
         }
-        st4<DT>(dx + base + ((int64_t)pix * C + c4 * 4) * 2, o);
+        st4<DT>(dx, base + (int64_t)pix * C + c4 * 4, o);
     }
 }
 
@@ -146,11 +174,11 @@ template <int DT> __global__ __launch_bounds__(256) void geglu_fwd_kernel(const 
     const int64_t m = i / nch;
     const int c = (int)(i - m * nch);
     float v[8], g[8], o[8];
-    unpack8<DT>(*reinterpret_cast<const uint4*>(proj + (m * 2 * N + c * 8) * 2), v);
-    unpack8<DT>(*reinterpret_cast<const uint4*>(proj + (m * 2 * N + N + c * 8) * 2), g);
+    ld8<DT>(proj, m * 2 * N + c * 8, v);
+    ld8<DT>(proj, m * 2 * N + N + c * 8, g);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = v[j] * gelu_erf_f(g[j]);
-    *reinterpret_cast<uint4*>(h + (m * N + c * 8) * 2) = pack8<DT>(o);
+    for (int j = 0; j < 8; ++j) o[j] = v[j] * (DT == APAD_F32 ? 0.5f * g[j] * (1.0f + erff(g[j] * 0.70710678118654752440f)) : gelu_erf_f(g[j]));
+    st8<DT>(h, m * N + c * 8, o);
 }
 template <int DT> __global__ __launch_bounds__(256) void geglu_bwd_kernel(const uint8_t* proj, const uint8_t* dh, uint8_t* dproj, int64_t M, int N) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -159,18 +187,18 @@ template <int DT> __global__ __launch_bounds__(256) void geglu_bwd_kernel(const 
     const int64_t m = i / nch;
     const int c = (int)(i - m * nch);
     float v[8], g[8], d[8], dv[8], dg[8];
-    unpack8<DT>(*reinterpret_cast<const uint4*>(proj + (m * 2 * N + c * 8) * 2), v);
-    unpack8<DT>(*reinterpret_cast<const uint4*>(proj + (m * 2 * N + N + c * 8) * 2), g);
-    unpack8<DT>(*reinterpret_cast<const uint4*>(dh + (m * N + c * 8) * 2), d);
+    ld8<DT>(proj, m * 2 * N + c * 8, v);
+    ld8<DT>(proj, m * 2 * N + N + c * 8, g);
+    ld8<DT>(dh, m * N + c * 8, d);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const float cdf = 0.5f * (1.0f + erf_as(g[j] * 0.70710678118654752440f));
-        const float pdf = 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * g[j] * g[j]);  // exp(-g^2/2)/sqrt(2 pi)
+        const float cdf = 0.5f * (1.0f + (DT == APAD_F32 ? erff(g[j] * 0.70710678118654752440f) : erf_as(g[j] * 0.70710678118654752440f)));
+        const float pdf = 0.3989422804014327f * (DT == APAD_F32 ? expf(-0.5f * g[j] * g[j]) : __builtin_amdgcn_exp2f(-0.72134752044448170368f * g[j] * g[j]));  // exp(-g^2/2)/sqrt(2 pi)
         dv[j] = d[j] * g[j] * cdf;
         dg[j] = d[j] * v[j] * (cdf + g[j] * pdf);
     }
-    *reinterpret_cast<uint4*>(dproj + (m * 2 * N + c * 8) * 2) = pack8<DT>(dv);
-    *reinterpret_cast<uint4*>(dproj + (m * 2 * N + N + c * 8) * 2) = pack8<DT>(dg);
+    st8<DT>(dproj, m * 2 * N + c * 8, dv);
+    st8<DT>(dproj, m * 2 * N + N + c * 8, dg);
 }
 
 // ---- duals of the convolution gathers ---------------------------------------------------------------------------------
@@ -191,11 +219,11 @@ template <int DT> __global__ __launch_bounds__(256) void upsample_bwd_kernel(con
     for (int hh = h0; hh < h1; ++hh)
         for (int ww = w0; ww < w1; ++ww) {
             float v[8];
-            unpack8<DT>(*reinterpret_cast<const uint4*>(dup + ((((int64_t)b * Hup + hh) * Wup + ww) * C + c * 8) * 2), v);
+            ld8<DT>(dup, (((int64_t)b * Hup + hh) * Wup + ww) * C + c * 8, v);
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] += v[j];
         }
-    *reinterpret_cast<uint4*>(dx + ((((int64_t)b * H + h) * W + w) * C + c * 8) * 2) = pack8<DT>(acc);
+    st8<DT>(dx, (((int64_t)b * H + h) * W + w) * C + c * 8, acc);
 }
 // stride-2 convolution backward, step 1: z[b][2i][2j] = dy[b][i][j], zero elsewhere (z is [B][H][W][C]); the stride-1
 // convolution of z with the flipped weights is then the input gradient
@@ -208,10 +236,10 @@ template <int DT> __global__ __launch_bounds__(256) void zero_stuff_kernel(const
     const int w = (int)(r % W); r /= W;
     const int h = (int)(r % H);
     const int b = (int)(r / H);
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if ((h & 1) == 0 && (w & 1) == 0 && (h >> 1) < Ho && (w >> 1) < Wo)
-        v = *reinterpret_cast<const uint4*>(dy + ((((int64_t)b * Ho + (h >> 1)) * Wo + (w >> 1)) * C + c * 8) * 2);
-    *reinterpret_cast<uint4*>(z + ((((int64_t)b * H + h) * W + w) * C + c * 8) * 2) = v;
+        ld8<DT>(dy, (((int64_t)b * Ho + (h >> 1)) * Wo + (w >> 1)) * C + c * 8, v);
+    st8<DT>(z, (((int64_t)b * H + h) * W + w) * C + c * 8, v);
 }
 // x [M][C] -> xt [C][Mpad] (columns m >= M zero): both operands of the adapter weight-gradient GEMM dW = dK^T . ehs
 template <int DT> __global__ __launch_bounds__(256) void transpose_pad_kernel(const uint8_t* x, uint8_t* xt, int M, int C, int Mpad) {
@@ -291,10 +319,11 @@ constexpr int REDUCE_BLOCKS = 1024;
 
 }  // namespace
 
-#define TRAIN_DT_CHECK(name) APAD_CHECK(dtype == APAD_BF16 || dtype == APAD_F16, name ": dtype %d not supported", dtype)
+#define TRAIN_DT_CHECK(name) APAD_CHECK(dtype == APAD_BF16 || dtype == APAD_F16 || dtype == APAD_F32, name ": dtype %d not supported", dtype)
 #define LAUNCH_DT(kern, grid, ...)                                                              \
     do {                                                                                        \
         if (dtype == APAD_BF16) hipLaunchKernelGGL((kern<APAD_BF16>), grid, dim3(256), 0, s, __VA_ARGS__); \
+        else if (dtype == APAD_F32) hipLaunchKernelGGL((kern<APAD_F32>), grid, dim3(256), 0, s, __VA_ARGS__); \
         else hipLaunchKernelGGL((kern<APAD_F16>), grid, dim3(256), 0, s, __VA_ARGS__);          \
     } while (0)
 
@@ -318,6 +347,9 @@ extern "C" int apad_groupnorm_bwd(const void* x, const void* gamma, const void* 
     if (dtype == APAD_BF16) {
         if (silu) hipLaunchKernelGGL((gn_bwd_kernel<APAD_BF16, true>), grid, dim3(256), 0, s, GN_ARGS);
         else hipLaunchKernelGGL((gn_bwd_kernel<APAD_BF16, false>), grid, dim3(256), 0, s, GN_ARGS);
+    } else if (dtype == APAD_F32) {
+        if (silu) hipLaunchKernelGGL((gn_bwd_kernel<APAD_F32, true>), grid, dim3(256), 0, s, GN_ARGS);
+        else hipLaunchKernelGGL((gn_bwd_kernel<APAD_F32, false>), grid, dim3(256), 0, s, GN_ARGS);
     } else {
         if (silu) hipLaunchKernelGGL((gn_bwd_kernel<APAD_F16, true>), grid, dim3(256), 0, s, GN_ARGS);
         else hipLaunchKernelGGL((gn_bwd_kernel<APAD_F16, false>), grid, dim3(256), 0, s, GN_ARGS);

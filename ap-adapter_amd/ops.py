@@ -501,9 +501,10 @@ def attention_bwd(q, k, v, out, dout, lse, heads, key_bias=None, dout_scale=1.0,
     Lk = k.shape[1]
     Npad, Lpad = round_up(N, 32), round_up(Lk, 32)
     d = L.AttnBwdDesc()
-    kt = head_transpose(k, heads, Lpad)
+    f32 = q.dtype == torch.float32  # fp32 training mode: plain-FMA kernels on the row-major operands, no transposed copies
+    kt = None if f32 else head_transpose(k, heads, Lpad)
     keep = [kt]
-    d.q, d.k, d.v, d.kt, d.out, d.dout, d.lse = (q.data_ptr(), k.data_ptr(), v.data_ptr(), kt.data_ptr(), out.data_ptr(),
+    d.q, d.k, d.v, d.kt, d.out, d.dout, d.lse = (q.data_ptr(), k.data_ptr(), v.data_ptr(), _ptr(kt), out.data_ptr(),
                                                  dout.data_ptr(), lse.data_ptr())
     d.key_bias = _ptr(key_bias)
     delta = torch.zeros(B, heads, Npad, dtype=torch.float32, device=q.device)
@@ -514,10 +515,12 @@ def attention_bwd(q, k, v, out, dout, lse, heads, key_bias=None, dout_scale=1.0,
     d.dq = dq.data_ptr()
     dk = dv = None
     if need_dkv:
-        qt, dot = head_transpose(q, heads, Npad), head_transpose(dout, heads, Npad)
         dk, dv = torch.empty_like(k), torch.empty_like(v)
-        keep += [qt, dot]
-        d.qt, d.doutt, d.dk, d.dv = qt.data_ptr(), dot.data_ptr(), dk.data_ptr(), dv.data_ptr()
+        d.dk, d.dv = dk.data_ptr(), dv.data_ptr()
+        if not f32:
+            qt, dot = head_transpose(q, heads, Npad), head_transpose(dout, heads, Npad)
+            keep += [qt, dot]
+            d.qt, d.doutt = qt.data_ptr(), dot.data_ptr()
     d.B, d.N, d.H, d.D, d.L, d.Npad, d.Lpad, d.dtype = B, N, heads, Cc // heads, Lk, Npad, Lpad, _DT[q.dtype]
     d.softmax_scale, d.dout_scale, d.accumulate_dq = 1.0 / math.sqrt(Cc // heads), float(dout_scale), 1 if acc else 0
     L.check(L.lib().apad_attention_bwd(C.byref(d), _stream()), "apad_attention_bwd")

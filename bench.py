@@ -286,7 +286,8 @@ def train_main(args, A, rank, world, dev):
     AdamW; the micro-step replays as one hipGraph.  One bench step = one optimizer step; value = samples/s over all ranks."""
     import torch.distributed as dist
     from ap_adapter_amd.synthetic import init_synthetic_
-    dtype, B, La = torch.bfloat16, args.train_batch, args.la
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.train_dtype]  # f32 = the reference's default (train.sh)
+    B, La = args.train_batch, args.la
     with torch.device(dev):
         u = A.AudioLDM2UNet2DConditionModel()
         A.install_ap_adapter(u, None, scale=0.5)
@@ -327,8 +328,8 @@ def train_main(args, A, rank, world, dev):
         print(json.dumps({
             "metric": "adapter training samples/sec, AudioLDM2-large+AP (BASELINE cfg 5)", "value": round(B * world / (ms * 1e-3), 3),
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"train_apadapter_v2.py step: batch {B}/GPU, random t per sample, La={La}, bf16 compute, fp32 master + "
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.train_dtype, "data": "synthetic",
+            "config": {"workload": f"train_apadapter_v2.py step: batch {B}/GPU, random t per sample, La={La}, {args.train_dtype} compute, fp32 master + "
                                    f"AdamW, adapter-only gradients (21 626 880 parameters), micro-step replayed as one hipGraph",
                        "global_batch": B * world, "parallelism": f"dp{world} (one flat 86.5 MB fp32 all-reduce per optimizer step)"},
             "loss_first": float(losses[0]), "loss_last": float(losses[-1]), "finite": bool(torch.isfinite(torch.stack(losses)).all())}))
@@ -352,6 +353,7 @@ def main():
     ap.add_argument("--step-only", action="store_true", help="only the timed step (for rocprofv3 runs: no roofline re-timings, no AudioMAE, no CPU leg)")
     ap.add_argument("--train", action="store_true", help="time BASELINE cfg 5 (the adapter's training step) instead of the denoise step")
     ap.add_argument("--train-batch", type=int, default=4)
+    ap.add_argument("--train-dtype", choices=["bf16", "f16", "f32"], default="bf16", help="compute type of the training step (fp32 master weights in every mode)")
     args = ap.parse_args()
 
     import ap_adapter_amd as A
@@ -470,7 +472,7 @@ def main():
         line = {
             "metric": "10s-clips/sec @200 DDIM steps, AudioLDM2-large+AP", "value": round(clips_per_s, 4), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.train_dtype, "data": "synthetic",
             "config": {"workload": f"AudioLDM2-large geometry + 32 AP processors, style_transfer preset "
                                    f"(ap_scale {args.ap_scale}, La={args.la}, CFG {args.guidance}), batch {B}/GPU, 10 s clips "
                                    f"(latents 8x250x16), 200-step DDIM, hipGraph-captured step; one bench step = one DDIM step",
