@@ -11,6 +11,7 @@
 // chunk are staged through double-buffered LDS by all threads, one chunk ahead.  The kernel needs ~330 VGPRs (x panel
 // 64-96 + output accumulators 128-192 + pipeline), so it runs one wave per SIMD by design; what it removes is the
 // 2 x 131 MB (C=256, 64 samples) round trip of the activation through HBM, one launch, and two LayerNorm/GEMM passes.
+#include <stdlib.h>
 #include "rp_shared.h"
 
 // Optional scheduler hint (VALU instructions requested after each first-GEMM MFMA); 0 = leave it to the scheduler,
@@ -391,6 +392,241 @@ __global__ __launch_bounds__(NWV * 64, 1) void mlp_kernel(MlpP p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Two waves per SIMD (round 2).  mlp_kernel keeps a whole 32-token panel's output (128 accumulator registers) in one wave
+// and therefore runs ONE wave per SIMD: nothing covers that wave's own LDS / dependency latencies (PMC: parked 28 %, issue
+// stalled 29 %).  Here the 8 waves of a 512-thread workgroup form 4 PAIRS; the two waves of a pair share one token panel and
+// split the work of every 32-hidden-unit chunk by ROWS: wave `hh` runs the first GEMM and the GEGLU arithmetic of hidden units
+// 16hh..16hh+15 of the chunk, hands its 1 KB of activations to its partner through LDS, and accumulates output columns
+// 128hh..128hh+127 from BOTH halves.  Per wave: x panel 64 + output accumulators 64 registers -> the kernel fits the 256
+// registers of two waves per SIMD.  MFMA count, LDS fragment traffic and GELU work per token are those of mlp_kernel; the
+// exchange rides on the per-chunk barrier the weight staging needs anyway (the second GEMM runs one chunk late).
+template <int KC> struct Mlp2Cfg {
+    static constexpr int C = KC * 16, CT = C / 64, HID = 4 * C, NCHUNK = HID / 32;
+    static constexpr int ROWB1 = Cfg<KC>::ROWB;
+    static constexpr int W1_BYTES = 64 * ROWB1;    // per half: 16 value rows, 16 gate rows
+    static constexpr int ROWB2 = 72;               // 32 hidden units (64 B) + 8 B pad: conflict-free b64 reads
+    static constexpr int W2_BYTES = C * ROWB2;
+    static constexpr int HX_BYTES = 4 * 2 * 1024;  // [pair][half] x 64 lanes x 16 B
+    static constexpr int LDS = 2 * W1_BYTES + 3 * W2_BYTES + 2 * HX_BYTES + (2 * HID + C) * 4;
+};
+
+template <int DT, int KC, bool LN>
+__global__ __launch_bounds__(512, 1) void mlp2_kernel(MlpP p) {
+    using E = ET<DT>;
+    using G = Mlp2Cfg<KC>;
+    constexpr int NTH = 512;
+    constexpr int N1 = 64 * KC * 2 / NTH, N2 = G::C * 4 / NTH, NG = KC / 4;
+    static_assert(NG == 4 && G::CT == 4, "C = 256");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int pair = wave >> 1, hh = wave & 1;
+    const int64_t mw0 = ((int64_t)blockIdx.x * 4 + pair) * 32;
+
+    uint8_t* const w1s = smem;                                        // 2 stages
+    uint8_t* const w2s = smem + 2 * G::W1_BYTES;                      // 3 slots (the second GEMM lags one chunk)
+    uint8_t* const hxs = w2s + 3 * G::W2_BYTES;                       // 2 parities of the activation hand-over
+    float* const lb1 = reinterpret_cast<float*>(hxs + 2 * G::HX_BYTES);
+    float* const lb2 = lb1 + 2 * G::HID;
+
+    u32x4 s1[N1], s2[N2];
+    // staging addresses: thread t moves 16-byte chunk (t % 32) of W1-tile rows (t / 32) + 16 i -- i = 0..3 are the value / gate rows of
+    // half 0, then of half 1, i.e. compile-time row offsets -- and chunk (t % 4) of W2 rows (t / 4) + 128 i
+    static_assert(N1 == 4 && N2 == 2, "C = 256, 512 threads");
+    const uint32_t o1 = (uint32_t)((((tid >> 5)) * G::C + (tid & 31) * 8) * 2);
+    const uint32_t d1 = (uint32_t)((tid >> 5) * G::ROWB1 + (tid & 31) * 16);
+    const uint32_t o2 = (uint32_t)((((int64_t)(tid >> 2)) * G::HID + (tid & 3) * 8) * 2);
+    const uint32_t d2 = (uint32_t)((tid >> 2) * G::ROWB2 + (tid & 3) * 16);
+    constexpr int64_t SRC1[4] = {0, (int64_t)G::HID * G::C * 2, 16 * G::C * 2, ((int64_t)G::HID + 16) * G::C * 2};
+    auto load_w1 = [&](int jc) {
+        const uint8_t* base = p.w1 + (int64_t)jc * 32 * G::C * 2 + o1;
+#pragma unroll
+        for (int i = 0; i < N1; ++i) s1[i] = *reinterpret_cast<const u32x4*>(base + SRC1[i]);
+    };
+    auto load_w2 = [&](int jc) {
+        const uint8_t* base = p.w2 + (int64_t)jc * 32 * 2 + o2;
+#pragma unroll
+        for (int i = 0; i < N2; ++i) s2[i] = *reinterpret_cast<const u32x4*>(base + (int64_t)i * 128 * G::HID * 2);
+    };
+    auto store_w1 = [&](uint8_t* st) {
+#pragma unroll
+        for (int i = 0; i < N1; ++i) *reinterpret_cast<u32x4*>(st + d1 + i * 16 * G::ROWB1) = s1[i];
+    };
+    auto store_w2 = [&](uint8_t* st) {
+#pragma unroll
+        for (int i = 0; i < N2; ++i) {
+            const u32x2 lo = {s2[i][0], s2[i][1]}, hi = {s2[i][2], s2[i][3]};
+            *reinterpret_cast<u32x2*>(st + d2 + i * 128 * G::ROWB2) = lo;
+            *reinterpret_cast<u32x2*>(st + d2 + i * 128 * G::ROWB2 + 8) = hi;
+        }
+    };
+    load_w1(0);
+    load_w2(0);
+    for (int i = tid; i < 2 * G::HID; i += NTH) lb1[i] = p.b1 ? ld_elem<DT>(p.b1, i) : 0.f;
+    for (int i = tid; i < G::C; i += NTH) lb2[i] = p.b2 ? ld_elem<DT>(p.b2, i) : 0.f;
+    // the "chunk -1" the first iteration's second GEMM consumes: zero activations against a zeroed weight slot
+    for (int i = tid; i < G::HX_BYTES / 4; i += NTH) reinterpret_cast<uint32_t*>(hxs + G::HX_BYTES)[i] = 0u;
+    for (int i = tid; i < G::W2_BYTES / 4; i += NTH) reinterpret_cast<uint32_t*>(w2s + 2 * G::W2_BYTES)[i] = 0u;
+
+    typename E::v8 xf[KC];
+    load_panel<DT, KC>(xf, p.x, G::C, p.M, mw0, l31, half);
+    if (LN) layernorm_panel<DT, KC>(xf, p.gamma, p.beta, p.eps, l31, half);
+
+    f32x16 yacc[G::CT];
+#pragma unroll
+    for (int ct = 0; ct < G::CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yacc[ct][r] = 0.f;
+
+    store_w1(w1s);
+    store_w2(w2s);
+    load_w1(1);
+    store_w1(w1s + G::W1_BYTES);
+    __syncthreads();
+
+    const int wrow = (32 * hh + l31) * G::ROWB1 + half * 16;  // this wave's rows of a W1 stage
+    f32x16 acur;
+    {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acur[r] = 0.f;
+        typename E::v8 wf[4][1];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            rp_load_group<DT, KC>(wf, w1s + wrow, g * 4);
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) acur = E::mfma32(wf[cc][0], xf[g * 4 + cc], acur);
+        }
+    }
+    __syncthreads();
+
+    auto load_bias = [&](int jc, float4 (&b)[4]) {
+        const int u0 = jc * 32 + 16 * hh + 4 * half;
+        b[0] = *reinterpret_cast<const float4*>(lb1 + u0);
+        b[1] = *reinterpret_cast<const float4*>(lb1 + u0 + 8);
+        b[2] = *reinterpret_cast<const float4*>(lb1 + G::HID + u0);
+        b[3] = *reinterpret_cast<const float4*>(lb1 + G::HID + u0 + 8);
+    };
+    const int w2row = (128 * hh + l31) * G::ROWB2 + half * 8;
+    const int hxoff = pair * 2048 + lane * 16;
+    auto gemm2 = [&](int slot, int parity) {  // y (this wave's 128 columns) += W2[:, chunk] . h(chunk), both halves of the chunk
+        const uint8_t* w2t = w2s + slot * G::W2_BYTES + w2row;
+        const uint8_t* hx = hxs + parity * G::HX_BYTES + hxoff;
+        const typename E::v8 h0 = as_v8<DT>(*reinterpret_cast<const uint4*>(hx));
+        const typename E::v8 h1 = as_v8<DT>(*reinterpret_cast<const uint4*>(hx + 1024));
+#pragma unroll
+        for (int ct = 0; ct < G::CT; ++ct) {
+            const uint8_t* wp = w2t + ct * 32 * G::ROWB2;
+            const uint2 a0 = *reinterpret_cast<const uint2*>(wp), a1 = *reinterpret_cast<const uint2*>(wp + 16);
+            const uint2 c0 = *reinterpret_cast<const uint2*>(wp + 32), c1 = *reinterpret_cast<const uint2*>(wp + 48);
+            yacc[ct] = E::mfma32(as_v8<DT>(make_uint4(a0.x, a0.y, a1.x, a1.y)), h0, yacc[ct]);
+            yacc[ct] = E::mfma32(as_v8<DT>(make_uint4(c0.x, c0.y, c1.x, c1.y)), h1, yacc[ct]);
+        }
+    };
+
+    for (int jc = 0; jc < G::NCHUNK; ++jc) {
+        load_w1(jc + 2 < G::NCHUNK ? jc + 2 : G::NCHUNK - 1);
+        load_w2(jc + 1 < G::NCHUNK ? jc + 1 : G::NCHUNK - 1);
+        float4 bcur[4];
+        load_bias(jc, bcur);
+        const float bv[8] = {bcur[0].x, bcur[0].y, bcur[0].z, bcur[0].w, bcur[1].x, bcur[1].y, bcur[1].z, bcur[1].w};
+        const float bg[8] = {bcur[2].x, bcur[2].y, bcur[2].z, bcur[2].w, bcur[3].x, bcur[3].y, bcur[3].z, bcur[3].w};
+        // operands of the second GEMM of chunk jc-1 (weights in slot (jc+2)%3, activations of both halves handed over at the last
+        // barrier) and the first fragment group of the first GEMM of chunk jc+1: one batch of LDS reads
+        typename E::v8 w2f[G::CT][2], hp[2];
+        {
+            const uint8_t* w2t = w2s + ((jc + 2) % 3) * G::W2_BYTES + w2row;
+            const uint8_t* hx = hxs + ((jc + 1) & 1) * G::HX_BYTES + hxoff;
+            hp[0] = as_v8<DT>(*reinterpret_cast<const uint4*>(hx));
+            hp[1] = as_v8<DT>(*reinterpret_cast<const uint4*>(hx + 1024));
+#pragma unroll
+            for (int ct = 0; ct < G::CT; ++ct)
+#pragma unroll
+                for (int sh = 0; sh < 2; ++sh) {
+                    const uint8_t* wp = w2t + ct * 32 * G::ROWB2 + sh * 32;
+                    const uint2 a0 = *reinterpret_cast<const uint2*>(wp), a1 = *reinterpret_cast<const uint2*>(wp + 16);
+                    w2f[ct][sh] = as_v8<DT>(make_uint4(a0.x, a0.y, a1.x, a1.y));
+                }
+        }
+        f32x16 anxt;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) anxt[r] = 0.f;
+        typename E::v8 hb;
+        auto geglu_step = [&](int r) {
+            const float v0 = acur[r] + bv[r];
+            const float v1 = acur[r + 1] + bv[r + 1];
+            const apad_f32x2 gt = {acur[8 + r] + bg[r], acur[9 + r] + bg[r + 1]};
+            const apad_f32x2 ge = gelu_erf_2(gt);
+            hb[r] = (typename E::elem)(v0 * ge[0]);
+            hb[r + 1] = (typename E::elem)(v1 * ge[1]);
+        };
+        const uint8_t* wt = w1s + ((jc + 1) & 1) * G::W1_BYTES + wrow;
+        typename E::v8 wfa[4][1], wfb[4][1];
+        rp_load_group<DT, KC>(wfa, wt, 0);
+#pragma unroll
+        for (int g = 0; g < NG; g += 2) {
+            rp_load_group<DT, KC>(wfb, wt, (g + 1) * 4);
+            yacc[g] = E::mfma32(w2f[g][0], hp[0], yacc[g]);
+            yacc[g] = E::mfma32(w2f[g][1], hp[1], yacc[g]);
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) anxt = E::mfma32(wfa[cc][0], xf[g * 4 + cc], anxt);
+            geglu_step(2 * g);
+            if (g + 2 < NG) rp_load_group<DT, KC>(wfa, wt, (g + 2) * 4);
+            yacc[g + 1] = E::mfma32(w2f[g + 1][0], hp[0], yacc[g + 1]);
+            yacc[g + 1] = E::mfma32(w2f[g + 1][1], hp[1], yacc[g + 1]);
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) anxt = E::mfma32(wfb[cc][0], xf[(g + 1) * 4 + cc], anxt);
+            geglu_step(2 * g + 2);
+        }
+#ifndef MLP2_VALU
+#define MLP2_VALU 0
+#endif
+#if MLP2_VALU > 0
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, MLP2_VALU, 0);
+        }
+#endif
+        *reinterpret_cast<uint4*>(hxs + (jc & 1) * G::HX_BYTES + hxoff + hh * 1024) = as_u4<DT>(hb);
+        store_w1(w1s + (jc & 1) * G::W1_BYTES);
+        store_w2(w2s + ((jc + 1) % 3) * G::W2_BYTES);
+        __syncthreads();
+        acur = anxt;
+    }
+    gemm2((G::NCHUNK - 1) % 3, (G::NCHUNK - 1) & 1);
+    __syncthreads();  // every wave is done with the weight stages: the W1 ring becomes the per-wave output scratch
+
+    uint8_t* const scr = smem + wave * SCR_BYTES;
+#pragma unroll
+    for (int ct = 0; ct < G::CT; ++ct) {
+        const int col0 = 128 * hh + ct * 32;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 b4 = *reinterpret_cast<const float4*>(lb2 + col0 + 8 * g + 4 * half);
+            typename E::v4 y;
+            y[0] = (typename E::elem)(yacc[ct][4 * g + 0] + b4.x);
+            y[1] = (typename E::elem)(yacc[ct][4 * g + 1] + b4.y);
+            y[2] = (typename E::elem)(yacc[ct][4 * g + 2] + b4.z);
+            y[3] = (typename E::elem)(yacc[ct][4 * g + 3] + b4.w);
+            *reinterpret_cast<uint2*>(scr + l31 * SCR_ROWB + (8 * g + 4 * half) * 2) = __builtin_bit_cast(uint2, y);
+        }
+        scratch_flush<DT>(scr, 32, p.out, G::C, col0, p.x, G::C, mw0, p.M, lane);
+    }
+}
+
+template <int DT, int KC, bool LN> int mlp2_launch(const MlpP& p, hipStream_t s) {
+    using G = Mlp2Cfg<KC>;
+    auto kern = mlp2_kernel<DT, KC, LN>;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((p.M + 127) / 128)), dim3(512), G::LDS, s, p);
+    return apad_check_launch("apad_geglu_mlp");
+}
+
 template <int DT, int KC, int NWV, bool LN> int mlp_launch(const MlpP& p, hipStream_t s) {
     using G = MlpCfg<KC>;
     const size_t lds = 2 * G::STAGE + NWV * SCR_BYTES + (2 * G::HID + G::C) * sizeof(float);
@@ -408,6 +644,8 @@ template <int DT, int KC, int NWV, bool LN> int mlp_launch(const MlpP& p, hipStr
 template <int DT, int KC> int mlp_dispatch(const MlpP& p, bool ln, hipStream_t s) {
     // 4 waves (128 tokens) per workgroup when that still fills the chip, else 2 waves
     const bool big = (p.M + 127) / 128 >= 256;
+    static const int v2 = [] { const char* e = getenv("APAD_MLP_V2"); return e ? atoi(e) : 1; }();
+    if (big && v2) return ln ? mlp2_launch<DT, KC, true>(p, s) : mlp2_launch<DT, KC, false>(p, s);
     if (big) return ln ? mlp_launch<DT, KC, 4, true>(p, s) : mlp_launch<DT, KC, 4, false>(p, s);
     return ln ? mlp_launch<DT, KC, 2, true>(p, s) : mlp_launch<DT, KC, 2, false>(p, s);
 }
