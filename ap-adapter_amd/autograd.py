@@ -9,6 +9,8 @@ The un-fused training forward is taken only where a gradient is actually needed 
 first adapted attention nothing requires grad, so those layers keep running the fused inference kernels.
 Frozen weights need no weight gradient; their transposed / flipped copies for the dgrad GEMMs are cached.
 """
+import weakref
+
 import torch
 
 from . import ops
@@ -30,8 +32,13 @@ def _cached(w, tag, make):
     key = (id(w), tag)
     sig = (w.data_ptr(), w._version, w.dtype, w.device)
     hit = _wcache.get(key)
-    if hit is None or hit[0] != sig:
-        hit = (sig, make(w.detach()))
+    # the entry must belong to THIS tensor object: ids (and allocator addresses) are recycled once a model is freed, and a recycled
+    # id with an equal signature would otherwise serve another model's derived weight
+    if hit is None or hit[0] != sig or hit[2]() is not w:
+        if len(_wcache) > 4096:  # entries of freed models
+            for k in [k for k, v in _wcache.items() if v[2]() is None]:
+                del _wcache[k]
+        hit = (sig, make(w.detach()), weakref.ref(w))
         _wcache[key] = hit
     return hit[1]
 
