@@ -33,7 +33,10 @@ struct RpP {
 };
 
 template <int KC> struct Cfg {
-    static constexpr int BNT = 32;                     // weight rows per LDS tile (one MFMA tile)
+#ifndef RP_BNT
+#define RP_BNT 32
+#endif
+    static constexpr int BNT = RP_BNT;                 // weight rows per LDS tile (32 = one MFMA tile)
     static constexpr int NT = BNT / 32;               // MFMA tiles per LDS tile
     static constexpr int CPR = KC * 2;                // 16-byte chunks per weight row
     static constexpr int ROWB = KC * 32 + 16;         // padded LDS row stride (bytes)
