@@ -344,6 +344,18 @@ def test_cfg4_driver_world1_small(dev, tmp_path):
     assert tok.shape == unc.shape == (128, 768) and tok.dtype == torch.float32 and not torch.equal(tok, unc)
     solo = S.run_sharded([clips[3]], cfg, enc, den, batch=2, latent_shape=(8, 24, 16), device=dev)
     assert torch.equal(solo[3], out[3])
+    # the stages after the loop (inference.py:79-81): latents -> AutoencoderKL.decode -> SpeechT5HifiGan -> 16 kHz wav on disk
+    import wave
+    vae, voc = RS.build_decoder(dev, torch.bfloat16, small=True)
+    pipe.vae, pipe.vocoder = vae, voc
+    mel = vae.decode(out[0][None].to(dev, torch.bfloat16) / vae.config.scaling_factor).sample
+    assert mel.shape == (1, 1, 96, 64)
+    wav = pipe.mel_spectrogram_to_waveform(mel)[0]
+    assert wav.shape[0] >= 96 * 160 and bool(torch.isfinite(wav).all())  # (the first up-sampler's odd k - s adds a few samples)
+    wav = wav[: 96 * 160]  # the pipeline crops to the requested length (pipeline_audioldm2.py:1044)
+    RS.write_wav16(str(tmp_path / "clip0.wav"), wav)
+    with wave.open(str(tmp_path / "clip0.wav")) as w:
+        assert (w.getframerate(), w.getnframes(), w.getsampwidth(), w.getnchannels()) == (16000, 96 * 160, 2, 1)
 
 
 def test_rccl_world1_flat_gradient_allreduce(dev):

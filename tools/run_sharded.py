@@ -39,6 +39,22 @@ def write_synthetic_wavs(out_dir, n=8, seconds=10.0, sr=16000):
     return paths
 
 
+def write_wav16(path, x, sr=16000):
+    """mono float waveform in [-1, 1] -> 16-bit PCM (the reference writes float32 through scipy.io.wavfile, inference.py:79-81)"""
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(sr)
+        w.writeframes((x.clamp(-1, 1) * 32767).to(torch.int16).cpu().numpy().tobytes())
+
+
+def build_decoder(dev, dtype, small=False, seed=300):
+    """latents -> mel -> waveform stages (f-4): AutoencoderKL + SpeechT5HifiGan on the HIP path, random-init weights of the real shapes"""
+    import ap_adapter_amd as A
+    torch.manual_seed(seed)
+    vae = A.AutoencoderKL(A.VaeConfig(block_out_channels=(32, 64, 64), layers_per_block=1, norm_num_groups=8) if small else A.VaeConfig())
+    voc = A.SpeechT5HifiGan(A.HifiGanConfig(upsample_initial_channel=256) if small else A.HifiGanConfig())
+    return vae.to(dev, dtype).requires_grad_(False), voc.to(dev, dtype).requires_grad_(False)
+
+
 def build_job(dev, dtype, task_cfg, small=False, seed=100, adapter_ckpt=None):
     """UNet + adapter + AudioMAE (fp32, the reference's type) on ``dev``; random-init weights of the real shapes unless an adapter
     checkpoint (reference key scheme) is given"""
@@ -72,6 +88,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--adapter-ckpt", default=None)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--wav-dir", default=None, help="decode every clip (VAE + vocoder on the HIP path) and write 16 kHz wavs named as "
+                                                     "inference.py:79 names them")
     args = ap.parse_args()
 
     import ap_adapter_amd as A
@@ -101,12 +119,25 @@ def main():
     local_out = S.run_sharded(clips, cfg, encode_audio, denoise, args.batch, rank, world, latent_shape=(8, H, 16), device=dev)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    n_wavs = 0
+    if args.wav_dir:  # each rank decodes and writes its own clips (no collective): latents / scaling_factor -> mel -> waveform
+        os.makedirs(args.wav_dir, exist_ok=True)
+        vae, voc = build_decoder(dev, dtype, small=args.small)
+        pipe.vae, pipe.vocoder = vae, voc
+        for idx in sorted(local_out):
+            mel = vae.decode(local_out[idx][None].to(dev, dtype) / vae.config.scaling_factor).sample
+            wav = pipe.mel_spectrogram_to_waveform(mel)[0, : int(args.seconds * 16000)]
+            c = clips[idx]
+            name = f"{c['prompt']}_{idx}_ip{cfg['ap_scale']}_t{cfg['time_pooling']}_f{cfg['freq_pooling']}.wav".replace("/", "_")
+            write_wav16(os.path.join(args.wav_dir, name), wav)
+            n_wavs += 1
     allc = S.gather_clips(local_out, len(clips), rank, world)
     if rank == 0:
         finite = all(bool(torch.isfinite(x).all()) for x in allc)
         print(json.dumps({"task": args.task, "clips": len(clips), "world": world, "batch": args.batch, "steps": args.steps,
                           "La": A.config.audio_tokens(cfg), "seconds_rank0": round(dt, 2), "clips_per_s": round(len(clips) / dt, 4),
-                          "graph_captures": pipe.graph_captures, "graph_hits": pipe.graph_hits, "finite": finite}))
+                          "graph_captures": pipe.graph_captures, "graph_hits": pipe.graph_hits, "finite": finite,
+                          "wavs_written_rank0": n_wavs}))
         if args.out:
             torch.save({"latents": torch.stack([x.cpu() for x in allc]), "clips": clips}, args.out)
     if world > 1:
