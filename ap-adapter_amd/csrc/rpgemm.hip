@@ -22,12 +22,12 @@ namespace {
 
 // per-thread byte offsets of the staging loads inside weight tile 0, computed once per kernel; tile t adds a wave-uniform
 // stride (the per-tile 64-bit address arithmetic otherwise sits on the vector ALU in front of every tile)
-template <int KC, bool GEGLU>
-__device__ __forceinline__ void stage_offsets(int64_t (&off)[Cfg<KC>::NCH], int64_t ldw, int n_total, int tid) {
+template <int KC, bool GEGLU, int NTH>
+__device__ __forceinline__ void stage_offsets(int64_t (&off)[Cfg<KC>::BNT * Cfg<KC>::CPR / NTH], int64_t ldw, int n_total, int tid) {
     using C = Cfg<KC>;
 #pragma unroll
-    for (int i = 0; i < C::NCH; ++i) {
-        const int idx = tid + 256 * i;
+    for (int i = 0; i < C::BNT * C::CPR / NTH; ++i) {
+        const int idx = tid + NTH * i;
         const int j = idx / C::CPR, ch = idx - j * C::CPR;
         int64_t row;
         if (GEGLU) {  // LDS tile rows: per 32-row MFMA tile, 16 value rows then the 16 matching gate rows
@@ -41,30 +41,33 @@ __device__ __forceinline__ void stage_offsets(int64_t (&off)[Cfg<KC>::NCH], int6
     }
 }
 
-template <int KC, bool GEGLU>
-__device__ __forceinline__ void stage_load(u32x4 (&st)[Cfg<KC>::NCH], const uint8_t* w, int64_t ldw, const int64_t (&off)[Cfg<KC>::NCH],
-                                           int tile) {
+template <int KC, bool GEGLU, int NTH>
+__device__ __forceinline__ void stage_load(u32x4 (&st)[Cfg<KC>::BNT * Cfg<KC>::CPR / NTH], const uint8_t* w, int64_t ldw,
+                                           const int64_t (&off)[Cfg<KC>::BNT * Cfg<KC>::CPR / NTH], int tile) {
     using C = Cfg<KC>;
     const uint8_t* base = w + (int64_t)tile * (GEGLU ? C::NT * 16 : C::BNT) * ldw * 2;
 #pragma unroll
-    for (int i = 0; i < C::NCH; ++i) st[i] = *reinterpret_cast<const u32x4*>(base + off[i]);
+    for (int i = 0; i < C::BNT * C::CPR / NTH; ++i) st[i] = *reinterpret_cast<const u32x4*>(base + off[i]);
 }
 
-template <int KC>
-__device__ __forceinline__ void stage_store(const u32x4 (&st)[Cfg<KC>::NCH], uint8_t* base, int tid) {
+template <int KC, int NTH>
+__device__ __forceinline__ void stage_store(const u32x4 (&st)[Cfg<KC>::BNT * Cfg<KC>::CPR / NTH], uint8_t* base, int tid) {
     using C = Cfg<KC>;
 #pragma unroll
-    for (int i = 0; i < C::NCH; ++i) {
-        const int idx = tid + 256 * i;
+    for (int i = 0; i < C::BNT * C::CPR / NTH; ++i) {
+        const int idx = tid + NTH * i;
         const int j = idx / C::CPR, ch = idx - j * C::CPR;
         *reinterpret_cast<u32x4*>(base + j * C::ROWB + ch * 16) = st[i];
     }
 }
 
-template <int DT, int KC, bool LN, bool GEGLU>
-__global__ __launch_bounds__(256, 2) void rpgemm_kernel(RpP p) {
+// NW = waves (32-row panels) per workgroup: 4 (two workgroups per CU) or 8 (one: every weight tile is staged once per CU
+// instead of twice)
+template <int DT, int KC, bool LN, bool GEGLU, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void rpgemm_kernel(RpP p) {
     using E = ET<DT>;
     using C = Cfg<KC>;
+    constexpr int NTH = NW * 64, NCHW = C::BNT * C::CPR / NTH;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void rpgemm_kernel(RpP p) {
     const int t_begin = sp * p.tiles_per_block;
     const int t_end = min(t_begin + p.tiles_per_block, p.n_tiles);
     if (t_begin >= t_end) return;
-    const int64_t mw0 = (int64_t)mt * 128 + wave * 32;  // first row of this wave
+    const int64_t mw0 = (int64_t)mt * (NW * 32) + wave * 32;  // first row of this wave
     int64_t mrow = mw0 + l31;
     const bool mvalid = mrow < p.M;
     mrow = mvalid ? mrow : p.M - 1;
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void rpgemm_kernel(RpP p) {
     }
 
     // ---- weight staging (registers -> LDS); first tile's loads are issued after the x panel is in flight ----
-    u32x4 st[C::NCH];
+    u32x4 st[NCHW];
     const uint8_t* const wbase = p.w;
     const int64_t ldw = p.ldw;
     const int n_total = p.n_total;
@@ -130,21 +133,21 @@ __global__ __launch_bounds__(256, 2) void rpgemm_kernel(RpP p) {
         }
     }
 
-    int64_t soff[C::NCH];
-    stage_offsets<KC, GEGLU>(soff, ldw, n_total, tid);
-    stage_load<KC, GEGLU>(st, wbase, ldw, soff, t_begin);
-    stage_store<KC>(st, smem, tid);
+    int64_t soff[NCHW];
+    stage_offsets<KC, GEGLU, NTH>(soff, ldw, n_total, tid);
+    stage_load<KC, GEGLU, NTH>(st, wbase, ldw, soff, t_begin);
+    stage_store<KC, NTH>(st, smem, tid);
     __syncthreads();
     uint8_t* const scr = smem + 2 * C::TILE_BYTES + wave * SCR_BYTES;  // this wave's output transpose scratch
     int cursor = 0, win_col0 = 0;
     // bias of this workgroup's column range -> LDS once (a global bias load per epilogue group put a full memory
     // latency on the critical path of every tile).  Layout: [value cols | gate cols] for GEGLU, fp32.
-    float* const lbias = reinterpret_cast<float*>(smem + 2 * C::TILE_BYTES + 4 * SCR_BYTES);
+    float* const lbias = reinterpret_cast<float*>(smem + 2 * C::TILE_BYTES + NW * SCR_BYTES);
     const int bias_cols = (t_end - t_begin) * COLS_PER_TILE;
     const int bias_c0 = t_begin * COLS_PER_TILE;
     {
         const int reps = GEGLU ? 2 : 1;
-        for (int i = tid; i < bias_cols * reps; i += 256) {
+        for (int i = tid; i < bias_cols * reps; i += NTH) {
             const int part = i / bias_cols, c = i - part * bias_cols;
             const int n = bias_c0 + c;  // global output column
             float v = 0.f;
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void rpgemm_kernel(RpP p) {
 
     for (int t = t_begin; t < t_end; ++t) {
         const int buf = (t - t_begin) & 1;
-        if (t + 1 < t_end) stage_load<KC, GEGLU>(st, wbase, ldw, soff, t + 1);
+        if (t + 1 < t_end) stage_load<KC, GEGLU, NTH>(st, wbase, ldw, soff, t + 1);
         const uint8_t* wt = smem + buf * C::TILE_BYTES + l31 * C::ROWB + half * 16;
 
         // segment of this tile (tiles never straddle segments: host checks n_cols % COLS_PER_TILE == 0)
@@ -263,22 +266,26 @@ __global__ __launch_bounds__(256, 2) void rpgemm_kernel(RpP p) {
             }
         }
 
-        if (t + 1 < t_end) stage_store<KC>(st, smem + (buf ^ 1) * C::TILE_BYTES, tid);
+        if (t + 1 < t_end) stage_store<KC, NTH>(st, smem + (buf ^ 1) * C::TILE_BYTES, tid);
         __syncthreads();
     }
     if (GEGLU && cursor > 0)  // odd number of 16-column sub-tiles in this workgroup's range
         scratch_flush<DT>(scr, cursor, p.seg[0].out, p.seg[0].ldo, win_col0, nullptr, 0, mw0, p.M, lane);
 }
 
-template <int DT, int KC, bool LN, bool GEGLU> int launch(RpP& p, hipStream_t s) {
+template <int DT, int KC, bool LN, bool GEGLU, int NW = 4> int launch(RpP& p, hipStream_t s) {
     using C = Cfg<KC>;
     constexpr int COLS_PER_TILE = GEGLU ? C::NT * 16 : C::BNT;
+    if constexpr (NW == 4) {
+        static const int nw8 = [] { const char* e = getenv("APAD_RP_NW8"); return e ? atoi(e) : 1; }();  // step 49.12 -> 48.95 ms
+        if (nw8 && p.M >= 256 * 128) return launch<DT, KC, LN, GEGLU, 8>(p, s);
+    }
     p.n_tiles = p.n_total / COLS_PER_TILE;
-    const int m_tiles = (int)((p.M + 127) / 128);
+    const int m_tiles = (int)((p.M + NW * 32 - 1) / (NW * 32));
     // Split the column tiles over `nsplit` workgroups per row panel so that the grid is a near-integer number of
     // "rounds" of the workgroups the chip can hold at once (256 CUs x wgs/CU): 1000 workgroups on a 768-slot chip run
     // two rounds for 1.3 rounds of work.  Candidates 1..8, fewest wasted slots wins (ties -> fewer splits).
-    const int wg_per_cu = (GEGLU && KC <= 16) ? 3 : 2;  // from the kernels' VGPR / LDS footprints
+    const int wg_per_cu = NW == 8 ? 1 : ((GEGLU && KC <= 16) ? 3 : 2);  // from the kernels' VGPR / LDS footprints
     const int cap = 256 * wg_per_cu;
     int nsplit = 1;
     double best = 1e30;
@@ -296,14 +303,14 @@ template <int DT, int KC, bool LN, bool GEGLU> int launch(RpP& p, hipStream_t s)
     }
     p.tiles_per_block = (p.n_tiles + nsplit - 1) / nsplit;
     p.nsplit = (p.n_tiles + p.tiles_per_block - 1) / p.tiles_per_block;
-    const size_t lds = 2 * C::TILE_BYTES + 4 * SCR_BYTES + (size_t)p.tiles_per_block * COLS_PER_TILE * (GEGLU ? 2 : 1) * sizeof(float);
-    auto kern = rpgemm_kernel<DT, KC, LN, GEGLU>;
+    const size_t lds = 2 * C::TILE_BYTES + NW * SCR_BYTES + (size_t)p.tiles_per_block * COLS_PER_TILE * (GEGLU ? 2 : 1) * sizeof(float);
+    auto kern = rpgemm_kernel<DT, KC, LN, GEGLU, NW>;
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_lds = lds;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(m_tiles * p.nsplit)), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(m_tiles * p.nsplit)), dim3(NW * 64), lds, s, p);
     return apad_check_launch("apad_rowpanel_gemm");
 }
 

@@ -332,7 +332,7 @@ def test_errors_are_python_exceptions(dev):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,K", [(1000, 256), (333, 384), (128, 256), (4000, 384)])
+@pytest.mark.parametrize("M,K", [(1000, 256), (333, 384), (128, 256), (4000, 384), (33000, 256)])  # >= 32768 rows: 8-wave workgroups
 @pytest.mark.parametrize("ln", [False, True])
 def test_rowpanel_plain_bias_act_residual(dev, dtype, M, K, ln):
     from ap_adapter_amd import ops
@@ -352,7 +352,7 @@ def test_rowpanel_plain_bias_act_residual(dev, dtype, M, K, ln):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,K", [(1000, 256), (300, 384)])
+@pytest.mark.parametrize("M,K", [(1000, 256), (300, 384), (33000, 256), (32900, 384)])
 @pytest.mark.parametrize("ln", [False, True])
 def test_rowpanel_geglu(dev, dtype, M, K, ln):
     from ap_adapter_amd import ops
@@ -401,7 +401,8 @@ def test_geglu_mlp_outside_envelope_is_an_error(dev):
 
 
 @pytest.mark.parametrize("dtype", DTYPES16)
-@pytest.mark.parametrize("B,L,K,heads", [(2, 1000, 256, 8), (3, 252, 384, 8), (2, 100, 256, 4), (1, 513, 384, 12), (2, 63, 256, 8)])
+@pytest.mark.parametrize("B,L,K,heads", [(2, 1000, 256, 8), (3, 252, 384, 8), (2, 100, 256, 4), (1, 513, 384, 12), (2, 63, 256, 8),
+                                         (34, 1000, 256, 8)])  # 34000 rows: the 8-wave workgroup variant, sample boundaries inside a workgroup
 def test_rowpanel_fused_qkv_with_vt(dev, dtype, B, L, K, heads):
     """LayerNorm + q|k|v in one launch; V per-head transposed (incl. token counts that are not multiples of 4)"""
     from ap_adapter_amd import ops
