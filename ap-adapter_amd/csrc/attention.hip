@@ -530,23 +530,26 @@ __device__ __forceinline__ void tile_compute2(const uint8_t* buf, int key0, int 
     }
 }
 
-template <int DT, int D>
-__global__ __launch_bounds__(256) void attn2q_kernel(AttnP p) {
+// NW = waves per workgroup: 4 (256 queries) or, for d = 32, 8 (512 queries: the K / V^T tile of a (batch, head) is staged once
+// per CU instead of twice; waves 0-3 stage K, waves 4-7 stage V^T, one 16-byte chunk per thread)
+template <int DT, int D, int NW>
+__global__ __launch_bounds__(NW * 64) void attn2q_kernel(AttnP p) {
     using E = ET<DT>;
     using Y = Lay<D>;
-    constexpr int KC = D / 16;
+    constexpr int KC = D / 16, QPW = NW * 64;
+    static_assert(NW == 4 || (NW == 8 && D == 32), "the 8-wave staging split is written for d = 32");
     __shared__ __attribute__((aligned(16))) uint8_t smem[2 * Y::BUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int nbh = p.B * p.H;
-    const int nqt = (p.N + 255) >> 8;
+    const int nqt = (p.N + QPW - 1) / QPW;
     const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;  // XCD-aware order as in attn_kernel
     const int bh = (seq / nqt) * 8 + xcd, qtile = seq % nqt;
     if (bh >= nbh) return;
     const int h = bh % p.H, b = bh / p.H;
-    const int q0 = qtile * 256 + wave * 64;
+    const int q0 = qtile * QPW + wave * 64;
     if (Y::VROWS > D) {
-        for (int i = tid; i < 2 * Y::BUF / 4; i += 256) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
+        for (int i = tid; i < 2 * Y::BUF / 4; i += NW * 64) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
     }
     typename E::v8 qf[2][KC];
 #pragma unroll
@@ -579,36 +582,68 @@ __global__ __launch_bounds__(256) void attn2q_kernel(AttnP p) {
         const int ntiles = (L + KT - 1) / KT, nfull = L / KT;
         u32x4 rk[Y::NK], rv[Y::NV];
         uint32_t koff[Y::NK], voff[Y::NV];
+        // 8-wave staging: this thread's ONE chunk of the tile -- K row (t2 / 4), chunk (t2 % 4) for waves 0-3; V^T row (t2 / 8),
+        // chunk (t2 % 8) for waves 4-7
+        const bool isK = tid < 256;
+        const int t2 = tid & 255;
+        const int srow = isK ? (t2 >> 2) : (t2 >> 3), sch = isK ? (t2 & 3) : (t2 & 7);
+        const uint32_t soff8 = isK ? (uint32_t)(((int64_t)srow * k_sl + sch * 8) * 2) : (uint32_t)(((int64_t)srow * Lpad + sch * 8) * 2);
+        u32x4 sreg = {0u, 0u, 0u, 0u};
+        if constexpr (NW == 4) {
 #pragma unroll
-        for (int i = 0; i < Y::NK; ++i) {
-            const int idx = tid + 256 * i;
-            const int row = idx / (D / 8), ch = idx - row * (D / 8);
-            koff[i] = (uint32_t)(((int64_t)row * k_sl + ch * 8) * 2);
-        }
+            for (int i = 0; i < Y::NK; ++i) {
+                const int idx = tid + 256 * i;
+                const int row = idx / (D / 8), ch = idx - row * (D / 8);
+                koff[i] = (uint32_t)(((int64_t)row * k_sl + ch * 8) * 2);
+            }
 #pragma unroll
-        for (int i = 0; i < Y::NV; ++i) {
-            const int idx = tid + 256 * i;
-            voff[i] = (uint32_t)((((int64_t)(idx >> 3)) * Lpad + (idx & 7) * 8) * 2);
+            for (int i = 0; i < Y::NV; ++i) {
+                const int idx = tid + 256 * i;
+                voff[i] = (uint32_t)((((int64_t)(idx >> 3)) * Lpad + (idx & 7) * 8) * 2);
+            }
         }
-        tile_load<D>(rk, rv, kbase, k_sl, vbase, L, Lpad, 0, tid);
+        auto load_tile = [&](int tile, bool full) {
+            const int key0 = tile * KT;
+            if constexpr (NW == 4) {
+                if (full) tile_load_full<D>(rk, rv, kbase + (int64_t)key0 * k_sl * 2, vbase + (int64_t)key0 * 2, koff, voff, tid);
+                else tile_load<D>(rk, rv, kbase, k_sl, vbase, L, Lpad, key0, tid);
+            } else {
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                if (isK) sreg = (full || key0 + srow < L) ? *reinterpret_cast<const u32x4*>(kbase + (int64_t)key0 * k_sl * 2 + soff8) : z;
+                else sreg = (full || key0 + sch * 8 < Lpad) ? *reinterpret_cast<const u32x4*>(vbase + (int64_t)key0 * 2 + soff8) : z;
+            }
+        };
+        auto store_tile = [&](uint8_t* buf) {
+            if constexpr (NW == 4) {
+                tile_store<D>(rk, rv, buf, tid);
+            } else {
+                if (isK) {
+                    *reinterpret_cast<u32x4*>(buf + srow * Y::KROW + sch * 16) = sreg;
+                } else {  // V^T row stride is 8 (mod 16): two 8-byte stores
+                    uint8_t* dst = buf + Y::K_BYTES + srow * Y::VROW + sch * 16;
+                    *reinterpret_cast<u32x2*>(dst) = (u32x2){sreg[0], sreg[1]};
+                    *reinterpret_cast<u32x2*>(dst + 8) = (u32x2){sreg[2], sreg[3]};
+                }
+            }
+        };
+        load_tile(0, false);
         __syncthreads();
-        tile_store<D>(rk, rv, smem, tid);
+        store_tile(smem);
         __syncthreads();
         int t = 0;
         for (; t < nfull; ++t) {
             const uint8_t* buf = smem + (t & 1) * Y::BUF;
-            if (t + 1 < nfull)
-                tile_load_full<D>(rk, rv, kbase + (int64_t)(t + 1) * KT * k_sl * 2, vbase + (int64_t)(t + 1) * KT * 2, koff, voff, tid);
-            else if (t + 1 < ntiles) tile_load<D>(rk, rv, kbase, k_sl, vbase, L, Lpad, (t + 1) * KT, tid);
+            if (t + 1 < nfull) load_tile(t + 1, true);
+            else if (t + 1 < ntiles) load_tile(t + 1, false);
             tile_compute2<DT, D, false>(buf, t * KT, L, c, qf, o, osum, m, l31, half);
-            if (t + 1 < ntiles) tile_store<D>(rk, rv, smem + ((t + 1) & 1) * Y::BUF, tid);
+            if (t + 1 < ntiles) store_tile(smem + ((t + 1) & 1) * Y::BUF);
             __syncthreads();
         }
         for (; t < ntiles; ++t) {
             const uint8_t* buf = smem + (t & 1) * Y::BUF;
-            if (t + 1 < ntiles) tile_load<D>(rk, rv, kbase, k_sl, vbase, L, Lpad, (t + 1) * KT, tid);
+            if (t + 1 < ntiles) load_tile(t + 1, false);
             tile_compute2<DT, D, true>(buf, t * KT, L, c, qf, o, osum, m, l31, half);
-            if (t + 1 < ntiles) tile_store<D>(rk, rv, smem + ((t + 1) & 1) * Y::BUF, tid);
+            if (t + 1 < ntiles) store_tile(smem + ((t + 1) & 1) * Y::BUF);
             __syncthreads();
         }
     }
@@ -825,8 +860,16 @@ template <int DT, int D> int launch_d(const AttnP& p, bool dual, dim3 grid, hipS
         // long single-segment launches without a key bias (the UNet's self-attention): two query tiles per wave
         static const int two_q = [] { const char* e = getenv("APAD_ATTN_2Q"); return e ? atoi(e) : 1; }();
         if (two_q && !dual && p.key_bias == nullptr && p.N >= 512 && p.L >= 256 && (D == 32 || two_q > 1)) {
+            if constexpr (D == 32) {
+                static const int nw8 = [] { const char* e = getenv("APAD_ATTN_NW8"); return e ? atoi(e) : 0; }();  // off: step 49.68 -> 50.12 ms (the 8-wave barrier costs more than the halved staging saves)
+                if (nw8) {
+                    dim3 g8((unsigned)(((p.N + 511) / 512) * (((p.H * p.B) + 7) / 8 * 8)));
+                    hipLaunchKernelGGL((attn2q_kernel<DT, D, 8>), g8, dim3(512), 0, s, p);
+                    return apad_check_launch("apad_attention");
+                }
+            }
             dim3 g2((unsigned)(((p.N + 255) / 256) * (((p.H * p.B) + 7) / 8 * 8)));
-            hipLaunchKernelGGL((attn2q_kernel<DT, D>), g2, dim3(256), 0, s, p);
+            hipLaunchKernelGGL((attn2q_kernel<DT, D, 4>), g2, dim3(256), 0, s, p);
             return apad_check_launch("apad_attention");
         }
     }
