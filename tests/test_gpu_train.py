@@ -402,13 +402,15 @@ def test_graph_captured_micro_step_equals_eager(dev):
     assert float(tr.micro_step(*args2)) == l2 and torch.equal(tr.grad, g2)
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-def test_full_geometry_adapter_gradients_vs_oracle(dev, dtype):
+@pytest.mark.parametrize("dtype,frames", [(torch.bfloat16, 250), (torch.float32, 64)])
+def test_full_geometry_adapter_gradients_vs_oracle(dev, dtype, frames):
     """BASELINE config 5 geometry (AudioLDM2-large, 718 M frozen parameters, 64 trainable tensors = 21 626 880 elements),
     one 10 s sample at a random t: every adapter gradient after a backward through the whole UNet vs torch autograd
     through the fp32 oracle.  Bound (bf16): the flat gradient's direction within 1 - cos < 5e-3 and its norm within 3 %;
     per tensor, max-abs error below 0.15 of that tensor's largest entry (the smallest gradients sit deep in the stack).
-    fp32 (the reference's default training precision, train.sh): 1 - cos < 1e-7, norm within 1e-4, every tensor within 1e-3 of its max."""
+    fp32 (the reference's default training precision, train.sh): 1 - cos < 1e-7, norm within 1e-4, every tensor within 1e-3 of its max
+    (on a 2.56 s sample, ``frames`` = 64: same network, a quarter of the oracle's autograd work; the 10 s fp32 run measured cos 1.000000,
+    worst tensor 2.1e-5)."""
     import ap_adapter_amd as A
     from ap_adapter_amd.synthetic import init_synthetic_, synthetic_inputs
     from oracle import train as OT
@@ -424,9 +426,9 @@ def test_full_geometry_adapter_gradients_vs_oracle(dev, dtype):
     ehs1 = inp["prompt_embeds"].to(dtype)[1:]
     m1 = inp["attention_mask"].float()[1:]
     g = torch.Generator().manual_seed(9)
-    noise = torch.randn(1, 8, 250, 16, generator=g)
+    noise = torch.randn(1, 8, 250, 16, generator=g)[:, :, :frames].contiguous()
     t = torch.tensor([437])
-    noisy = q(OT.add_noise(inp["latents"].float(), noise, t), dtype)
+    noisy = q(OT.add_noise(inp["latents"].float()[:, :, :frames].contiguous(), noise, t), dtype)
     ref_loss, ref_grads, _ = OT.loss_and_grads(sd, u.config.geometry_dict(), procs, noisy, t, ehs.float(), ehs1.float(), m1, noise)
     u = u.to(dev)
     tr = A.AdapterTrainer(u)

@@ -84,10 +84,12 @@ def test_audiomae_vs_oracle(dev, dtype, tol):
     assert rel_err(out, ref) < tol
 
 
-def _full_geometry_case(dev, dtype, La=32, scale=0.55, t=501):
+def _full_geometry_case(dev, dtype, La=32, scale=0.55, t=501, frames=250):
     """AudioLDM2-large geometry (718 M parameters, 256 attention sites, 32 AP processors), one CFG pair of a 10 s clip
-    (latents 8x250x16): returns (noise_pred of the HIP path, a closure running the oracle chain on the same
-    storage-rounded weights and inputs).  noise_pred is the tensor the north-star tolerance is stated on."""
+    (latents 8x250x16; ``frames`` = 64 is the same network on a 2.56 s clip, a quarter of the CPU oracle's work -- the GPU suite
+    has a 20-minute budget and the full-length oracle runs are its bulk): returns (noise_pred of the HIP path, a closure running
+    the oracle chain on the same storage-rounded weights and inputs).  noise_pred is the tensor the north-star tolerance is
+    stated on."""
     import ap_adapter_amd as A
     from ap_adapter_amd.synthetic import init_synthetic_, synthetic_inputs
     from oracle import unet as OU
@@ -101,7 +103,7 @@ def _full_geometry_case(dev, dtype, La=32, scale=0.55, t=501):
     pipe = A.AudioLDM2Pipeline(u)
     ehs = pipe.assemble_condition(inp["generated_prompt_embeds"], inp["audio_tokens"], inp["uncond_audio_tokens"], dtype)
     ehs1 = inp["prompt_embeds"].to(dtype)
-    x = torch.cat([inp["latents"]] * 2).to(dtype)
+    x = torch.cat([inp["latents"][:, :, :frames]] * 2).to(dtype).contiguous()
     tt = torch.tensor(t)
     geo = u.config.geometry_dict()
 
@@ -116,29 +118,29 @@ def _full_geometry_case(dev, dtype, La=32, scale=0.55, t=501):
     return out.float().cpu(), oracle
 
 
-@pytest.mark.parametrize("La,scale", [(32, 0.55), (512, 1.0)])
-def test_full_geometry_noise_pred_fp32_within_north_star(dev, La, scale):
+@pytest.mark.parametrize("La,scale,frames", [(32, 0.55, 250), (512, 1.0, 64)])
+def test_full_geometry_noise_pred_fp32_within_north_star(dev, La, scale, frames):
     """North-star bar: <= 1e-3 max-abs error on noise_pred vs the reference chain.  In the fp32 precision mode (APAD_F32
     storage, exact-f32 MFMA; the reference's own arithmetic type for cfg 1 / training / AudioMAE) the only difference to
     the oracle chain is summation order, so the bound is asserted as stated -- absolute, not relative, not calibrated.
-    (La, scale) = the style preset and the La = 512 / ap_scale = 1.0 corner of BASELINE cfg 3."""
-    out, oracle = _full_geometry_case(dev, torch.float32, La, scale)
+    (La, scale) = the style preset on the full 10 s clip, and the La = 512 / ap_scale = 1.0 corner of BASELINE cfg 3 on a 2.56 s clip."""
+    out, oracle = _full_geometry_case(dev, torch.float32, La, scale, frames=frames)
     ref = oracle()
-    assert out.shape == ref.shape == (2, 8, 250, 16)
+    assert out.shape == ref.shape == (2, 8, frames, 16)
     err = (out - ref).abs()
     print(f"\n[full-geometry noise_pred, fp32, La={La}] max|ref|={float(ref.abs().max()):.4f} max-abs err={float(err.max()):.3e} "
           f"mean-abs err={float(err.mean()):.3e}")
     assert float(err.max()) <= 1e-3
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_full_geometry_noise_pred_same_precision(dev, dtype):
+@pytest.mark.parametrize("dtype,frames", [(torch.bfloat16, 250), (torch.float16, 64)])
+def test_full_geometry_noise_pred_same_precision(dev, dtype, frames):
     """16-bit storage cannot meet 1e-3 absolute through ~300 stacked layers -- the reference pipeline itself does not at
     that storage type.  So the 16-bit bound is a SAME-PRECISION one: the HIP path's error vs the fp32 oracle chain must not
     exceed 1.25x the error of the reference chain run at the same storage type (the oracle under per-op rounding, which
     is how PyTorch executes it in half / bfloat16).  UNet-level twin of test_processor_bf16_not_worse_than_reference_bf16."""
     from util import PerOpRounding
-    out, oracle = _full_geometry_case(dev, dtype)
+    out, oracle = _full_geometry_case(dev, dtype, frames=frames)
     ref = oracle()
     with PerOpRounding(dtype):
         ref_lp = oracle()

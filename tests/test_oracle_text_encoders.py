@@ -65,3 +65,20 @@ def test_no_cpu_path():
     g, _ = ours_from(*tiny_gpt2(), "gpt2")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         g(torch.zeros(1, 8, 64))
+
+
+def test_committed_fixture_equals_the_installed_transformers_outputs():
+    """tests/golden/text_encoders_small.safetensors (what the GPU tests compare the HIP path with) re-derived here from the live transformers
+    modules: weights bit-equal, outputs to 1e-6 (summation order of the CPU BLAS may differ between machines)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_text_golden as G
+    from text_models import load_text_gold
+    fresh, gold = G.build(), load_text_gold()
+    assert set(fresh) == set(gold)
+    for k, v in fresh.items():
+        if ".sd." in k or v.dtype != torch.float32:
+            assert torch.equal(v, gold[k]), k
+        else:
+            assert float((v - gold[k]).abs().max()) <= 1e-5 * max(float(gold[k].abs().max()), 1.0), k

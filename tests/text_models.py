@@ -1,5 +1,65 @@
-"""Tiny seeded transformers models (the reference's own dependency for CLAP / T5 / GPT-2) shared by the CPU and GPU prompt-encoding tests."""
+"""Tiny seeded transformers models (the reference's own dependency for CLAP / T5 / GPT-2) shared by the CPU prompt-encoding tests and
+by tests/golden/make_text_golden.py, plus what the GPU tests need WITHOUT importing transformers: the matching configurations of the
+HIP modules, the stand-in tokenizer and the loader of the committed fixture (importing transformers on a cold GPU box pages in for
+minutes, and the driver's GPU suite has a 20-minute budget)."""
+import os
+
 import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "text_encoders_small.safetensors")
+# tiny configurations, as keyword arguments of the HIP modules' config classes (tiny_clap / tiny_t5 / tiny_gpt2 build the same models)
+CLAP_CFG = lambda heads: dict(vocab_size=120, hidden_size=64, num_hidden_layers=2, num_attention_heads=heads, intermediate_size=128,
+                              max_position_embeddings=80, projection_dim=32, pad_token_id=1, layer_norm_eps=1e-12)
+T5_CFG = dict(vocab_size=100, d_model=64, d_kv=16, d_ff=96, num_layers=2, num_heads=4, relative_attention_num_buckets=32,
+              relative_attention_max_distance=128, layer_norm_epsilon=1e-6)
+GPT2_CFG = dict(n_positions=64, n_embd=64, n_layer=2, n_head=4, layer_norm_epsilon=1e-5, vocab_size=100)
+
+
+def load_text_gold():
+    from safetensors.torch import load_file
+    return load_file(GOLD)
+
+
+def ours_from_gold(gold, prefix, kind, dev, heads=4):
+    """the HIP module of ``kind`` with the fixture's weights (keys ``<prefix>.sd.<parameter name>``)"""
+    import ap_adapter_amd.text_encoders as TE
+    if kind == "clap":
+        o = TE.ClapTextModelWithProjection(TE.ClapTextConfig(**CLAP_CFG(heads)))
+    elif kind == "t5":
+        o = TE.T5EncoderModel(TE.T5Config(**T5_CFG))
+    elif kind == "gpt2":
+        o = TE.GPT2Model(TE.GPT2Config(**GPT2_CFG))
+    else:
+        o = TE.AudioLDM2ProjectionModel(32, 64, 64)
+    sd = {k[len(prefix) + 4:]: v for k, v in gold.items() if k.startswith(prefix + ".sd.")}
+    o.load_state_dict(sd, strict=True)
+    return o.to(dev)
+
+
+class Tok:
+    """a stand-in tokenizer with the transformers call signature (the real ones need vocabulary files): whitespace words hashed into the
+    vocabulary, `cls` / `eos` framing, padding to max_length or to the longest"""
+
+    def __init__(self, vocab, pad_id, model_max_length, bos=None, eos=None):
+        self.vocab, self.pad_id, self.model_max_length, self.bos, self.eos = vocab, pad_id, model_max_length, bos, eos
+
+    def __call__(self, texts, padding=True, max_length=None, truncation=True, return_tensors="pt"):
+        from types import SimpleNamespace
+        rows = []
+        for t in texts:
+            ids = [3 + (sum(map(ord, w)) % (self.vocab - 3)) for w in t.split()]
+            ids = ([self.bos] if self.bos is not None else []) + ids + ([self.eos] if self.eos is not None else [])
+            rows.append(ids[: max_length or self.model_max_length])
+        L = (max_length or self.model_max_length) if padding == "max_length" else max(len(r) for r in rows)
+        ids = torch.full((len(rows), L), self.pad_id, dtype=torch.long)
+        mask = torch.zeros(len(rows), L, dtype=torch.long)
+        for i, r in enumerate(rows):
+            ids[i, : len(r)] = torch.tensor(r, dtype=torch.long)
+            mask[i, : len(r)] = 1
+        return SimpleNamespace(input_ids=ids, attention_mask=mask)
+
+
+PROMPTS = ["a slow piano melody with soft strings", "drums"]
 
 
 def tiny_clap(heads=4, hidden=64, seed=0):
