@@ -414,9 +414,8 @@ def test_full_geometry_adapter_gradients_vs_oracle(dev, dtype, frames):
     import ap_adapter_amd as A
     from ap_adapter_amd.synthetic import init_synthetic_, synthetic_inputs
     from oracle import train as OT
-    u = A.AudioLDM2UNet2DConditionModel()
-    A.install_ap_adapter(u, None, scale=0.55)
-    init_synthetic_(u, 100, bias_std=0.01)
+    from util import full_unet
+    u = full_unet(0.55)
     u = u.to(dtype)
     sd = {k: v.detach().float() for k, v in u.state_dict().items()}
     procs = {n: dict(scale=p.scale, num_tokens=p.num_tokens) for n, p in u.attn_processors.items() if hasattr(p, "to_k_ip")}

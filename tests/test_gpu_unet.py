@@ -93,9 +93,8 @@ def _full_geometry_case(dev, dtype, La=32, scale=0.55, t=501, frames=250):
     import ap_adapter_amd as A
     from ap_adapter_amd.synthetic import init_synthetic_, synthetic_inputs
     from oracle import unet as OU
-    u = A.AudioLDM2UNet2DConditionModel()
-    A.install_ap_adapter(u, None, scale=scale)
-    init_synthetic_(u, 100, bias_std=0.01)
+    from util import full_unet
+    u = full_unet(scale)
     u = u.to(dtype)
     sd = {k: v.detach().float() for k, v in u.state_dict().items()}
     procs = {n: dict(scale=p.scale, num_tokens=p.num_tokens) for n, p in u.attn_processors.items() if hasattr(p, "to_k_ip")}
@@ -184,9 +183,8 @@ def test_cfg1_timbre_fp32_five_steps_vs_oracle_loop(dev):
     import ap_adapter_amd as A
     from ap_adapter_amd.synthetic import init_synthetic_, synthetic_inputs
     from oracle import unet as OU, ddim
-    u = A.AudioLDM2UNet2DConditionModel()
-    A.install_ap_adapter(u, None, scale=0.5)
-    init_synthetic_(u, 100, bias_std=0.01)
+    from util import full_unet
+    u = full_unet(0.5)
     sd = {k: v.detach().float() for k, v in u.state_dict().items()}
     procs = {n: dict(scale=p.scale, num_tokens=p.num_tokens) for n, p in u.attn_processors.items() if hasattr(p, "to_k_ip")}
     inp = synthetic_inputs(1, 128)
@@ -211,9 +209,8 @@ def test_cfg1_timbre_fp32_five_steps_vs_oracle_loop(dev):
 def full_pipe(dev):
     import ap_adapter_amd as A
     from ap_adapter_amd.synthetic import init_synthetic_
-    u = A.AudioLDM2UNet2DConditionModel()
-    A.install_ap_adapter(u, None, scale=0.55)
-    init_synthetic_(u, 100, bias_std=0.01)
+    from util import full_unet
+    u = full_unet(0.55)
     return A.AudioLDM2Pipeline(u.to(dev, torch.bfloat16))
 
 

@@ -32,3 +32,24 @@ def q(t, dtype):
 
 # float32 = the fp32 precision mode (exact-f32 MFMA): only the summation order differs from the oracle
 TOL = {torch.bfloat16: 2e-2, torch.float16: 3e-3, torch.float32: 1e-5}
+
+
+_FULL_UNET = []
+
+
+def full_unet(scale):
+    """a fresh fp32 CPU copy of the AudioLDM2-large UNet (718 M parameters) with the adapter installed and the synthetic init the
+    full-geometry tests share (seed 100, bias_std 0.01): built once per process, deep-copied per test (construction + init is ~15 s)"""
+    import copy
+    import ap_adapter_amd as A
+    from ap_adapter_amd.synthetic import init_synthetic_
+    if not _FULL_UNET:
+        u = A.AudioLDM2UNet2DConditionModel()
+        A.install_ap_adapter(u, None, scale=0.55)
+        init_synthetic_(u, 100, bias_std=0.01)
+        _FULL_UNET.append(u)
+    u = copy.deepcopy(_FULL_UNET[0])
+    for p in u.attn_processors.values():
+        if hasattr(p, "to_k_ip"):
+            p.scale = scale
+    return u
