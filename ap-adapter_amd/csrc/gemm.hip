@@ -607,7 +607,8 @@ int launch(const GemmP& p, hipStream_t s) {
     }
     // long reductions amortise the under-fill: with K >= 1024 the 128-tile wins from ~1.25 workgroups per CU (measured:
     // conv 63x4 384->384 76.5 -> 71.5 us, FF2 M=16128 K=1536 38.5 -> 37.1 us), short-K launches prefer the 64-tile
-    const bool t128 = blocks128 >= 512 || (blocks128 >= 320 && p.K >= 1024);
+    static const int t128_min = [] { const char* e = getenv("APAD_GEMM_T128_MIN"); return e ? atoi(e) : 512; }();  // (A/B knob)
+    const bool t128 = blocks128 >= t128_min || (blocks128 >= 320 && t128_min <= 512 && p.K >= 1024);
     if constexpr (AMODE == APAD_A_CONV3X3_FAST || AMODE == APAD_A_CONV3X3 || AMODE == APAD_A_CONV1D) {
         static const bool one_stage = getenv("APAD_GEMM_ONE_STAGE") != nullptr;
         // long reductions on launches of <= ~4 workgroups per CU: two LDS stages, one barrier per k-tile (larger grids
