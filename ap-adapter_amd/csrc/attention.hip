@@ -859,7 +859,8 @@ template <int DT, int D> int launch_d(const AttnP& p, bool dual, dim3 grid, hipS
     if constexpr (D == 32 || D == 48 || D == 64) {
         // long single-segment launches without a key bias (the UNet's self-attention): two query tiles per wave
         static const int two_q = [] { const char* e = getenv("APAD_ATTN_2Q"); return e ? atoi(e) : 1; }();
-        if (two_q && !dual && p.key_bias == nullptr && p.N >= 512 && p.L >= 256 && (D == 32 || two_q > 1)) {
+        static const int two_q_min = [] { const char* e = getenv("APAD_ATTN_2Q_MIN_N"); return e ? atoi(e) : 512; }();  // (A/B knob)
+        if (two_q && !dual && p.key_bias == nullptr && p.N >= two_q_min && p.L >= (two_q_min < 256 ? two_q_min : 256) && (D == 32 || two_q > 1)) {
             if constexpr (D == 32) {
                 static const int nw8 = [] { const char* e = getenv("APAD_ATTN_NW8"); return e ? atoi(e) : 0; }();  // off: step 49.68 -> 50.12 ms (the 8-wave barrier costs more than the halved staging saves)
                 if (nw8) {
