@@ -157,7 +157,7 @@ def dominant_kernel_roofline(dev, dtype, B2):
                 traffic = json.load(f).get("traffic_bytes_per_launch")
             traffic, tsrc = (None if traffic is None else int(traffic)), os.path.relpath(tp, ROOT)
             break
-    in_step, psrc = profile_in_step_avg_us("attn2q_kernel<0, 32>")
+    in_step, psrc = profile_in_step_avg_us("attn2q_kernel<0, 32")
     return {"kernel": "attn2q_kernel<bf16,D=32> self-attention B'=%d heads=8 N=L=1000" % B2, "bound": "mfma",
             "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
             "avg_launch_ms": round(ms, 4), "avg_launch_is": "isolated re-timing (20 launches in one hipGraph, HIP events)",
