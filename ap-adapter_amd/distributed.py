@@ -22,6 +22,59 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def launched_by_torchrun():
+    """True inside a rank process (torch.distributed.run / torchrun exports RANK and WORLD_SIZE)"""
+    return "RANK" in os.environ and "WORLD_SIZE" in os.environ
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, script, argv, extra_env=None, timeout=None):
+    """``python script --gpus n ...`` typed without a launcher: start the n rank processes of ONE node ourselves -- the same command the
+    round driver uses (python -m torch.distributed.run --nnodes=1 --nproc-per-node n --master-addr 127.0.0.1 --master-port P script
+    argv...), one rank per GPU.  The reference gets its ranks from ``accelerate launch`` (train_apadapter_v2.py:831-833); rank 0's
+    stdout (the JSON line) passes through.  Returns the launcher's exit code."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this host driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(n, 1))))
+    env.update(extra_env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), script] + list(argv)
+    return subprocess.run(cmd, env=env, timeout=timeout).returncode
+
+
+def timed_steps(run_steps, steps, world, sync, device=None):
+    """The bench contract's timed region: barrier + sync, EXACTLY ``steps`` steps, sync + barrier.  Returns (MAX over ranks of the
+    seconds between the two barriers -- what the job took --, [each rank's own seconds up to its sync, before the closing barrier]).
+    ``sync`` = torch.cuda.synchronize on a GPU rank (a no-op for CPU stubs)."""
+    import time
+    if world > 1:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    run_steps(steps)
+    sync()
+    own = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        mine = torch.tensor([dt, own], dtype=torch.float64, device=device)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        mx = mine[:1].clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        return float(mx.item()), [float(t[1].item()) for t in every]
+    return dt, [own]
+
+
 def shard_clips(n_clips, rank, world):
     """clip i -> rank i mod world (seeds are per clip, so results do not depend on the rank count)."""
     return list(range(rank, n_clips, world))

@@ -200,7 +200,10 @@ class AudioLDM2Pipeline:
                 e["mask"].copy_(attention_mask)
             e["step_ptr"].zero_()
             unet.set_kv_cache(True, clear=False)
-            unet.refresh_kv_cache()  # hoisted K/V of the new conditions, recomputed into the buffers the graph reads
+            try:
+                unet.refresh_kv_cache()  # hoisted K/V of the new conditions, recomputed into the buffers the graph reads
+            finally:
+                unet.set_kv_cache(False, clear=False)  # (see the end of the capture branch)
             for _ in range(num_inference_steps):
                 e["graph"].replay()
             self.graph_hits += 1
@@ -265,8 +268,10 @@ class AudioLDM2Pipeline:
                 unet.clear_time_tables()  # (a captured step keeps reading its own tables: e["tables"])
                 if key not in self._graphs:  # eager call, or a failed capture: nothing will read its hoisted K/V again
                     unet.drop_kv_owner(owner)
-                if not self._graphs:
-                    unet.set_kv_cache(False, clear=False)
+                # the hoist is a property of THIS call: outside it the processors recompute K/V per call like the reference's (a
+                # cached graph keeps its hoisted buffers -- they are refreshed in place before each replay -- but a direct
+                # unet(...) / a training step on the same UNet never enters the cache, so nothing accumulates there)
+                unet.set_kv_cache(False, clear=False)
         eps_out = e["eps_out"]
         self.last_noise_pred = None if eps_out is None else eps_out.reshape(B, H, W, Cc).permute(0, 3, 1, 2).clone()
         return e["lat"].reshape(B, H, W, Cc).permute(0, 3, 1, 2).contiguous()

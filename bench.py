@@ -22,6 +22,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 DDIM_STEPS_PER_CLIP = 200
+SELF_ATTN_KERNEL_SUBSTR = "attn2q_kernel<0, 32"  # name of the 1000-token self-attention kernel in the rocprofv3 summaries
+DTYPE_NAME = {torch.bfloat16: "bf16", torch.float16: "f16", torch.float32: "f32"}
 MFMA_PEAK_TFLOPS = 2500.0   # bf16 dense, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
@@ -111,6 +113,65 @@ def time_kernel_graphed(fn, iters=20, reps=3):
     return e0.elapsed_time(e1) / (iters * reps)
 
 
+class _Bracket:
+    """wraps ``ops.<name>`` so that every call accepted by ``pred`` is bracketed by a pair of HIP events recorded on the launching
+    stream; ``external`` events become event-record NODES when the call is captured into a hipGraph, so the pair times that one
+    launch inside every replay of the graph"""
+
+    def __init__(self, ops, name, pred, external):
+        self.ops, self.name, self.pred, self.external, self.pairs = ops, name, pred, external, []
+
+    def __enter__(self):
+        self.real = getattr(self.ops, self.name)
+
+        def wrapped(*a, **kw):
+            if not self.pred(*a, **kw):
+                return self.real(*a, **kw)
+            kw_ev = dict(enable_timing=True, external=True) if self.external else dict(enable_timing=True)
+            e0, e1 = torch.cuda.Event(**kw_ev), torch.cuda.Event(**kw_ev)
+            e0.record()
+            out = self.real(*a, **kw)
+            e1.record()
+            self.pairs.append((e0, e1))
+            return out
+
+        setattr(self.ops, self.name, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        setattr(self.ops, self.name, self.real)
+
+    def avg_us(self):
+        return sum(a.elapsed_time(b) for a, b in self.pairs) * 1e3 / max(len(self.pairs), 1)
+
+
+def in_step_launch_times(step, ops, probes, reps=3):
+    """Average duration of selected launches INSIDE the step, measured live: a replica of the captured step is captured once more
+    with event-record nodes around the selected launches (HIP events on the capture stream = the stream the kernels are launched
+    on) and replayed ``reps`` times after the timed region (the timed graph itself carries no events).  probes: {label: (ops
+    function name, predicate)}.  Returns {label: {"avg_us", "launches"}} and how it was measured; falls back to plain events around
+    the same launches of one eager step if event nodes cannot be captured."""
+    def measure(external):
+        import contextlib
+        with contextlib.ExitStack() as st:
+            br = {k: st.enter_context(_Bracket(ops, fn, pred, external)) for k, (fn, pred) in probes.items()}
+            if external:
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2):
+                    step()
+                for _ in range(reps):
+                    g2.replay()
+            else:
+                step()
+            torch.cuda.synchronize()
+            return {k: {"avg_us": round(b.avg_us(), 2), "launches": len(b.pairs)} for k, b in br.items()}
+    try:
+        return measure(True), "HIP event-record nodes around each launch inside a replica of the captured step (hipGraph replay)"
+    except Exception as e:  # noqa: BLE001 -- event nodes unsupported: eager events (same kernels, same order, host-paced)
+        torch.cuda.synchronize()
+        return measure(False), "HIP events around each launch of one eager step (event nodes unavailable: %r)" % (e,)
+
+
 def profile_in_step_avg_us(substr):
     """average in-step duration (us) of the kernel whose name contains `substr`, from the committed rocprofv3 kernel-trace
     summary of `bench.py --step-only` (profiles/r*_bench_kernel_stats*.txt: columns pct calls avg_us min_us max_us name; newest
@@ -125,13 +186,14 @@ def profile_in_step_avg_us(substr):
     return None, None
 
 
-def dominant_kernel_roofline(dev, dtype, B2):
+def dominant_kernel_roofline(dev, dtype, B2, in_step=None, in_step_how=None):
     """Roofline of the kernel with the largest share of the step in the committed rocprof summary: the self-attention of the
-    1000-token level (attn2q_kernel<bf16, d=32>: single segment, two query tiles per wave), softmax(Q K^T / sqrt(32)) V over B2 samples x 8 heads x
-    1000 x 1000.  Algorithmic FLOPs = 4 * N^2 * C * B2 (QK^T + PV); bound = MFMA (AI = 512 F/B > ridge 310).
-    `avg_launch_ms` is an ISOLATED re-timing (20 back-to-back launches inside one hipGraph, HIP events on the replaying
-    stream, q / k / v produced the way the model produces them); `in_step_avg_us` is the same kernel's average inside the
-    captured step from the committed rocprofv3 summary."""
+    1000-token level (single segment, d = 32), softmax(Q K^T / sqrt(32)) V over B2 samples x 8 heads x 1000 x 1000.
+    Algorithmic FLOPs = 4 * N^2 * C * B2 (QK^T + PV); bound = MFMA (AI = 512 F/B > ridge 310).
+    ONE source for `achieved` / `frac` / `avg_launch_ms`: the kernel's average duration INSIDE the step, measured live by
+    in_step_launch_times (HIP events on the launching stream).  Beside it: `frac_isolated` (20 back-to-back launches inside one
+    hipGraph on operands produced the way the model produces them) and `rocprof_in_step_avg_us`, the same kernel's average in the
+    committed `rocprofv3 --kernel-trace --stats` summary of `bench.py --step-only`, which must agree with `avg_launch_ms`."""
     from ap_adapter_amd import ops
     N, C, heads = 1000, 256, 8
     x = torch.randn(B2, N, C, device=dev).to(dtype)
@@ -157,16 +219,22 @@ def dominant_kernel_roofline(dev, dtype, B2):
                 traffic = json.load(f).get("traffic_bytes_per_launch")
             traffic, tsrc = (None if traffic is None else int(traffic)), os.path.relpath(tp, ROOT)
             break
-    in_step, psrc = profile_in_step_avg_us("attn2q_kernel<0, 32")
-    return {"kernel": "attn2q_kernel<bf16,D=32> self-attention B'=%d heads=8 N=L=1000" % B2, "bound": "mfma",
-            "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-            "avg_launch_ms": round(ms, 4), "avg_launch_is": "isolated re-timing (20 launches in one hipGraph, HIP events)",
-            "in_step_avg_us": in_step, "in_step_source": psrc,
-            "algorithmic_bytes": 4 * B2 * N * C * 2, "traffic": traffic,
+    prof_us, psrc = profile_in_step_avg_us(SELF_ATTN_KERNEL_SUBSTR)
+    if in_step is not None and in_step["launches"] > 0:
+        ms_src, how, n_l = in_step["avg_us"] * 1e-3, in_step_how, in_step["launches"]
+    else:  # (--no-in-step: only the isolated timing exists)
+        ms_src, how, n_l = ms, "isolated re-timing (20 launches in one hipGraph, HIP events)", 20
+    ach_src = flops / (ms_src * 1e-3) / 1e12
+    return {"kernel": "self-attention of the 1000-token level (apad_attention, single segment, d=32) B'=%d heads=8 N=L=1000" % B2,
+            "bound": "mfma", "achieved": round(ach_src, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach_src / MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(ms_src, 4), "avg_launch_is": how, "launches_timed": n_l,
+            "frac_isolated": round(ach / MFMA_PEAK_TFLOPS, 4), "isolated_avg_launch_ms": round(ms, 4),
+            "rocprof_in_step_avg_us": prof_us, "rocprof_source": psrc,
+            "flops_per_launch": flops, "algorithmic_bytes": 4 * B2 * N * C * 2, "traffic": traffic,
             "traffic_source": (tsrc + " (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes)") if traffic else None}
 
 
-def fused_attn2_roofline(dev, dtype, B2, La, ap_scale):
+def fused_attn2_roofline(dev, dtype, B2, La, ap_scale, in_step=None, in_step_how=None):
     """The adapter's own kernel, the one the north star names: apad_fused_cross_attention -- LayerNorm + to_q + decoupled
     attention (8 text + La audio keys, two softmaxes blended by ap_scale) + to_out + bias + residual of one attn2
     sub-layer in ONE launch, at the 1000-token level (the 10 adapted + 10 T5 sites that cost most).
@@ -201,13 +269,56 @@ def fused_attn2_roofline(dev, dtype, B2, La, ap_scale):
         nbytes += 4 * B2 * N * C * 2
     ms = time_kernel_graphed(fn)
     tf, gbs = flops / (ms * 1e-3) / 1e12, nbytes / (ms * 1e-3) / 1e9
-    in_step, psrc = profile_in_step_avg_us("xattn_kernel<0, 1, 1, 1, 4, false>")
+    iso = {"avg_launch_ms": round(ms, 4), "mfma_frac": round(tf / MFMA_PEAK_TFLOPS, 4), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
+    how = "isolated re-timing (20 launches in one hipGraph, HIP events)"
+    if in_step is not None and in_step["launches"] > 0:  # ONE source for the fractions: the live in-step average
+        ms, how = in_step["avg_us"] * 1e-3, in_step_how
+        tf, gbs = flops / (ms * 1e-3) / 1e12, nbytes / (ms * 1e-3) / 1e9
     return {"kernel": name + " B'=%d N=1000 C=256 Lt=8 La=%d" % (B2, La),
             "bound": "mfma" if tf / MFMA_PEAK_TFLOPS >= gbs / HBM_PEAK_GBS else "hbm",
             "mfma": {"achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4)},
             "hbm": {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)},
-            "avg_launch_ms": round(ms, 4), "avg_launch_is": "isolated re-timing (20 launches in one hipGraph, HIP events)",
-            "in_step_avg_us": in_step, "in_step_source": psrc, "flops": flops, "algorithmic_bytes": nbytes}
+            "avg_launch_ms": round(ms, 4), "avg_launch_is": how, "launches_timed": (in_step or {}).get("launches", 20),
+            "isolated": iso, "flops": flops, "algorithmic_bytes": nbytes}
+
+
+def fused_attn2_grid(dev, dtype, B2, ap_scale):
+    """the adapter's attn2 sub-layer (LayerNorm + to_q + text/audio softmaxes blended by ap_scale + to_out + bias +
+    residual; K/V hoisted) at every adapted level x every pooling setting of cfg 3's sweep, entered exactly as the UNet enters it
+    (Attention module + IPAttnProcessor2_0 with residual / ln, hoist on), so each cell times whatever route the processor takes
+    there.  Isolated timing (20 calls in one hipGraph).  FLOPs 4 N C^2 + 4 N (8 + La) C, bytes 2 x N C 2 + weights + K/V per sample."""
+    import ap_adapter_amd as A
+    from ap_adapter_amd import ops
+    from ap_adapter_amd.unet import Attention
+    from ap_adapter_amd.synthetic import init_synthetic_
+    grid = {}
+    for C_, N in ((256, 1000), (384, 252), (640, 64)):
+        with torch.device(dev):
+            attn = Attention(C_, 768, 8, C_ // 8)
+            proc = A.IPAttnProcessor2_0(hidden_size=C_, name="bench", cross_attention_dim=768, num_tokens=8, scale=ap_scale)
+        attn.set_processor(proc)
+        init_synthetic_(attn, 5, on_device=True)
+        attn = attn.to(dev, dtype).requires_grad_(False)
+        proc.kv_cache_enabled = True
+        x = torch.randn(B2, N, C_, device=dev).to(dtype)
+        ln = (torch.ones(C_, device=dev, dtype=dtype), torch.zeros(C_, device=dev, dtype=dtype), 1e-5)
+        for La in (8, 32, 128, 512):
+            ehs = torch.randn(B2, 8 + La, 768, device=dev).to(dtype)
+            calls = []
+            real = ops.fused_cross_attention
+            ops.fused_cross_attention = lambda *a, **kw: (calls.append(1), real(*a, **kw))[1]
+            try:
+                with torch.no_grad():
+                    ms = time_kernel_graphed(lambda: attn(x, encoder_hidden_states=ehs, residual=x, ln=ln))
+            finally:
+                ops.fused_cross_attention = real
+            flops = (4.0 * N * C_ * C_ + 4.0 * N * (8 + La) * C_) * B2
+            nbytes = 2 * B2 * N * C_ * 2 + 2 * C_ * C_ * 2 + 2 * B2 * (8 + La) * C_ * 2
+            grid[f"C{C_}_N{N}_La{La}"] = {"us": round(ms * 1e3, 2), "route": "one launch" if calls else "three launches",
+                                         "mfma_frac": round(flops / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                                         "hbm_frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            proc.clear_kv_cache()
+    return grid
 
 
 def audiomae_ms(dev, dtype=torch.float32):
@@ -280,8 +391,8 @@ def cpu_baseline():
             "processor_microbench_ms": micro}
 
 
-def train_main(args, A, rank, world, dev):
-    """--train: BASELINE cfg 5 -- the adapter's training step (train_apadapter_v2.py:892-979) at per-GPU batch 4: UNet forward
+def train_measure(args, A, rank, world, dev, steps, warmup):
+    """BASELINE cfg 5 -- the adapter's training step (train_apadapter_v2.py:892-979) at per-GPU batch 4: UNet forward
     at a random t per sample, fp32 MSE, backward to the 64 adapter tensors, ONE flat fp32 all-reduce (RCCL) when N > 1, clip +
     AdamW; the micro-step replays as one hipGraph.  One bench step = one optimizer step; value = samples/s over all ranks."""
     import torch.distributed as dist
@@ -308,31 +419,45 @@ def train_main(args, A, rank, world, dev):
         losses.append(replay(A.add_noise(lat, noise, t, tr.alphas_cumprod), t, ehs, ehs1, m1, noise).clone())
         tr.optimizer_step()  # (all-reduce of the flat gradient inside, when world > 1)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         one()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    tt = torch.tensor([time.perf_counter() - t0], device=dev)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt.item())
-    if rank == 0:
-        ms = dt / args.steps * 1e3
-        print(json.dumps({
-            "metric": "adapter training samples/sec, AudioLDM2-large+AP (BASELINE cfg 5)", "value": round(B * world / (ms * 1e-3), 3),
-            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+    dt, every = A.distributed.timed_steps(lambda n: [one() for _ in range(n)], steps, world, torch.cuda.synchronize, dev)
+    ms = dt / steps * 1e3
+    return {"metric": "adapter training samples/sec, AudioLDM2-large+AP (BASELINE cfg 5)", "value": round(B * world / (ms * 1e-3), 3),
+            "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 3),
+            "rank_ms_per_step": [round(t / steps * 1e3, 3) for t in every],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.train_dtype, "data": "synthetic",
             "config": {"workload": f"train_apadapter_v2.py step: batch {B}/GPU, random t per sample, La={La}, {args.train_dtype} compute, fp32 master + "
                                    f"AdamW, adapter-only gradients (21 626 880 parameters), micro-step replayed as one hipGraph",
                        "global_batch": B * world, "parallelism": f"dp{world} (one flat 86.5 MB fp32 all-reduce per optimizer step)"},
-            "loss_first": float(losses[0]), "loss_last": float(losses[-1]), "finite": bool(torch.isfinite(torch.stack(losses)).all())}))
+            "loss_first": float(losses[0]), "loss_last": float(losses[-1]), "finite": bool(torch.isfinite(torch.stack(losses)).all())}
+
+
+def train_main(args, A, rank, world, dev):
+    """--train: the training step as the bench's step (same launch contract); prints ONE JSON line on rank 0"""
+    import torch.distributed as dist
+    line = train_measure(args, A, rank, world, dev, args.steps, args.warmup)
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def stub_main(args):
+    """--stub-step-ms: the launch / timing contract alone, no GPU and no model -- every rank sleeps (1 + rank / 2) x the given
+    milliseconds per step over gloo.  What tests/test_distributed.py drives to check that `bench.py --gpus N` starts N ranks by itself,
+    that they all join, and that the reported time is the MAX over ranks."""
+    import ap_adapter_amd as A
+    import torch.distributed as dist
+    rank, world, _ = A.distributed.init_from_env("gloo")
+    per = args.stub_step_ms * (1.0 + 0.5 * rank) * 1e-3
+    dt, every = A.distributed.timed_steps(lambda n: [time.sleep(per) for _ in range(n)], args.steps, world, lambda: None)
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        print(json.dumps({"metric": "stub", "stub": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(ms, 3), "rank_ms_per_step": [round(t / args.steps * 1e3, 3) for t in every],
+                          "value": round(args.batch * world / (DDIM_STEPS_PER_CLIP * ms * 1e-3), 4), "unit": "clips/s", "scaling": "weak"}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -354,7 +479,18 @@ def main():
     ap.add_argument("--train", action="store_true", help="time BASELINE cfg 5 (the adapter's training step) instead of the denoise step")
     ap.add_argument("--train-batch", type=int, default=4)
     ap.add_argument("--train-dtype", choices=["bf16", "f16", "f32"], default="bf16", help="compute type of the training step (fp32 master weights in every mode)")
+    ap.add_argument("--no-train-leg", action="store_true", help="skip the `train` sub-object (cfg 5: 5 optimizer steps at batch 4) of the default line")
+    ap.add_argument("--no-in-step", action="store_true", help="skip the live in-step kernel timing (roofline falls back to the isolated timing)")
+    ap.add_argument("--stub-step-ms", type=float, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    from ap_adapter_amd import distributed as D
+    if args.gpus > 1 and not D.launched_by_torchrun():
+        # `python bench.py --gpus N` typed without a launcher: start the N ranks of this node ourselves (one per GPU) with the
+        # driver's own command; rank 0 of that job prints the line
+        sys.exit(D.spawn_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
+    if args.stub_step_ms is not None:
+        return stub_main(args)
 
     import ap_adapter_amd as A
     from ap_adapter_amd import ops
@@ -450,19 +586,7 @@ def main():
     reset()
     run(args.warmup)
     reset()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(args.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], device=dev)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt.item())
+    dt, every = D.timed_steps(run, args.steps, world, torch.cuda.synchronize, dev)  # barrier + sync | K steps | sync + barrier; MAX over ranks
     finite = bool(torch.isfinite(lat).all().item())
 
     if rank == 0:
@@ -472,7 +596,8 @@ def main():
         line = {
             "metric": "10s-clips/sec @200 DDIM steps, AudioLDM2-large+AP", "value": round(clips_per_s, 4), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.train_dtype, "data": "synthetic",
+            "rank_ms_per_step": [round(t / args.steps * 1e3, 3) for t in every],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_NAME[dtype], "data": "synthetic",
             "config": {"workload": f"AudioLDM2-large geometry + 32 AP processors, style_transfer preset "
                                    f"(ap_scale {args.ap_scale}, La={args.la}, CFG {args.guidance}), batch {B}/GPU, 10 s clips "
                                    f"(latents 8x250x16), 200-step DDIM, hipGraph-captured step; one bench step = one DDIM step",
@@ -487,8 +612,20 @@ def main():
         if args.step_only:
             print(json.dumps(line))
             return
-        line["roofline"] = dominant_kernel_roofline(dev, dtype, 2 * B)
-        line["fused_attn2"] = fused_attn2_roofline(dev, dtype, 2 * B, args.la, args.ap_scale)
+        ins, how = {}, None
+        if not args.no_in_step:
+            with torch.no_grad():
+                ins, how = in_step_launch_times(step, ops, {
+                    "self_attn_1000": ("attention", lambda q, k, vt, Lk, heads, **kw: q.shape[1] == 1000 and Lk == 1000 and not kw.get("L2")),
+                    "fused_attn2_ip": ("fused_cross_attention", lambda x, *a, **kw: kw.get("L2", 0) > 0),
+                    "fused_attn2_t5": ("fused_cross_attention", lambda x, *a, **kw: not kw.get("L2", 0))})
+        line["roofline"] = dominant_kernel_roofline(dev, dtype, 2 * B, ins.get("self_attn_1000"), how)
+        line["fused_attn2"] = fused_attn2_roofline(dev, dtype, 2 * B, args.la, args.ap_scale, ins.get("fused_attn2_ip"), how)
+        line["fused_attn2"]["t5_sites_in_step"] = ins.get("fused_attn2_t5")
+        try:
+            line["fused_attn2"]["grid"] = fused_attn2_grid(dev, dtype, 2 * B, args.ap_scale)
+        except Exception as e:  # noqa: BLE001
+            line["fused_attn2"]["grid"] = {"error": repr(e)}
         # the audio-condition encoder (2 mels per call: clip + zeros) is outside the timed loop; reported
         # separately and folded into a per-clip "included" figure (one pipeline call of B clips pays it once)
         try:
@@ -498,6 +635,15 @@ def main():
                                 "clips_per_s_including_it": round(B * world / per_call_s, 4)}
         except Exception as e:  # never lose the headline line over the side measurement
             line["audiomae"] = {"error": repr(e)}
+        if not args.no_train_leg and world == 1:
+            # BASELINE cfg 5 beside the headline (driver-observed): 5 graph-replayed optimizer steps at per-GPU batch 4
+            try:
+                targs = argparse.Namespace(**{**vars(args), "la": 32})
+                t_ = train_measure(targs, A, rank, world, dev, steps=5, warmup=2)
+                line["train"] = {k: t_[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "loss_first",
+                                                     "loss_last", "finite")}
+            except Exception as e:  # noqa: BLE001
+                line["train"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:  # the host baseline is reported at N = 1 only
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

@@ -19,3 +19,21 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU visible")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _knobs_do_not_leak():
+    """module-level A/B switches must leave every test the way they entered it (a test that wants another route uses
+    monkeypatch.setattr): a leaked switch silently changes which kernels the REST of the suite exercises"""
+    import importlib
+    mods = {}
+    for name, attrs in (("ap_adapter_amd.processors", ("USE_FUSED_XATTN",)), ("ap_adapter_amd.ops", ("XATTN_MAXL", "MLP_C", "RP_K", "FUSED_DTYPES"))):
+        try:
+            m = importlib.import_module(name)
+        except Exception:  # the CPU suite may run without the built library
+            continue
+        mods[m] = {a: getattr(m, a) for a in attrs if hasattr(m, a)}
+    yield
+    for m, saved in mods.items():
+        for a, v in saved.items():
+            assert getattr(m, a) == v, f"{m.__name__}.{a} leaked out of a test: {getattr(m, a)!r} (was {v!r})"

@@ -22,7 +22,7 @@ sys.path.insert(0, HERE)
 sys.dont_write_bytecode = True
 sys.path.insert(0, "/root/reference")
 
-from cases import CASES, make_inputs  # noqa: E402
+from cases import CASES, BLOCK_CASES, LN_EPS, make_inputs  # noqa: E402
 from APadapter.ap_adapter.attention_processor import AttnProcessor2_0, IPAttnProcessor2_0  # noqa: E402
 from safetensors.torch import save_file  # noqa: E402
 
@@ -76,6 +76,13 @@ def run_case(case, dtype):
     else:
         proc = AttnProcessor2_0()
     with torch.no_grad():
+        if case.get("block"):
+            # diffusers 0.21.2 BasicTransformerBlock.forward, the attn2 sub-layer: norm2 -> attn2 -> + hidden_states
+            ln = torch.nn.LayerNorm(C, eps=LN_EPS)
+            ln.weight.copy_(t["ln_g"])
+            ln.bias.copy_(t["ln_b"])
+            ln = ln.to(dtype)
+            return proc(attn, ln(hs), encoder_hidden_states=ehs, attention_mask=mask) + hs
         out = proc(attn, hs, encoder_hidden_states=ehs, attention_mask=mask)
     return out
 
@@ -93,6 +100,15 @@ def main():
     save_file(tensors, os.path.join(HERE, "attn_processors.safetensors"), metadata=meta)
     sz = os.path.getsize(os.path.join(HERE, "attn_processors.safetensors"))
     print("wrote attn_processors.safetensors", sz, "bytes")
+    blocks = {}
+    for case in BLOCK_CASES:
+        blocks[case["name"] + ".fp32"] = run_case(case, torch.float32).contiguous()
+        if case.get("bf16"):
+            blocks[case["name"] + ".bf16"] = run_case(case, torch.bfloat16).contiguous()
+        print(case["name"], tuple(blocks[case["name"] + ".fp32"].shape))
+    meta["cases"] = json.dumps([c["name"] for c in BLOCK_CASES])
+    save_file(blocks, os.path.join(HERE, "attn_blocks.safetensors"), metadata=meta)
+    print("wrote attn_blocks.safetensors", os.path.getsize(os.path.join(HERE, "attn_blocks.safetensors")), "bytes")
 
 
 if __name__ == "__main__":

@@ -121,3 +121,26 @@ def test_single_process_is_a_noop():
     assert torch.equal(p.grad, torch.ones(3))
     f = torch.full((4,), 6.0)
     assert D.average_flat_gradient_(f, micro_batches=3) == 3.0 and torch.allclose(f, torch.full((4,), 2.0))
+
+
+def test_bench_gpus_n_starts_its_own_ranks_and_reports_the_max(tmp_path):
+    """`python bench.py --gpus 2` typed WITHOUT a launcher (the form the round driver uses for --gpus 1) must start 2 ranks itself
+    (train_apadapter_v2.py:831-833: the reference gets its ranks from accelerate).  Driven here over gloo with the stubbed step
+    (rank r sleeps (1 + r/2) x 20 ms per step): both ranks join, n_gpus = 2, the step time is the MAX over ranks (rank 1's 30 ms),
+    the value is the whole-job aggregate."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub-step-ms", "20", "--steps", "5", "--warmup", "1",
+                        "--batch", "32"], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout  # ONE JSON line, from rank 0 only
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and len(line["rank_ms_per_step"]) == 2
+    r0, r1 = line["rank_ms_per_step"]
+    assert 19.0 < r0 < 27.0 and 29.0 < r1 < 40.0, line
+    assert line["ms_per_step"] >= r1 - 0.5 and line["ms_per_step"] < 45.0  # the MAX, not rank 0's own time
+    assert abs(line["value"] - 32 * 2 / (200 * line["ms_per_step"] * 1e-3)) < 1e-2 * line["value"]

@@ -4,6 +4,7 @@ wav -> Kaldi fbank -> AudioMAE (fp32) -> per-clip condition -> 200-step CFG + DD
 gathered in clip order on every rank; rank 0 writes them.
 
     python tools/run_sharded.py --task style_transfer --clips 256 --batch 32 --steps 200 [--audio-dir DIR] [--out latents.pt]
+    python tools/run_sharded.py --gpus 8 --clips 256 ...        (starts its 8 ranks itself; equivalent to the line below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/run_sharded.py --clips 256 ...
 """
 import argparse
@@ -90,7 +91,12 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--wav-dir", default=None, help="decode every clip (VAE + vocoder on the HIP path) and write 16 kHz wavs named as "
                                                      "inference.py:79 names them")
+    ap.add_argument("--gpus", type=int, default=1, help="N > 1 without a launcher: this script starts its N ranks itself (one per GPU)")
     args = ap.parse_args()
+
+    from ap_adapter_amd import distributed as D
+    if args.gpus > 1 and not D.launched_by_torchrun():
+        sys.exit(D.spawn_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
 
     import ap_adapter_amd as A
     from ap_adapter_amd import sharded as S
