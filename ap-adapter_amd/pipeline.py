@@ -96,7 +96,9 @@ class AudioLDM2Pipeline:
             if negative_prompt is None:
                 uncond_tokens = [""] * batch_size
             elif isinstance(negative_prompt, str):
-                uncond_tokens = [negative_prompt]
+                # the reference takes [negative_prompt] here and only works at batch 1 (a longer prompt list trips over the
+                # mismatched halves downstream); one negative prompt for the whole batch is the evident intent
+                uncond_tokens = [negative_prompt] * batch_size
             elif batch_size != len(negative_prompt):
                 raise ValueError(f"`negative_prompt` has batch size {len(negative_prompt)}, but `prompt` has batch size {batch_size}")
             else:
@@ -282,13 +284,21 @@ class AudioLDM2Pipeline:
                  num_waveforms_per_prompt=1, eta=0.0, generator=None, latents=None, prompt_embeds=None,
                  negative_prompt_embeds=None, generated_prompt_embeds=None, negative_generated_prompt_embeds=None,
                  attention_mask=None, negative_attention_mask=None, max_new_tokens=None, return_dict=True,
-                 callback=None, callback_steps=1, cross_attention_kwargs=None, output_type="latent", mel=None,
+                 callback=None, callback_steps=1, cross_attention_kwargs=None, output_type="np", mel=None,
                  use_graph=True):
+        """Same keyword surface and defaults as the reference (pipeline_audioldm2.py:748-775, ``output_type="np"`` included): a
+        pipeline built with ``vae=`` and ``vocoder=`` returns waveforms by default; ``output_type="latent"`` is the exit for a pipeline
+        that holds the denoise path only."""
         if output_type != "latent" and (self.vae is None or self.vocoder is None):
             raise NotImplementedError("waveform output needs latents -> mel (vae=ap_adapter_amd.AutoencoderKL) and mel -> waveform "
                                       "(vocoder=ap_adapter_amd.SpeechT5HifiGan); or use output_type='latent'")
         if eta != 0.0:
             raise NotImplementedError("eta != 0 is not used by the reference drivers")
+        if num_waveforms_per_prompt > 1 and prompt is not None and output_type != "latent":
+            # pipeline_audioldm2.py:1048-1056 re-orders the candidates by CLAP text-audio similarity (score_waveforms); the CLAP audio
+            # tower is outside this path (SURVEY 2), and returning them un-ranked would silently differ from the reference
+            raise NotImplementedError("num_waveforms_per_prompt > 1 with text prompts needs the CLAP audio tower for score_waveforms "
+                                      "(not on this path); use output_type='latent' or rank the waveforms yourself")
         if prompt is None:
             for n, v in (("prompt_embeds", prompt_embeds), ("negative_prompt_embeds", negative_prompt_embeds),
                          ("generated_prompt_embeds", generated_prompt_embeds),

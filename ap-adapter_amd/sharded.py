@@ -92,10 +92,11 @@ def gather_clips(local, n_clips, rank=0, world=1):
     shape = [torch.zeros(8, dtype=torch.int64)]
     if sample is not None:
         shape[0][:sample.dim()] = torch.tensor(sample.shape)
-    shape_t = shape[0].to(sample.device if sample is not None and dist.get_backend() == "nccl" else "cpu")
+    # RCCL moves device tensors only: under "nccl" everything exchanged lives on this rank's GPU, also on a rank that holds no clip
+    dev = sample.device if sample is not None else (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu")
+    shape_t = shape[0].to(dev if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(shape_t, op=dist.ReduceOp.MAX)  # ranks without clips learn the latent shape
     dims = [int(x) for x in shape_t.tolist() if x > 0]
-    dev = sample.device if sample is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
     dtype = sample.dtype if sample is not None else torch.float32
     mine = torch.zeros(per, *dims, dtype=dtype, device=dev)
     for j, i in enumerate(shard_clips(n_clips, rank, world)):

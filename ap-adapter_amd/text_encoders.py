@@ -329,6 +329,17 @@ class T5EncoderModel(nn.Module):
         cfg = self.config = config or T5Config()
         self.shared = nn.Embedding(cfg.vocab_size, cfg.d_model)
         self.encoder = _T5Stack(cfg)
+        # transformers ties the two tables (T5EncoderModel._tied_weights_keys) and an HF checkpoint stores only ``shared.weight``:
+        # ONE parameter under both names, so a state dict with either key (or both) fills the table the forward reads
+        self.encoder.embed_tokens.weight = self.shared.weight
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        a, b = prefix + "shared.weight", prefix + "encoder.embed_tokens.weight"
+        if a in state_dict and b not in state_dict:
+            state_dict[b] = state_dict[a]
+        elif b in state_dict and a not in state_dict:
+            state_dict[a] = state_dict[b]
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     @torch.no_grad()
     def forward(self, input_ids, attention_mask=None):

@@ -146,6 +146,15 @@ class AdapterTrainer:
         self._micro = 0
         self.global_step += 1
 
+    @property
+    def skipped_steps(self):
+        """optimizer steps skipped on the device because the (loss-scaled) gradient norm was not finite: ``global_step`` counts every
+        boundary like the reference's (train_apadapter_v2.py:961-963 advances on ``sync_gradients`` whether or not the GradScaler
+        skipped), the device counter only the applied updates.  Reading it synchronises; poll it at logging cadence.  The f16 loss
+        scale is STATIC (a kernel argument inside the captured micro-step): a run whose skipped_steps keeps growing needs a smaller
+        ``loss_scale=`` -- accelerate's GradScaler would have halved it."""
+        return self.global_step - int(self.step_t.item())
+
     def train_step(self, latents, noise, timesteps, generated_prompt_embeds, prompt_embeds, attention_mask):
         """noise the latents, run one micro-batch, and step the optimizer on the accumulation boundary (:892-979)."""
         noisy = add_noise(latents, noise, timesteps, self.alphas_cumprod)

@@ -359,7 +359,7 @@ def test_graph_is_captured_once_and_replayed_on_new_conditions(dev):
     n_held = sum(len(p._kv_cache or {}) for p in procs_)
     lat_, ehs_, ehs1_, m1_ = inputs(5)
     for _ in range(2):
-        u(torch.cat([lat_, lat_]).to(dtype), torch.tensor(10), encoder_hidden_states=ehs_.clone(), encoder_hidden_states_1=ehs1_.clone(),
+        u(torch.cat([lat_, lat_]).to(dtype), torch.tensor(10), encoder_hidden_states=ehs_.to(dtype), encoder_hidden_states_1=ehs1_.to(dtype),
           encoder_attention_mask_1=m1_, return_dict=False)
     assert sum(len(p._kv_cache or {}) for p in procs_) == n_held
     assert torch.equal(pipe.denoise(*inputs(2), steps, gs), a2) and pipe.graph_hits == 4
