@@ -20,13 +20,21 @@ constexpr int BK = 64;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // TM = block tile edge: 128 (4 waves x 64x64) for big problems, 64 (4 waves x 32x32) when a 128-tiling would leave
 // most of the 256 CUs idle (the 64-token / 4096-row level of the UNet, 32x2 convolutions)
-template <int TM, int NS = 1> struct Tile {
+// KG = K groups: KG x 4 waves per workgroup, group g reduces the k-tiles g, g + KG, ... of the SAME output tile from its own LDS
+// stages and the partial accumulators are summed through LDS before the epilogue (in-workgroup split-K).  For the latency-bound
+// launches of the 640- / 384-wide levels (a few hundred 64x64 tiles with 6..40 k-tiles each): the serial k-loop per workgroup is
+// what those launches wait for, and a second wave per SIMD covers the first one's LDS round trips.
+template <int TM, int NS = 1, int KG = 1> struct Tile {
     static constexpr int BM = TM, BN = TM;
     static constexpr int MI = TM / 64;              // MFMA tiles per wave per dimension
     static constexpr int A_BYTES = TM * BK * 2;
     static constexpr int C_LD = TM + 8;             // epilogue tile row stride (elements)
     static constexpr int STAGE = 2 * A_BYTES;       // one k-tile of A and of W; NS stages
-    static constexpr int SMEM_BYTES = (TM * C_LD * 2 > NS * STAGE) ? TM * C_LD * 2 : NS * STAGE;
+    static constexpr int RED_BYTES = (KG > 1) ? (KG - 1) * 256 * MI * MI * 16 * 4 : 0;  // fp32 partials of groups 1..KG-1
+    static constexpr int CT_BYTES = TM * C_LD * 2;
+    // epilogue tile at offset 0; the partials behind it (both are used after the last k-loop barrier, when the stages are dead)
+    static constexpr int EPI_BYTES = (KG > 1) ? ((CT_BYTES + 15) / 16 * 16 + RED_BYTES) : CT_BYTES;
+    static constexpr int SMEM_BYTES = (EPI_BYTES > KG * NS * STAGE) ? EPI_BYTES : KG * NS * STAGE;
     static constexpr int NLD = TM / 32;             // staging vectors per thread per operand
 };
 
@@ -113,13 +121,17 @@ __device__ __forceinline__ uint4 load_a(const GemmP& p, const RowInfo<AMODE>& r,
     }
 }
 
-template <int DT, int AMODE, int EPI, int OUTMODE, int TM, int NS = 1>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
-    using T = Tile<TM, NS>;
+template <int DT, int AMODE, int EPI, int OUTMODE, int TM, int NS = 1, int KG = 1>
+__global__ __launch_bounds__(256 * KG) void gemm_kernel(GemmP p) {
+    using T = Tile<TM, NS, KG>;
     constexpr int BM = T::BM, BN = T::BN, MI = T::MI, A_BYTES = T::A_BYTES, C_LD = T::C_LD, NLD = T::NLD, WT = TM / 2;
+    constexpr int NT = 256 * KG;
     __shared__ __attribute__((aligned(16))) uint8_t smem[T::SMEM_BYTES];
     using E = ET<DT>;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // tid = thread index inside its K group (the staging / fragment roles of the 4-wave kernel); kg = K group (wave-uniform)
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    const int kg = (KG > 1) ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;
+    const int gso = kg * NS * T::STAGE;  // this group's LDS stages
     const int wm = wave >> 1, wn = wave & 1;
     const int half = lane >> 5, l31 = lane & 31;
     constexpr int BN_OUT = (EPI == APAD_EPI_GEGLU) ? BN / 2 : BN;
@@ -248,8 +260,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             int rl = (tid >> 3) + 32 * i;
-            *reinterpret_cast<u32x4*>(smem + so + lds_off(rl, chunk)) = gA[i];
-            *reinterpret_cast<u32x4*>(smem + so + A_BYTES + lds_off(rl, chunk)) = gB[i];
+            *reinterpret_cast<u32x4*>(smem + gso + so + lds_off(rl, chunk)) = gA[i];
+            *reinterpret_cast<u32x4*>(smem + gso + so + A_BYTES + lds_off(rl, chunk)) = gB[i];
         }
     };
     auto compute = [&](int so = 0) {
@@ -259,9 +271,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
             typename E::v8 af[MI], bf[MI];
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                af[i] = as_v8<DT>(*reinterpret_cast<const uint4*>(smem + so + lds_off(wm * WT + i * 32 + l31, ch)));
+                af[i] = as_v8<DT>(*reinterpret_cast<const uint4*>(smem + gso + so + lds_off(wm * WT + i * 32 + l31, ch)));
                 bf[i] = as_v8<DT>(
-                    *reinterpret_cast<const uint4*>(smem + so + A_BYTES + lds_off(wn * WT + i * 32 + l31, ch)));
+                    *reinterpret_cast<const uint4*>(smem + gso + so + A_BYTES + lds_off(wn * WT + i * 32 + l31, ch)));
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
@@ -270,6 +282,53 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         }
     };
 
+    if constexpr (KG > 1) {
+    // in-workgroup split-K: group kg owns k-tiles kg, kg + KG, ...; every group runs the same number of barriers
+    static_assert(KG == 1 || (NS == 1 && PF == 1), "the K-group loop is written for one LDS stage per group");
+    const int nit = (nk + KG - 1) / KG;
+    if (kg < nk) {
+        gload(kg, ga[0], gb[0]);
+        sstore(ga[0], gb[0]);
+    }
+    __syncthreads();
+    for (int it = 0; it < nit; ++it) {
+        const int kt = it * KG + kg;
+        const bool more = kt + KG < nk;  // wave-uniform
+        if (more) gload(kt + KG, ga[0], gb[0]);
+        if (kt < nk) compute();
+        if (it + 1 < nit) {
+            __syncthreads();
+            if (more) sstore(ga[0], gb[0]);
+        }
+        __syncthreads();
+    }
+    // partial accumulators of groups 1.. -> LDS (behind the epilogue tile), summed by group 0 in group order (deterministic)
+    float* red = reinterpret_cast<float*>(smem + (T::CT_BYTES + 15) / 16 * 16);
+    if (kg > 0) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < MI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; r += 4)
+                    *reinterpret_cast<float4*>(&red[((((kg - 1) * MI + i) * MI + j) * 4 + (r >> 2)) * 1024 + tid * 4]) =
+                        make_float4(acc[i][j][r], acc[i][j][r + 1], acc[i][j][r + 2], acc[i][j][r + 3]);
+    }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+        for (int g = 1; g < KG; ++g)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < MI; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 4) {
+                        const float4 v = *reinterpret_cast<const float4*>(&red[((((g - 1) * MI + i) * MI + j) * 4 + (r >> 2)) * 1024 + tid * 4]);
+                        acc[i][j][r] += v.x; acc[i][j][r + 1] += v.y; acc[i][j][r + 2] += v.z; acc[i][j][r + 3] += v.w;
+                    }
+    }
+    } else
     if constexpr (NS == 2) {
     // Two LDS stages: the next k-tile is written while the current one is being read -> ONE barrier per k-tile.  Pays
     // on long reductions (3x3 convolutions with K >= 2048: -3..7 %); the doubled LDS footprint halves the resident
@@ -314,6 +373,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     typename E::elem* ct = reinterpret_cast<typename E::elem*>(smem);
     int64_t step = p.step_ptr ? (int64_t)*p.step_ptr : 0;
     const bool one_group = p.rows_per_group >= p.M;  // table mode: every row reads row `step` (no 64-bit divisions)
+    if (kg == 0)
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
         const int nl = wn * WT + j * 32 + l31;
@@ -347,7 +407,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         uint8_t* const obase = (OUTMODE == APAD_OUT_QKV && qseg == 1) ? p.out2 : p.out;
         const int64_t ncol0 = (OUTMODE == APAD_OUT_QKV) ? (int64_t)qseg * Cq : 0;
         constexpr int VPR = BN_OUT / 8;  // 16-byte vectors per output row
-        for (int idx = tid; idx < BM * VPR; idx += 256) {
+        for (int idx = threadIdx.x; idx < BM * VPR; idx += NT) {
             const int rl = idx / VPR, vc = idx - rl * VPR;
             const int64_t m = m0 + rl, n = n0 + vc * 8;
             if (m >= p.M || n >= p.N) continue;
@@ -376,7 +436,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     } else {  // APAD_OUT_VT (or the v third of APAD_OUT_QKV): consecutive lanes -> consecutive tokens of one (head, dd) row
         typename E::elem* o = reinterpret_cast<typename E::elem*>(OUTMODE == APAD_OUT_QKV ? p.out3 : p.out);
         const int64_t nsub = (OUTMODE == APAD_OUT_QKV) ? 2 * (int64_t)Cq : 0;
-        for (int idx = tid; idx < BM * BN; idx += 256) {
+        for (int idx = threadIdx.x; idx < BM * BN; idx += NT) {
             const int nl = idx / BM, rl = idx % BM;
             const int64_t m = m0 + rl;
             int64_t n = n0 + nl;
@@ -585,14 +645,14 @@ template <int DT, int EPI> int launch_dma(const GemmP& p, hipStream_t s) {
     return apad_check_launch("apad_gemm(dma)");
 }
 
-template <int DT, int AMODE, int EPI, int OUTMODE, int TM, int NS = 1>
+template <int DT, int AMODE, int EPI, int OUTMODE, int TM, int NS = 1, int KG = 1>
 int launch_tm(const GemmP& p, hipStream_t s) {
     constexpr int BN_OUT = (EPI == APAD_EPI_GEGLU) ? TM / 2 : TM;
     GemmP q = p;
     q.n_tiles = (int)((p.N + BN_OUT - 1) / BN_OUT);
     q.m_tiles = (int)((p.M + TM - 1) / TM);
     dim3 grid((unsigned)(q.n_tiles * q.m_tiles));
-    hipLaunchKernelGGL((gemm_kernel<DT, AMODE, EPI, OUTMODE, TM, NS>), grid, dim3(256), 0, s, q);
+    hipLaunchKernelGGL((gemm_kernel<DT, AMODE, EPI, OUTMODE, TM, NS, KG>), grid, dim3(256 * KG), 0, s, q);
     return apad_check_launch("apad_gemm");
 }
 
@@ -617,6 +677,13 @@ int launch(const GemmP& p, hipStream_t s) {
             return t128 ? launch_tm<DT, AMODE, EPI, OUTMODE, 128, 2>(p, s) : launch_tm<DT, AMODE, EPI, OUTMODE, 64, 2>(p, s);
     }
     if (t128) return launch_tm<DT, AMODE, EPI, OUTMODE, 128>(p, s);
+    if constexpr (AMODE == APAD_A_PLAIN && (EPI == APAD_EPI_NONE || EPI == APAD_EPI_GEGLU)) {
+        // under-filled launches with a k-loop worth splitting: K groups inside the workgroup (APAD_GEMM_KG = 1 | 2 | 4, A/B knob)
+        static const int kg_mode = [] { const char* e = getenv("APAD_GEMM_KG"); return e ? atoi(e) : 2; }();
+        const int nk = (int)((p.K + BK - 1) / BK);
+        if (kg_mode >= 4 && nk >= 16) return launch_tm<DT, AMODE, EPI, OUTMODE, 64, 1, 4>(p, s);
+        if (kg_mode >= 2 && nk >= 4) return launch_tm<DT, AMODE, EPI, OUTMODE, 64, 1, 2>(p, s);
+    }
     return launch_tm<DT, AMODE, EPI, OUTMODE, 64>(p, s);
 }
 
