@@ -39,7 +39,7 @@ class AttnDesc(C.Structure):
                                     "k2_stride_b", "k2_stride_l", "vt2_stride_b", "o_stride_b", "o_stride_n")] + \
                [(n, _i32) for n in ("B", "N", "H", "D", "L", "Lpad", "L2", "Lpad2", "kv_batch_div", "kv2_batch_div",
                                     "dtype")] + \
-               [("softmax_scale", _f32), ("scale2", _f32)]
+               [("softmax_scale", _f32), ("scale2", _f32), ("q_prescaled", _i32)]
 
 
 class RpSegment(C.Structure):
@@ -158,7 +158,7 @@ def lib():
                 fn = getattr(h, name)  # AttributeError if the ABI lost a symbol
                 fn.restype = res
                 fn.argtypes = args
-            if h.apad_abi_version() != 4:
+            if h.apad_abi_version() != 5:
                 raise RuntimeError("libapadapter_hip.so ABI version mismatch")
             if h.apad_sizeof_gemm_desc() != C.sizeof(GemmDesc) or h.apad_sizeof_attn_desc() != C.sizeof(AttnDesc) \
                     or h.apad_sizeof_rp_desc() != C.sizeof(RpDesc) \

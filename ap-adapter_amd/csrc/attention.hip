@@ -40,6 +40,7 @@ struct AttnP {
     int64_t q_sb, q_sn, k_sb, k_sl, vt_sb, k2_sb, k2_sl, vt2_sb, o_sb, o_sn;
     int32_t B, N, H, L, Lpad, L2, Lpad2, kvdiv, kvdiv2;
     float scale_log2, scale2;
+    int32_t prescaled;  // q already carries softmax_scale * log2(e) (scale_log2 is then exactly 1)
 };
 
 constexpr float LOG2E = 1.4426950408889634f;
@@ -421,12 +422,23 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
 // tile the key loop is one dependency chain (scores -> softmax -> P.V).  Two tiles give the instruction stream independent
 // work: tile B's score MFMAs run under tile A's softmax, tile A's P.V MFMAs under tile B's softmax; each K fragment read
 // from LDS feeds two MFMAs and the staging / barrier cost per query halves.  No key bias, one segment (the UNet's attn1).
-template <int DT, int D, bool MASK>
+//
+// DIRECT (q pre-scaled by softmax_scale * log2 e, full tiles): the softmax costs exp + sum + pack per score and nothing else.
+//   * the running max enters through the score MFMA's C operand: mi[qt] holds -m in all 16 accumulator registers, so the MFMA
+//     returns s - m and the exponential is taken of the accumulator as it is (no scale / subtract instruction per score);
+//   * no per-tile max either: probabilities are allowed to exceed 1.  bf16 / fp32 carry 8 exponent bits, so a score that runs
+//     up to log2(BIG) above the running max is harmless; the tile's probability SUM (needed anyway) is the range check, and only
+//     when some lane's sum leaves [0, BIG) -- the first tile, or a genuine jump of the maximum -- the wave takes the classic path
+//     (raw scores, new maximum, rescale of O and the denominators) for that tile.  Exact arithmetic otherwise: the result is a
+//     softmax with a different, equally valid, reference point.
+template <int DT, int D, bool MASK, bool DIRECT = false>
 __device__ __forceinline__ void tile_compute2(const uint8_t* buf, int key0, int L, float c, const typename ET<DT>::v8 (&qf)[2][D / 16],
-                                              f32x16 (&o)[2][Lay<D>::DT_TILES], f32x2 (&osum)[2], float (&m)[2], int l31, int half) {
+                                              f32x16 (&o)[2][Lay<D>::DT_TILES], f32x2 (&osum)[2], float (&m)[2], f32x16 (&mi)[2], int l31, int half) {
     using E = ET<DT>;
     using Y = Lay<D>;
     constexpr int KC = D / 16;
+    // largest tile sum the fast path accepts: P is rounded to the storage type for the P.V product (f16 overflows at 65504)
+    constexpr float BIG = (DT == APAD_F16) ? 4096.f : 1073741824.f;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 s[2][2];  // [query tile][32-key sub-tile]
     // every fragment of the tile is requested from LDS up front, in one batch: K (A operand of both tiles' score MFMAs) and V^T
@@ -451,7 +463,7 @@ __device__ __forceinline__ void tile_compute2(const uint8_t* buf, int key0, int 
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            s[qt][u] = E::mfma32(kf[u][0], qf[qt][0], zero16);
+            s[qt][u] = E::mfma32(kf[u][0], qf[qt][0], (DIRECT && !MASK) ? mi[qt] : zero16);
 #pragma unroll
             for (int cc = 1; cc < KC; ++cc) s[qt][u] = E::mfma32(kf[u][cc], qf[qt][cc], s[qt][u]);
         }
@@ -463,6 +475,49 @@ __device__ __forceinline__ void tile_compute2(const uint8_t* buf, int key0, int 
         for (int dt = 0; dt < Y::DT_TILES; ++dt) asm volatile("" : "+v"(vf[st][dt]));
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
+        if constexpr (DIRECT && !MASK) {
+            f32x2 part[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    s[qt][u][r] = __builtin_amdgcn_exp2f(s[qt][u][r]);
+                    s[qt][u][r + 1] = __builtin_amdgcn_exp2f(s[qt][u][r + 1]);
+                    part[(r >> 1) & 3] += (f32x2){s[qt][u][r], s[qt][u][r + 1]};
+                }
+            f32x2 ts = (part[0] + part[1]) + (part[2] + part[3]);
+            if (__any(!(ts[0] + ts[1] < BIG))) {  // wave-uniform, rare: first tile / the maximum jumped by more than log2(BIG)
+                float tmax = NEG_BIG;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    s[qt][u] = E::mfma32(kf[u][0], qf[qt][0], zero16);
+#pragma unroll
+                    for (int cc = 1; cc < KC; ++cc) s[qt][u] = E::mfma32(kf[u][cc], qf[qt][cc], s[qt][u]);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[qt][u][r]);
+                }
+                const float mnew = fmaxf(m[qt], half_max(tmax));
+                const float alpha = __builtin_amdgcn_exp2f(m[qt] - mnew);
+                osum[qt] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < Y::DT_TILES; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[qt][dt][r] *= alpha;
+                m[qt] = mnew;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mi[qt][r] = -mnew;
+                ts = (f32x2){0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        s[qt][u][r] = __builtin_amdgcn_exp2f(s[qt][u][r] - mnew);
+                        s[qt][u][r + 1] = __builtin_amdgcn_exp2f(s[qt][u][r + 1] - mnew);
+                        ts += (f32x2){s[qt][u][r], s[qt][u][r + 1]};
+                    }
+            }
+            osum[qt] += ts;
+        } else {
         float tmax = NEG_BIG;
         if (MASK) {
 #pragma unroll
@@ -519,6 +574,7 @@ __device__ __forceinline__ void tile_compute2(const uint8_t* buf, int key0, int 
                 }
             osum[qt] += (part[0] + part[1]) + (part[2] + part[3]);
         }
+        }
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
             typename E::v8 pf;
@@ -532,7 +588,7 @@ __device__ __forceinline__ void tile_compute2(const uint8_t* buf, int key0, int 
 
 // NW = waves per workgroup: 4 (256 queries) or, for d = 32, 8 (512 queries: the K / V^T tile of a (batch, head) is staged once
 // per CU instead of twice; waves 0-3 stage K, waves 4-7 stage V^T, one 16-byte chunk per thread)
-template <int DT, int D, int NW>
+template <int DT, int D, int NW, bool DIRECT = false>
 __global__ __launch_bounds__(NW * 64) void attn2q_kernel(AttnP p) {
     using E = ET<DT>;
     using Y = Lay<D>;
@@ -563,10 +619,13 @@ __global__ __launch_bounds__(NW * 64) void attn2q_kernel(AttnP p) {
     f32x16 o[2][Y::DT_TILES];
     f32x2 osum[2];
     float m[2];
+    f32x16 mi[2];  // DIRECT: -m in every accumulator register of a score tile (the score MFMA's C operand)
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         osum[qt] = (f32x2){0.f, 0.f};
         m[qt] = NEG_BIG;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mi[qt][r] = -NEG_BIG;  // exp2(s + 1e30) = inf: the first tile takes the classic path
 #pragma unroll
         for (int dt = 0; dt < Y::DT_TILES; ++dt)
 #pragma unroll
@@ -635,14 +694,14 @@ __global__ __launch_bounds__(NW * 64) void attn2q_kernel(AttnP p) {
             const uint8_t* buf = smem + (t & 1) * Y::BUF;
             if (t + 1 < nfull) load_tile(t + 1, true);
             else if (t + 1 < ntiles) load_tile(t + 1, false);
-            tile_compute2<DT, D, false>(buf, t * KT, L, c, qf, o, osum, m, l31, half);
+            tile_compute2<DT, D, false, DIRECT>(buf, t * KT, L, c, qf, o, osum, m, mi, l31, half);
             if (t + 1 < ntiles) store_tile(smem + ((t + 1) & 1) * Y::BUF);
             __syncthreads();
         }
         for (; t < ntiles; ++t) {
             const uint8_t* buf = smem + (t & 1) * Y::BUF;
             if (t + 1 < ntiles) load_tile(t + 1, false);
-            tile_compute2<DT, D, true>(buf, t * KT, L, c, qf, o, osum, m, l31, half);
+            tile_compute2<DT, D, true, DIRECT>(buf, t * KT, L, c, qf, o, osum, m, mi, l31, half);
             if (t + 1 < ntiles) store_tile(smem + ((t + 1) & 1) * Y::BUF);
             __syncthreads();
         }
@@ -870,6 +929,14 @@ template <int DT, int D> int launch_d(const AttnP& p, bool dual, dim3 grid, hipS
                 }
             }
             dim3 g2((unsigned)(((p.N + 255) / 256) * (((p.H * p.B) + 7) / 8 * 8)));
+            if constexpr (D == 32) {
+                // pre-scaled q: the softmax without per-score max / scale instructions (APAD_ATTN_DIRECT=0: A/B switch)
+                static const int direct = [] { const char* e = getenv("APAD_ATTN_DIRECT"); return e ? atoi(e) : 1; }();
+                if (direct && p.prescaled) {
+                    hipLaunchKernelGGL((attn2q_kernel<DT, D, 4, true>), g2, dim3(256), 0, s, p);
+                    return apad_check_launch("apad_attention");
+                }
+            }
             hipLaunchKernelGGL((attn2q_kernel<DT, D, 4>), g2, dim3(256), 0, s, p);
             return apad_check_launch("apad_attention");
         }
@@ -931,7 +998,8 @@ extern "C" int apad_attention(const apad_attn_desc* d, void* stream) {
     p.k2_sb = d->k2_stride_b; p.k2_sl = d->k2_stride_l; p.vt2_sb = d->vt2_stride_b; p.o_sb = d->o_stride_b; p.o_sn = d->o_stride_n;
     p.B = d->B; p.N = d->N; p.H = d->H; p.L = d->L; p.Lpad = d->Lpad; p.L2 = d->L2; p.Lpad2 = d->Lpad2;
     p.kvdiv = d->kv_batch_div; p.kvdiv2 = dual ? d->kv2_batch_div : 1;
-    p.scale_log2 = d->softmax_scale * 1.4426950408889634f;
+    p.prescaled = d->q_prescaled ? 1 : 0;
+    p.scale_log2 = p.prescaled ? 1.0f : d->softmax_scale * 1.4426950408889634f;
     p.scale2 = d->scale2;
     dim3 grid((unsigned)(((d->N + 127) / 128) * (((d->H * d->B) + 7) / 8 * 8)));
     hipStream_t s = (hipStream_t)stream;

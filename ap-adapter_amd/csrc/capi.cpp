@@ -54,7 +54,7 @@ extern "C" int apad_echo_attn_desc(const apad_attn_desc* d, double* out, int cap
     PUT(d->q_stride_b); PUT(d->q_stride_n); PUT(d->k_stride_b); PUT(d->k_stride_l); PUT(d->vt_stride_b);
     PUT(d->k2_stride_b); PUT(d->k2_stride_l); PUT(d->vt2_stride_b); PUT(d->o_stride_b); PUT(d->o_stride_n);
     PUT(d->B); PUT(d->N); PUT(d->H); PUT(d->D); PUT(d->L); PUT(d->Lpad); PUT(d->L2); PUT(d->Lpad2);
-    PUT(d->kv_batch_div); PUT(d->kv2_batch_div); PUT(d->dtype); PUT(d->softmax_scale); PUT(d->scale2);
+    PUT(d->kv_batch_div); PUT(d->kv2_batch_div); PUT(d->dtype); PUT(d->softmax_scale); PUT(d->scale2); PUT(d->q_prescaled);
     return n;
 }
 

@@ -756,7 +756,7 @@ int apad_f32_attention(const apad_attn_desc* d, hipStream_t s) {
     p.k2_sb = d->k2_stride_b; p.k2_sl = d->k2_stride_l; p.vt2_sb = d->vt2_stride_b; p.o_sb = d->o_stride_b; p.o_sn = d->o_stride_n;
     p.B = d->B; p.N = d->N; p.H = d->H; p.L = d->L; p.Lpad = d->Lpad; p.L2 = dual ? d->L2 : 0; p.Lpad2 = d->Lpad2;
     p.kvdiv = d->kv_batch_div; p.kvdiv2 = dual ? d->kv2_batch_div : 1;
-    p.scale_log2 = d->softmax_scale * LOG2E_F;
+    p.scale_log2 = d->q_prescaled ? 1.0f : d->softmax_scale * LOG2E_F;
     p.scale2 = d->scale2;
     switch (d->D) {
         case 16: return attn_launch<16>(p, s);

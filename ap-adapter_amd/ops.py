@@ -366,10 +366,14 @@ def patch_embed(mel, w, bias, dtype):
     return out
 
 
+LOG2E = 1.4426950408889634
+
+
 def attention(q, k, vt, Lk, heads, key_bias=None, k2=None, vt2=None, L2=0, scale2=0.0, kv_batch_div=1,
-              kv2_batch_div=1, out=None):
+              kv2_batch_div=1, out=None, q_prescaled=False):
     """q [B,N,C]; k [Bk,Lk,C]; vt [Bk,heads,d,Lpad]; optional second (audio) segment k2/vt2 with its own softmax,
-    blended as seg1 + scale2*seg2.  key_bias: fp32 [B,Lk] additive."""
+    blended as seg1 + scale2*seg2.  key_bias: fp32 [B,Lk] additive.  q_prescaled: q was projected with to_q rows already
+    multiplied by log2(e) / sqrt(d) (processors._qkv_weight), i.e. it is the base-2 exponent operand."""
     _req(q, "attention.q")
     _req(k, "attention.k", q.dtype)
     _req(vt, "attention.vt", q.dtype)
@@ -388,6 +392,7 @@ def attention(q, k, vt, Lk, heads, key_bias=None, k2=None, vt2=None, L2=0, scale
     d.dtype = _DT[q.dtype]
     d.softmax_scale = 1.0 / math.sqrt(d_head)
     d.scale2 = float(scale2)
+    d.q_prescaled = 1 if q_prescaled else 0
     if L2 > 0:
         d.k2, d.vt2 = k2.data_ptr(), vt2.data_ptr()
         d.k2_stride_b, d.k2_stride_l, d.vt2_stride_b = k2.stride(0), k2.stride(1), vt2.stride(0)

@@ -26,6 +26,9 @@ _vt_pool = {}
 # three-kernel chain it replaces (A/B measurements, tests).
 import os as _os
 USE_FUSED_XATTN = _os.environ.get("APAD_FUSED_XATTN", "1") == "1"
+# Self-attention behind the row-panel projection: scale the to_q rows by log2(e) / sqrt(d) once (cached with the stacked weight) so
+# that apad_attention takes q as the base-2 exponent operand (q_prescaled; APAD_PRESCALE_Q=0: A/B switch)
+PRESCALE_Q = _os.environ.get("APAD_PRESCALE_Q", "1") == "1"
 
 
 def _fused_xattn_ok(attn, hidden_states, residual, ln, L1, L2=0):
@@ -160,12 +163,19 @@ class AttnProcessor2_0(nn.Module):
         ops.linear_vt(src, attn.to_v.weight, B, Lk, attn.heads, vt)
         return k, vt
 
-    def _qkv_weight(self, attn):
+    def _qkv_weight(self, attn, prescale=False):
+        """to_q | to_k | to_v stacked for the one-launch projection.  prescale: the to_q rows carry log2(e) / sqrt(d) (scaled in
+        fp32, rounded to the storage type once), so the projection writes q as the base-2 exponent operand of the softmax --
+        rounded ONCE, like the reference's q -- and the attention kernel spends no instruction per score on the scale."""
         ps = (attn.to_q.weight, attn.to_k.weight, attn.to_v.weight)
-        key = tuple((id(p), p.data_ptr(), p._version, p.dtype, p.device) for p in ps)
+        key = tuple((id(p), p.data_ptr(), p._version, p.dtype, p.device) for p in ps) + (bool(prescale),)
         # cached on the Attention module (a processor instance may be shared by many sites)
         if getattr(attn, "_qkv_key", None) != key:
-            attn._qkv_w = torch.cat([p.detach() for p in ps], dim=0).contiguous()
+            wq = attn.to_q.weight.detach()
+            if prescale:
+                d = wq.shape[0] // attn.heads
+                wq = (wq.float() * (ops.LOG2E / d ** 0.5)).to(wq.dtype)
+            attn._qkv_w = torch.cat([wq, attn.to_k.weight.detach(), attn.to_v.weight.detach()], dim=0).contiguous()
             attn._qkv_key = key
         return attn._qkv_w
 
@@ -182,6 +192,7 @@ class AttnProcessor2_0(nn.Module):
         heads = attn.heads
         if AG.on(hidden_states, encoder_hidden_states):
             return self._call_train(attn, hidden_states, encoder_hidden_states, attention_mask, _residual, _ln)
+        prescaled = False
         if encoder_hidden_states is None:
             Lk = N
             if ops.rp_ok(hidden_states) and attn.to_q.weight.shape[0] == C_:
@@ -189,7 +200,8 @@ class AttnProcessor2_0(nn.Module):
                 q = torch.empty(B, N, C_, dtype=hidden_states.dtype, device=hidden_states.device)
                 k = torch.empty_like(q)
                 vt = vt_buffer("self", B, heads, C_ // heads, N, hidden_states.dtype, hidden_states.device)
-                ops.rowpanel(hidden_states, self._qkv_weight(attn), [(q, None, C_, "row"), (k, None, C_, "row"), (vt, None, C_, "vt")],
+                prescaled = PRESCALE_Q and attn.to_q.bias is None
+                ops.rowpanel(hidden_states, self._qkv_weight(attn, prescaled), [(q, None, C_, "row"), (k, None, C_, "row"), (vt, None, C_, "vt")],
                              ln=_ln, vt_geom=(heads, C_ // heads, N, vt.shape[-1]))
             elif attn.to_q.weight.shape[0] == C_ and C_ % 128 == 0:  # (fp32 mode: every width whose C % 128 == 0)
                 # widths outside the row-panel envelope (the 640-wide level): LayerNorm, then q|k|v in ONE tiled launch
@@ -231,7 +243,7 @@ class AttnProcessor2_0(nn.Module):
             return ops.fused_cross_attention(hidden_states, wq_p, wo_p, attn.to_out[0].bias, pk, Lk, heads, ln=_ln, key_bias=bias)
         if q is None:
             q = ops.fused_linear(hidden_states, attn.to_q.weight, ln=_ln)
-        o = ops.attention(q, k, vt, Lk, heads, key_bias=bias)
+        o = ops.attention(q, k, vt, Lk, heads, key_bias=bias, q_prescaled=prescaled)
         out = ops.fused_linear(o, attn.to_out[0].weight, attn.to_out[0].bias, residual=_residual)
         if attn.residual_connection:
             raise NotImplementedError("residual_connection=True is not on the AudioLDM2 path")

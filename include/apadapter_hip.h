@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define APAD_ABI_VERSION 4
+#define APAD_ABI_VERSION 5
 
 /* element types of activations / weights */
 enum { APAD_BF16 = 0, APAD_F16 = 1, APAD_F32 = 2 };
@@ -127,6 +127,9 @@ typedef struct apad_attn_desc {
     int32_t dtype;
     float softmax_scale;        /* 1/sqrt(D)                                                           */
     float scale2;               /* out = softmax1.V1 + scale2 * softmax2.V2  (ap_scale)                */
+    int32_t q_prescaled;        /* 1: q already carries softmax_scale * log2(e) (e.g. the to_q weight rows were scaled
+                                   before the projection, so q is rounded to the storage type ONCE): scores are used as
+                                   base-2 exponents directly and softmax_scale is ignored                    */
 } apad_attn_desc;
 
 /* Row-panel GEMM: the fused projection kernel of the transformer blocks.  Each workgroup keeps a 128-row panel of

@@ -189,6 +189,63 @@ def test_attention_two_query_tile_kernel_lse_and_equality(dev, dtype):
 
 
 
+def _prescaled(qq, d, dtype):
+    """q as the processors hand it over with q_prescaled: multiplied by log2(e) / sqrt(d) BEFORE the one rounding to the storage
+    type (there through the scaled to_q rows); the reference of such a call is softmax over base-2 exponents q' . k"""
+    return q(qq * (math.log2(math.e) / math.sqrt(d)), dtype)
+
+
+def _attn_ref_exp2(qh, kh, vh):
+    s = (qh @ kh.transpose(-1, -2)) * math.log(2.0)  # 2^x = e^(x ln 2)
+    return torch.softmax(s, -1) @ vh, s
+
+
+@pytest.mark.parametrize("dtype", DTYPES16)
+@pytest.mark.parametrize("B,N,L,heads,d", [(2, 1000, 1000, 8, 32), (1, 777, 1029, 2, 32), (2, 600, 300, 4, 32), (3, 512, 256, 8, 32),
+                                           (2, 252, 252, 8, 48), (2, 100, 100, 8, 32)])
+def test_attention_prescaled_q(dev, dtype, B, N, L, heads, d):
+    """q_prescaled (the self-attention route behind the row-panel projection): scores are base-2 exponents as they come out of
+    the MFMA.  The long d = 32 shapes run the two-query-tile kernel's direct form (running max in the score MFMA's C operand, the
+    tile's probability sum as the range check); the others the generic kernels with scale 1.  Output and log-sum-exp."""
+    from ap_adapter_amd import ops
+    C_ = heads * d
+    qp = _prescaled(R(B, N, C_, seed=43), d, dtype)
+    kk, vv = q(R(B, L, C_, seed=44), dtype), q(R(B, L, C_, seed=45), dtype)
+    ref, sc = _attn_ref_exp2(_heads(qp, heads), _heads(kk, heads), _heads(vv, heads))
+    ref = ref.transpose(1, 2).reshape(B, N, C_)
+    qd, kd, vt = qp.to(dev, dtype), kk.to(dev, dtype), _vt(vv, heads, dev, dtype)
+    out = ops.attention(qd, kd, vt, L, heads, q_prescaled=True)
+    assert rel_err(out, ref) < TOL[dtype]
+    # the same scores through the classic form (scale applied in the kernel) differ by one rounding of q only
+    q0 = q(R(B, N, C_, seed=43), dtype)
+    base = ops.attention(q0.to(dev, dtype), kd, vt, L, heads)
+    assert rel_err(out, base.float().cpu()) < 2.5 * TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES16)
+@pytest.mark.parametrize("spike_tile,gain", [(0, 6.0), (7, 6.0), (7, 30.0), (15, 12.0), (3, -8.0)])
+def test_attention_direct_form_range_check_branches(dev, dtype, spike_tile, gain):
+    """the direct form skips the per-tile maximum; a key whose score jumps far above the running max must trip the range check
+    (classic update for that tile), one that stays inside the window must not change the result either.  One key row is set to
+    gain x a query, in a chosen 64-key tile: +6 stays inside the bf16 window (2^30) for most rows, +30 / +12 leave it (and leave
+    f16's 2^12 window), a negative spike exercises the far-below side.  Full-tensor fp32 reference."""
+    from ap_adapter_amd import ops
+    B, N, heads, d = 1, 1000, 2, 32
+    L, C_ = N, heads * d
+    qp = _prescaled(R(B, N, C_, seed=46) * 2.0, d, dtype)
+    kk, vv = R(B, L, C_, seed=47), q(R(B, L, C_, seed=48), dtype)
+    kk[:, spike_tile * 64 + 17] = (qp[:, 333] * gain)
+    kk[:, min(spike_tile * 64 + 70, L - 1)] = (qp[:, 900] * gain * 0.5)
+    kk = q(kk, dtype)
+    ref, sc = _attn_ref_exp2(_heads(qp, heads), _heads(kk, heads), _heads(vv, heads))
+    ref = ref.transpose(1, 2).reshape(B, N, C_)
+    if gain > 0:
+        assert float(sc.max()) / math.log(2.0) > (35.0 if gain >= 12 else 12.0)  # the spike really is outside / inside the window
+    out = ops.attention(qp.to(dev, dtype), kk.to(dev, dtype), _vt(vv, heads, dev, dtype), L, heads, q_prescaled=True)
+    assert torch.isfinite(out).all()
+    assert rel_err(out, ref) < TOL[dtype]
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,N,heads,d,Lt,La,scale", [
     (2, 100, 8, 32, 8, 32, 0.55), (1, 1000, 8, 32, 8, 512, 0.5), (2, 252, 8, 48, 8, 128, 0.5), (2, 64, 8, 80, 8, 8, 1.0),

@@ -175,13 +175,13 @@ def test_scheduler_matches_oracle():
 def test_pipeline_rejects_out_of_scope_stages(unet):
     pipe = A.AudioLDM2Pipeline(unet)
     with pytest.raises(NotImplementedError, match="text prompts need prompt_encoder"):
-        pipe(prompt="jazz")
+        pipe(prompt="jazz", output_type="latent")
     e = torch.zeros(1, 16, 1024)
-    with pytest.raises(NotImplementedError, match="AutoencoderKL"):
+    with pytest.raises(NotImplementedError, match="AutoencoderKL"):  # the default output_type is the reference's "np" (:775)
         pipe(prompt_embeds=e, negative_prompt_embeds=e, generated_prompt_embeds=e, negative_generated_prompt_embeds=e,
-             attention_mask=e[..., 0], negative_attention_mask=e[..., 0], output_type="np")
+             attention_mask=e[..., 0], negative_attention_mask=e[..., 0])
     with pytest.raises(ValueError, match="required"):
-        pipe(prompt_embeds=e)
+        pipe(prompt_embeds=e, output_type="latent")
 
 
 def test_library_exports_every_declared_symbol():
