@@ -48,6 +48,7 @@ constexpr float NEG_BIG = -1.0e30f;
 constexpr int KT = 64;  // keys per LDS tile
 #ifndef APAD_ABL
 #define APAD_ABL 0  // ablation probes of the key loop (tools/ab_build.sh builds only): 1 no exp, 2 no score MFMAs, 4 no P.V MFMAs, 8 no staging
+                    // (two-tile kernel also: 16 no barrier (staging kept), 32 no LDS fragment reads, 64 no sums / range check)
 #endif
 
 
@@ -448,12 +449,16 @@ __device__ __forceinline__ void tile_compute2(const uint8_t* buf, int key0, int 
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int cc = 0; cc < KC; ++cc)
+        for (int cc = 0; cc < KC; ++cc) {
+            if (APAD_ABL & 32) kf[u][cc] = qf[0][cc];
+            else
             kf[u][cc] = as_v8<DT>(*reinterpret_cast<const uint4*>(buf + (u * 32 + l31) * Y::KROW + half * 16 + cc * 32));
+        }
 #pragma unroll
     for (int st = 0; st < 4; ++st)
 #pragma unroll
         for (int dt = 0; dt < Y::DT_TILES; ++dt) {
+            if (APAD_ABL & 32) { vf[st][dt] = qf[1][0]; continue; }
             const uint8_t* vp = buf + Y::K_BYTES + (dt * 32 + l31) * Y::VROW + (st * 16 + 4 * half) * 2;
             const uint2 v0 = *reinterpret_cast<const uint2*>(vp);
             const uint2 v1 = *reinterpret_cast<const uint2*>(vp + 16);
@@ -463,6 +468,11 @@ __device__ __forceinline__ void tile_compute2(const uint8_t* buf, int key0, int 
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
+            if (APAD_ABL & 2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[qt][u][r] = mi[qt][r] * 1e-30f + (float)kf[u][0][r & 7] * (float)qf[qt][0][r & 7];
+                continue;
+            }
             s[qt][u] = E::mfma32(kf[u][0], qf[qt][0], (DIRECT && !MASK) ? mi[qt] : zero16);
 #pragma unroll
             for (int cc = 1; cc < KC; ++cc) s[qt][u] = E::mfma32(kf[u][cc], qf[qt][cc], s[qt][u]);
@@ -481,12 +491,12 @@ __device__ __forceinline__ void tile_compute2(const uint8_t* buf, int key0, int 
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    s[qt][u][r] = __builtin_amdgcn_exp2f(s[qt][u][r]);
-                    s[qt][u][r + 1] = __builtin_amdgcn_exp2f(s[qt][u][r + 1]);
-                    part[(r >> 1) & 3] += (f32x2){s[qt][u][r], s[qt][u][r + 1]};
+                    s[qt][u][r] = (APAD_ABL & 1) ? s[qt][u][r] * 0.5f : __builtin_amdgcn_exp2f(s[qt][u][r]);
+                    s[qt][u][r + 1] = (APAD_ABL & 1) ? s[qt][u][r + 1] * 0.5f : __builtin_amdgcn_exp2f(s[qt][u][r + 1]);
+                    if (!(APAD_ABL & 64)) part[(r >> 1) & 3] += (f32x2){s[qt][u][r], s[qt][u][r + 1]};
                 }
             f32x2 ts = (part[0] + part[1]) + (part[2] + part[3]);
-            if (__any(!(ts[0] + ts[1] < BIG))) {  // wave-uniform, rare: first tile / the maximum jumped by more than log2(BIG)
+            if (!(APAD_ABL & 64) && __any(!(ts[0] + ts[1] < BIG))) {  // wave-uniform, rare: first tile / the maximum jumped by more than log2(BIG)
                 float tmax = NEG_BIG;
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
@@ -581,20 +591,34 @@ __device__ __forceinline__ void tile_compute2(const uint8_t* buf, int key0, int 
 #pragma unroll
             for (int j = 0; j < 8; ++j) pf[j] = (typename E::elem)s[qt][st >> 1][(st & 1) * 8 + j];
 #pragma unroll
-            for (int dt = 0; dt < Y::DT_TILES; ++dt) o[qt][dt] = E::mfma32(vf[st][dt], pf, o[qt][dt]);
+            for (int dt = 0; dt < Y::DT_TILES; ++dt) {
+                if (APAD_ABL & 4) o[qt][dt][st] += (float)vf[st][dt][0] * (float)pf[0] + (float)pf[7];
+                else
+                o[qt][dt] = E::mfma32(vf[st][dt], pf, o[qt][dt]);
+            }
         }
     }
 }
 
+// Measured and removed (round 3; tools/ab_build.sh ablations of the direct loop, isolated, 64 x 8 heads x 1000 x 1000, 128.7 us):
+// without the exponentials 120.2, without the P.V MFMAs 117.0, without staging 114.6 (the barrier alone: 128.0), without the LDS
+// fragment reads 103.9, without staging AND fragment reads 83.2, without the denominators / range check 100.1, skeleton 26.9.
+//   * a three-stage LDS ring with the next tile's K fragments requested behind the score MFMAs, scalar-add denominators and one
+//     range check per tile pair: 130.8 us (no gain -- the exposed latencies are not the fragment reads');
+//   * the same ring with a BRANCH-FREE key loop (tile 0 classic to fix the reference point, a sticky out-of-window flag, classic
+//     recomputation of a flagged workgroup after the loop): 122 us with the recomputation compiled out, but 154 us with it
+//     inlined (+23 VGPRs, 6 scalar spills in the hot loop) and worse as a noinline call (scratch + 16 scalar spills).  A 5 % gain
+//     that needs a second launch per attention call for the flagged workgroups was not worth it.
+// An inline-asm v_add_f32 for the denominators read STALE registers: hipcc pads no hazards around asm, and a v_exp_f32 result
+// consumed by the next VALU instruction needs a wait state (caught by tests/test_gpu_kernels.py::test_attention_prescaled_q).
 // NW = waves per workgroup: 4 (256 queries) or, for d = 32, 8 (512 queries: the K / V^T tile of a (batch, head) is staged once
 // per CU instead of twice; waves 0-3 stage K, waves 4-7 stage V^T, one 16-byte chunk per thread)
-template <int DT, int D, int NW, bool DIRECT = false>
-__global__ __launch_bounds__(NW * 64) void attn2q_kernel(AttnP p) {
+template <int DT, int D, int NW, bool DIRECT>
+__device__ __forceinline__ void attn2q_body(const AttnP& p, uint8_t* smem) {
     using E = ET<DT>;
     using Y = Lay<D>;
     constexpr int KC = D / 16, QPW = NW * 64;
     static_assert(NW == 4 || (NW == 8 && D == 32), "the 8-wave staging split is written for d = 32");
-    __shared__ __attribute__((aligned(16))) uint8_t smem[2 * Y::BUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int nbh = p.B * p.H;
@@ -692,11 +716,15 @@ __global__ __launch_bounds__(NW * 64) void attn2q_kernel(AttnP p) {
         int t = 0;
         for (; t < nfull; ++t) {
             const uint8_t* buf = smem + (t & 1) * Y::BUF;
+            if (!(APAD_ABL & 8)) {
             if (t + 1 < nfull) load_tile(t + 1, true);
             else if (t + 1 < ntiles) load_tile(t + 1, false);
+            }
             tile_compute2<DT, D, false, DIRECT>(buf, t * KT, L, c, qf, o, osum, m, mi, l31, half);
+            if (!(APAD_ABL & 8)) {
             if (t + 1 < ntiles) store_tile(smem + ((t + 1) & 1) * Y::BUF);
-            __syncthreads();
+            if (!(APAD_ABL & 16)) __syncthreads();
+            }
         }
         for (; t < ntiles; ++t) {
             const uint8_t* buf = smem + (t & 1) * Y::BUF;
@@ -740,6 +768,12 @@ __global__ __launch_bounds__(NW * 64) void attn2q_kernel(AttnP p) {
             }
         }
     }
+}
+
+template <int DT, int D, int NW, bool DIRECT = false>
+__global__ __launch_bounds__(NW * 64) void attn2q_kernel(AttnP p) {
+    __shared__ __attribute__((aligned(16))) uint8_t smem[2 * Lay<D>::BUF];
+    attn2q_body<DT, D, NW, DIRECT>(p, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
