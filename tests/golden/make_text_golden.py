@@ -95,9 +95,47 @@ def build():
     return out
 
 
+def build_real_widths():
+    """outputs of the installed transformers modules at the real layer widths, on the seeded weights of text_models.real_width_modules
+    (copied INTO the transformers modules: the HIP modules use their parameter names)"""
+    from text_models import REAL_CLAP_CFG, REAL_GPT2_CFG, REAL_T5_CFG, real_width_inputs, real_width_modules
+    from transformers import ClapAudioConfig, ClapConfig, ClapModel, ClapTextConfig, GPT2Config, GPT2Model, T5Config, T5EncoderModel
+    ours_clap, ours_t5, ours_gpt = real_width_modules()
+
+    def fill(hf, ours):
+        sd = ours.state_dict()
+        missing, unexpected = hf.load_state_dict(sd, strict=False)
+        assert not unexpected, unexpected  # every HIP-module parameter exists under the same name in the transformers module
+        return [k for k in missing]
+
+    tc = ClapTextConfig(**{k: v for k, v in REAL_CLAP_CFG.items()})
+    ac = ClapAudioConfig(patch_embeds_hidden_size=8, depths=[1, 1], num_attention_heads=[1, 1], hidden_size=16, num_mel_bins=16, spec_size=32,
+                         patch_size=4, patch_stride=[4, 4], window_size=2, projection_dim=512)
+    clap = ClapModel(ClapConfig(text_config=tc.to_dict(), audio_config=ac.to_dict(), projection_dim=512)).eval()
+    left = [k for k in fill(clap, ours_clap) if k.startswith("text_") and "position_ids" not in k and "token_type_ids" not in k]
+    assert not left, left  # the whole text branch was overwritten (the audio tower keeps its own init: unused by get_text_features)
+    c5 = T5Config(feed_forward_proj="gated-gelu", **{k: v for k, v in REAL_T5_CFG.items()})
+    t5 = T5EncoderModel(c5).eval()
+    assert not fill(t5, ours_t5)
+    cg = GPT2Config(**REAL_GPT2_CFG)
+    gpt = GPT2Model(cg).eval()
+    left = [k for k in fill(gpt, ours_gpt) if not k.endswith(".attn.bias") and not k.endswith(".attn.masked_bias")]
+    assert not left, left
+    ids, mask, tid, tmask, x = real_width_inputs()
+    with torch.no_grad():
+        rc = clap.get_text_features(ids, attention_mask=mask)
+        rc = getattr(rc, "pooler_output", rc)
+        r5 = t5(tid, attention_mask=tmask)[0]
+        rg = gpt(inputs_embeds=x).last_hidden_state
+    return {"clap.out": rc.contiguous(), "t5.out": r5.contiguous(), "gpt2.out": rg.contiguous()}
+
+
 if __name__ == "__main__":
     from safetensors.torch import save_file
-    from text_models import GOLD
+    from text_models import GOLD, GOLD_REAL
+    real = build_real_widths()
+    save_file(real, GOLD_REAL)
+    print(f"wrote {GOLD_REAL}: {len(real)} tensors, {sum(v.numel() * v.element_size() for v in real.values()) / 1e6:.2f} MB")
     o = {k: v.detach().clone().contiguous() for k, v in build().items()}  # (some entries alias one another: masks handed through)
     save_file(o, GOLD)
     print(f"wrote {GOLD}: {len(o)} tensors, {sum(v.numel() * v.element_size() for v in o.values()) / 1e6:.2f} MB")

@@ -82,3 +82,18 @@ def test_committed_fixture_equals_the_installed_transformers_outputs():
             assert torch.equal(v, gold[k]), k
         else:
             assert float((v - gold[k]).abs().max()) <= 1e-5 * max(float(gold[k].abs().max()), 1.0), k
+
+
+def test_real_width_fixture_equals_the_installed_transformers_outputs():
+    """tests/golden/text_encoders_real_widths.safetensors re-derived from the live transformers modules carrying the seeded weights (the
+    GPU test builds the same weights from the same seed and never imports transformers)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_text_golden as G
+    from safetensors.torch import load_file
+    from text_models import GOLD_REAL
+    fresh, gold = G.build_real_widths(), load_file(GOLD_REAL)
+    assert set(fresh) == set(gold)
+    for k, v in fresh.items():
+        assert float((v - gold[k]).abs().max()) <= 1e-5 * max(float(gold[k].abs().max()), 1.0), k

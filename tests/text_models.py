@@ -114,3 +114,52 @@ def ours_from(tm, tc, kind, dev=None):
     missing, unexpected = o.load_state_dict(sd, strict=False)
     assert not missing, missing  # every parameter of the HIP module exists under the same name in the transformers module
     return (o.to(dev) if dev is not None else o), unexpected
+
+
+# ---- real layer widths (cvssp/audioldm2: CLAP text tower 768 / 12 heads / 3072 at its 512-token padding, flan-t5-large 1024 / 16 heads /
+# d_ff 2816, GPT-2 768 / 12 heads), depth and vocabulary cut so the check stays light.  The weights are NOT stored: both sides build them
+# from a seed with seeded_weights_ (the generator copies them into the transformers modules), the fixture holds inputs and outputs only.
+GOLD_REAL = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "text_encoders_real_widths.safetensors")
+REAL_CLAP_CFG = dict(vocab_size=2000, hidden_size=768, num_hidden_layers=2, num_attention_heads=12, intermediate_size=3072,
+                     max_position_embeddings=514, projection_dim=512, pad_token_id=1, layer_norm_eps=1e-12)
+REAL_T5_CFG = dict(vocab_size=2000, d_model=1024, d_kv=64, d_ff=2816, num_layers=2, num_heads=16, relative_attention_num_buckets=32,
+                   relative_attention_max_distance=128, layer_norm_epsilon=1e-6)
+REAL_GPT2_CFG = dict(n_positions=1024, n_embd=768, n_layer=2, n_head=12, layer_norm_epsilon=1e-5, vocab_size=2000)
+
+
+def seeded_weights_(module, seed):
+    """fill every parameter of ``module`` (CPU) from a frozen per-parameter stream, in name order: matrices N(0, 0.05^2) (T5's
+    relative-position table N(0, 0.5^2) so that it matters), normalisation gains 1 + 0.1 N(0,1), other vectors N(0, 0.02^2)"""
+    with torch.no_grad():
+        for i, (name, p) in enumerate(sorted(module.named_parameters(), key=lambda kv: kv[0])):
+            g = torch.Generator().manual_seed(seed * 1000 + i)
+            r = torch.randn(p.shape, generator=g)
+            if p.dim() > 1:
+                p.copy_(r * (0.5 if "relative_attention_bias" in name else 0.05))
+            elif name.endswith("weight") and any(t in name.lower() for t in ("norm", "ln_")):
+                p.copy_(1.0 + 0.1 * r)
+            else:
+                p.copy_(0.02 * r)
+    return module
+
+
+def real_width_modules():
+    """the three HIP modules at the real widths with their seeded weights (CPU)"""
+    import ap_adapter_amd.text_encoders as TE
+    clap = seeded_weights_(TE.ClapTextModelWithProjection(TE.ClapTextConfig(**REAL_CLAP_CFG)), 31)
+    t5 = seeded_weights_(TE.T5EncoderModel(TE.T5Config(**REAL_T5_CFG)), 32)
+    gpt = seeded_weights_(TE.GPT2Model(TE.GPT2Config(**REAL_GPT2_CFG)), 33)
+    return clap, t5, gpt
+
+
+def real_width_inputs():
+    ids = torch.randint(3, 2000, (2, 512), generator=torch.Generator().manual_seed(21))
+    mask = torch.ones_like(ids)
+    for b, n in enumerate((11, 40)):  # "max_length" padding: a few tokens, then ~500 pads
+        mask[b, n:] = 0
+        ids[b, n:] = REAL_CLAP_CFG["pad_token_id"]
+    tid = torch.randint(0, 2000, (2, 27), generator=torch.Generator().manual_seed(22))
+    tmask = torch.ones_like(tid)
+    tmask[1, 19:] = 0
+    x = torch.randn(2, 33, 768, generator=torch.Generator().manual_seed(23))
+    return ids, mask, tid, tmask, x
