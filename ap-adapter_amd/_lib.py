@@ -30,7 +30,8 @@ class GemmDesc(C.Structure):
                                     "stride", "Hup", "Wup", "src_batch_mod", "residual_row_mod", "heads", "head_dim", "L", "Lpad")] + \
                [("out2", _vp), ("out3", _vp)] + \
                [(n, _i32) for n in ("taps", "dilation", "pad", "transposed", "a_pre_act")] + [("a_pre_slope", _f32)] + \
-               [("conv_asym_pad", _i32), ("reserved_conv", _i32)]
+               [("conv_asym_pad", _i32), ("reserved_conv", _i32)] + \
+               [(n, _vp) for n in ("rowstat_out", "rowstat_in", "ln_colsum", "ln_bias")] + [("rowstat_in_tiles", _i32), ("ln_eps", _f32)]
 
 
 class AttnDesc(C.Structure):

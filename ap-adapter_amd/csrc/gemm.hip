@@ -56,6 +56,14 @@ struct GemmP {
     int32_t taps, dilation, pad, transposed, pre_act;  // APAD_A_CONV1D
     float pre_slope;
     int32_t lead;  // conv3x3: zero rows / columns before the first source row / column (1, or 0 with conv_asym_pad)
+    // LayerNorm folded into the contraction (apad_gemm_desc::rowstat_in): a = RAW rows, w = gamma-scaled weights,
+    // out = rstd_m * (acc - mean_m * ln_cs[n]) + ln_bb[n]; the row statistics are summed from the producing kernel's partials
+    float* rs_out;        // [M][rs_out_tiles][2]: per 64-column block (sum, sum of squares) of the stored output row
+    const float* rs_in;   // [M][rs_in_tiles][2]
+    const float* ln_cs;   // [w rows]
+    const float* ln_bb;   // [w rows]
+    int32_t rs_in_tiles, rs_out_tiles;
+    float ln_eps;
 };
 
 // byte offset of 16-byte chunk `chunk` (0..7) of tile row `row` (128-byte rows)
@@ -166,6 +174,23 @@ __global__ __launch_bounds__(256 * KG) void gemm_kernel(GemmP p) {
         return n0 + nl < p.N;
     };
 
+    // LayerNorm-by-algebra: mean / rstd of this tile's rows, summed in a fixed order from the producer's 64-column partials
+    __shared__ float rstat[TM][2];
+    if (p.rs_in != nullptr && threadIdx.x < BM) {
+        const int64_t m = m0 + threadIdx.x;
+        float s1 = 0.f, s2 = 0.f;
+        if (m < p.M) {
+            const float* src = p.rs_in + m * p.rs_in_tiles * 2;
+            for (int t_ = 0; t_ < p.rs_in_tiles; ++t_) {
+                s1 += src[2 * t_];
+                s2 += src[2 * t_ + 1];
+            }
+        }
+        const float mean = s1 / (float)p.K;
+        const float var = fmaxf(s2 / (float)p.K - mean * mean, 0.f);
+        rstat[threadIdx.x][0] = mean;
+        rstat[threadIdx.x][1] = rsqrtf(var + p.ln_eps);
+    }
     // per-thread staging assignment: rows (tid>>3) + 32*i, 16-byte chunk tid&7
     const int chunk = tid & 7;
     RowInfo<AMODE> ra[NLD];
@@ -282,19 +307,33 @@ __global__ __launch_bounds__(256 * KG) void gemm_kernel(GemmP p) {
         }
     };
 
+    // CONV3X3_FAST tracks (tap, channel) of the next tile to load incrementally: skip n tiles
+    auto fskip = [&](int n) {
+        if constexpr (AMODE == APAD_A_CONV3X3_FAST) {
+            for (int i = 0; i < n; ++i) {
+                fc0 += BK;
+                if (fc0 >= p.Cin) { fc0 = 0; ++ftap; }
+            }
+        }
+    };
     if constexpr (KG > 1) {
     // in-workgroup split-K: group kg owns k-tiles kg, kg + KG, ...; every group runs the same number of barriers
     static_assert(KG == 1 || (NS == 1 && PF == 1), "the K-group loop is written for one LDS stage per group");
     const int nit = (nk + KG - 1) / KG;
+    fskip(kg);
     if (kg < nk) {
         gload(kg, ga[0], gb[0]);
+        fskip(KG - 1);
         sstore(ga[0], gb[0]);
     }
     __syncthreads();
     for (int it = 0; it < nit; ++it) {
         const int kt = it * KG + kg;
         const bool more = kt + KG < nk;  // wave-uniform
-        if (more) gload(kt + KG, ga[0], gb[0]);
+        if (more) {
+            gload(kt + KG, ga[0], gb[0]);
+            fskip(KG - 1);
+        }
         if (kt < nk) compute();
         if (it + 1 < nit) {
             __syncthreads();
@@ -381,12 +420,15 @@ __global__ __launch_bounds__(256 * KG) void gemm_kernel(GemmP p) {
         const int64_t wr = nvalid ? wrow(nl) : 0;
         const float bv = (p.bias && nvalid) ? ld_elem<DT>(p.bias, wr) : 0.f;
         const float rg0 = (p.rg && one_group && nvalid) ? ld_elem<DT>(p.rg, step * p.ld_rg + wr) : 0.f;
+        const bool lnf = p.rs_in != nullptr;
+        const float lcs = (lnf && nvalid) ? p.ln_cs[wr] : 0.f, lbb = (lnf && nvalid) ? p.ln_bb[wr] : 0.f;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ml = wm * WT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 float v = acc[i][j][r] + bv + rg0;
+                if (lnf) v = rstat[ml][1] * (acc[i][j][r] - rstat[ml][0] * lcs) + lbb + rg0;
                 if (p.rg && !one_group) {
                     int64_t m = m0 + ml;
                     if (m < p.M && nvalid) v += ld_elem<DT>(p.rg, (m / p.rows_per_group + step) * p.ld_rg + wr);
@@ -407,6 +449,46 @@ __global__ __launch_bounds__(256 * KG) void gemm_kernel(GemmP p) {
         uint8_t* const obase = (OUTMODE == APAD_OUT_QKV && qseg == 1) ? p.out2 : p.out;
         const int64_t ncol0 = (OUTMODE == APAD_OUT_QKV) ? (int64_t)qseg * Cq : 0;
         constexpr int VPR = BN_OUT / 8;  // 16-byte vectors per output row
+        if (p.rs_out != nullptr && VPR >= 8 && OUTMODE == APAD_OUT_ROWMAJOR) {
+            // the same store loop, plus the row statistics of what is stored: 8 consecutive lanes own 64 consecutive columns of one
+            // row (BM * VPR is a multiple of the thread count, so a group is never split and every lane takes part in the shuffles)
+            for (int idx = threadIdx.x; idx < BM * VPR; idx += NT) {
+                const int rl = idx / VPR, vc = idx - rl * VPR;
+                const int64_t m = m0 + rl, n = n0 + vc * 8;
+                const bool ok = m < p.M && n < p.N;
+                float f[8];
+                unpack8<DT>(*reinterpret_cast<const uint4*>(&ct[rl * C_LD + vc * 8]), f);
+                if (p.residual && ok) {
+                    float rr[8];
+                    const int64_t rm = p.res_mod > 0 ? m % p.res_mod : m;
+                    unpack8<DT>(*reinterpret_cast<const uint4*>(p.residual + (rm * p.ldr + n) * 2), rr);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = (float)(typename E::elem)f[e] + rr[e];
+                }
+                const uint4 pk = pack8<DT>(f);
+                float s1 = 0.f, s2 = 0.f;
+                if (ok) {
+                    *reinterpret_cast<uint4*>(obase + (m * p.ldo + (n - ncol0)) * 2) = pk;
+                    float g[8];
+                    unpack8<DT>(pk, g);  // statistics of the ROUNDED values: what the consumer will read
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        s1 += g[e];
+                        s2 = __builtin_fmaf(g[e], g[e], s2);
+                    }
+                }
+#pragma unroll
+                for (int o_ = 1; o_ < 8; o_ <<= 1) {
+                    s1 += __shfl_xor(s1, o_);
+                    s2 += __shfl_xor(s2, o_);
+                }
+                if (ok && (vc & 7) == 0) {
+                    float* dst = p.rs_out + (m * p.rs_out_tiles + (n >> 6)) * 2;
+                    dst[0] = s1;
+                    dst[1] = s2;
+                }
+            }
+        } else
         for (int idx = threadIdx.x; idx < BM * VPR; idx += NT) {
             const int rl = idx / VPR, vc = idx - rl * VPR;
             const int64_t m = m0 + rl, n = n0 + vc * 8;
@@ -669,6 +751,12 @@ int launch(const GemmP& p, hipStream_t s) {
     // conv 63x4 384->384 76.5 -> 71.5 us, FF2 M=16128 K=1536 38.5 -> 37.1 us), short-K launches prefer the 64-tile
     static const int t128_min = [] { const char* e = getenv("APAD_GEMM_T128_MIN"); return e ? atoi(e) : 512; }();  // (A/B knob)
     const bool t128 = blocks128 >= t128_min || (blocks128 >= 320 && t128_min <= 512 && p.K >= 1024);
+    if constexpr (AMODE == APAD_A_CONV3X3_FAST && EPI == APAD_EPI_NONE && OUTMODE == APAD_OUT_ROWMAJOR) {
+        // under-filled 3x3 convolutions (the 640- / 384-wide resnets: 90..180 k-tiles on a few hundred 64x64 tiles): K groups
+        static const int conv_kg = [] { const char* e = getenv("APAD_CONV_KG"); return e ? atoi(e) : 0; }();  // (A/B knob)
+        if (!t128 && conv_kg >= 4) return launch_tm<DT, AMODE, EPI, OUTMODE, 64, 1, 4>(p, s);
+        if (!t128 && conv_kg >= 2) return launch_tm<DT, AMODE, EPI, OUTMODE, 64, 1, 2>(p, s);
+    }
     if constexpr (AMODE == APAD_A_CONV3X3_FAST || AMODE == APAD_A_CONV3X3 || AMODE == APAD_A_CONV1D) {
         static const bool one_stage = getenv("APAD_GEMM_ONE_STAGE") != nullptr;
         // long reductions on launches of <= ~4 workgroups per CU: two LDS stages, one barrier per k-tile (larger grids
@@ -676,14 +764,15 @@ int launch(const GemmP& p, hipStream_t s) {
         if (p.K >= 2048 && blocks128 <= 1024 && !one_stage)
             return t128 ? launch_tm<DT, AMODE, EPI, OUTMODE, 128, 2>(p, s) : launch_tm<DT, AMODE, EPI, OUTMODE, 64, 2>(p, s);
     }
-    if (t128) return launch_tm<DT, AMODE, EPI, OUTMODE, 128>(p, s);
-    if constexpr (AMODE == APAD_A_PLAIN && (EPI == APAD_EPI_NONE || EPI == APAD_EPI_GEGLU)) {
-        // under-filled launches with a k-loop worth splitting: K groups inside the workgroup (APAD_GEMM_KG = 1 | 2 | 4, A/B knob)
-        static const int kg_mode = [] { const char* e = getenv("APAD_GEMM_KG"); return e ? atoi(e) : 2; }();
-        const int nk = (int)((p.K + BK - 1) / BK);
-        if (kg_mode >= 4 && nk >= 16) return launch_tm<DT, AMODE, EPI, OUTMODE, 64, 1, 4>(p, s);
-        if (kg_mode >= 2 && nk >= 4) return launch_tm<DT, AMODE, EPI, OUTMODE, 64, 1, 2>(p, s);
+    if constexpr (AMODE == APAD_A_PLAIN && EPI == APAD_EPI_NONE) {
+        // K groups inside the workgroup for the skinny launches of the 640- / 384-wide levels.  The choice depends on (N, K) ONLY,
+        // never on M, and both tile sizes implement it: a row's k-summation order must not change with the batch size -- a clip's
+        // result is bit-identical whatever batch it rides in (tests/test_gpu_unet.py::test_full_size_clips_are_independent_of_their_batch)
+        static const int kg_mode = [] { const char* e = getenv("APAD_GEMM_KG"); return e ? atoi(e) : 2; }();  // (A/B knob: 1 = off)
+        if (kg_mode >= 2 && p.K >= 384 && p.N >= 384)
+            return t128 ? launch_tm<DT, AMODE, EPI, OUTMODE, 128, 1, 2>(p, s) : launch_tm<DT, AMODE, EPI, OUTMODE, 64, 1, 2>(p, s);
     }
+    if (t128) return launch_tm<DT, AMODE, EPI, OUTMODE, 128>(p, s);
     return launch_tm<DT, AMODE, EPI, OUTMODE, 64>(p, s);
 }
 
@@ -804,6 +893,14 @@ extern "C" int apad_gemm(const apad_gemm_desc* d, void* stream) {
         return -1;
     }
     if (d->rowgroup_bias) APAD_CHECK(d->ld_rg > 0, "apad_gemm: rowgroup_bias needs ld_rg");
+    p.rs_out = d->rowstat_out; p.rs_in = d->rowstat_in; p.ln_cs = d->ln_colsum; p.ln_bb = d->ln_bias;
+    p.rs_in_tiles = d->rowstat_in_tiles; p.rs_out_tiles = (int32_t)((d->N + 63) / 64); p.ln_eps = d->ln_eps;
+    if (d->rowstat_out)
+        APAD_CHECK(d->out_mode == APAD_OUT_ROWMAJOR && (d->epilogue == APAD_EPI_NONE || d->epilogue == APAD_EPI_SILU || d->epilogue == APAD_EPI_GELU) &&
+                       d->N % 64 == 0, "apad_gemm: rowstat_out needs a row-major output with N %% 64 == 0 and no GEGLU");
+    if (d->rowstat_in)
+        APAD_CHECK(d->ln_colsum && d->ln_bias && d->rowstat_in_tiles > 0 && d->a_mode == APAD_A_PLAIN && !d->bias,
+                   "apad_gemm: rowstat_in (folded LayerNorm) needs ln_colsum, ln_bias (which carries the layer's bias), rowstat_in_tiles, a plain A operand");
     hipStream_t s = (hipStream_t)stream;
     return d->dtype == APAD_BF16 ? dispatch_amode<APAD_BF16>(p, d, s) : dispatch_amode<APAD_F16>(p, d, s);
 }

@@ -40,9 +40,15 @@ def round_up(x, m):
 
 def gemm(a, w, *, M, N, K, lda, out, ldo, bias=None, residual=None, ldr=0, act=None, rowgroup_bias=None, ld_rg=0,
          rows_per_group=0, step_ptr=None, a_mode=L.A_PLAIN, out_mode=L.OUT_ROWMAJOR, conv=None, vt=None, ldw=None,
-         residual_row_mod=0, asym_pad=False):
-    """Raw descriptor call; the typed helpers below are what the model code uses."""
+         residual_row_mod=0, asym_pad=False, rowstat_out=None, ln_fold=None):
+    """Raw descriptor call; the typed helpers below are what the model code uses.  rowstat_out: fp32 [M, N/64, 2] side output
+    (row statistics of the stored rows); ln_fold = (rowstat_in [M, T, 2], colsum, bias_fp32, eps): LayerNorm by algebra."""
     d = L.GemmDesc()
+    if rowstat_out is not None:
+        d.rowstat_out = rowstat_out.data_ptr()
+    if ln_fold is not None:
+        rs, cs, bb, eps = ln_fold
+        d.rowstat_in, d.ln_colsum, d.ln_bias, d.rowstat_in_tiles, d.ln_eps = rs.data_ptr(), cs.data_ptr(), bb.data_ptr(), rs.shape[-2], float(eps)
     d.a, d.w, d.out = a.data_ptr(), w.data_ptr(), out.data_ptr()
     d.bias, d.residual, d.rowgroup_bias, d.step_ptr = _ptr(bias), _ptr(residual), _ptr(rowgroup_bias), _ptr(step_ptr)
     d.M, d.N, d.K, d.lda, d.ldw, d.ldo, d.ldr, d.ld_rg = M, N, K, lda, (K if ldw is None else ldw), ldo, ldr, ld_rg
@@ -58,9 +64,47 @@ def gemm(a, w, *, M, N, K, lda, out, ldo, bias=None, residual=None, ldr=0, act=N
     return out
 
 
+import os as _os
+import weakref as _weakref
+
+# LayerNorm folded into the Linear behind it where no fused row-panel kernel covers the width (the 640-wide level): the producing
+# GEMM emits row statistics, the consuming GEMM applies (x - mean) * rstd * gamma + beta by algebra.  APAD_LN_FOLD=0: A/B switch
+LN_FOLD = _os.environ.get("APAD_LN_FOLD", "1") == "1"
+_fold_cache = {}
+
+
+def rowstat_of(x):
+    """the row statistics [M, C/64, 2] the producing GEMM left for x (an attribute of THAT tensor object: views and copies do not
+    carry it, and nothing on this path writes into x after its producer), or None"""
+    return getattr(x, "_apad_rowstat", None)
+
+
+def _ln_folded(w, bias, gamma, beta):
+    """(w * gamma in the storage type, its fp32 row sums, fp32 beta . W^T + bias) of a Linear behind a LayerNorm; cached per weight,
+    rebuilt when any of the four parameters is re-assigned or updated"""
+    ps = (w, bias, gamma, beta)
+    sig = tuple(None if p is None else (id(p), p.data_ptr(), p._version, p.dtype, p.device) for p in ps)
+    hit = _fold_cache.get(id(w))
+    if hit is None or hit[0] != sig or hit[2]() is not w:
+        if len(_fold_cache) > 1024:
+            for k in [k for k, v in _fold_cache.items() if v[2]() is None]:
+                del _fold_cache[k]
+        wf = w.detach().float()
+        wg = (wf * gamma.detach().float()).to(w.dtype).contiguous()
+        cs = wg.float().sum(1).contiguous()
+        bb = wf @ beta.detach().float()
+        if bias is not None:
+            bb = bb + bias.detach().float()
+        hit = (sig, (wg, cs, bb.contiguous()), _weakref.ref(w))
+        _fold_cache[id(w)] = hit
+    return hit[1]
+
+
 def linear(x, w, bias=None, residual=None, act=None, out=None, rowgroup_bias=None, rows_per_group=0, step_ptr=None,
-           residual_row_mod=0):
-    """x [..., K] (row stride = K) @ w[N(or 2N for geglu), K]^T -> [..., N]."""
+           residual_row_mod=0, rowstat=False, ln=None):
+    """x [..., K] (row stride = K) @ w[N(or 2N for geglu), K]^T -> [..., N].
+    rowstat: also emit the row statistics of the result (for a folded LayerNorm in the NEXT Linear; retrieved with rowstat_of).
+    ln = (gamma, beta, eps): LayerNorm(x) first -- only valid when rowstat_of(x) exists (the caller checks ln_foldable)."""
     _req(x, "linear.x", w.dtype)
     _req(w, "linear.w")
     K = x.shape[-1]
@@ -70,10 +114,27 @@ def linear(x, w, bias=None, residual=None, act=None, out=None, rowgroup_bias=Non
     if out is None:
         out = torch.empty(*x.shape[:-1], N, dtype=w.dtype, device=x.device)
     r2 = None if residual is None else _req(residual, "linear.residual", w.dtype).reshape(-1, N)
+    fold = rs_out = None
+    if ln is not None:
+        rs = rowstat_of(x)
+        if rs is None:
+            raise RuntimeError("linear(ln=...): no row statistics for x (use fused_linear, which falls back to apad_layernorm)")
+        w, cs, bb = _ln_folded(w, bias, ln[0], ln[1])
+        bias, fold = None, (rs, cs, bb, ln[2])
+    if rowstat and LN_FOLD and N % 64 == 0 and N not in RP_K and act in (None, "none") and w.dtype in FUSED_DTYPES:
+        rs_out = torch.empty(M, N // 64, 2, dtype=torch.float32, device=x.device)
     gemm(x2, w, M=M, N=N, K=K, lda=x2.stride(0), out=out, ldo=N, bias=bias, residual=r2, ldr=N, act=act,
          rowgroup_bias=rowgroup_bias, ld_rg=(rowgroup_bias.stride(0) if rowgroup_bias is not None else 0),
-         rows_per_group=rows_per_group, step_ptr=step_ptr, ldw=w.stride(0), residual_row_mod=residual_row_mod)
+         rows_per_group=rows_per_group, step_ptr=step_ptr, ldw=w.stride(0), residual_row_mod=residual_row_mod,
+         rowstat_out=rs_out, ln_fold=fold)
+    if rs_out is not None:
+        out._apad_rowstat = rs_out
     return out
+
+
+def ln_foldable(x, w):
+    """a LayerNorm in front of this Linear can be folded: 16-bit, statistics available, a width the row-panel kernel does not cover"""
+    return LN_FOLD and x.dtype in FUSED_DTYPES and not rp_ok(x) and rowstat_of(x) is not None and w.shape[1] == x.shape[-1]
 
 
 RP_K = (256, 384)  # reduction dims the row-panel kernel covers
@@ -110,8 +171,9 @@ def rowpanel(x, w, segs, ln=None, residual=None, act=None, vt_geom=None):
     return [s[0] for s in segs]
 
 
-def fused_linear(x, w, bias=None, ln=None, residual=None, act=None, out=None):
-    """LayerNorm? -> Linear -> activation? (+ residual).  One row-panel launch when K is in its envelope, otherwise
+def fused_linear(x, w, bias=None, ln=None, residual=None, act=None, out=None, rowstat=False):
+    """LayerNorm? -> Linear -> activation? (+ residual).  One row-panel launch when K is in its envelope; otherwise apad_gemm with
+    the LayerNorm folded in when the kernel that produced x left its row statistics (rowstat=True on that call), else
     apad_layernorm + apad_gemm."""
     K = x.shape[-1]
     N = w.shape[0] // 2 if act == "geglu" else w.shape[0]
@@ -120,9 +182,11 @@ def fused_linear(x, w, bias=None, ln=None, residual=None, act=None, out=None):
             out = torch.empty(*x.shape[:-1], N, dtype=w.dtype, device=x.device)
         rowpanel(x, w, [(out, bias, N, "row")], ln=ln, residual=residual, act=act)
         return out
+    if ln is not None and ln_foldable(x, w):
+        return linear(x, w, bias, residual=residual, act=act, out=out, rowstat=rowstat, ln=ln)
     if ln is not None:
         x = layer_norm(x, ln[0], ln[1], ln[2])
-    return linear(x, w, bias, residual=residual, act=act, out=out)
+    return linear(x, w, bias, residual=residual, act=act, out=out, rowstat=rowstat)
 
 
 XATTN_C, XATTN_HEADS, XATTN_MAXL = 256, 8, 64  # envelope of apad_fused_cross_attention
@@ -213,10 +277,15 @@ def linear_vt(x, w, B, Lk, heads, out_vt, bias=None):
     return out_vt
 
 
-def linear_qkv(x, w_qkv, B, Lk, heads, q, k, vt, bias=None):
+def linear_qkv(x, w_qkv, B, Lk, heads, q, k, vt, bias=None, ln=None):
     """Fused q|k|v projection on the tiled kernel (any K): x [B*Lk, K] @ w_qkv[3C, K]^T -> q, k [B*Lk, C] row-major and
-    vt [B, heads, d, Lpad] per-head transposed, one launch."""
+    vt [B, heads, d, Lpad] per-head transposed, one launch.  ln = (gamma, beta, eps): LayerNorm(x) folded in (needs rowstat_of(x))."""
     _req(x, "linear_qkv.x", w_qkv.dtype)
+    fold = None
+    if ln is not None:
+        rs = rowstat_of(x)
+        w_qkv, cs, bb = _ln_folded(w_qkv, bias, ln[0], ln[1])
+        bias, fold = None, (rs, cs, bb, ln[2])
     K = x.shape[-1]
     C3 = w_qkv.shape[0]
     Cc = C3 // 3
@@ -227,6 +296,9 @@ def linear_qkv(x, w_qkv, B, Lk, heads, q, k, vt, bias=None):
     d.M, d.N, d.K, d.lda, d.ldw, d.ldo = B * Lk, C3, K, x2.stride(0), w_qkv.stride(0), Cc
     d.a_mode, d.epilogue, d.out_mode, d.dtype = L.A_PLAIN, L.EPI_NONE, L.OUT_QKV, _DT[w_qkv.dtype]
     d.heads, d.head_dim, d.L, d.Lpad = heads, Cc // heads, Lk, vt.shape[-1]
+    if fold is not None:
+        rs, cs, bb, eps = fold
+        d.rowstat_in, d.ln_colsum, d.ln_bias, d.rowstat_in_tiles, d.ln_eps = rs.data_ptr(), cs.data_ptr(), bb.data_ptr(), rs.shape[-2], float(eps)
     L.check(L.lib().apad_gemm(C.byref(d), _stream()), "apad_gemm(qkv)")
     return q, k, vt
 

@@ -204,12 +204,15 @@ class AttnProcessor2_0(nn.Module):
                 ops.rowpanel(hidden_states, self._qkv_weight(attn, prescaled), [(q, None, C_, "row"), (k, None, C_, "row"), (vt, None, C_, "vt")],
                              ln=_ln, vt_geom=(heads, C_ // heads, N, vt.shape[-1]))
             elif attn.to_q.weight.shape[0] == C_ and C_ % 128 == 0:  # (fp32 mode: every width whose C % 128 == 0)
-                # widths outside the row-panel envelope (the 640-wide level): LayerNorm, then q|k|v in ONE tiled launch
-                hs = hidden_states if _ln is None else ops.layer_norm(hidden_states, *_ln)
+                # widths outside the row-panel envelope (the 640-wide level): q|k|v in ONE tiled launch, the LayerNorm folded into
+                # it when the GEMM that produced hidden_states left its row statistics (ops.LN_FOLD), else a LayerNorm launch first
+                qkv_w = self._qkv_weight(attn)
+                fold = _ln is not None and ops.ln_foldable(hidden_states, qkv_w)
+                hs = hidden_states if (_ln is None or fold) else ops.layer_norm(hidden_states, *_ln)
                 q = torch.empty(B, N, C_, dtype=hidden_states.dtype, device=hidden_states.device)
                 k = torch.empty_like(q)
                 vt = vt_buffer("self", B, heads, C_ // heads, N, hidden_states.dtype, hidden_states.device)
-                ops.linear_qkv(hs, self._qkv_weight(attn), B, N, heads, q, k, vt)
+                ops.linear_qkv(hs, qkv_w, B, N, heads, q, k, vt, ln=_ln if fold else None)
             else:
                 hs = hidden_states if _ln is None else ops.layer_norm(hidden_states, *_ln)
                 q = ops.linear(hs, attn.to_q.weight)
@@ -244,7 +247,7 @@ class AttnProcessor2_0(nn.Module):
         if q is None:
             q = ops.fused_linear(hidden_states, attn.to_q.weight, ln=_ln)
         o = ops.attention(q, k, vt, Lk, heads, key_bias=bias, q_prescaled=prescaled)
-        out = ops.fused_linear(o, attn.to_out[0].weight, attn.to_out[0].bias, residual=_residual)
+        out = ops.fused_linear(o, attn.to_out[0].weight, attn.to_out[0].bias, residual=_residual, rowstat=True)
         if attn.residual_connection:
             raise NotImplementedError("residual_connection=True is not on the AudioLDM2 path")
         if attn.rescale_output_factor != 1.0:
@@ -374,7 +377,7 @@ class IPAttnProcessor2_0(nn.Module):
                                              key_bias=bias, kv2_packed=pk_a, L2=La, scale2=self.scale)
         q = ops.fused_linear(hidden_states, attn.to_q.weight, ln=_ln)
         o = ops.attention(q, k_t, vt_t, Lt, attn.heads, key_bias=bias, k2=k_a, vt2=vt_a, L2=La, scale2=self.scale)
-        out = ops.fused_linear(o, attn.to_out[0].weight, attn.to_out[0].bias, residual=_residual)
+        out = ops.fused_linear(o, attn.to_out[0].weight, attn.to_out[0].bias, residual=_residual, rowstat=True)
         if attn.residual_connection or attn.rescale_output_factor != 1.0:
             raise NotImplementedError("residual_connection / rescale_output_factor are not on the AudioLDM2 path")
         return out

@@ -157,7 +157,7 @@ class FeedForward(nn.Module):
         if x.shape[-1] in ops.MLP_C and x.dtype in ops.FUSED_DTYPES and os.environ.get("APAD_FUSED_MLP", "1") != "0":
             return ops.geglu_mlp(x, self.net[0].proj.weight, self.net[0].proj.bias, self.net[2].weight, self.net[2].bias, ln=ln)
         h = ops.fused_linear(x, self.net[0].proj.weight, self.net[0].proj.bias, ln=ln, act="geglu")
-        return ops.linear(h, self.net[2].weight, self.net[2].bias, residual=x)
+        return ops.linear(h, self.net[2].weight, self.net[2].bias, residual=x, rowstat=True)  # (the next block's norm1 folds into its q|k|v)
 
 
 class BasicTransformerBlock(nn.Module):
@@ -197,7 +197,7 @@ class Transformer2DModel(nn.Module):
             h = AG.linear(h, self.proj_in.weight, self.proj_in.bias)
         else:
             h = ops.group_norm(x, self.norm.weight, self.norm.bias, self.groups, self.norm.eps, silu=False)
-            h = ops.fused_linear(h, _w2d(self.proj_in), self.proj_in.bias)
+            h = ops.fused_linear(h, _w2d(self.proj_in), self.proj_in.bias, rowstat=True)
         for blk in self.transformer_blocks:
             h = blk(h, ehs, emask)
         if AG.on(h, x):

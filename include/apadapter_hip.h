@@ -104,6 +104,20 @@ typedef struct apad_gemm_desc {
                                   1 = none on the top / left, one at the bottom / right (diffusers
                                   Downsample2D(padding=0): F.pad(x, (0,1,0,1)) then a stride-2 conv, the VAE encoder) */
     int32_t reserved_conv;
+    /* LayerNorm folded into the contraction (16-bit dtypes).  diffusers' BasicTransformerBlock runs norm -> Linear three times per
+       block; where no fused row-panel kernel covers the width (C = 640), the LayerNorm costs no launch and no pass over x:
+         producer  (the GEMM that writes x, e.g. to_out + residual):  rowstat_out[m][N/64][2] = per 64-column block (sum, sum of
+                   squares) of the stored row;
+         consumer  (the Linear behind the LayerNorm):  a = x RAW, w = weight * gamma (caller-prepared, storage type),
+                   out = epilogue( rstd_m * (a_m . w^T - mean_m * ln_colsum[n]) + ln_bias[n] ),
+                   ln_colsum[n] = sum_k w[n][k] (of the scaled, rounded weight), ln_bias[n] = sum_k beta[k] W[n][k] + bias[n] (fp32),
+                   mean_m / rstd_m summed in a fixed order from rowstat_in[m][0..rowstat_in_tiles). */
+    float* rowstat_out;
+    const float* rowstat_in;
+    const float* ln_colsum;
+    const float* ln_bias;
+    int32_t rowstat_in_tiles;
+    float ln_eps;
 } apad_gemm_desc;
 
 typedef struct apad_attn_desc {

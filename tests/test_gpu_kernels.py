@@ -591,3 +591,67 @@ def test_fused_cross_attention_outside_envelope(dev):
         ops.xattn_pack_kv(torch.zeros(1, 8, 384, device=dev, dtype=torch.bfloat16), torch.zeros(1, 8, 48, 32, device=dev, dtype=torch.bfloat16), 8)
     with pytest.raises(ValueError):
         ops.fused_cross_attention(x, w, w, None, w, 8, 8)
+
+
+# ---- LayerNorm folded into the Linear behind it (the 640-wide level: no row-panel kernel covers K = 640) ----
+@pytest.mark.parametrize("dtype", DTYPES16)
+@pytest.mark.parametrize("M,C_,mean_shift", [(2048, 640, 0.0), (300, 640, 3.0), (4096, 640, -8.0), (130, 768, 1.0)])
+def test_layernorm_folded_into_gemm(dev, dtype, M, C_, mean_shift):
+    """producer: a GEMM (+ bias + residual) that also emits the row statistics of what it stores; consumers: the three Linear
+    flavours a BasicTransformerBlock puts behind a LayerNorm (plain to_q, the GEGLU projection, fused q|k|v) with the normalisation
+    applied by algebra -- against fp32 LayerNorm + Linear on the stored rows.  mean_shift puts the rows far from zero mean (the
+    algebra subtracts mean * colsum from the accumulator)."""
+    from ap_adapter_amd import ops
+    D = lambda t: t.to(dev, dtype)
+    a, w0, b0 = q(R(M, 256, seed=201), dtype), q(R(C_, 256, seed=202, std=0.06), dtype), q(R(C_, seed=203, std=0.1) + mean_shift, dtype)
+    res = q(R(M, C_, seed=204), dtype)
+    x = ops.linear(D(a), D(w0), D(b0), residual=D(res), rowstat=True)                 # producer
+    x_ref = q((F.linear(a, w0, b0)).to(dtype).float() + res, dtype)                     # (linear output rounded before the add)
+    assert rel_err(x, x_ref) < TOL[dtype]
+    rs = ops.rowstat_of(x)
+    assert rs is not None and tuple(rs.shape) == (M, C_ // 64, 2)
+    xs = x.float().cpu()                                                               # statistics are those of the STORED rows
+    assert rel_err(rs[..., 0].sum(1), xs.sum(1)) < 1e-5 and rel_err(rs[..., 1].sum(1), (xs * xs).sum(1)) < 1e-5
+    g, be = q(1 + 0.2 * R(C_, seed=205), dtype), q(0.2 * R(C_, seed=206), dtype)
+    ln = (D(g), D(be), 1e-5)
+    xn = F.layer_norm(xs, (C_,), g, be, 1e-5)
+    # plain Linear (+ bias + residual), folded
+    w1, b1 = q(R(C_, C_, seed=207, std=0.05), dtype), q(R(C_, seed=208, std=0.1), dtype)
+    out = ops.fused_linear(x, D(w1), D(b1), ln=ln, residual=x)
+    assert rel_err(out, (F.linear(xn, w1, b1)).to(dtype).float() + xs) < TOL[dtype]
+    unf = ops.linear(ops.layer_norm(x, *ln), D(w1), D(b1), residual=x)                 # the un-folded chain it replaces
+    assert rel_err(out, unf.float().cpu()) < 1.5 * TOL[dtype]
+    # GEGLU projection, folded
+    w2, b2 = q(R(2 * 512, C_, seed=209, std=0.05), dtype), q(R(2 * 512, seed=210, std=0.2), dtype)
+    h = ops.fused_linear(x, D(w2), D(b2), ln=ln, act="geglu")
+    va, ga = F.linear(xn, w2, b2).chunk(2, dim=-1)
+    assert rel_err(h, va * F.gelu(ga)) < TOL[dtype]
+    # fused q|k|v, folded (C % 128 == 0 shapes only)
+    if C_ % 128 == 0 and M % 4 == 0:
+        heads, B = 8, 4
+        Lk = M // B
+        wq = q(R(3 * C_, C_, seed=211, std=0.05), dtype)
+        qo = torch.empty(B, Lk, C_, device=dev, dtype=dtype)
+        ko = torch.empty_like(qo)
+        vt = torch.zeros(B, heads, C_ // heads, ops.round_up(Lk, 32), device=dev, dtype=dtype)
+        ops.linear_qkv(x, D(wq), B, Lk, heads, qo, ko, vt, ln=ln)
+        qr, kr, vr = F.linear(xn, wq).chunk(3, dim=-1)
+        assert rel_err(qo.view(M, C_), qr) < TOL[dtype] and rel_err(ko.view(M, C_), kr) < TOL[dtype]
+        vref = vr.view(B, Lk, heads, C_ // heads).permute(0, 2, 3, 1)
+        assert rel_err(vt[..., :Lk], vref) < TOL[dtype]
+
+
+def test_layernorm_fold_needs_the_producers_statistics(dev):
+    """without row statistics on x (a tensor from anywhere else) fused_linear runs apad_layernorm + apad_gemm; a view of a
+    statistics-carrying tensor does not inherit them"""
+    from ap_adapter_amd import ops
+    dtype, M, C_ = torch.bfloat16, 256, 640
+    D = lambda t: t.to(dev, dtype)
+    x = D(q(R(M, C_, seed=220), dtype))
+    w, g, be = D(q(R(C_, C_, seed=221, std=0.05), dtype)), D(q(1 + 0.1 * R(C_, seed=222), dtype)), D(q(0.1 * R(C_, seed=223), dtype))
+    assert ops.rowstat_of(x) is None and not ops.ln_foldable(x, w)
+    out = ops.fused_linear(x, w, None, ln=(g, be, 1e-5))
+    ref = F.linear(F.layer_norm(x.float().cpu(), (C_,), g.float().cpu(), be.float().cpu(), 1e-5), w.float().cpu())
+    assert rel_err(out, ref) < TOL[dtype]
+    y = ops.linear(x, w, None, rowstat=True)
+    assert ops.rowstat_of(y) is not None and ops.rowstat_of(y[:128]) is None and ops.rowstat_of(y.clone()) is None

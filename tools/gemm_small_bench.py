@@ -36,3 +36,19 @@ for M, K, N, res, what in SHAPES:
     err = float((out.float() - ref).abs().max() / ref.abs().max())
     ms = time_kernel_graphed(lambda: ops.linear(x, w, b, residual=r, out=out))
     print(f"M={M:6d} K={K:5d} N={N:5d}  {ms * 1e3:7.2f} us  {2.0 * M * K * N / (ms * 1e-3) / 1e12:7.1f} TF/s  rel err {err:.2e}   {what}")
+
+# 3x3 convolutions of the low-resolution resnets (implicit GEMM, K = 9 Cin); APAD_CONV_KG=0|2|4
+import torch.nn.functional as F  # noqa: E402
+print("APAD_CONV_KG =", os.environ.get("APAD_CONV_KG", "(default)"))
+for B, H, W, Cin, Cout, what in [(32, 32, 2, 640, 640, "640 level, one stream half"), (64, 32, 2, 640, 640, "640 level"),
+                                 (32, 32, 2, 1280, 640, "640 level up-block, half"), (64, 32, 2, 1280, 640, "640 level up-block"),
+                                 (64, 63, 4, 384, 384, "384 level"), (64, 63, 4, 768, 384, "384 level up-block"),
+                                 (64, 125, 8, 256, 256, "256 level (128-tile)")]:
+    x = (torch.randn(B, H * W, Cin, device=dev) * 0.5).to(dt)
+    w = (torch.randn(Cout, 3, 3, Cin, device=dev) * 0.02).to(dt)
+    b = (torch.randn(Cout, device=dev) * 0.1).to(dt)
+    out, Ho, Wo = ops.conv3x3(x, w.reshape(Cout, -1), b, B, H, W)
+    ref = F.conv2d(x.float().view(B, H, W, Cin).permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), b.float(), padding=1)
+    err = float((out.float().view(B, H, W, Cout).permute(0, 3, 1, 2) - ref).abs().max() / ref.abs().max())
+    ms = time_kernel_graphed(lambda: ops.conv3x3(x, w.reshape(Cout, -1), b, B, H, W, out=out))
+    print(f"conv B={B:3d} {H}x{W} {Cin:4d}->{Cout:4d}  {ms * 1e3:7.2f} us  {2.0 * B * H * W * 9 * Cin * Cout / (ms * 1e-3) / 1e12:7.1f} TF/s  rel err {err:.2e}   {what}")
