@@ -769,7 +769,9 @@ int launch(const GemmP& p, hipStream_t s) {
         // never on M, and both tile sizes implement it: a row's k-summation order must not change with the batch size -- a clip's
         // result is bit-identical whatever batch it rides in (tests/test_gpu_unet.py::test_full_size_clips_are_independent_of_their_batch)
         static const int kg_mode = [] { const char* e = getenv("APAD_GEMM_KG"); return e ? atoi(e) : 2; }();  // (A/B knob: 1 = off)
-        if (kg_mode >= 2 && p.K >= 384 && p.N >= 384)
+        // (N >= 640: the 640-wide level's to_q / to_out / FF2 / q|k|v.  At N = 384 the FF2 of the 384-wide level, M = 16128 on 128-tiles,
+        //  measured 39 -> 58 us with K groups: the rule stops short of it)
+        if (kg_mode >= 2 && p.K >= 384 && p.N >= 640)
             return t128 ? launch_tm<DT, AMODE, EPI, OUTMODE, 128, 1, 2>(p, s) : launch_tm<DT, AMODE, EPI, OUTMODE, 64, 1, 2>(p, s);
     }
     if (t128) return launch_tm<DT, AMODE, EPI, OUTMODE, 128>(p, s);
