@@ -110,6 +110,7 @@ SYMBOLS = {
     "apad_echo_attn_bwd_desc": (C.c_int, [C.POINTER(AttnBwdDesc), C.POINTER(C.c_double), C.c_int]),
     "apad_attention_bwd": (C.c_int, [C.POINTER(AttnBwdDesc), _vp]),
     "apad_head_transpose": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "apad_head_transpose3": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "apad_layernorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _i32, _vp]),
     "apad_groupnorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp]),
     "apad_geglu": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),

@@ -354,8 +354,11 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
     // denominator of query l31: the two partial sums of both half-wave lanes that own it
     const float den = half_sum(osum[0] + osum[1]);
     float inv = 1.0f / den;
-    if (p.lse != nullptr && half == 0 && qvalid)  // log2 sum exp2 of the scaled (+biased) scores: what the backward re-uses
-        p.lse[((int64_t)b * p.H + h) * ((p.N + 31) & ~31) + q0 + l31] = m + __builtin_log2f(den);
+    // log2 sum exp2 of the scaled (+biased) scores: what the backward re-uses.  The pad entries [N, round_up(N, 32)) are written too
+    // (0): the backward multiplies exp2(s - lse) of padded queries by zero-padded operands, so they must be finite, and the caller
+    // need not pre-fill the buffer
+    if (p.lse != nullptr && half == 0 && q0 + l31 < ((p.N + 31) & ~31))
+        p.lse[((int64_t)b * p.H + h) * ((p.N + 31) & ~31) + q0 + l31] = qvalid ? m + __builtin_log2f(den) : 0.f;
 #pragma unroll
     for (int dt = 0; dt < Y::DT_TILES; ++dt)
 #pragma unroll
@@ -743,8 +746,8 @@ __device__ __forceinline__ void attn2q_body(const AttnP& p, uint8_t* smem) {
         const float den = half_sum(osum[qt][0] + osum[qt][1]);
         const float inv = 1.0f / den;
         const int qb = q0 + qt * 32;
-        if (p.lse != nullptr && half == 0 && qb + l31 < p.N)
-            p.lse[((int64_t)b * p.H + h) * ((p.N + 31) & ~31) + qb + l31] = m[qt] + __builtin_log2f(den);
+        if (p.lse != nullptr && half == 0 && qb + l31 < ((p.N + 31) & ~31))  // (pad entries: 0, see attn_kernel)
+            p.lse[((int64_t)b * p.H + h) * ((p.N + 31) & ~31) + qb + l31] = qb + l31 < p.N ? m[qt] + __builtin_log2f(den) : 0.f;
 #pragma unroll
         for (int dt = 0; dt < Y::DT_TILES; ++dt) {
 #pragma unroll

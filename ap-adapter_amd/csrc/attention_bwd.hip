@@ -40,12 +40,17 @@ struct BwdP {
 
 // delta[b][h][n] = dout_scale * sum_d dO[b][n][h*D+d] * O[b][n][h*D+d]
 template <int DT, int D> __global__ __launch_bounds__(256) void delta_kernel(BwdP p) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (b, n, h)
-    const int64_t total = (int64_t)p.B * p.N * p.H;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (b, n, h), n over the PADDED range: pad entries are written 0
+    const int64_t total = (int64_t)p.B * p.Npad * p.H;
     if (idx >= total) return;
     const int h = (int)(idx % p.H);
-    const int64_t bn = idx / p.H;
-    const int n = (int)(bn % p.N), b = (int)(bn / p.N);
+    const int64_t bnp = idx / p.H;
+    const int n = (int)(bnp % p.Npad), b = (int)(bnp / p.Npad);
+    if (n >= p.N) {
+        p.delta[((int64_t)b * p.H + h) * p.Npad + n] = 0.f;
+        return;
+    }
+    const int64_t bn = (int64_t)b * p.N + n;
     const int C = p.H * D;
     const uint8_t* o = p.out + (bn * C + h * D) * 2;
     const uint8_t* g = p.dout + (bn * C + h * D) * 2;
@@ -242,7 +247,7 @@ template <int DT, int D> __global__ __launch_bounds__(256) void dkv_kernel(BwdP 
 }
 
 template <int DT, int D> int launch_bwd(const BwdP& p, hipStream_t s) {
-    const int64_t total = (int64_t)p.B * p.N * p.H;
+    const int64_t total = (int64_t)p.B * p.Npad * p.H;
     hipLaunchKernelGGL((delta_kernel<DT, D>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
     hipLaunchKernelGGL((dq_kernel<DT, D>), dim3((unsigned)((p.N + 127) / 128), (unsigned)(p.B * p.H)), dim3(256), 0, s, p);
     if (p.dk != nullptr)
@@ -262,11 +267,19 @@ template <int DT> int launch_bwd_dt(const BwdP& p, int D, hipStream_t s) {
     return -1;
 }
 
-// x [B][N][H*D] -> xt [B][H][D][pad], columns n >= N zero-filled: the transposed operand layout of both attention passes
-template <int DT> __global__ __launch_bounds__(256) void head_transpose_kernel(const uint8_t* x, uint8_t* xt, int N, int H, int D, int pad) {
+// x [B][N][H*D] -> xt [B][H][D][pad], columns n >= N zero-filled: the transposed operand layout of both attention passes.
+// Up to three tensors of one shape per launch (q, k and dO of a self-attention backward): blockIdx.z = tensor * B + b.
+struct HtP {
+    const uint8_t* x[3];
+    uint8_t* xt[3];
+};
+template <int DT> __global__ __launch_bounds__(256) void head_transpose_kernel(HtP ptrs, int B, int N, int H, int D, int pad) {
     using E = ET<DT>;
     __shared__ typename E::elem tile[32][33];
-    const int b = blockIdx.z, c0 = blockIdx.y * 32, n0 = blockIdx.x * 32;  // c = h*D + d runs over H*D
+    const int which = blockIdx.z / B;
+    const uint8_t* x = which == 0 ? ptrs.x[0] : (which == 1 ? ptrs.x[1] : ptrs.x[2]);
+    uint8_t* xt = which == 0 ? ptrs.xt[0] : (which == 1 ? ptrs.xt[1] : ptrs.xt[2]);
+    const int b = blockIdx.z - which * B, c0 = blockIdx.y * 32, n0 = blockIdx.x * 32;  // c = h*D + d runs over H*D
     const int C = H * D;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
     const typename E::elem* xin = reinterpret_cast<const typename E::elem*>(x);
@@ -284,20 +297,29 @@ template <int DT> __global__ __launch_bounds__(256) void head_transpose_kernel(c
 
 }  // namespace
 
-extern "C" int apad_head_transpose(const void* x, void* xt, int32_t B, int32_t N, int32_t H, int32_t D, int32_t pad,
-                                   int32_t dtype, void* stream) {
-    APAD_CHECK(x && xt && B > 0 && N > 0 && H > 0 && D > 0, "apad_head_transpose: null operand / empty problem");
+extern "C" int apad_head_transpose3(const void* x0, void* xt0, const void* x1, void* xt1, const void* x2, void* xt2, int32_t B,
+                                    int32_t N, int32_t H, int32_t D, int32_t pad, int32_t dtype, void* stream) {
+    APAD_CHECK(x0 && xt0 && B > 0 && N > 0 && H > 0 && D > 0, "apad_head_transpose: null operand / empty problem");
+    APAD_CHECK((x1 == nullptr) == (xt1 == nullptr) && (x2 == nullptr) == (xt2 == nullptr) && (x1 != nullptr || x2 == nullptr),
+               "apad_head_transpose3: tensors are given in order, each with its destination");
     APAD_CHECK(pad >= N && pad % 32 == 0, "apad_head_transpose: pad must be >= N and a multiple of 32");
     APAD_CHECK(dtype == APAD_BF16 || dtype == APAD_F16 || dtype == APAD_F32, "apad_head_transpose: dtype %d not supported", dtype);
-    dim3 grid((unsigned)(pad / 32), (unsigned)((H * D + 31) / 32), (unsigned)B);
+    const int nt = x2 ? 3 : (x1 ? 2 : 1);
+    HtP ptrs{{(const uint8_t*)x0, (const uint8_t*)x1, (const uint8_t*)x2}, {(uint8_t*)xt0, (uint8_t*)xt1, (uint8_t*)xt2}};
+    dim3 grid((unsigned)(pad / 32), (unsigned)((H * D + 31) / 32), (unsigned)(B * nt));
     hipStream_t s = (hipStream_t)stream;
     if (dtype == APAD_F32)
-        hipLaunchKernelGGL(head_transpose_kernel<APAD_F32>, grid, dim3(256), 0, s, (const uint8_t*)x, (uint8_t*)xt, N, H, D, pad);
+        hipLaunchKernelGGL(head_transpose_kernel<APAD_F32>, grid, dim3(256), 0, s, ptrs, B, N, H, D, pad);
     else if (dtype == APAD_BF16)
-        hipLaunchKernelGGL(head_transpose_kernel<APAD_BF16>, grid, dim3(256), 0, s, (const uint8_t*)x, (uint8_t*)xt, N, H, D, pad);
+        hipLaunchKernelGGL(head_transpose_kernel<APAD_BF16>, grid, dim3(256), 0, s, ptrs, B, N, H, D, pad);
     else
-        hipLaunchKernelGGL(head_transpose_kernel<APAD_F16>, grid, dim3(256), 0, s, (const uint8_t*)x, (uint8_t*)xt, N, H, D, pad);
+        hipLaunchKernelGGL(head_transpose_kernel<APAD_F16>, grid, dim3(256), 0, s, ptrs, B, N, H, D, pad);
     return apad_check_launch("apad_head_transpose");
+}
+
+extern "C" int apad_head_transpose(const void* x, void* xt, int32_t B, int32_t N, int32_t H, int32_t D, int32_t pad,
+                                   int32_t dtype, void* stream) {
+    return apad_head_transpose3(x, xt, nullptr, nullptr, nullptr, nullptr, B, N, H, D, pad, dtype, stream);
 }
 
 extern "C" int apad_attention_bwd(const apad_attn_bwd_desc* d, void* stream) {

@@ -371,8 +371,8 @@ template <int D> __global__ __launch_bounds__(256) void attn_f32_kernel(A32P p) 
         segment32<D>(p.k + (int64_t)bk * p.k_sb + h * D, p.k_sl, p.vt + (int64_t)bk * p.vt_sb + (int64_t)h * D * p.Lpad, p.L, p.Lpad,
                      bias, p.scale_log2, qf, o, den, m, l31, half);
     }
-    if (p.lse != nullptr && half == 0 && qvalid)
-        p.lse[((int64_t)b * p.H + h) * ((p.N + 31) & ~31) + q0 + l31] = m + log2f(den);
+    if (p.lse != nullptr && half == 0 && q0 + l31 < ((p.N + 31) & ~31))  // (pad entries: 0, see attention.hip)
+        p.lse[((int64_t)b * p.H + h) * ((p.N + 31) & ~31) + q0 + l31] = qvalid ? m + log2f(den) : 0.f;
     const float inv = 1.0f / den;
 #pragma unroll
     for (int dt = 0; dt < DT_TILES; ++dt)

@@ -543,7 +543,7 @@ def attention_lse(q, k, vt, Lk, heads, key_bias=None):
     _req(q, "attention_lse.q")
     B, N, Cc = q.shape
     out = torch.empty_like(q)
-    lse = torch.zeros(B, heads, round_up(N, 32), dtype=torch.float32, device=q.device)
+    lse = torch.empty(B, heads, round_up(N, 32), dtype=torch.float32, device=q.device)  # (the kernels write the pad entries: 0)
     d = L.AttnDesc()
     d.q, d.k, d.vt, d.out, d.key_bias, d.lse = q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), _ptr(key_bias), lse.data_ptr()
     d.q_stride_b, d.q_stride_n = q.stride(0), q.stride(1)
@@ -568,6 +568,18 @@ def head_transpose(x, heads, pad=None):
     return xt
 
 
+def head_transpose_many(xs, heads, pad):
+    """several [B, N, C] tensors of ONE shape -> their [B, heads, C/heads, pad] transposes in ONE launch (up to three per launch)"""
+    B, N, Cc = xs[0].shape
+    outs = [torch.empty(B, heads, Cc // heads, pad, dtype=x.dtype, device=x.device) for x in xs]
+    for i in range(0, len(xs), 3):
+        a = [(_req(x, "head_transpose.x").data_ptr(), y.data_ptr()) for x, y in zip(xs[i:i + 3], outs[i:i + 3])]
+        a += [(None, None)] * (3 - len(a))
+        L.check(L.lib().apad_head_transpose3(a[0][0], a[0][1], a[1][0], a[1][1], a[2][0], a[2][1], B, N, heads, Cc // heads, pad,
+                                             _DT[xs[0].dtype], _stream()), "apad_head_transpose3")
+    return outs
+
+
 def attention_bwd(q, k, v, out, dout, lse, heads, key_bias=None, dout_scale=1.0, need_dkv=True, dq=None):
     """gradients of one softmax segment; dq given -> accumulated into.  Returns (dq, dk, dv)."""
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (out, "out"), (dout, "dout")):
@@ -579,12 +591,17 @@ def attention_bwd(q, k, v, out, dout, lse, heads, key_bias=None, dout_scale=1.0,
     Npad, Lpad = round_up(N, 32), round_up(Lk, 32)
     d = L.AttnBwdDesc()
     f32 = q.dtype == torch.float32  # fp32 training mode: plain-FMA kernels on the row-major operands, no transposed copies
-    kt = None if f32 else head_transpose(k, heads, Lpad)
+    same = need_dkv and not f32 and N == Lk  # self-attention: q, k and dO transposed by ONE launch
+    if same:
+        kt, qt, dot = head_transpose_many([k, q, dout], heads, Lpad)
+    else:
+        kt = None if f32 else head_transpose(k, heads, Lpad)
     keep = [kt]
     d.q, d.k, d.v, d.kt, d.out, d.dout, d.lse = (q.data_ptr(), k.data_ptr(), v.data_ptr(), _ptr(kt), out.data_ptr(),
                                                  dout.data_ptr(), lse.data_ptr())
     d.key_bias = _ptr(key_bias)
-    delta = torch.zeros(B, heads, Npad, dtype=torch.float32, device=q.device)
+    # (16-bit kernels write the pad entries of delta themselves; the fp32 kernels never read them)
+    delta = torch.empty(B, heads, Npad, dtype=torch.float32, device=q.device)
     d.delta = delta.data_ptr()
     acc = dq is not None
     if dq is None:
@@ -595,7 +612,8 @@ def attention_bwd(q, k, v, out, dout, lse, heads, key_bias=None, dout_scale=1.0,
         dk, dv = torch.empty_like(k), torch.empty_like(v)
         d.dk, d.dv = dk.data_ptr(), dv.data_ptr()
         if not f32:
-            qt, dot = head_transpose(q, heads, Npad), head_transpose(dout, heads, Npad)
+            if not same:
+                qt, dot = head_transpose_many([q, dout], heads, Npad)
             keep += [qt, dot]
             d.qt, d.doutt = qt.data_ptr(), dot.data_ptr()
     d.B, d.N, d.H, d.D, d.L, d.Npad, d.Lpad, d.dtype = B, N, heads, Cc // heads, Lk, Npad, Lpad, _DT[q.dtype]

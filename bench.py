@@ -141,8 +141,21 @@ class _Bracket:
     def __exit__(self, *exc):
         setattr(self.ops, self.name, self.real)
 
-    def avg_us(self):
-        return sum(a.elapsed_time(b) for a, b in self.pairs) * 1e3 / max(len(self.pairs), 1)
+    def avg_us(self, overhead_us=0.0):
+        return sum(a.elapsed_time(b) for a, b in self.pairs) * 1e3 / max(len(self.pairs), 1) - overhead_us
+
+
+def event_pair_overhead_us(n=40):
+    """what a pair of HIP events recorded back to back on one stream reads with NOTHING between them (median): subtracted from the
+    eager per-launch timings (an event record is a packet of its own on the queue)"""
+    ts = []
+    for _ in range(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    return sorted(ts)[len(ts) // 2]
 
 
 def in_step_launch_times(step, ops, probes, reps=3):
@@ -164,12 +177,14 @@ def in_step_launch_times(step, ops, probes, reps=3):
             else:
                 step()
             torch.cuda.synchronize()
-            return {k: {"avg_us": round(b.avg_us(), 2), "launches": len(b.pairs)} for k, b in br.items()}
+            ov = 0.0 if external else event_pair_overhead_us()
+            return {k: {"avg_us": round(b.avg_us(ov), 2), "launches": len(b.pairs), "event_pair_overhead_us": round(ov, 2)} for k, b in br.items()}
     try:
         return measure(True), "HIP event-record nodes around each launch inside a replica of the captured step (hipGraph replay)"
     except Exception as e:  # noqa: BLE001 -- event nodes unsupported: eager events (same kernels, same order, host-paced)
         torch.cuda.synchronize()
-        return measure(False), "HIP events around each launch of one eager step (event nodes unavailable: %r)" % (e,)
+        return measure(False), ("HIP events around each launch of one eager step of the same kernels in the same order, minus the reading of an "
+                                "empty event pair (event-record nodes cannot be captured into a hipGraph on ROCm: %r)" % (e,))
 
 
 def profile_in_step_avg_us(substr):

@@ -337,6 +337,9 @@ int apad_attention_bwd(const apad_attn_bwd_desc* d, void* stream);
 /* x [B][N][H*D] -> xt [B][H][D][pad], zero-filled for n >= N (pad % 32 == 0) */
 int apad_head_transpose(const void* x, void* xt, int32_t B, int32_t N, int32_t H, int32_t D, int32_t pad, int32_t dtype,
                         void* stream);
+/* the same for up to three tensors of ONE shape in one launch (q, k and dO of a self-attention backward); unused pairs NULL */
+int apad_head_transpose3(const void* x0, void* xt0, const void* x1, void* xt1, const void* x2, void* xt2, int32_t B, int32_t N,
+                         int32_t H, int32_t D, int32_t pad, int32_t dtype, void* stream);
 
 int apad_layernorm_bwd(const void* x, const void* gamma, const void* dy, void* dx, int64_t M, int32_t C, float eps,
                        int32_t dtype, void* stream);

@@ -158,6 +158,8 @@ def test_real_widths_vs_transformers_fixture(dev):
     gold = load_file(GOLD_REAL)
     clap, t5, gpt = real_width_modules()
     ids, mask, tid, tmask, x = real_width_inputs()
-    assert rel_err(clap.to(dev).get_text_features(ids.to(dev), attention_mask=mask.to(dev)), gold["clap.out"]) < TOL
-    assert rel_err(t5.to(dev)(tid.to(dev), attention_mask=tmask.to(dev))[0].cpu()[tmask.bool()], gold["t5.out"][tmask.bool()]) < TOL
-    assert rel_err(gpt.to(dev)(x.to(dev)), gold["gpt2.out"]) < TOL
+    # fp32 on both sides; only the summation order differs (reductions of 768 ... 3072 terms, two layers deep): 5e-5 of max
+    tol = 5e-5
+    assert rel_err(clap.to(dev).get_text_features(ids.to(dev), attention_mask=mask.to(dev)), gold["clap.out"]) < tol
+    assert rel_err(t5.to(dev)(tid.to(dev), attention_mask=tmask.to(dev))[0].cpu()[tmask.bool()], gold["t5.out"][tmask.bool()]) < tol
+    assert rel_err(gpt.to(dev)(x.to(dev)), gold["gpt2.out"]) < tol
