@@ -97,6 +97,31 @@ def linear(x, w, b=None, residual=None):
     return _Linear.apply(x, w, b, residual)
 
 
+class _QKV(torch.autograd.Function):
+    """q, k, v = x Wq^T, x Wk^T, x Wv^T with FROZEN weights (the UNet's self-attention): three forward GEMMs, but ONE input-gradient
+    GEMM -- dx = [dq | dk | dv] . [Wq; Wk; Wv] -- instead of three GEMMs and two accumulation kernels (the training step at batch 4 is
+    bound by its launch count)"""
+
+    @staticmethod
+    def forward(ctx, x, wq, wk, wv):
+        x = _c(x)
+        ctx.save_for_backward(wq, wk, wv)
+        return ops.linear(x, wq), ops.linear(x, wk), ops.linear(x, wv)
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv):
+        wq, wk, wv = ctx.saved_tensors
+        wst = _cached(wq, ("qkvT", id(wk), id(wv), wk._version, wv._version),
+                      lambda t: torch.cat([t, wk.detach(), wv.detach()], 0).t().contiguous())  # [C, 3C]
+        return ops.linear(torch.cat([_c(dq), _c(dk), _c(dv)], dim=-1), wst), None, None, None
+
+
+def qkv(x, wq, wk, wv):
+    if wq.requires_grad or wk.requires_grad or wv.requires_grad:
+        return linear(x, wq), linear(x, wk), linear(x, wv)
+    return _QKV.apply(x, wq, wk, wv)
+
+
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, g, b, eps):

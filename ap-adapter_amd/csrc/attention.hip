@@ -626,10 +626,15 @@ __device__ __forceinline__ void attn2q_body(const AttnP& p, uint8_t* smem) {
     const int half = lane >> 5, l31 = lane & 31;
     const int nbh = p.B * p.H;
     const int nqt = (p.N + QPW - 1) / QPW;
-    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;  // XCD-aware order as in attn_kernel
-    const int bh = (seq / nqt) * 8 + xcd, qtile = seq % nqt;
-    if (bh >= nbh) return;
-    const int h = bh % p.H, b = bh / p.H;
+    // XCD-aware order (workgroup id w runs on XCD w % 8: observed, speed only): an XCD walks whole SAMPLES -- all query tiles of
+    // head 0, then head 1, ... of sample b = 8 i + xcd.  The query tiles of one (sample, head) share its K / V^T through that XCD's
+    // L2, and so do NEIGHBOURING HEADS: a 128-byte line of K [B][L][H*32] holds the 64-byte rows of two heads, so with heads spread
+    // over the XCDs (the earlier order) every K line was fetched by two L2s (PMC: 164.8 MB read per launch against 98.3 MB)
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int grp = seq / nqt, qtile = seq % nqt;
+    const int b = (grp / p.H) * 8 + xcd, h = grp % p.H;
+    if (b >= p.B) return;
+    (void)nbh;
     const int q0 = qtile * QPW + wave * 64;
     if (Y::VROWS > D) {
         for (int i = tid; i < 2 * Y::BUF / 4; i += NW * 64) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
@@ -960,12 +965,12 @@ template <int DT, int D> int launch_d(const AttnP& p, bool dual, dim3 grid, hipS
             if constexpr (D == 32) {
                 static const int nw8 = [] { const char* e = getenv("APAD_ATTN_NW8"); return e ? atoi(e) : 0; }();  // off: step 49.68 -> 50.12 ms (the 8-wave barrier costs more than the halved staging saves)
                 if (nw8) {
-                    dim3 g8((unsigned)(((p.N + 511) / 512) * (((p.H * p.B) + 7) / 8 * 8)));
+                    dim3 g8((unsigned)(((p.N + 511) / 512) * 8 * ((p.B + 7) / 8) * p.H));
                     hipLaunchKernelGGL((attn2q_kernel<DT, D, 8>), g8, dim3(512), 0, s, p);
                     return apad_check_launch("apad_attention");
                 }
             }
-            dim3 g2((unsigned)(((p.N + 255) / 256) * (((p.H * p.B) + 7) / 8 * 8)));
+            dim3 g2((unsigned)(((p.N + 255) / 256) * 8 * ((p.B + 7) / 8) * p.H));  // (sample-major XCD order: attn2q_body)
             if constexpr (D == 32) {
                 // pre-scaled q: the softmax without per-score max / scale instructions (APAD_ATTN_DIRECT=0: A/B switch)
                 static const int direct = [] { const char* e = getenv("APAD_ATTN_DIRECT"); return e ? atoi(e) : 1; }();
