@@ -1,0 +1,352 @@
+// Big-tile GEMM / implicit 3x3 convolution for the compute-bound launches of the path (the resnet convolutions of the 4000- and
+// 1000-pixel UNet levels: M = 64 000 .. 256 000 output pixels, K = 9 Cin = 1152 .. 4608, N = 128 / 256; modeling_audioldm2.py's
+// ResnetBlock2D conv1 / conv2), selected by apad_gemm (gemm.hip) when the problem fits -- same descriptor, same results.
+//
+// What differs from the 128x128 tiled kernel (gemm.hip), whose k-loop spends as many issue cycles on the gather's address
+// arithmetic, its exec-masked loads and the register -> LDS copy as on its MFMAs:
+//   * 256 x 128 x 64 tile, 512 threads = 8 waves (4 x 2, 64 x 64 per wave = 2 x 2 MFMA 32x32x16 tiles)
+//   * operands go HBM / L2 -> LDS directly (`buffer_load_dwordx4 ... lds`): no staging registers, no ds_write pass.  The DMA writes
+//     lane-linear, so the bank-conflict-free XOR layout of the tile is produced on the SOURCE side (lane -> (row, 16-byte chunk)).
+//     The convolution's zero padding is the buffer range check: a lane whose filter tap falls outside the image gets an
+//     out-of-range offset and the hardware writes zeros (tools/probes/buflds.hip) -- no branches, no selects on data
+//   * three 48 KB LDS stages; a tile is requested two k-tiles ahead and waited for with a COUNTED s_waitcnt vmcnt(6), raw s_barrier
+//     (a __syncthreads() would drain the queue), so loads stay in flight across barriers
+//   * the two waves of a SIMD (waves w and w + 4) run half a phase apart: a phase is [fragment reads + DMA issue | barrier | 8 MFMAs |
+//     barrier]; while one wave of the SIMD is in its MFMA segment the other is in its read / issue segment
+//     (MI355X_MICROARCH.md, "Two waves per SIMD")
+#include <stdlib.h>
+#include <type_traits>
+#include "common.h"
+
+namespace {
+
+constexpr int CBM = 256, CBN = 128, CBK = 64;
+constexpr int CA_BYTES = CBM * CBK * 2;       // 32 768
+constexpr int CB_BYTES = CBN * CBK * 2;       // 16 384
+constexpr int CSTAGE = CA_BYTES + CB_BYTES;   // 49 152
+constexpr int CSMEM = 3 * CSTAGE;             // 147 456 (the epilogue tile, 256 x 136 elements, reuses it)
+constexpr int CC_LD = CBN + 8;
+constexpr uint32_t C_OOB = 0x80000000u;       // an offset no operand reaches (sizes are checked < 2 GB on the host)
+
+struct CgP {
+    const uint8_t* a;
+    const uint8_t* w;
+    uint8_t* out;
+    const uint8_t* bias;
+    const uint8_t* residual;
+    const uint8_t* rg;
+    const int32_t* step_ptr;
+    int64_t ldo, ldr, ld_rg;
+    int32_t M, N, K, lda, ldw;
+    int32_t Hin, Win, Cin, res_mod;
+    int32_t m_tiles, n_tiles;
+    uint32_t a_bytes, w_bytes;
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t c_rsrc(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+#define C_FENCE() asm volatile("" ::: "memory")
+#define C_BARRIER()                          \
+    do {                                     \
+        __builtin_amdgcn_sched_barrier(0);   \
+        C_FENCE();                           \
+        __builtin_amdgcn_s_barrier();        \
+        C_FENCE();                           \
+        __builtin_amdgcn_sched_barrier(0);   \
+    } while (0)
+
+template <int DT, bool CONV>
+__global__ __launch_bounds__(512) void cgemm_kernel(CgP p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    using E = ET<DT>;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;  // waves w and w + 4 share a SIMD: the second half of the workgroup runs one barrier behind
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    // XCD-aware tile order (speed only): all N-tiles of one M-tile share blockIdx % 8, i.e. one XCD's L2 fetches an A panel once
+    int mt, nt;
+    {
+        const int nN = p.n_tiles, nM = p.m_tiles;
+        const int b = blockIdx.x;
+        const int full = (nM / 8) * 8 * nN;
+        if (b < full) {
+            const int g = b / (8 * nN), rem = b - g * 8 * nN;
+            nt = rem >> 3;
+            mt = g * 8 + (rem & 7);
+        } else {
+            const int rem = b - full, tail = nM - (nM / 8) * 8;
+            nt = rem / tail;
+            mt = (nM / 8) * 8 + rem - nt * tail;
+        }
+    }
+    const int m0 = mt * CBM, n0 = nt * CBN;
+
+    // ---- DMA sources.  One instruction of a wave fills one 1 KB block = 8 tile rows x 128 bytes; lane -> (row r = lane / 8,
+    //      LDS slot lane % 8), and the slot holds source chunk slot ^ ((row >> 1) & 7): the swizzle the fragment reads undo. ----
+    const __amdgpu_buffer_rsrc_t ra = c_rsrc(p.a, p.a_bytes), rw = c_rsrc(p.w, p.w_bytes);
+    uint32_t aoff[4];   // plain: byte offset of (row, chunk) at k = 0, or C_OOB; conv: of the CENTRE tap, channel 0
+    uint32_t amask[4];  // conv: bit (3 ky + kx) = that tap lies inside the image (0 for rows past M)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int R = (wave * 4 + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((R >> 1) & 7);
+        const int m = m0 + R;
+        const bool valid = m < p.M;
+        amask[i] = 0;
+        if (CONV) {
+            const int hw = p.Hin * p.Win;
+            const int b = m / hw, rem = m - b * hw;
+            const int oy = rem / p.Win, ox = rem - oy * p.Win;
+            aoff[i] = (uint32_t)(((b * p.Hin + oy) * p.Win + ox) * p.Cin * 2 + c * 16);
+            if (valid) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
+                    if ((unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win) amask[i] |= 1u << t;
+                }
+            }
+        } else {
+            aoff[i] = valid ? (uint32_t)(m * p.lda * 2 + c * 16) : C_OOB;
+        }
+    }
+    uint32_t boff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int R = (wave * 2 + j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((R >> 1) & 7);
+        boff[j] = (uint32_t)((n0 + R) * p.ldw * 2 + c * 16);
+    }
+    const int nk = p.K / CBK;
+    const int tiles_per_tap = CONV ? p.Cin / CBK : 1;
+    // (tap, channel block) of the next tile to REQUEST: tiles are requested in order, one per iteration
+    int rq_tap = 0, rq_cb = 0;
+    uint32_t av[4];
+    int a_soff = 0;
+    auto next_tile_sources = [&](int kt) {  // per-lane A offsets + the scalar offset of k-tile kt
+        if (CONV) {
+            const int ky = rq_tap / 3, kx = rq_tap - ky * 3;
+            const int delta = ((ky - 1) * p.Win + (kx - 1)) * p.Cin * 2;  // wave-uniform, may be negative
+            const uint32_t bit = 1u << rq_tap;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) av[i] = (amask[i] & bit) ? aoff[i] + (uint32_t)delta : C_OOB;
+            a_soff = rq_cb * (CBK * 2);
+            if (++rq_cb == tiles_per_tap) {
+                rq_cb = 0;
+                ++rq_tap;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) av[i] = aoff[i];
+            a_soff = kt * (CBK * 2);
+        }
+    };
+    auto issue_a = [&](int i, int stage) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(smem + stage * CSTAGE + (wave * 4 + i) * 1024), 16, av[i], a_soff, 0, 0);
+    };
+    auto issue_b = [&](int j, int stage, int kt) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(smem + stage * CSTAGE + CA_BYTES + (wave * 2 + j) * 1024), 16, boff[j],
+                                                 kt * (CBK * 2), 0, 0);
+    };
+
+    // ---- fragment addresses: row (base + l31), chunk ks*2 + half -> row*128 + ((chunk ^ ((row >> 1) & 7)) << 4); the row bases are
+    //      multiples of 32, so the swizzle term depends on l31 only ----
+    uint32_t fo[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fo[ks] = (uint32_t)(l31 * 128 + (((ks * 2 + half) ^ ((l31 >> 1) & 7)) << 4));
+    const uint32_t abase = (uint32_t)(wm * 64 * 128), bbase = (uint32_t)(CA_BYTES + wn * 64 * 128);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // Fragment reads are inline asm: the compiler's wait-count pass orders every ds_read it can see behind ALL outstanding LDS-DMA
+    // (it inserts s_waitcnt vmcnt(0) in front of the first read of each phase, which drains the two tiles in flight); the ordering
+    // that is actually needed -- the tile being read was waited for with the counted vmcnt below, by every wave, one barrier ago --
+    // is kept by hand.  The values are consumed behind an explicit lgkmcnt(0) + sched_barrier (the pass does not see the reads).
+    u32x4 fa[2][2], fb[2][2];  // [k-step of the phase][MFMA tile]
+    const uint32_t lds0 = (uint32_t)(size_t)(lds_ptr)smem;
+    auto read_frags = [&](int stage, int ph) {
+        const uint32_t st = lds0 + (uint32_t)(stage * CSTAGE);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t aa = st + abase + fo[ph * 2 + u], bb = st + bbase + fo[ph * 2 + u];
+            asm volatile("ds_read_b128 %0, %1" : "=v"(fa[u][0]) : "v"(aa));
+            asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fa[u][1]) : "v"(aa));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(fb[u][0]) : "v"(bb));
+            asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fb[u][1]) : "v"(bb));
+        }
+    };
+    auto mfmas = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = E::mfma32(__builtin_bit_cast(typename E::v8, fa[u][i]), __builtin_bit_cast(typename E::v8, fb[u][j]), acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- prologue: tiles 0 and 1 requested; tile 0 waited for ----
+    next_tile_sources(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_a(i, 0);
+    issue_b(0, 0, 0);
+    issue_b(1, 0, 0);
+    if (nk > 1) {
+        next_tile_sources(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue_a(i, 1);
+        issue_b(0, 1, 1);
+        issue_b(1, 1, 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    C_BARRIER();
+    if (grp == 1) C_BARRIER();  // the stagger
+
+    // One k-tile = two phases.  Stage indices are compile-time (the loop is unrolled by the three stages).
+    auto ktile = [&](int t, auto stage_tag) {
+        constexpr int S = decltype(stage_tag)::value, S2 = (S + 2) % 3;
+        const bool has2 = t + 2 < nk;  // wave-uniform
+        // ---- read / issue segment of phase 0 ----
+        if (has2) {
+            next_tile_sources(t + 2);
+            issue_a(0, S2);
+            issue_a(1, S2);
+            issue_a(2, S2);
+        }
+        read_frags(S, 0);
+        C_BARRIER();
+        mfmas();
+        C_BARRIER();
+        // ---- phase 1 ----
+        if (has2) {
+            issue_a(3, S2);
+            issue_b(0, S2, t + 2);
+            issue_b(1, S2, t + 2);
+        }
+        read_frags(S, 1);
+        // tile t + 1 (requested one iteration ago) must have landed before anyone reads it after the next barriers; only the six
+        // requests of tile t + 2 may stay in flight
+        if (has2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the last reads of stage S are complete before the barrier behind which the other half may overwrite it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        C_BARRIER();
+        mfmas();
+        C_BARRIER();
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2_ = std::integral_constant<int, 2>;
+#pragma unroll 1
+    for (int t = 0; t < nk; t += 3) {
+        ktile(t, S0{});
+        if (t + 1 < nk) ktile(t + 1, S1{});
+        if (t + 2 < nk) ktile(t + 2, S2_{});
+    }
+    if (grp == 0) C_BARRIER();
+    // (every wave is past its last fragment read and its last DMA wait: the stages are dead)
+
+    // ---- epilogue: acc + bias + time-embedding row -> storage type -> LDS tile -> + residual -> full-row 16-byte stores ----
+    typename E::elem* ct = reinterpret_cast<typename E::elem*>(smem);
+    const int64_t step = p.step_ptr ? (int64_t)*p.step_ptr : 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int nl = wn * 64 + j * 32 + l31;
+        const int n = n0 + nl;
+        const float bv = p.bias ? ld_elem<DT>(p.bias, n) : 0.f;
+        const float rg0 = p.rg ? ld_elem<DT>(p.rg, step * p.ld_rg + n) : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                ct[ml * CC_LD + nl] = (typename E::elem)(acc[i][j][r] + bv + rg0);
+            }
+    }
+    __syncthreads();
+    constexpr int VPR = CBN / 8;
+    for (int idx = tid; idx < CBM * VPR; idx += 512) {
+        const int rl = idx / VPR, vc = idx - rl * VPR;
+        const int m = m0 + rl, n = n0 + vc * 8;
+        if (m >= p.M) continue;
+        uint4 v = *reinterpret_cast<const uint4*>(&ct[rl * CC_LD + vc * 8]);
+        if (p.residual) {
+            float f[8], rr[8];
+            unpack8<DT>(v, f);
+            const int64_t rm = p.res_mod > 0 ? m % p.res_mod : m;
+            unpack8<DT>(*reinterpret_cast<const uint4*>(p.residual + (rm * p.ldr + n) * 2), rr);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += rr[e];
+            v = pack8<DT>(f);
+        }
+        *reinterpret_cast<uint4*>(p.out + ((int64_t)m * p.ldo + n) * 2) = v;
+    }
+}
+
+template <int DT, bool CONV> int cg_launch(const CgP& p, hipStream_t s) {
+    auto kern = cgemm_kernel<DT, CONV>;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CSMEM);
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.m_tiles * p.n_tiles)), dim3(512), CSMEM, s, p);
+    return apad_check_launch("apad_gemm(big tile)");
+}
+
+}  // namespace
+
+// Called by apad_gemm before its own dispatch.  Returns 1 when the problem is outside this kernel's envelope (the caller goes on),
+// 0 after a launch, < 0 on a launch error.
+int apad_cgemm_try(const apad_gemm_desc* d, hipStream_t s) {
+    static const int mode = [] { const char* e = getenv("APAD_CGEMM"); return e ? atoi(e) : 1; }();  // A/B knob: 0 = off
+    static const long min_rows = [] { const char* e = getenv("APAD_CGEMM_MIN_M"); return e ? atol(e) : 32768L; }();
+    if (!mode) return 1;
+    if (d->dtype != APAD_BF16 && d->dtype != APAD_F16) return 1;
+    if (d->epilogue != APAD_EPI_NONE || d->out_mode != APAD_OUT_ROWMAJOR || d->rowstat_out || d->rowstat_in) return 1;
+    if (d->N % CBN != 0 || d->K % CBK != 0 || d->M < min_rows || d->M >= (1LL << 30)) return 1;
+    if (d->rowgroup_bias && d->rows_per_group < d->M) return 1;  // only the table form (every row reads row *step_ptr)
+    const bool conv = d->a_mode == APAD_A_CONV3X3;
+    int64_t a_bytes;
+    if (conv) {
+        if (d->stride != 1 || d->Hup != 0 || d->src_batch_mod != 0 || d->conv_asym_pad || d->Cin % CBK != 0 || d->Hout != d->Hin ||
+            d->Wout != d->Win)
+            return 1;
+        a_bytes = d->M * (int64_t)d->Cin * 2;
+    } else if (d->a_mode == APAD_A_PLAIN) {
+        if (d->lda % 8 != 0) return 1;
+        a_bytes = ((d->M - 1) * d->lda + d->K) * 2;
+    } else {
+        return 1;
+    }
+    const int64_t w_bytes = ((d->N - 1) * d->ldw + d->K) * 2;
+    if (a_bytes >= (1LL << 31) || w_bytes >= (1LL << 31)) return 1;
+    CgP p;
+    p.a = (const uint8_t*)d->a; p.w = (const uint8_t*)d->w; p.out = (uint8_t*)d->out; p.bias = (const uint8_t*)d->bias;
+    p.residual = (const uint8_t*)d->residual; p.rg = (const uint8_t*)d->rowgroup_bias; p.step_ptr = d->step_ptr;
+    p.ldo = d->ldo; p.ldr = d->ldr; p.ld_rg = d->ld_rg;
+    p.M = (int32_t)d->M; p.N = (int32_t)d->N; p.K = (int32_t)d->K; p.lda = (int32_t)d->lda; p.ldw = (int32_t)d->ldw;
+    p.Hin = d->Hin; p.Win = d->Win; p.Cin = d->Cin; p.res_mod = d->residual_row_mod;
+    p.m_tiles = (int32_t)((d->M + CBM - 1) / CBM); p.n_tiles = (int32_t)(d->N / CBN);
+    p.a_bytes = (uint32_t)a_bytes; p.w_bytes = (uint32_t)w_bytes;
+    if (d->dtype == APAD_BF16) return conv ? cg_launch<APAD_BF16, true>(p, s) : cg_launch<APAD_BF16, false>(p, s);
+    return conv ? cg_launch<APAD_F16, true>(p, s) : cg_launch<APAD_F16, false>(p, s);
+}

@@ -130,3 +130,5 @@ void apad_set_error(const char* fmt, ...);
         }                                \
     } while (0)
 int apad_check_launch(const char* what);
+// big-tile GEMM / implicit convolution (cgemm.hip): 1 = not applicable, 0 = launched, < 0 = error
+int apad_cgemm_try(const apad_gemm_desc* d, hipStream_t s);

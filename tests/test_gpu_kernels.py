@@ -103,6 +103,38 @@ def test_conv3x3_implicit_gemm(dev, dtype, B, H, W, Cin, Cout, stride, up):
     assert rel_err(out, ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", DTYPES16)
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(9, 125, 30, 64, 128), (3, 250, 45, 128, 256), (5, 111, 60, 192, 128)])
+def test_conv3x3_big_tile_kernel(dev, dtype, B, H, W, Cin, Cout):
+    """csrc/cgemm.hip (256x128 tile, LDS-DMA operands, zero padding through the buffer range check): >= 32768 output pixels, ragged
+    last tile, every border, + bias + table-mode time embedding (row *step_ptr) + residual -- the resnet call"""
+    from ap_adapter_amd import ops
+    assert B * H * W >= 32768 and (B * H * W) % 256 != 0
+    x = q(R(B, Cin, H, W, seed=14), dtype)
+    w = q(R(Cout, Cin, 3, 3, seed=15, std=0.05), dtype)
+    b = q(R(Cout, seed=16), dtype)
+    t = q(R(4, Cout, seed=17), dtype)
+    r = q(R(B, Cout, H, W, seed=18), dtype)
+    ref = q(_conv_ref(x, w, b) + t[2][None, :, None, None], dtype) + r
+    nhwc = lambda a: a.permute(0, 2, 3, 1).reshape(B, H * W, -1).contiguous().to(dev, dtype)
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(dev, dtype)
+    step = torch.tensor([2], dtype=torch.int32, device=dev)
+    out, Ho, Wo = ops.conv3x3(nhwc(x), wp, b.to(dev, dtype), B, H, W, residual=nhwc(r), rowgroup_bias=t.to(dev, dtype),
+                              rows_per_group=1 << 40, step_ptr=step)
+    out = out.reshape(B, Ho, Wo, Cout).permute(0, 3, 1, 2)
+    assert rel_err(out, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES16)
+@pytest.mark.parametrize("M,N,K", [(40001, 128, 192), (33000, 384, 1024), (32768, 256, 64)])
+def test_gemm_big_tile_kernel(dev, dtype, M, N, K):
+    """the same kernel on a plain A operand (1, 3, 16 k-tiles: prologue-only, one round of the three LDS stages, many)"""
+    from ap_adapter_amd import ops
+    x, w, b, r = q(R(M, K, seed=1), dtype), q(R(N, K, seed=2, std=0.05), dtype), q(R(N, seed=3), dtype), q(R(M, N, seed=4), dtype)
+    out = ops.linear(x.to(dev, dtype), w.to(dev, dtype), b.to(dev, dtype), residual=r.to(dev, dtype))
+    assert rel_err(out, q(F.linear(x, w, b), dtype) + r) < TOL[dtype]
+
+
 def test_conv3x3_cfg_duplication_and_temb(dev):
     from ap_adapter_amd import ops
     dtype = torch.bfloat16
