@@ -1,18 +1,21 @@
 // Big-tile GEMM / implicit 3x3 convolution for the compute-bound launches of the path (the resnet convolutions of the 4000- and
-// 1000-pixel UNet levels: M = 64 000 .. 256 000 output pixels, K = 9 Cin = 1152 .. 4608, N = 128 / 256; modeling_audioldm2.py's
+// 1000-pixel UNet levels: M = 64 000 .. 256 000 output pixels, K = 9 Cin = 1152 .. 5760, N = 128 / 256; modeling_audioldm2.py's
 // ResnetBlock2D conv1 / conv2), selected by apad_gemm (gemm.hip) when the problem fits -- same descriptor, same results.
 //
 // What differs from the 128x128 tiled kernel (gemm.hip), whose k-loop spends as many issue cycles on the gather's address
 // arithmetic, its exec-masked loads and the register -> LDS copy as on its MFMAs:
-//   * 256 x 128 x 64 tile, 512 threads = 8 waves (4 x 2, 64 x 64 per wave = 2 x 2 MFMA 32x32x16 tiles)
+//   * 512 threads = 8 waves on a 256 x 128 x 64 tile (4 x 2 waves of 64 x 64, three 48 KB LDS stages) or, when N % 256 == 0, a
+//     256 x 256 x 64 tile (2 x 4 waves of 128 x 64, two 64 KB stages): measured with ablation builds (CG_ABL), the 256 x 128 form is
+//     bound by the CU's LDS fill + fragment-read traffic (48 KB in, 128 KB out per k-tile against 1024 MFMA cycles), not by the MFMAs
+//     -- the square tile moves a third fewer bytes per FLOP through L2 -> LDS and a quarter fewer through LDS -> registers
 //   * operands go HBM / L2 -> LDS directly (`buffer_load_dwordx4 ... lds`): no staging registers, no ds_write pass.  The DMA writes
 //     lane-linear, so the bank-conflict-free XOR layout of the tile is produced on the SOURCE side (lane -> (row, 16-byte chunk)).
 //     The convolution's zero padding is the buffer range check: a lane whose filter tap falls outside the image gets an
 //     out-of-range offset and the hardware writes zeros (tools/probes/buflds.hip) -- no branches, no selects on data
-//   * three 48 KB LDS stages; a tile is requested two k-tiles ahead and waited for with a COUNTED s_waitcnt vmcnt(6), raw s_barrier
-//     (a __syncthreads() would drain the queue), so loads stay in flight across barriers
-//   * the two waves of a SIMD (waves w and w + 4) run half a phase apart: a phase is [fragment reads + DMA issue | barrier | 8 MFMAs |
-//     barrier]; while one wave of the SIMD is in its MFMA segment the other is in its read / issue segment
+//   * a tile is requested NST - 1 k-tiles ahead and waited for with a COUNTED s_waitcnt vmcnt, raw s_barrier (a __syncthreads()
+//     would drain the queue), so loads stay in flight across barriers; the DMA instructions are issued between the MFMAs
+//   * the two waves of a SIMD (waves w and w + 4) run half a phase apart: a phase is [fragment reads | barrier | 8 MFMAs + DMA issue |
+//     barrier]; while one wave of the SIMD is in its MFMA segment the other is in its read segment
 //     (MI355X_MICROARCH.md, "Two waves per SIMD")
 #include <stdlib.h>
 #include <type_traits>
@@ -20,13 +23,30 @@
 
 namespace {
 
-constexpr int CBM = 256, CBN = 128, CBK = 64;
+#ifndef CG_ABL
+#define CG_ABL 0  // ablation bits for timing-only probe builds (tools/ab_build.sh): 1 no DMA in the loop, 2 no fragment reads, 4 no MFMAs
+#endif
+constexpr int CBM = 256, CBK = 64;
 constexpr int CA_BYTES = CBM * CBK * 2;       // 32 768
-constexpr int CB_BYTES = CBN * CBK * 2;       // 16 384
-constexpr int CSTAGE = CA_BYTES + CB_BYTES;   // 49 152
-constexpr int CSMEM = 3 * CSTAGE;             // 147 456 (the epilogue tile, 256 x 136 elements, reuses it)
-constexpr int CC_LD = CBN + 8;
 constexpr uint32_t C_OOB = 0x80000000u;       // an offset no operand reaches (sizes are checked < 2 GB on the host)
+
+// BN = 128: 4 x 2 waves of 64 x 64 (MI = 2 MFMA tiles down), phases of two k-steps, 3 stages.  BN = 256: 2 x 4 waves of 128 x 64
+// (MI = 4), phases of one k-step, 2 stages.  Either way a phase is 8 MFMAs of 32x32x16 per wave.
+template <int BN> struct CgT {
+    static constexpr int MI = BN == 128 ? 2 : 4;         // 32-row MFMA tiles per wave
+    static constexpr int WAVES_N = BN / 64;              // 64 columns per wave
+    static constexpr int KSP = BN == 128 ? 2 : 1;        // k-steps (of 16) per phase
+    static constexpr int NPH = 4 / KSP;                  // phases per k-tile
+    static constexpr int NST = BN == 128 ? 3 : 2;        // LDS stages
+    static constexpr int D = NST - 1;                    // a tile is requested D k-tiles ahead
+    static constexpr int B_BYTES = BN * CBK * 2;
+    static constexpr int STAGE = CA_BYTES + B_BYTES;     // 49 152 / 65 536
+    static constexpr int PB = BN / 64;                   // B pieces (1 KB DMA instructions) per wave and k-tile; A: 4
+    static constexpr int P = 4 + PB;                     // 6 / 8
+    static constexpr int C_LD = BN + 8;                  // epilogue tile row stride (elements); the tile holds 128 rows
+    static constexpr int SMEM = NST * STAGE;             // 147 456 / 131 072  (>= 128 * C_LD * 2)
+    static_assert(P <= 3 * (NST == 2 ? NPH - 1 : NPH), "three DMA pieces per phase; none in the last phase of a two-stage pipeline");
+};
 
 struct CgP {
     const uint8_t* a;
@@ -60,14 +80,24 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t c_rsrc(const void* p, uint32_t
         __builtin_amdgcn_sched_barrier(0);   \
     } while (0)
 
-template <int DT, bool CONV>
+template <int N_> __device__ __forceinline__ void c_wait_vm() {
+    if constexpr (N_ == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N_ == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N_ == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N_ == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else static_assert(N_ == 0, "add the count");
+}
+
+template <int DT, bool CONV, int BN>
 __global__ __launch_bounds__(512) void cgemm_kernel(CgP p) {
+    using T = CgT<BN>;
+    constexpr int MI = T::MI, KSP = T::KSP, NPH = T::NPH, NST = T::NST, D = T::D, PB = T::PB, P = T::P, STAGE = T::STAGE, C_LD = T::C_LD;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     using E = ET<DT>;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2;  // waves w and w + 4 share a SIMD: the second half of the workgroup runs one barrier behind
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / T::WAVES_N, wn = wave % T::WAVES_N;
     const int half = lane >> 5, l31 = lane & 31;
 
     // XCD-aware tile order (speed only): all N-tiles of one M-tile share blockIdx % 8, i.e. one XCD's L2 fetches an A panel once
@@ -86,7 +116,7 @@ __global__ __launch_bounds__(512) void cgemm_kernel(CgP p) {
             mt = (nM / 8) * 8 + rem - nt * tail;
         }
     }
-    const int m0 = mt * CBM, n0 = nt * CBN;
+    const int m0 = mt * CBM, n0 = nt * BN;
 
     // ---- DMA sources.  One instruction of a wave fills one 1 KB block = 8 tile rows x 128 bytes; lane -> (row r = lane / 8,
     //      LDS slot lane % 8), and the slot holds source chunk slot ^ ((row >> 1) & 7): the swizzle the fragment reads undo. ----
@@ -116,10 +146,10 @@ __global__ __launch_bounds__(512) void cgemm_kernel(CgP p) {
             aoff[i] = valid ? (uint32_t)(m * p.lda * 2 + c * 16) : C_OOB;
         }
     }
-    uint32_t boff[2];
+    uint32_t boff[4];  // (PB used; a template-dependent array bound captured by the lambdas below loses the kernel's host stub: hipcc 7.2)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int R = (wave * 2 + j) * 8 + (lane >> 3);
+    for (int j = 0; j < PB; ++j) {
+        const int R = (wave * PB + j) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((R >> 1) & 7);
         boff[j] = (uint32_t)((n0 + R) * p.ldw * 2 + c * 16);
     }
@@ -147,12 +177,13 @@ __global__ __launch_bounds__(512) void cgemm_kernel(CgP p) {
             a_soff = kt * (CBK * 2);
         }
     };
-    auto issue_a = [&](int i, int stage) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(smem + stage * CSTAGE + (wave * 4 + i) * 1024), 16, av[i], a_soff, 0, 0);
-    };
-    auto issue_b = [&](int j, int stage, int kt) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(smem + stage * CSTAGE + CA_BYTES + (wave * 2 + j) * 1024), 16, boff[j],
-                                                 kt * (CBK * 2), 0, 0);
+    // piece q of k-tile kt (its sources prepared by next_tile_sources) -> LDS stage `stage`: q < 4 an A block, else a B block
+    auto issue = [&](int q, int stage, int kt) {
+        if (q < 4)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(smem + stage * STAGE + (wave * 4 + q) * 1024), 16, av[q], a_soff, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(smem + stage * STAGE + CA_BYTES + (wave * PB + q - 4) * 1024), 16,
+                                                     boff[q - 4], kt * (CBK * 2), 0, 0);
     };
 
     // ---- fragment addresses: row (base + l31), chunk ks*2 + half -> row*128 + ((chunk ^ ((row >> 1) & 7)) << 4); the row bases are
@@ -160,149 +191,170 @@ __global__ __launch_bounds__(512) void cgemm_kernel(CgP p) {
     uint32_t fo[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) fo[ks] = (uint32_t)(l31 * 128 + (((ks * 2 + half) ^ ((l31 >> 1) & 7)) << 4));
-    const uint32_t abase = (uint32_t)(wm * 64 * 128), bbase = (uint32_t)(CA_BYTES + wn * 64 * 128);
+    const uint32_t abase = (uint32_t)(wm * MI * 32 * 128), bbase = (uint32_t)(CA_BYTES + wn * 64 * 128);
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // Fragment reads are inline asm: the compiler's wait-count pass orders every ds_read it can see behind ALL outstanding LDS-DMA
-    // (it inserts s_waitcnt vmcnt(0) in front of the first read of each phase, which drains the two tiles in flight); the ordering
+    // (it inserts s_waitcnt vmcnt(0) in front of the first read of each phase, which drains the tiles in flight); the ordering
     // that is actually needed -- the tile being read was waited for with the counted vmcnt below, by every wave, one barrier ago --
     // is kept by hand.  The values are consumed behind an explicit lgkmcnt(0) + sched_barrier (the pass does not see the reads).
-    u32x4 fa[2][2], fb[2][2];  // [k-step of the phase][MFMA tile]
+    u32x4 fa[KSP][MI] = {}, fb[KSP][2] = {};  // [k-step of the phase][MFMA tile]
     const uint32_t lds0 = (uint32_t)(size_t)(lds_ptr)smem;
     auto read_frags = [&](int stage, int ph) {
-        const uint32_t st = lds0 + (uint32_t)(stage * CSTAGE);
+        if (CG_ABL & 2) return;
+        const uint32_t st = lds0 + (uint32_t)(stage * STAGE);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const uint32_t aa = st + abase + fo[ph * 2 + u], bb = st + bbase + fo[ph * 2 + u];
+        for (int u = 0; u < KSP; ++u) {
+            const uint32_t aa = st + abase + fo[ph * KSP + u], bb = st + bbase + fo[ph * KSP + u];
             asm volatile("ds_read_b128 %0, %1" : "=v"(fa[u][0]) : "v"(aa));
             asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fa[u][1]) : "v"(aa));
+            if constexpr (MI == 4) {
+                asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(fa[u][2]) : "v"(aa));
+                asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(fa[u][3]) : "v"(aa));
+            }
             asm volatile("ds_read_b128 %0, %1" : "=v"(fb[u][0]) : "v"(bb));
             asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fb[u][1]) : "v"(bb));
         }
     };
-    auto mfmas = [&]() {
+    // the MFMA segment of a phase; `dma(u)` (u = 0..2) issues this wave's next DMA pieces BETWEEN the MFMAs (an LDS-DMA instruction
+    // costs ~60 issue cycles among bare MFMAs and 100+ in a segment that also carries the fragment reads: MI355X_MICROARCH.md)
+    auto mfmas = [&](auto&& dma) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
+        int n = 0;
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < KSP; ++u)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = E::mfma32(__builtin_bit_cast(typename E::v8, fa[u][i]), __builtin_bit_cast(typename E::v8, fb[u][j]), acc[i][j]);
+                for (int j = 0; j < 2; ++j) {
+                    if (!(CG_ABL & 4))
+                        acc[i][j] = E::mfma32(__builtin_bit_cast(typename E::v8, fa[u][i]), __builtin_bit_cast(typename E::v8, fb[u][j]), acc[i][j]);
+                    if (n < 3) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        dma(n);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    ++n;
+                }
         __builtin_amdgcn_s_setprio(0);
     };
 
-    // ---- prologue: tiles 0 and 1 requested; tile 0 waited for ----
-    next_tile_sources(0);
+    // ---- prologue: the first D tiles requested; tile 0 waited for ----
 #pragma unroll
-    for (int i = 0; i < 4; ++i) issue_a(i, 0);
-    issue_b(0, 0, 0);
-    issue_b(1, 0, 0);
-    if (nk > 1) {
-        next_tile_sources(1);
+    for (int t = 0; t < D; ++t)
+        if (t < nk) {
+            next_tile_sources(t);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) issue_a(i, 1);
-        issue_b(0, 1, 1);
-        issue_b(1, 1, 1);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+            for (int q = 0; q < P; ++q) issue(q, t, t);
+        }
+    if (D > 1 && nk > 1) c_wait_vm<(D > 1 ? P : 0)>();  // (D == 2: the second tile's pieces may stay in flight)
+    else c_wait_vm<0>();
     C_BARRIER();
     if (grp == 1) C_BARRIER();  // the stagger
 
-    // One k-tile = two phases.  Stage indices are compile-time (the loop is unrolled by the three stages).
+    // One k-tile.  Stage indices are compile-time (the loop is unrolled by the stage count).
     auto ktile = [&](int t, auto stage_tag) {
-        constexpr int S = decltype(stage_tag)::value, S2 = (S + 2) % 3;
-        const bool has2 = t + 2 < nk;  // wave-uniform
-        // ---- read / issue segment of phase 0 ----
-        if (has2) {
-            next_tile_sources(t + 2);
-            issue_a(0, S2);
-            issue_a(1, S2);
-            issue_a(2, S2);
+        constexpr int S = decltype(stage_tag)::value, SR = (S + D) % NST;  // SR: the stage tile t + D goes to (it held tile t - 1)
+        const bool req = (CG_ABL & 1) ? false : t + D < nk;  // wave-uniform
+#pragma unroll
+        for (int ph = 0; ph < NPH; ++ph) {
+            read_frags(S, ph);
+            if (ph == 0 && req) next_tile_sources(t + D);
+            if (ph == NPH - 1) {
+                // tile t + 1 must have landed before anyone reads it behind the next barriers; with three stages the pieces of
+                // tile t + 2 issued in this tile's earlier phases may stay in flight
+                constexpr int inflight = NST == 3 ? (3 * (NPH - 1) < P ? 3 * (NPH - 1) : P) : 0;
+                if (NST == 3 && req) c_wait_vm<inflight>();
+                else c_wait_vm<0>();
+                // the last reads of stage S are complete before the barrier behind which the other half may overwrite it
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            C_BARRIER();
+            mfmas([&](int u) {
+                const int q = ph * 3 + u;
+                if (q < P && req) issue(q, SR, t + D);
+            });
+            C_BARRIER();
         }
-        read_frags(S, 0);
-        C_BARRIER();
-        mfmas();
-        C_BARRIER();
-        // ---- phase 1 ----
-        if (has2) {
-            issue_a(3, S2);
-            issue_b(0, S2, t + 2);
-            issue_b(1, S2, t + 2);
-        }
-        read_frags(S, 1);
-        // tile t + 1 (requested one iteration ago) must have landed before anyone reads it after the next barriers; only the six
-        // requests of tile t + 2 may stay in flight
-        if (has2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // the last reads of stage S are complete before the barrier behind which the other half may overwrite it
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        C_BARRIER();
-        mfmas();
-        C_BARRIER();
     };
-    using S0 = std::integral_constant<int, 0>;
-    using S1 = std::integral_constant<int, 1>;
-    using S2_ = std::integral_constant<int, 2>;
+    if constexpr (NST == 3) {
 #pragma unroll 1
-    for (int t = 0; t < nk; t += 3) {
-        ktile(t, S0{});
-        if (t + 1 < nk) ktile(t + 1, S1{});
-        if (t + 2 < nk) ktile(t + 2, S2_{});
+        for (int t = 0; t < nk; t += 3) {
+            ktile(t, std::integral_constant<int, 0>{});
+            if (t + 1 < nk) ktile(t + 1, std::integral_constant<int, 1>{});
+            if (t + 2 < nk) ktile(t + 2, std::integral_constant<int, 2>{});
+        }
+    } else {
+#pragma unroll 1
+        for (int t = 0; t < nk; t += 2) {
+            ktile(t, std::integral_constant<int, 0>{});
+            if (t + 1 < nk) ktile(t + 1, std::integral_constant<int, 1>{});
+        }
     }
     if (grp == 0) C_BARRIER();
     // (every wave is past its last fragment read and its last DMA wait: the stages are dead)
 
-    // ---- epilogue: acc + bias + time-embedding row -> storage type -> LDS tile -> + residual -> full-row 16-byte stores ----
+    // ---- epilogue, 128 tile rows at a time: acc + bias + time-embedding row -> storage type -> LDS tile -> + residual -> full-row
+    //      16-byte stores ----
     typename E::elem* ct = reinterpret_cast<typename E::elem*>(smem);
     const int64_t step = p.step_ptr ? (int64_t)*p.step_ptr : 0;
+    float bv[2], rg0[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int nl = wn * 64 + j * 32 + l31;
-        const int n = n0 + nl;
-        const float bv = p.bias ? ld_elem<DT>(p.bias, n) : 0.f;
-        const float rg0 = p.rg ? ld_elem<DT>(p.rg, step * p.ld_rg + n) : 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                ct[ml * CC_LD + nl] = (typename E::elem)(acc[i][j][r] + bv + rg0);
-            }
+        const int n = n0 + wn * 64 + j * 32 + l31;
+        bv[j] = p.bias ? ld_elem<DT>(p.bias, n) : 0.f;
+        rg0[j] = p.rg ? ld_elem<DT>(p.rg, step * p.ld_rg + n) : 0.f;
     }
-    __syncthreads();
-    constexpr int VPR = CBN / 8;
-    for (int idx = tid; idx < CBM * VPR; idx += 512) {
-        const int rl = idx / VPR, vc = idx - rl * VPR;
-        const int m = m0 + rl, n = n0 + vc * 8;
-        if (m >= p.M) continue;
-        uint4 v = *reinterpret_cast<const uint4*>(&ct[rl * CC_LD + vc * 8]);
-        if (p.residual) {
-            float f[8], rr[8];
-            unpack8<DT>(v, f);
-            const int64_t rm = p.res_mod > 0 ? m % p.res_mod : m;
-            unpack8<DT>(*reinterpret_cast<const uint4*>(p.residual + (rm * p.ldr + n) * 2), rr);
+    constexpr int VPR = BN / 8;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] += rr[e];
-            v = pack8<DT>(f);
+    for (int hh = 0; hh < 2; ++hh) {
+        if ((wm * MI * 32) / 128 == hh) {  // this wave's rows lie in this half (wave-uniform)
+            const int rbase = wm * MI * 32 - hh * 128;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int nl = wn * 64 + j * 32 + l31;
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ml = rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        ct[ml * C_LD + nl] = (typename E::elem)(acc[i][j][r] + bv[j] + rg0[j]);
+                    }
+            }
         }
-        *reinterpret_cast<uint4*>(p.out + ((int64_t)m * p.ldo + n) * 2) = v;
+        __syncthreads();
+        for (int idx = tid; idx < 128 * VPR; idx += 512) {
+            const int rl = idx / VPR, vc = idx - rl * VPR;
+            const int m = m0 + hh * 128 + rl, n = n0 + vc * 8;
+            if (m >= p.M) continue;
+            uint4 v = *reinterpret_cast<const uint4*>(&ct[rl * C_LD + vc * 8]);
+            if (p.residual) {
+                float f[8], rr[8];
+                unpack8<DT>(v, f);
+                const int64_t rm = p.res_mod > 0 ? m % p.res_mod : m;
+                unpack8<DT>(*reinterpret_cast<const uint4*>(p.residual + (rm * p.ldr + n) * 2), rr);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] += rr[e];
+                v = pack8<DT>(f);
+            }
+            *reinterpret_cast<uint4*>(p.out + ((int64_t)m * p.ldo + n) * 2) = v;
+        }
+        if (hh == 0) __syncthreads();
     }
 }
 
-template <int DT, bool CONV> int cg_launch(const CgP& p, hipStream_t s) {
-    auto kern = cgemm_kernel<DT, CONV>;
+template <int DT, bool CONV, int BN> int cg_launch(const CgP& p, hipStream_t s) {
+    auto kern = cgemm_kernel<DT, CONV, BN>;
+    constexpr int CSMEM = CgT<BN>::SMEM;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CSMEM);
@@ -318,11 +370,13 @@ template <int DT, bool CONV> int cg_launch(const CgP& p, hipStream_t s) {
 // 0 after a launch, < 0 on a launch error.
 int apad_cgemm_try(const apad_gemm_desc* d, hipStream_t s) {
     static const int mode = [] { const char* e = getenv("APAD_CGEMM"); return e ? atoi(e) : 1; }();  // A/B knob: 0 = off
-    static const long min_rows = [] { const char* e = getenv("APAD_CGEMM_MIN_M"); return e ? atol(e) : 32768L; }();
+    static const long min_rows = [] { const char* e = getenv("APAD_CGEMM_MIN_M"); return e ? atol(e) : 16000L; }();  // (step-level A/B: 32768 -> 16000 = -1.0 ms, 4000 / 2000: no further gain)
     if (!mode) return 1;
     if (d->dtype != APAD_BF16 && d->dtype != APAD_F16) return 1;
     if (d->epilogue != APAD_EPI_NONE || d->out_mode != APAD_OUT_ROWMAJOR || d->rowstat_out || d->rowstat_in) return 1;
-    if (d->N % CBN != 0 || d->K % CBK != 0 || d->M < min_rows || d->M >= (1LL << 30)) return 1;
+    static const int bn_mode = [] { const char* e = getenv("APAD_CGEMM_BN"); return e ? atoi(e) : 0; }();  // A/B knob: 128 = never the square tile
+    if (d->N % 128 != 0 || d->K % CBK != 0 || d->M < min_rows || d->M >= (1LL << 30)) return 1;
+    const bool sq = d->N % 256 == 0 && bn_mode != 128;
     if (d->rowgroup_bias && d->rows_per_group < d->M) return 1;  // only the table form (every row reads row *step_ptr)
     const bool conv = d->a_mode == APAD_A_CONV3X3;
     int64_t a_bytes;
@@ -345,8 +399,12 @@ int apad_cgemm_try(const apad_gemm_desc* d, hipStream_t s) {
     p.ldo = d->ldo; p.ldr = d->ldr; p.ld_rg = d->ld_rg;
     p.M = (int32_t)d->M; p.N = (int32_t)d->N; p.K = (int32_t)d->K; p.lda = (int32_t)d->lda; p.ldw = (int32_t)d->ldw;
     p.Hin = d->Hin; p.Win = d->Win; p.Cin = d->Cin; p.res_mod = d->residual_row_mod;
-    p.m_tiles = (int32_t)((d->M + CBM - 1) / CBM); p.n_tiles = (int32_t)(d->N / CBN);
+    p.m_tiles = (int32_t)((d->M + CBM - 1) / CBM); p.n_tiles = (int32_t)(d->N / (sq ? 256 : 128));
     p.a_bytes = (uint32_t)a_bytes; p.w_bytes = (uint32_t)w_bytes;
-    if (d->dtype == APAD_BF16) return conv ? cg_launch<APAD_BF16, true>(p, s) : cg_launch<APAD_BF16, false>(p, s);
-    return conv ? cg_launch<APAD_F16, true>(p, s) : cg_launch<APAD_F16, false>(p, s);
+#define CG_GO(DT_)                                                                                              \
+    return sq ? (conv ? cg_launch<DT_, true, 256>(p, s) : cg_launch<DT_, false, 256>(p, s))                     \
+              : (conv ? cg_launch<DT_, true, 128>(p, s) : cg_launch<DT_, false, 128>(p, s));
+    if (d->dtype == APAD_BF16) { CG_GO(APAD_BF16) }
+    CG_GO(APAD_F16)
+#undef CG_GO
 }
