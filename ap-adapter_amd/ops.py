@@ -138,6 +138,8 @@ def ln_foldable(x, w):
 
 
 RP_K = (256, 384)  # reduction dims the row-panel kernel covers
+CGEMM_LINEAR = _os.environ.get("APAD_CGEMM_LINEAR", "0") == "1"  # A/B switch (read once)
+CGEMM_MIN_M = int(_os.environ.get("APAD_CGEMM_MIN_M", "16000"))  # the row threshold of csrc/cgemm.hip
 FUSED_DTYPES = (torch.bfloat16, torch.float16)  # the fused kernels (row-panel, feed-forward, cross-attention) are 16-bit only;
 # the fp32 precision mode (exact-f32 MFMA, csrc/f32_ops.hip) runs the un-fused apad_layernorm / apad_gemm / apad_attention chain
 
@@ -177,6 +179,11 @@ def fused_linear(x, w, bias=None, ln=None, residual=None, act=None, out=None, ro
     apad_layernorm + apad_gemm."""
     K = x.shape[-1]
     N = w.shape[0] // 2 if act == "geglu" else w.shape[0]
+    if (CGEMM_LINEAR and ln is None and act is None and x.dtype in FUSED_DTYPES and N % 128 == 0 and K % 64 == 0
+            and x.numel() // K >= CGEMM_MIN_M):
+        # plain projections of the large levels (to_out + residual, proj_in / proj_out at >= 16000 rows): apad_gemm's big-tile
+        # LDS-DMA kernel (csrc/cgemm.hip) instead of the weight-stationary row-panel kernel
+        return linear(x, w, bias, residual=residual, out=out)
     if rp_ok(x, K) and N % 64 == 0:
         if out is None:
             out = torch.empty(*x.shape[:-1], N, dtype=w.dtype, device=x.device)
