@@ -387,6 +387,9 @@ int apad_cgemm_try(const apad_gemm_desc* d, hipStream_t s) {
         a_bytes = d->M * (int64_t)d->Cin * 2;
     } else if (d->a_mode == APAD_A_PLAIN) {
         if (d->lda % 8 != 0) return 1;
+        // the tiled kernel sums these in K groups (gemm.hip: chosen by (N, K) alone so that a row's result does not depend on the
+        // batch it rides in); this kernel sums k-tiles in order, so it must not take them for SOME row counts only
+        if (d->K >= 384 && d->N >= 640) return 1;
         a_bytes = ((d->M - 1) * d->lda + d->K) * 2;
     } else {
         return 1;

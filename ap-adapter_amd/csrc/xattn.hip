@@ -33,7 +33,7 @@ constexpr int XTM = 128;                  // tokens per workgroup
 constexpr int TROWB = XC * 2 + 16;        // tile row stride (bytes): 33 sixteen-byte slots (odd -> conflict-free fragment reads)
 constexpr int TILE_BYTES = XTM * TROWB;   // 67 584
 constexpr int XA_LDS = 2 * TILE_BYTES + XC * 4;
-constexpr int XMAXSUB = 2;                // <= 64 keys per segment
+constexpr int XMAXSUB = 4;                // <= 128 keys per segment (segment 1: <= 64)
 #ifndef XA_SPLIT_Q
 #define XA_SPLIT_Q 0
 #endif
@@ -238,6 +238,11 @@ template <int DT, int NS1, int NS2, int G1 = 0, int G2 = 0, bool BIAS1 = false>
 __global__ __launch_bounds__(512) void xattn_kernel(XaP p) {
     constexpr bool DUAL = NS2 > 0;
     constexpr bool EXACT = G1 > 0;
+    // more than 64 audio keys (La = 128: the timbre / accompaniment presets, config.py:8-11, :50-53): the segment's 16 K / V^T
+    // fragments + four score tiles do not fit beside the stationary Wq rows, so the q-projection of all four panels runs first (q parked
+    // in LDS, Wq registers dead afterwards), the fragments are fetched behind it, and panels are attended one at a time
+    constexpr bool BIG2 = NS2 > 2;
+    constexpr bool SPLIT = XA_SPLIT || BIG2;
     using E = ET<DT>;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* const xt = smem;                 // x^ tile, later the output tile
@@ -380,8 +385,8 @@ __global__ __launch_bounds__(512) void xattn_kernel(XaP p) {
             if (DUAL) xa_fetch<DT, DUAL ? NS2 : 1>(f2, p.kv2 + ((int64_t)b * XH + h) * xa_kv_block(p.L2), p.L2, lane);
         };
         const int bfirst = (tile * 4) / p.ppn;
-        if constexpr (EXACT) fetch_kv(bfirst < p.B ? bfirst : p.B - 1);  // (general form: after the q-projection -- registers)
-        if constexpr (XA_SPLIT) {
+        if constexpr (EXACT && !BIG2) fetch_kv(bfirst < p.B ? bfirst : p.B - 1);  // (general form: after the q-projection -- registers)
+        if constexpr (SPLIT) {
             f32x16 qa[4];
             const uint8_t* bt = xt + l31 * TROWB + half * 16;
             typename E::v8 fb[2][4];
@@ -411,13 +416,13 @@ __global__ __launch_bounds__(512) void xattn_kernel(XaP p) {
                 *reinterpret_cast<uint4*>(qd + 16) = as_u4<DT>(qb[1]);
             }
         }
-        if constexpr (!EXACT) fetch_kv(bfirst < p.B ? bfirst : p.B - 1);
+        if constexpr (!EXACT || BIG2) fetch_kv(bfirst < p.B ? bfirst : p.B - 1);
         XA_STAMP(3);
         // attention of `n` panels (pp, pp + 1) of ONE sample, interleaved: the panels share the K / V fragments
         auto attend = [&](int pp, auto n_tag, int b) {
             constexpr int NP = decltype(n_tag)::value;
             typename E::v8 qb[NP][2];
-            if constexpr (XA_SPLIT) {
+            if constexpr (SPLIT) {
 #pragma unroll
                 for (int u = 0; u < NP; ++u) {
                     const uint8_t* qd = ot + ((pp + u) * 32 + l31) * TROWB + h * 64 + half * 32;
@@ -478,7 +483,7 @@ __global__ __launch_bounds__(512) void xattn_kernel(XaP p) {
             }
         };
         using One = std::integral_constant<int, 1>;
-        using Two = std::integral_constant<int, EXACT ? 2 : 1>;  // (the general form's fragment sets leave no room for two chains)
+        using Two = std::integral_constant<int, (EXACT && !BIG2) ? 2 : 1>;  // (the general form's / a big segment's fragment sets leave no room for two chains)
         int bnext = bfirst, rem = tile * 4 - bfirst * p.ppn;  // sample / panel-in-sample walk over the tile's panels
         int bcur = bfirst < p.B ? bfirst : p.B - 1;           // sample whose fragments are loaded
 #pragma unroll 1
@@ -710,8 +715,8 @@ extern "C" int apad_xattn_pack_kv(const void* k, const void* vt, void* packed, i
 extern "C" int apad_fused_cross_attention(const apad_xattn_desc* d, void* stream) {
     APAD_CHECK(d != nullptr, "apad_fused_cross_attention: null descriptor");
     APAD_CHECK(d->dtype == APAD_BF16 || d->dtype == APAD_F16, "apad_fused_cross_attention: dtype %d not supported", d->dtype);
-    if (d->C != XC || d->heads != XH || d->L1 > 32 * XMAXSUB || d->L2 > 32 * XMAXSUB) {
-        apad_set_error("apad_fused_cross_attention: C=%d heads=%d L1=%d L2=%d outside the kernel envelope (C 256, 8 heads, <= %d keys)",
+    if (d->C != XC || d->heads != XH || d->L1 > 64 || d->L2 > 32 * XMAXSUB) {
+        apad_set_error("apad_fused_cross_attention: C=%d heads=%d L1=%d L2=%d outside the kernel envelope (C 256, 8 heads, <= 64 + %d keys)",
                        d->C, d->heads, d->L1, d->L2, 32 * XMAXSUB);
         return -3;
     }
@@ -739,7 +744,7 @@ extern "C" int apad_fused_cross_attention(const apad_xattn_desc* d, void* stream
     if (d->L1 == 8 * g1 && d->L2 == 8 * g2 && (d->key_bias != nullptr) == hasb)                                        \
         return d->dtype == APAD_BF16 ? xa_launch<APAD_BF16, (g1 + 3) / 4, (g2 + 3) / 4, g1, g2, hasb>(p, s)              \
                                      : xa_launch<APAD_F16, (g1 + 3) / 4, (g2 + 3) / 4, g1, g2, hasb>(p, s);
-    XA_EXACT(1, 4, false) XA_EXACT(1, 1, false) XA_EXACT(1, 8, false) XA_EXACT(2, 0, true)
+    XA_EXACT(1, 4, false) XA_EXACT(1, 1, false) XA_EXACT(1, 8, false) XA_EXACT(2, 0, true) XA_EXACT(1, 16, false)
 #undef XA_EXACT
 #define XA_CASE(A, B2) \
     if (ns1 == A && ns2 == B2) return d->dtype == APAD_BF16 ? xa_launch<APAD_BF16, A, B2>(p, s) : xa_launch<APAD_F16, A, B2>(p, s);

@@ -197,6 +197,12 @@ def fused_linear(x, w, bias=None, ln=None, residual=None, act=None, out=None, ro
 
 
 XATTN_C, XATTN_HEADS, XATTN_MAXL = 256, 8, 64  # envelope of apad_fused_cross_attention
+XATTN_MAXL2 = 128  # ... plus the adapter's 8 text + 128 audio keys (pooling 2: the timbre / accompaniment presets), unmasked
+
+
+def xattn_lengths_ok(L1, L2=0, masked=False):
+    """key counts apad_fused_cross_attention has a kernel for: <= 64 per segment, or exactly 8 + 128 without a key bias"""
+    return L1 <= XATTN_MAXL and (L2 <= XATTN_MAXL or (L2 == XATTN_MAXL2 and L1 == 8 and not masked))
 
 
 def xattn_pack_weight(w):
@@ -214,7 +220,7 @@ def xattn_pack_kv(k, vt, Lk):
     _req(k, "xattn_pack_kv.k")
     _req(vt, "xattn_pack_kv.vt", k.dtype)
     B = k.shape[0]
-    if k.shape[-1] != XATTN_C or Lk > XATTN_MAXL or tuple(vt.shape[:3]) != (B, XATTN_HEADS, XATTN_C // XATTN_HEADS) or not vt.is_contiguous():
+    if k.shape[-1] != XATTN_C or Lk > XATTN_MAXL2 or tuple(vt.shape[:3]) != (B, XATTN_HEADS, XATTN_C // XATTN_HEADS) or not vt.is_contiguous():
         raise ValueError(f"xattn_pack_kv: k {tuple(k.shape)}, vt {tuple(vt.shape)}, Lk={Lk} outside the kernel envelope")
     nbytes = L.lib().apad_xattn_packed_kv_bytes(B, Lk)
     out = torch.empty(nbytes // k.element_size(), dtype=k.dtype, device=k.device)
@@ -229,7 +235,7 @@ def fused_cross_attention(x, wq_packed, wo_packed, bo, kv1_packed, L1, heads, ln
     cross-attention sub-layer in one launch.  x [B, N, C]; weights from xattn_pack_weight, K/V from xattn_pack_kv."""
     _req(x, "fused_cross_attention.x", wq_packed.dtype)
     B, N, Cc = x.shape
-    if Cc != XATTN_C or heads != XATTN_HEADS or L1 > XATTN_MAXL or L2 > XATTN_MAXL or x.dtype not in FUSED_DTYPES:
+    if Cc != XATTN_C or heads != XATTN_HEADS or not xattn_lengths_ok(L1, L2, key_bias is not None) or x.dtype not in FUSED_DTYPES:
         raise ValueError(f"fused_cross_attention: C={Cc} heads={heads} L1={L1} L2={L2} outside the kernel envelope")
     if not x.is_contiguous():
         raise ValueError("fused_cross_attention.x: must be contiguous")

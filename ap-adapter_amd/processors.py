@@ -31,10 +31,10 @@ USE_FUSED_XATTN = _os.environ.get("APAD_FUSED_XATTN", "1") == "1"
 PRESCALE_Q = _os.environ.get("APAD_PRESCALE_Q", "1") == "1"
 
 
-def _fused_xattn_ok(attn, hidden_states, residual, ln, L1, L2=0):
+def _fused_xattn_ok(attn, hidden_states, residual, ln, L1, L2=0, masked=False):
     C_ = hidden_states.shape[-1]
     return (USE_FUSED_XATTN and residual is hidden_states and ln is not None and C_ == ops.XATTN_C and attn.heads == ops.XATTN_HEADS
-            and tuple(attn.to_q.weight.shape) == (C_, C_) and L1 <= ops.XATTN_MAXL and L2 <= ops.XATTN_MAXL
+            and tuple(attn.to_q.weight.shape) == (C_, C_) and ops.xattn_lengths_ok(L1, L2, masked)
             and hidden_states.is_contiguous() and hidden_states.dtype in ops.FUSED_DTYPES)
 
 
@@ -356,7 +356,7 @@ class IPAttnProcessor2_0(nn.Module):
         # see AttnProcessor2_0: one entry per (site, condition buffer), valid for one condition content and one set of the four
         # projection weights, so a re-assigned to_k_ip / to_v_ip (inference.py:56-57) or an optimizer step is never served stale K/V
         Lt0 = min(self.num_tokens, ehs.shape[1])
-        fused = _fused_xattn_ok(attn, hidden_states, _residual, _ln, Lt0, ehs.shape[1] - Lt0)  # (no activation captured below)
+        fused = _fused_xattn_ok(attn, hidden_states, _residual, _ln, Lt0, ehs.shape[1] - Lt0, attention_mask is not None)  # (no activation captured below)
 
         def make(attn=attn, ehs=ehs, fused=fused):
             kv_ = self._project(attn, ehs)
@@ -374,7 +374,7 @@ class IPAttnProcessor2_0(nn.Module):
             # over the text keys
             m = attention_mask.reshape(B, -1)[:, :1].float()
             bias = m.expand(B, Lt).contiguous()
-        if pk_t is not None and _fused_xattn_ok(attn, hidden_states, _residual, _ln, Lt, La):
+        if pk_t is not None and _fused_xattn_ok(attn, hidden_states, _residual, _ln, Lt, La, bias is not None):
             wq_p, wo_p = _xattn_weights(attn)
             return ops.fused_cross_attention(hidden_states, wq_p, wo_p, attn.to_out[0].bias, pk_t, Lt, attn.heads, ln=_ln,
                                              key_bias=bias, kv2_packed=pk_a, L2=La, scale2=self.scale)
