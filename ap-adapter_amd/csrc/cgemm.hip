@@ -314,9 +314,21 @@ __global__ __launch_bounds__(512) void cgemm_kernel(CgP p) {
         bv[j] = p.bias ? ld_elem<DT>(p.bias, n) : 0.f;
         rg0[j] = p.rg ? ld_elem<DT>(p.rg, step * p.ld_rg + n) : 0.f;
     }
-    constexpr int VPR = BN / 8;
+    constexpr int VPR = BN / 8, NV = 128 * VPR / 512;  // 16-byte vectors per output row; vectors per thread and half
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
+        // the residual rows of this half are requested first: their latency runs under the accumulator -> LDS pass
+        uint4 rres[NV];
+        if (p.residual) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int idx = tid + v * 512, rl = idx / VPR, vc = idx - rl * VPR;
+                int m = m0 + hh * 128 + rl;
+                m = m < p.M ? m : p.M - 1;
+                const int64_t rm = p.res_mod > 0 ? m % p.res_mod : m;
+                rres[v] = *reinterpret_cast<const uint4*>(p.residual + (rm * p.ldr + n0 + vc * 8) * 2);
+            }
+        }
         if ((wm * MI * 32) / 128 == hh) {  // this wave's rows lie in this half (wave-uniform)
             const int rbase = wm * MI * 32 - hh * 128;
 #pragma unroll
@@ -332,21 +344,20 @@ __global__ __launch_bounds__(512) void cgemm_kernel(CgP p) {
             }
         }
         __syncthreads();
-        for (int idx = tid; idx < 128 * VPR; idx += 512) {
-            const int rl = idx / VPR, vc = idx - rl * VPR;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int idx = tid + v * 512, rl = idx / VPR, vc = idx - rl * VPR;
             const int m = m0 + hh * 128 + rl, n = n0 + vc * 8;
-            if (m >= p.M) continue;
-            uint4 v = *reinterpret_cast<const uint4*>(&ct[rl * C_LD + vc * 8]);
+            uint4 o = *reinterpret_cast<const uint4*>(&ct[rl * C_LD + vc * 8]);
             if (p.residual) {
                 float f[8], rr[8];
-                unpack8<DT>(v, f);
-                const int64_t rm = p.res_mod > 0 ? m % p.res_mod : m;
-                unpack8<DT>(*reinterpret_cast<const uint4*>(p.residual + (rm * p.ldr + n) * 2), rr);
+                unpack8<DT>(o, f);
+                unpack8<DT>(rres[v], rr);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] += rr[e];
-                v = pack8<DT>(f);
+                o = pack8<DT>(f);
             }
-            *reinterpret_cast<uint4*>(p.out + ((int64_t)m * p.ldo + n) * 2) = v;
+            if (m < p.M) *reinterpret_cast<uint4*>(p.out + ((int64_t)m * p.ldo + n) * 2) = o;
         }
         if (hh == 0) __syncthreads();
     }

@@ -160,6 +160,23 @@ class FeedForward(nn.Module):
         return ops.linear(h, self.net[2].weight, self.net[2].bias, residual=x, rowstat=True)  # (the next block's norm1 folds into its q|k|v)
 
 
+def cfg_expand(x, cond):
+    """The classifier-free-guidance batch is [latents] * 2 against [negative | positive] conditions (pipeline_audioldm2.py:1003,
+    :953-955): until the first attention that reads a condition, both halves of the UNet batch hold the SAME rows.  The denoise
+    step therefore enters the UNet with the un-duplicated latents (forward_nhwc, batch_repeat) and the hidden states are
+    replicated here, in front of the first conditioned attention: conv_in, the first down block, the first resnet and the whole
+    unconditioned (double-self-attention) transformer of the second one run once per clip instead of twice -- same values, row for
+    row, as the duplicated batch (the kernels' per-row arithmetic does not depend on the batch size)."""
+    if cond is None or cond.dim() != 3 or cond.shape[0] <= x.shape[0]:
+        return x
+    if cond.shape[0] % x.shape[0] != 0:
+        raise ValueError(f"condition batch {cond.shape[0]} is not a multiple of the hidden-state batch {x.shape[0]}")
+    return x.repeat(cond.shape[0] // x.shape[0], *([1] * (x.dim() - 1)))
+
+
+CFG_SHARED_PREFIX = os.environ.get("APAD_CFG_SHARED_PREFIX", "1") == "1"  # A/B switch (read once)
+
+
 class BasicTransformerBlock(nn.Module):
     """diffusers BasicTransformerBlock, pre-LN x3 + GEGLU FF; attn2 is self-attention when cross_attention_dim is
     None (double_self_attention, modeling_audioldm2.py:1058)."""
@@ -175,6 +192,7 @@ class BasicTransformerBlock(nn.Module):
 
     def forward(self, x, ehs, emask):
         x = self.attn1(x, residual=x, ln=(self.norm1.weight, self.norm1.bias, self.norm1.eps))
+        x = cfg_expand(x, ehs)
         x = self.attn2(x, encoder_hidden_states=ehs, attention_mask=emask, residual=x,
                        ln=(self.norm2.weight, self.norm2.bias, self.norm2.eps))
         return self.ff(x, (self.norm3.weight, self.norm3.bias, self.norm3.eps))
@@ -451,6 +469,10 @@ class AudioLDM2UNet2DConditionModel(nn.Module):
         dtype = self.conv_in.weight.dtype
         Bs = x.shape[0]
         B = Bs * batch_repeat
+        # CFG duplication deferred to the first conditioned attention (cfg_expand): inference only, and only when a condition of
+        # the full batch exists to trigger it (APAD_CFG_SHARED_PREFIX=0: duplicate in conv_in's gather, the A/B reference)
+        share = (batch_repeat > 1 and CFG_SHARED_PREFIX and not AG.on(x) and ehs is not None and ehs.dim() == 3 and ehs.shape[0] == B
+                 and (ehs1 is None or ehs1.shape[0] == B))
         # mask (1 keep / 0 drop) -> additive bias [B,1,L]  (:741-747).  Built in fp32, the type apad_attention takes its
         # key bias in: the reference's cast to the hidden dtype would only add one bf16 -> fp32 conversion launch in
         # front of every masked attention site (44 per captured step)
@@ -481,7 +503,10 @@ class AudioLDM2UNet2DConditionModel(nn.Module):
             return m(x, B_of(x), H, W, tab, rpg if rpg is not None else H * W, step_ptr)
 
         wp = self._pk_in.get(self.conv_in.weight, lambda w: w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous())
-        x, _, _ = ops.conv3x3(x, wp, self.conv_in.bias, B, H, W, src_batch_mod=(Bs if batch_repeat > 1 else 0))
+        if share:
+            x, _, _ = ops.conv3x3(x, wp, self.conv_in.bias, Bs, H, W)
+        else:
+            x, _, _ = ops.conv3x3(x, wp, self.conv_in.bias, B, H, W, src_batch_mod=(Bs if batch_repeat > 1 else 0))
         skips = [(x, H, W)]
         nb = len(cfg.block_out_channels)
         n_up = nb - 1
@@ -514,6 +539,8 @@ class AudioLDM2UNet2DConditionModel(nn.Module):
             up_size = skips[-1][1:] if (not final and fwd_up) else None
             for layer, rn in enumerate(blk.resnets):
                 s, _, _ = res.pop()
+                if s.shape[0] != x.shape[0]:  # a skip of the shared CFG prefix (cfg_expand): one row set for both halves
+                    s = s.repeat(x.shape[0] // s.shape[0], 1, 1)
                 x = torch.cat([x, s], dim=-1)  # channel concat of NHWC rows (data movement only)
                 x = resnet(f"up_blocks.{i}.resnets.{layer}", rn, x, H, W)
                 if blk.has_cross_attention:
@@ -528,6 +555,8 @@ class AudioLDM2UNet2DConditionModel(nn.Module):
         k0 = max(1, nb - self.low_res_levels) if split else nb  # first down block of the two-stream section
         for i in range(k0):
             x, H, W = down(i, x, H, W, skips, *cond)
+        if split and x.shape[0] != B:  # (no conditioned attention above the section: expand here)
+            x = x.repeat(B // x.shape[0], 1, 1)
         if split:
             # The lowest-resolution section (last down block(s), mid block, first up block(s): 64-token sequences) under-fills
             # the chip and is latency-bound kernel after kernel; its two batch halves are independent, so they run on two
@@ -541,7 +570,10 @@ class AudioLDM2UNet2DConditionModel(nn.Module):
                 st.wait_stream(cur)
                 with torch.cuda.stream(st):
                     c_h = tuple(None if c is None else c[sl] for c in cond)
-                    sk = [(t_[sl], hh, ww) for (t_, hh, ww) in shared]
+                    # (skips of the shared CFG prefix hold one row set for both halves of the batch: row b <-> b % rows)
+                    part = lambda t_: t_[sl] if t_.shape[0] == B else (
+                        t_[(h * hb) % t_.shape[0]:(h * hb) % t_.shape[0] + hb] if hb <= t_.shape[0] else t_)
+                    sk = [(part(t_), hh, ww) for (t_, hh, ww) in shared]
                     xh, Hh, Wh = x[sl], H, W
                     for i in range(k0, nb):
                         xh, Hh, Wh = down(i, xh, Hh, Wh, sk, *c_h)
@@ -561,6 +593,8 @@ class AudioLDM2UNet2DConditionModel(nn.Module):
         for i in range(first_up, nb):
             x, H, W = up(i, x, H, W, skips, *cond)
 
+        if x.shape[0] != B:  # no conditioned attention anywhere: the halves never differed
+            x = x.repeat(B // x.shape[0], 1, 1)
         if AG.on(x):
             x = AG.group_norm(x, self.conv_norm_out.weight, self.conv_norm_out.bias, cfg.norm_num_groups,
                               self.conv_norm_out.eps, True)

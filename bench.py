@@ -74,6 +74,20 @@ def unet_flops_per_sample(La, t5_len=16):
     return fl
 
 
+def cfg_shared_prefix_flops():
+    """FLOPs of the part of a sample-forward that reads no condition (conv_in, the first down block, the first resnet + the
+    double-self-attention transformer + proj_in / attn1 of the first conditioned one at the 1000-pixel level): identical rows in both
+    halves of the CFG batch, executed once per clip by the shared-prefix step (unet.cfg_expand)"""
+    n0, n1 = 250 * 16, 125 * 8
+    conv = lambda n, cin, cout, k=9: 2.0 * n * cin * cout * k
+    res = lambda n, cin, cout: conv(n, cin, cout) + conv(n, cout, cout) + 2.0 * 512 * cout + (conv(n, cin, cout, 1) if cin != cout else 0.0)
+    c = 256
+    self_block = 2 * (8.0 * n1 * c * c + 4.0 * n1 * n1 * c) + 24.0 * n1 * c * c
+    return (conv(n0, 8, 128) + 2 * res(n0, 128, 128) + conv(n1, 128, 128) + res(n1, 128, 256)
+            + 4.0 * n1 * c * c + 2 * self_block                      # transformer 1 (no condition): proj_in/out + 2 blocks
+            + 2.0 * n1 * c * c + 8.0 * n1 * c * c + 4.0 * n1 * n1 * c)  # transformer 2: proj_in + attn1 of its first block
+
+
 def time_kernel(fn, iters=20):
     """average duration (ms) of one launch, HIP events on the launching stream"""
     fn()
@@ -607,7 +621,10 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         clips_per_s = (B * world) / (DDIM_STEPS_PER_CLIP * ms_per_step * 1e-3)
-        fl = unet_flops_per_sample(args.la) * 2 * B
+        from ap_adapter_amd import unet as _U
+        shared = bool(_U.CFG_SHARED_PREFIX)
+        fl_model = unet_flops_per_sample(args.la) * 2 * B
+        fl = fl_model - (cfg_shared_prefix_flops() * B if shared else 0.0)  # EXECUTED FLOPs: the condition-free prefix runs once per clip
         line = {
             "metric": "10s-clips/sec @200 DDIM steps, AudioLDM2-large+AP", "value": round(clips_per_s, 4), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -621,6 +638,11 @@ def main():
             "step_tflops": round(fl / (ms_per_step * 1e-3) / 1e12, 2),
             "mfma_frac_whole_step": round(fl / (ms_per_step * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
             "finite": finite,
+            # the CFG batch's two halves are the same rows until the first conditioned attention: that prefix is executed once per
+            # clip (bit-identical latents, tests/test_gpu_unet.py::test_cfg_shared_prefix_equals_the_duplicated_batch); step_tflops
+            # counts executed FLOPs only
+            "cfg_shared_prefix": {"enabled": shared, "flops_not_repeated_per_step": cfg_shared_prefix_flops() * B if shared else 0.0,
+                                  "flops_model_per_step": fl_model},
             # one-off per pipeline call, outside the timed region: time tables, K/V hoist + packing, warm-up step, graph capture
             "setup_ms": round(setup_ms, 1), "model_build_ms": round(build_ms, 1),
         }

@@ -304,6 +304,26 @@ def _independent_of_batch(dev, full_pipe, La):
     assert err < 1e-2
 
 
+@pytest.mark.parametrize("B", [4, 32])
+def test_cfg_shared_prefix_equals_the_duplicated_batch(dev, full_pipe, monkeypatch, B):
+    """the CFG batch is [latents] * 2 (pipeline_audioldm2.py:1003): until the first conditioned attention its halves are the same
+    rows, so the denoise step enters the UNet un-duplicated and replicates the hidden states there (unet.cfg_expand).  Asserted:
+    conv_in really runs on B rows (2 B with the switch off) and the latents after two DDIM steps are BIT-equal either way."""
+    from ap_adapter_amd import ops, unet as U
+    d = _full_inputs(full_pipe, B, 32, dev)
+    first = []
+    real = ops.conv3x3
+    monkeypatch.setattr(ops, "conv3x3", lambda x, w, b, Bc, *a, **kw: (first.append(Bc) if not first else None, real(x, w, b, Bc, *a, **kw))[1])
+    out = {}
+    for share in (True, False):
+        monkeypatch.setattr(U, "CFG_SHARED_PREFIX", share)
+        del first[:]
+        with torch.no_grad():
+            out[share] = full_pipe.denoise(d["lat"], d["ehs"], d["pe"], d["mask"], 2, 9.5, use_graph=False)
+        assert first[0] == (B if share else 2 * B)
+    assert torch.isfinite(out[True]).all() and torch.equal(out[True], out[False])
+
+
 def test_full_size_scale_zero_ignores_the_audio_tokens(dev, full_pipe):
     """attention_processor.py:454 o = o_t + scale * o_a: with scale 0 the audio tokens must not reach the result, and a
     non-zero scale must (the adapter branch is live at every one of the 32 sites)."""
