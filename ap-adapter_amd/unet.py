@@ -218,6 +218,8 @@ class Transformer2DModel(nn.Module):
             h = ops.fused_linear(h, _w2d(self.proj_in), self.proj_in.bias, rowstat=True)
         for blk in self.transformer_blocks:
             h = blk(h, ehs, emask)
+        if h.shape[0] != x.shape[0]:  # the CFG batch was expanded inside (cfg_expand): the residual rows are the same for both halves
+            x = x.repeat(h.shape[0] // x.shape[0], 1, 1)
         if AG.on(h, x):
             return AG.linear(h, self.proj_out.weight, self.proj_out.bias, residual=x)
         return ops.fused_linear(h, _w2d(self.proj_out), self.proj_out.bias, residual=x)
