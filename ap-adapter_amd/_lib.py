@@ -31,7 +31,8 @@ class GemmDesc(C.Structure):
                [("out2", _vp), ("out3", _vp)] + \
                [(n, _i32) for n in ("taps", "dilation", "pad", "transposed", "a_pre_act")] + [("a_pre_slope", _f32)] + \
                [("conv_asym_pad", _i32), ("reserved_conv", _i32)] + \
-               [(n, _vp) for n in ("rowstat_out", "rowstat_in", "ln_colsum", "ln_bias")] + [("rowstat_in_tiles", _i32), ("ln_eps", _f32)]
+               [(n, _vp) for n in ("rowstat_out", "rowstat_in", "ln_colsum", "ln_bias")] + [("rowstat_in_tiles", _i32), ("ln_eps", _f32)] + \
+               [("a2", _vp), ("lda2", _i64), ("k_split", _i32), ("a_row_mod", _i32), ("a2_row_mod", _i32), ("reserved_a2", _i32)]
 
 
 class AttnDesc(C.Structure):
@@ -96,6 +97,7 @@ SYMBOLS = {
     "apad_layernorm": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _i64, _f32, _i32, _vp]),
     "apad_groupnorm_workspace_bytes": (_i64, [_i32, _i32, _i32]),
     "apad_groupnorm": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp]),
+    "apad_groupnorm2": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp]),
     "apad_audiomae_pool": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "apad_timestep_embedding": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
     "apad_cfg_ddim_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _i32, _i64, _i32, _vp]),
@@ -160,7 +162,7 @@ def lib():
                 fn = getattr(h, name)  # AttributeError if the ABI lost a symbol
                 fn.restype = res
                 fn.argtypes = args
-            if h.apad_abi_version() != 5:
+            if h.apad_abi_version() != 6:
                 raise RuntimeError("libapadapter_hip.so ABI version mismatch")
             if h.apad_sizeof_gemm_desc() != C.sizeof(GemmDesc) or h.apad_sizeof_attn_desc() != C.sizeof(AttnDesc) \
                     or h.apad_sizeof_rp_desc() != C.sizeof(RpDesc) \

@@ -61,6 +61,10 @@ struct CgP {
     int32_t Hin, Win, Cin, res_mod;
     int32_t m_tiles, n_tiles;
     uint32_t a_bytes, w_bytes;
+    // two-source plain A (apad_gemm_desc::a2): k-tiles from ksplit on come from a2
+    const uint8_t* a2;
+    int32_t lda2, ksplit, a_mod, a2_mod;
+    uint32_t a2_bytes;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -121,6 +125,8 @@ __global__ __launch_bounds__(512) void cgemm_kernel(CgP p) {
     // ---- DMA sources.  One instruction of a wave fills one 1 KB block = 8 tile rows x 128 bytes; lane -> (row r = lane / 8,
     //      LDS slot lane % 8), and the slot holds source chunk slot ^ ((row >> 1) & 7): the swizzle the fragment reads undo. ----
     const __amdgpu_buffer_rsrc_t ra = c_rsrc(p.a, p.a_bytes), rw = c_rsrc(p.w, p.w_bytes);
+    const __amdgpu_buffer_rsrc_t ra2 = c_rsrc(CONV || p.a2 == nullptr ? p.a : p.a2, CONV || p.a2 == nullptr ? p.a_bytes : p.a2_bytes);
+    uint32_t aoff2[4];  // plain, two sources: the row's offset in the second one
     uint32_t aoff[4];   // plain: byte offset of (row, chunk) at k = 0, or C_OOB; conv: of the CENTRE tap, channel 0
     uint32_t amask[4];  // conv: bit (3 ky + kx) = that tap lies inside the image (0 for rows past M)
 #pragma unroll
@@ -143,7 +149,8 @@ __global__ __launch_bounds__(512) void cgemm_kernel(CgP p) {
                 }
             }
         } else {
-            aoff[i] = valid ? (uint32_t)(m * p.lda * 2 + c * 16) : C_OOB;
+            aoff[i] = valid ? (uint32_t)((p.a_mod > 0 ? m % p.a_mod : m) * p.lda * 2 + c * 16) : C_OOB;
+            aoff2[i] = (valid && p.a2 != nullptr) ? (uint32_t)((p.a2_mod > 0 ? m % p.a2_mod : m) * p.lda2 * 2 + c * 16) : C_OOB;
         }
     }
     uint32_t boff[4];  // (PB used; a template-dependent array bound captured by the lambdas below loses the kernel's host stub: hipcc 7.2)
@@ -159,6 +166,7 @@ __global__ __launch_bounds__(512) void cgemm_kernel(CgP p) {
     int rq_tap = 0, rq_cb = 0;
     uint32_t av[4];
     int a_soff = 0;
+    bool a_second = false;  // (wave-uniform) the tile being requested lies in the second source
     auto next_tile_sources = [&](int kt) {  // per-lane A offsets + the scalar offset of k-tile kt
         if (CONV) {
             const int ky = rq_tap / 3, kx = rq_tap - ky * 3;
@@ -172,16 +180,20 @@ __global__ __launch_bounds__(512) void cgemm_kernel(CgP p) {
                 ++rq_tap;
             }
         } else {
+            a_second = p.a2 != nullptr && kt * CBK >= p.ksplit;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) av[i] = aoff[i];
-            a_soff = kt * (CBK * 2);
+            for (int i = 0; i < 4; ++i) av[i] = a_second ? aoff2[i] : aoff[i];
+            a_soff = (a_second ? kt * CBK - p.ksplit : kt * CBK) * 2;
         }
     };
     // piece q of k-tile kt (its sources prepared by next_tile_sources) -> LDS stage `stage`: q < 4 an A block, else a B block
     auto issue = [&](int q, int stage, int kt) {
-        if (q < 4)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(smem + stage * STAGE + (wave * 4 + q) * 1024), 16, av[q], a_soff, 0, 0);
-        else
+        if (q < 4) {
+            if (!CONV && a_second)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra2, (lds_ptr)(smem + stage * STAGE + (wave * 4 + q) * 1024), 16, av[q], a_soff, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(smem + stage * STAGE + (wave * 4 + q) * 1024), 16, av[q], a_soff, 0, 0);
+        } else
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(smem + stage * STAGE + CA_BYTES + (wave * PB + q - 4) * 1024), 16,
                                                      boff[q - 4], kt * (CBK * 2), 0, 0);
     };
@@ -398,15 +410,19 @@ int apad_cgemm_try(const apad_gemm_desc* d, hipStream_t s) {
         a_bytes = d->M * (int64_t)d->Cin * 2;
     } else if (d->a_mode == APAD_A_PLAIN) {
         if (d->lda % 8 != 0) return 1;
+        if (d->a2 != nullptr && (d->k_split % CBK != 0 || d->lda2 % 8 != 0)) return 1;
         // the tiled kernel sums these in K groups (gemm.hip: chosen by (N, K) alone so that a row's result does not depend on the
         // batch it rides in); this kernel sums k-tiles in order, so it must not take them for SOME row counts only
         if (d->K >= 384 && d->N >= 640) return 1;
-        a_bytes = ((d->M - 1) * d->lda + d->K) * 2;
+        const int64_t rows_a = d->a_row_mod > 0 ? d->a_row_mod : d->M;
+        a_bytes = ((rows_a - 1) * d->lda + (d->a2 ? d->k_split : d->K)) * 2;
     } else {
         return 1;
     }
     const int64_t w_bytes = ((d->N - 1) * d->ldw + d->K) * 2;
-    if (a_bytes >= (1LL << 31) || w_bytes >= (1LL << 31)) return 1;
+    int64_t a2_bytes = 0;
+    if (!conv && d->a2 != nullptr) a2_bytes = (((d->a2_row_mod > 0 ? d->a2_row_mod : d->M) - 1) * d->lda2 + (d->K - d->k_split)) * 2;
+    if (a_bytes >= (1LL << 31) || w_bytes >= (1LL << 31) || a2_bytes >= (1LL << 31)) return 1;
     CgP p;
     p.a = (const uint8_t*)d->a; p.w = (const uint8_t*)d->w; p.out = (uint8_t*)d->out; p.bias = (const uint8_t*)d->bias;
     p.residual = (const uint8_t*)d->residual; p.rg = (const uint8_t*)d->rowgroup_bias; p.step_ptr = d->step_ptr;
@@ -415,6 +431,8 @@ int apad_cgemm_try(const apad_gemm_desc* d, hipStream_t s) {
     p.Hin = d->Hin; p.Win = d->Win; p.Cin = d->Cin; p.res_mod = d->residual_row_mod;
     p.m_tiles = (int32_t)((d->M + CBM - 1) / CBM); p.n_tiles = (int32_t)(d->N / (sq ? 256 : 128));
     p.a_bytes = (uint32_t)a_bytes; p.w_bytes = (uint32_t)w_bytes;
+    p.a2 = conv ? nullptr : (const uint8_t*)d->a2; p.lda2 = (int32_t)d->lda2; p.ksplit = d->k_split; p.a_mod = conv ? 0 : d->a_row_mod;
+    p.a2_mod = d->a2_row_mod; p.a2_bytes = (uint32_t)a2_bytes;
 #define CG_GO(DT_)                                                                                              \
     return sq ? (conv ? cg_launch<DT_, true, 256>(p, s) : cg_launch<DT_, false, 256>(p, s))                     \
               : (conv ? cg_launch<DT_, true, 128>(p, s) : cg_launch<DT_, false, 128>(p, s));

@@ -64,6 +64,10 @@ struct GemmP {
     const float* ln_bb;   // [w rows]
     int32_t rs_in_tiles, rs_out_tiles;
     float ln_eps;
+    // two-source plain A (apad_gemm_desc::a2): columns >= ksplit of row m come from a2[(m % a2_mod) * lda2 + k - ksplit]
+    const uint8_t* a2;
+    int64_t lda2;
+    int32_t ksplit, a_mod, a2_mod;
 };
 
 // byte offset of 16-byte chunk `chunk` (0..7) of tile row `row` (128-byte rows)
@@ -85,6 +89,10 @@ __device__ __forceinline__ uint4 load_a(const GemmP& p, const RowInfo<AMODE>& r,
     uint4 z = make_uint4(0, 0, 0, 0);
     if (!r.valid || k >= p.K) return z;
     if (AMODE == APAD_A_PLAIN) {
+        if (p.a2 != nullptr && k >= p.ksplit) {  // (r.oy = the row index: the second source's offset is formed here)
+            const int64_t m2 = p.a2_mod > 0 ? r.oy % p.a2_mod : r.oy;
+            return *reinterpret_cast<const uint4*>(p.a2 + (m2 * p.lda2 + (k - p.ksplit)) * 2);
+        }
         return *reinterpret_cast<const uint4*>(p.a + (r.base + k) * 2);
     } else if (AMODE == APAD_A_CONV3X3) {
         int tap = k / p.Cin;
@@ -205,7 +213,8 @@ __global__ __launch_bounds__(256 * KG) void gemm_kernel(GemmP p) {
         ra[i].base = 0;
         if (ra[i].valid) {
             if (AMODE == APAD_A_PLAIN) {
-                ra[i].base = m * p.lda;
+                ra[i].base = (p.a_mod > 0 ? m % p.a_mod : m) * p.lda;
+                ra[i].oy = (int)m;
             } else if (AMODE == APAD_A_CONV3X3) {
                 int64_t hw = (int64_t)p.Hout * p.Wout;
                 int64_t b = m / hw;
@@ -745,7 +754,7 @@ int launch(const GemmP& p, hipStream_t s) {
     const int64_t blocks128 = ((p.N + BN_OUT - 1) / BN_OUT) * ((p.M + 127) / 128);
     static const int dma_mode = [] { const char* e = getenv("APAD_GEMM_DMA"); return e ? atoi(e) : 0; }();  // off by default: measured slower than the register-staged kernel (1 workgroup/CU)
     if constexpr (AMODE == APAD_A_PLAIN && OUTMODE == APAD_OUT_ROWMAJOR) {
-        if (dma_mode && p.K % 64 == 0 && p.K >= 128 && blocks128 >= 256) return launch_dma<DT, EPI>(p, s);
+        if (dma_mode && p.K % 64 == 0 && p.K >= 128 && blocks128 >= 256 && p.a2 == nullptr && p.a_mod == 0) return launch_dma<DT, EPI>(p, s);
     }
     // long reductions amortise the under-fill: with K >= 1024 the 128-tile wins from ~1.25 workgroups per CU (measured:
     // conv 63x4 384->384 76.5 -> 71.5 us, FF2 M=16128 K=1536 38.5 -> 37.1 us), short-K launches prefer the 64-tile
@@ -895,6 +904,13 @@ extern "C" int apad_gemm(const apad_gemm_desc* d, void* stream) {
         return -1;
     }
     if (d->rowgroup_bias) APAD_CHECK(d->ld_rg > 0, "apad_gemm: rowgroup_bias needs ld_rg");
+    p.a2 = (const uint8_t*)d->a2; p.lda2 = d->lda2; p.ksplit = d->k_split; p.a_mod = d->a_row_mod; p.a2_mod = d->a2_row_mod;
+    if (d->a2 != nullptr)
+        APAD_CHECK(d->a_mode == APAD_A_PLAIN && d->k_split > 0 && d->k_split % 64 == 0 && d->k_split < d->K && d->lda2 % 8 == 0 && al16(d->a2) &&
+                       d->a_row_mod >= 0 && d->a2_row_mod >= 0 && d->M < (1LL << 31) && !d->rowstat_in,
+                   "apad_gemm: two-source A needs a plain A operand, 0 < k_split < K, k_split %% 64 == 0, lda2 %% 8 == 0");
+    else
+        APAD_CHECK(d->a_row_mod == 0 || d->a_mode == APAD_A_PLAIN, "apad_gemm: a_row_mod needs a plain A operand");
     p.rs_out = d->rowstat_out; p.rs_in = d->rowstat_in; p.ln_cs = d->ln_colsum; p.ln_bb = d->ln_bias;
     p.rs_in_tiles = d->rowstat_in_tiles; p.rs_out_tiles = (int32_t)((d->N + 63) / 64); p.ln_eps = d->ln_eps;
     if (d->rowstat_out)

@@ -60,8 +60,22 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const uint8_t* x, const 
 // group to mean / rstd in LDS, then all threads normalise (+ optional SiLU) with 16-byte loads/stores.
 constexpr int GN_CHUNK = 64;  // pixels per workgroup
 
+// The input of a GroupNorm as up to two channel-concatenated sources (the up blocks' torch.cat([hidden, skip], 1) is never
+// materialised): channels [0, Ca) from a [Ba][HW][Ca], [Ca, Ca + Cb) from b [Bb][HW][Cb]; sample index modulo the source's batch
+// (a skip of the CFG-shared prefix is stored once for both halves of the batch).  Cb = 0: one source.
+struct GnSrc {
+    const uint8_t* a;
+    const uint8_t* b;
+    int Ca, Cb, Ba, Bb;
+};
+// address of the 16-byte vector that starts at channel c (c % 8 == 0, Ca % 8 == 0) of pixel px of sample bi
+__device__ __forceinline__ const uint8_t* gn_vec(const GnSrc& s, int bi, int HW, int px, int c) {
+    return c < s.Ca ? s.a + (((int64_t)(bi % s.Ba) * HW + px) * s.Ca + c) * 2
+                    : s.b + (((int64_t)(bi % s.Bb) * HW + px) * s.Cb + (c - s.Ca)) * 2;
+}
+
 template <int DT>
-__global__ __launch_bounds__(256) void gn_partial_kernel(const uint8_t* x, float* partial, int HW, int C, int G, int nchunk) {
+__global__ __launch_bounds__(256) void gn_partial_kernel(GnSrc x, float* partial, int HW, int C, int G, int nchunk) {
     __shared__ float ls[2][2048];  // [sum|sumsq][thread * 8 + e]: per-thread channel partials (deterministic reduction)
     __shared__ float lc[2][1280];  // per-channel sums of this workgroup (C <= 1280)
     const int vpr = C >> 3;        // 16-byte vectors per pixel (<= 160)
@@ -74,10 +88,11 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const uint8_t* x, float
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = ss[e] = 0.f;
     if (py < PY) {
-        const uint8_t* base = x + (((int64_t)b * HW) * C + vc * 8) * 2;
+        const uint8_t* base = gn_vec(x, b, HW, 0, vc * 8);  // (a thread's vector lies in one source)
+        const int64_t pstride = (vc * 8 < x.Ca ? x.Ca : x.Cb) * 2;
         for (int px = p0 + py; px < p1; px += PY) {
             float v[8];
-            unpack8<DT>(*reinterpret_cast<const uint4*>(base + (int64_t)px * C * 2), v);
+            unpack8<DT>(*reinterpret_cast<const uint4*>(base + (int64_t)px * pstride), v);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 s[e] += v[e];
@@ -116,7 +131,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const uint8_t* x, float
 }
 
 template <int DT, bool SILU>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const uint8_t* x, const float* partial, const uint8_t* gamma,
+__global__ __launch_bounds__(256) void gn_apply_kernel(GnSrc x, const float* partial, const uint8_t* gamma,
                                                        const uint8_t* beta, uint8_t* out, int HW, int C, int G, int nchunk,
                                                        float eps) {
     __shared__ float lm[64], lr[64];
@@ -139,13 +154,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint8_t* x, const f
     __syncthreads();
     const int p0 = chunk * GN_CHUNK, p1 = min(p0 + GN_CHUNK, HW);
     const int nv = (p1 - p0) * vpr;
-    const uint8_t* xb = x + (((int64_t)b * HW + p0) * C) * 2;
     uint8_t* ob = out + (((int64_t)b * HW + p0) * C) * 2;
     for (int idx = tid; idx < nv; idx += 256) {
         const int vc = idx % vpr;
         const int c0 = vc * 8;
         float v[8], g[8], bt[8], y[8];
-        unpack8<DT>(*reinterpret_cast<const uint4*>(xb + (int64_t)idx * 16), v);
+        unpack8<DT>(*reinterpret_cast<const uint4*>(gn_vec(x, b, HW, p0 + idx / vpr, c0)), v);
         unpack8<DT>(*reinterpret_cast<const uint4*>(gamma + c0 * 2), g);
         unpack8<DT>(*reinterpret_cast<const uint4*>(beta + c0 * 2), bt);
         const int g0 = c0 / cg, g1 = (c0 + 4) / cg;
@@ -172,7 +186,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint8_t* x, const f
 constexpr int GN1_GPB = 4;
 
 template <int DT, bool SILU, int NTH, int MAXP>
-__global__ __launch_bounds__(NTH) void gn_onepass_kernel(const uint8_t* x, const uint8_t* gamma, const uint8_t* beta,
+__global__ __launch_bounds__(NTH) void gn_onepass_kernel(GnSrc x, const uint8_t* gamma, const uint8_t* beta,
                                                          uint8_t* out, int HW, int C, int G, float eps) {
     __shared__ float lh[NTH][4];   // per thread: (sum, sumsq) of the low and of the high 4 channels of its vector
     __shared__ float lcol[2][48];  // per 4-channel column of the slab (4 groups x cg <= 40 channels / 4)
@@ -183,14 +197,15 @@ __global__ __launch_bounds__(NTH) void gn_onepass_kernel(const uint8_t* x, const
     const int vc = tid % vps, py = tid / vps;
     const bool active = py < PY;
     const int cbase = blockIdx.x * wc + vc * 8;
-    const uint8_t* xb = x + ((int64_t)b * HW * C + cbase) * 2;
+    const uint8_t* xb = gn_vec(x, b, HW, 0, cbase);  // (a thread's vector lies in one source)
+    const int64_t pstride = (cbase < x.Ca ? x.Ca : x.Cb) * 2;
     uint4 keep[MAXP];
     float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
         const int px = py + i * PY;
         if (active && px < HW) {
-            keep[i] = *reinterpret_cast<const uint4*>(xb + (int64_t)px * C * 2);
+            keep[i] = *reinterpret_cast<const uint4*>(xb + (int64_t)px * pstride);
             float v[8];
             unpack8<DT>(keep[i], v);
 #pragma unroll
@@ -261,7 +276,7 @@ __global__ __launch_bounds__(NTH) void gn_onepass_kernel(const uint8_t* x, const
 }
 
 template <int DT, bool SILU>
-bool gn_onepass_launch(const void* x, const void* gamma, const void* beta, void* out, int B, int HW, int C, int G, float eps,
+bool gn_onepass_launch(const GnSrc& x, const void* gamma, const void* beta, void* out, int B, int HW, int C, int G, float eps,
                        hipStream_t s) {
     static const int max_hw = [] { const char* e = getenv("APAD_GN_ONEPASS_MAXHW"); return e ? atoi(e) : 1024; }();
     const int cg = C / G;
@@ -269,12 +284,12 @@ bool gn_onepass_launch(const void* x, const void* gamma, const void* beta, void*
     const int vps = GN1_GPB * cg / 8;
     dim3 grid(G / GN1_GPB, B);
     if ((HW + 256 / vps - 1) / (256 / vps) <= 24) {
-        hipLaunchKernelGGL((gn_onepass_kernel<DT, SILU, 256, 24>), grid, dim3(256), 0, s, (const uint8_t*)x, (const uint8_t*)gamma,
+        hipLaunchKernelGGL((gn_onepass_kernel<DT, SILU, 256, 24>), grid, dim3(256), 0, s, x, (const uint8_t*)gamma,
                            (const uint8_t*)beta, (uint8_t*)out, HW, C, G, eps);
         return true;
     }
     if ((HW + 1024 / vps - 1) / (1024 / vps) <= 12) {
-        hipLaunchKernelGGL((gn_onepass_kernel<DT, SILU, 1024, 12>), grid, dim3(1024), 0, s, (const uint8_t*)x,
+        hipLaunchKernelGGL((gn_onepass_kernel<DT, SILU, 1024, 12>), grid, dim3(1024), 0, s, x,
                            (const uint8_t*)gamma, (const uint8_t*)beta, (uint8_t*)out, HW, C, G, eps);
         return true;
     }
@@ -297,20 +312,20 @@ template <int DT> int ln_launch(const void* x, const void* gamma, const void* be
     return apad_check_launch("apad_layernorm");
 }
 
-template <int DT> int gn_launch(const void* x, const void* gamma, const void* beta, void* out, float* ws, int B, int HW, int C,
+template <int DT> int gn_launch(const GnSrc& x, const void* gamma, const void* beta, void* out, float* ws, int B, int HW, int C,
                                 int G, float eps, int silu, hipStream_t s) {
     if (silu ? gn_onepass_launch<DT, true>(x, gamma, beta, out, B, HW, C, G, eps, s)
              : gn_onepass_launch<DT, false>(x, gamma, beta, out, B, HW, C, G, eps, s))
         return apad_check_launch("apad_groupnorm(one pass)");
     const int nchunk = (HW + GN_CHUNK - 1) / GN_CHUNK;
-    hipLaunchKernelGGL((gn_partial_kernel<DT>), dim3(nchunk, B), dim3(256), 0, s, (const uint8_t*)x, ws, HW, C, G, nchunk);
+    hipLaunchKernelGGL((gn_partial_kernel<DT>), dim3(nchunk, B), dim3(256), 0, s, x, ws, HW, C, G, nchunk);
     int rc = apad_check_launch("apad_groupnorm(stats)");
     if (rc) return rc;
     if (silu)
-        hipLaunchKernelGGL((gn_apply_kernel<DT, true>), dim3(nchunk, B), dim3(256), 0, s, (const uint8_t*)x, ws,
+        hipLaunchKernelGGL((gn_apply_kernel<DT, true>), dim3(nchunk, B), dim3(256), 0, s, x, ws,
                            (const uint8_t*)gamma, (const uint8_t*)beta, (uint8_t*)out, HW, C, G, nchunk, eps);
     else
-        hipLaunchKernelGGL((gn_apply_kernel<DT, false>), dim3(nchunk, B), dim3(256), 0, s, (const uint8_t*)x, ws,
+        hipLaunchKernelGGL((gn_apply_kernel<DT, false>), dim3(nchunk, B), dim3(256), 0, s, x, ws,
                            (const uint8_t*)gamma, (const uint8_t*)beta, (uint8_t*)out, HW, C, G, nchunk, eps);
     return apad_check_launch("apad_groupnorm(apply)");
 }
@@ -336,15 +351,29 @@ extern "C" int64_t apad_groupnorm_workspace_bytes(int32_t B, int32_t HW, int32_t
     return (int64_t)B * ((HW + GN_CHUNK - 1) / GN_CHUNK) * G * 2 * sizeof(float);
 }
 
-extern "C" int apad_groupnorm(const void* x, const void* gamma, const void* beta, void* out, void* workspace, int32_t B,
-                              int32_t HW, int32_t C, int32_t G, float eps, int32_t silu, int32_t dtype, void* stream) {
-    APAD_CHECK(x && gamma && beta && out && workspace, "apad_groupnorm: null operand");
-    if (dtype == APAD_F32) return apad_f32_groupnorm(x, gamma, beta, out, B, HW, C, G, eps, silu, (hipStream_t)stream);
+extern "C" int apad_groupnorm2(const void* xa, const void* xb, const void* gamma, const void* beta, void* out, void* workspace,
+                               int32_t B, int32_t Ba, int32_t Bb, int32_t HW, int32_t Ca, int32_t Cb, int32_t G, float eps, int32_t silu,
+                               int32_t dtype, void* stream) {
+    APAD_CHECK(xa && gamma && beta && out && workspace, "apad_groupnorm: null operand");
+    const int C = Ca + (xb ? Cb : 0);
+    if (dtype == APAD_F32) {
+        APAD_CHECK(xb == nullptr && Ba == B, "apad_groupnorm2: the fp32 mode takes one source");
+        return apad_f32_groupnorm(xa, gamma, beta, out, B, HW, C, G, eps, silu, (hipStream_t)stream);
+    }
     APAD_CHECK(dtype == APAD_BF16 || dtype == APAD_F16, "apad_groupnorm: dtype %d not supported", dtype);
     APAD_CHECK(B > 0 && HW > 0 && G > 0 && G <= 64 && C % G == 0 && (C / G) % 4 == 0 && C % 8 == 0 && C <= 1280,
                "apad_groupnorm: need G<=64, C%%G==0, (C/G)%%4==0, C%%8==0, C<=1280 (B=%d HW=%d C=%d G=%d)", B, HW, C, G);
-    APAD_CHECK(al16(x) && al16(out) && al16(gamma) && al16(beta), "apad_groupnorm: pointers must be 16-byte aligned");
+    APAD_CHECK(Ca > 0 && Ca % 8 == 0 && Ba > 0 && B % Ba == 0 && (xb == nullptr || (Cb > 0 && Cb % 8 == 0 && Bb > 0 && B % Bb == 0)),
+               "apad_groupnorm2: need Ca%%8==0, Cb%%8==0 and source batches that divide B (B=%d Ba=%d Bb=%d Ca=%d Cb=%d)", B, Ba, Bb, Ca, Cb);
+    APAD_CHECK(al16(xa) && al16(xb) && al16(out) && al16(gamma) && al16(beta), "apad_groupnorm: pointers must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
+    GnSrc x;
+    x.a = (const uint8_t*)xa; x.b = (const uint8_t*)xb; x.Ca = Ca; x.Cb = xb ? Cb : 0; x.Ba = Ba; x.Bb = xb ? Bb : 1;
     return dtype == APAD_BF16 ? gn_launch<APAD_BF16>(x, gamma, beta, out, (float*)workspace, B, HW, C, G, eps, silu, s)
                               : gn_launch<APAD_F16>(x, gamma, beta, out, (float*)workspace, B, HW, C, G, eps, silu, s);
+}
+
+extern "C" int apad_groupnorm(const void* x, const void* gamma, const void* beta, void* out, void* workspace, int32_t B,
+                              int32_t HW, int32_t C, int32_t G, float eps, int32_t silu, int32_t dtype, void* stream) {
+    return apad_groupnorm2(x, nullptr, gamma, beta, out, workspace, B, B, B, HW, C, 0, G, eps, silu, dtype, stream);
 }

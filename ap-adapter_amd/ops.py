@@ -40,7 +40,7 @@ def round_up(x, m):
 
 def gemm(a, w, *, M, N, K, lda, out, ldo, bias=None, residual=None, ldr=0, act=None, rowgroup_bias=None, ld_rg=0,
          rows_per_group=0, step_ptr=None, a_mode=L.A_PLAIN, out_mode=L.OUT_ROWMAJOR, conv=None, vt=None, ldw=None,
-         residual_row_mod=0, asym_pad=False, rowstat_out=None, ln_fold=None):
+         residual_row_mod=0, asym_pad=False, rowstat_out=None, ln_fold=None, a2=None, lda2=0, k_split=0, a_row_mod=0, a2_row_mod=0):
     """Raw descriptor call; the typed helpers below are what the model code uses.  rowstat_out: fp32 [M, N/64, 2] side output
     (row statistics of the stored rows); ln_fold = (rowstat_in [M, T, 2], colsum, bias_fp32, eps): LayerNorm by algebra."""
     d = L.GemmDesc()
@@ -60,6 +60,9 @@ def gemm(a, w, *, M, N, K, lda, out, ldo, bias=None, residual=None, ldr=0, act=N
     if vt is not None:
         d.heads, d.head_dim, d.L, d.Lpad = vt
     d.conv_asym_pad = 1 if asym_pad else 0
+    if a2 is not None:
+        d.a2, d.lda2, d.k_split = a2.data_ptr(), lda2, k_split
+    d.a_row_mod, d.a2_row_mod = a_row_mod, a2_row_mod
     L.check(L.lib().apad_gemm(C.byref(d), _stream()), "apad_gemm")
     return out
 
@@ -129,6 +132,25 @@ def linear(x, w, bias=None, residual=None, act=None, out=None, rowgroup_bias=Non
          rowstat_out=rs_out, ln_fold=fold)
     if rs_out is not None:
         out._apad_rowstat = rs_out
+    return out
+
+
+def linear2(xa, xb, w, bias=None, out=None):
+    """Linear over the channel concatenation [xa | xb] without materialising it: xa [Ba, T, Ca], xb [Bb, T, Cb] (Ca % 64 == 0),
+    w [N, Ca + Cb] -> [B, T, N] with B = max(Ba, Bb); the smaller batch is read modulo (a skip tensor of the CFG-shared prefix holds
+    one row set for both halves of the batch).  The 1x1 shortcut convolution of an up-block resnet (modeling_audioldm2.py:1488)."""
+    _req(xa, "linear2.xa", w.dtype)
+    _req(xb, "linear2.xb", w.dtype)
+    Ba, T, Ca = xa.shape
+    Bb, Tb, Cb = xb.shape
+    B = max(Ba, Bb)
+    if Tb != T or B % Ba or B % Bb or Ca % 64 or w.shape[1] != Ca + Cb or not (xa.is_contiguous() and xb.is_contiguous()):
+        raise ValueError(f"linear2: xa {tuple(xa.shape)}, xb {tuple(xb.shape)}, w {tuple(w.shape)}")
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(B, T, N, dtype=w.dtype, device=xa.device)
+    gemm(xa, w, M=B * T, N=N, K=Ca + Cb, lda=Ca, out=out, ldo=N, bias=bias, ldw=w.stride(0), a2=xb, lda2=Cb, k_split=Ca,
+         a_row_mod=(Ba * T if Ba != B else 0), a2_row_mod=(Bb * T if Bb != B else 0))
     return out
 
 
@@ -500,19 +522,41 @@ def layer_norm(x, gamma, beta, eps, out=None):
 _gn_ws = {}
 
 
+def _gn_workspace(dev, B, HW, groups):
+    key = (dev, B, HW, groups, torch.cuda.current_stream().cuda_stream)
+    ws = _gn_ws.get(key)
+    if ws is None:
+        ws = torch.empty(L.lib().apad_groupnorm_workspace_bytes(B, HW, groups) // 4, dtype=torch.float32, device=dev)
+        _gn_ws[key] = ws
+    return ws
+
+
 def group_norm(x, gamma, beta, groups, eps, silu=False, out=None):
     """x [B, HW, C] (NHWC)."""
     _req(x, "group_norm.x", gamma.dtype)
     B, HW, Cc = x.shape
-    key = (x.device, B, HW, groups, torch.cuda.current_stream().cuda_stream)
-    ws = _gn_ws.get(key)
-    if ws is None:
-        ws = torch.empty(L.lib().apad_groupnorm_workspace_bytes(B, HW, groups) // 4, dtype=torch.float32, device=x.device)
-        _gn_ws[key] = ws
+    ws = _gn_workspace(x.device, B, HW, groups)
     if out is None:
         out = torch.empty_like(x)
     L.check(L.lib().apad_groupnorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), ws.data_ptr(), B, HW,
                                    Cc, groups, eps, 1 if silu else 0, _DT[x.dtype], _stream()), "apad_groupnorm")
+    return out
+
+
+def group_norm2(xa, xb, gamma, beta, groups, eps, silu=False):
+    """GroupNorm (+ SiLU) of torch.cat([xa, xb], -1) without the concatenation: xa [Ba, HW, Ca], xb [Bb, HW, Cb] -> [B, HW, Ca + Cb]
+    with B = max(Ba, Bb), the smaller batch read modulo (see linear2).  16-bit storage types."""
+    _req(xa, "group_norm2.xa", gamma.dtype)
+    _req(xb, "group_norm2.xb", gamma.dtype)
+    Ba, HW, Ca = xa.shape
+    Bb, HWb, Cb = xb.shape
+    B = max(Ba, Bb)
+    if HWb != HW or B % Ba or B % Bb or not (xa.is_contiguous() and xb.is_contiguous()) or xa.dtype not in FUSED_DTYPES:
+        raise ValueError(f"group_norm2: xa {tuple(xa.shape)}, xb {tuple(xb.shape)} {xa.dtype}")
+    ws = _gn_workspace(xa.device, B, HW, groups)
+    out = torch.empty(B, HW, Ca + Cb, dtype=xa.dtype, device=xa.device)
+    L.check(L.lib().apad_groupnorm2(xa.data_ptr(), xb.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), ws.data_ptr(), B, Ba, Bb,
+                                    HW, Ca, Cb, groups, eps, 1 if silu else 0, _DT[xa.dtype], _stream()), "apad_groupnorm2")
     return out
 
 

@@ -175,6 +175,7 @@ def cfg_expand(x, cond):
 
 
 CFG_SHARED_PREFIX = os.environ.get("APAD_CFG_SHARED_PREFIX", "1") == "1"  # A/B switch (read once)
+NO_CAT = os.environ.get("APAD_NO_CAT", "1") == "1"  # up blocks: two-source GroupNorm / shortcut instead of torch.cat (A/B switch)
 
 
 class BasicTransformerBlock(nn.Module):
@@ -241,7 +242,18 @@ class ResnetBlock2D(nn.Module):
         """emb_act = SiLU(time embedding) [rows, 512] -> [rows, Cout]"""
         return ops.linear(emb_act, self.time_emb_proj.weight, self.time_emb_proj.bias)
 
-    def forward(self, x, B, H, W, tproj, rows_per_group, step_ptr=None):
+    def forward(self, x, B, H, W, tproj, rows_per_group, step_ptr=None, skip=None):
+        """skip: the up blocks' second input -- the resnet of torch.cat([x, skip], -1) (modeling_audioldm2.py:1488) with the
+        concatenation never materialised (16-bit inference): norm1 and the 1x1 shortcut read both tensors, and a skip of the
+        CFG-shared prefix (half the batch) is read modulo its batch"""
+        if skip is not None:
+            h = ops.group_norm2(x, skip, self.norm1.weight, self.norm1.bias, self.groups, self.norm1.eps, silu=True)
+            B = h.shape[0]
+            h, _, _ = _conv3x3(self.conv1, self._pk1, h, B, H, W, rowgroup_bias=tproj, rows_per_group=rows_per_group, step_ptr=step_ptr)
+            h = ops.group_norm(h, self.norm2.weight, self.norm2.bias, self.groups, self.norm2.eps, silu=True)
+            sc = ops.linear2(x, skip, _w2d(self.conv_shortcut), self.conv_shortcut.bias)
+            out, _, _ = _conv3x3(self.conv2, self._pk2, h, B, H, W, residual=sc)
+            return out
         if AG.on(x):
             h = AG.group_norm(x, self.norm1.weight, self.norm1.bias, self.groups, self.norm1.eps, True)
             h, _, _ = AG.conv3x3(h, self.conv1.weight, self.conv1.bias, B, H, W, rowgroup_bias=tproj, rows_per_group=rows_per_group)
@@ -500,9 +512,9 @@ class AudioLDM2UNet2DConditionModel(nn.Module):
 
         B_of = lambda t_: t_.shape[0]
 
-        def resnet(name, m, x, H, W):
+        def resnet(name, m, x, H, W, skip=None):
             tab, rpg = tp(name, m)
-            return m(x, B_of(x), H, W, tab, rpg if rpg is not None else H * W, step_ptr)
+            return m(x, B_of(x), H, W, tab, rpg if rpg is not None else H * W, step_ptr, skip=skip)
 
         wp = self._pk_in.get(self.conv_in.weight, lambda w: w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous())
         if share:
@@ -541,10 +553,15 @@ class AudioLDM2UNet2DConditionModel(nn.Module):
             up_size = skips[-1][1:] if (not final and fwd_up) else None
             for layer, rn in enumerate(blk.resnets):
                 s, _, _ = res.pop()
-                if s.shape[0] != x.shape[0]:  # a skip of the shared CFG prefix (cfg_expand): one row set for both halves
-                    s = s.repeat(x.shape[0] // s.shape[0], 1, 1)
-                x = torch.cat([x, s], dim=-1)  # channel concat of NHWC rows (data movement only)
-                x = resnet(f"up_blocks.{i}.resnets.{layer}", rn, x, H, W)
+                if (NO_CAT and x.dtype in ops.FUSED_DTYPES and not AG.on(x, s) and x.shape[-1] % 64 == 0
+                        and x.shape[0] >= s.shape[0] and rn.conv_shortcut is not None):
+                    # (16-bit inference: both tensors go to the resnet as they are)
+                    x = resnet(f"up_blocks.{i}.resnets.{layer}", rn, x.contiguous(), H, W, skip=s.contiguous())
+                else:
+                    if s.shape[0] != x.shape[0]:  # a skip of the shared CFG prefix (cfg_expand): one row set for both halves
+                        s = s.repeat(x.shape[0] // s.shape[0], 1, 1)
+                    x = torch.cat([x, s], dim=-1)  # channel concat of NHWC rows (data movement only)
+                    x = resnet(f"up_blocks.{i}.resnets.{layer}", rn, x, H, W)
                 if blk.has_cross_attention:
                     x = blk._attn_stack(layer, x, ehs, emask, ehs1, emask1)
             if blk.upsamplers is not None:

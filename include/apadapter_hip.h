@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define APAD_ABI_VERSION 5
+#define APAD_ABI_VERSION 6
 
 /* element types of activations / weights */
 enum { APAD_BF16 = 0, APAD_F16 = 1, APAD_F32 = 2 };
@@ -118,6 +118,16 @@ typedef struct apad_gemm_desc {
     const float* ln_bias;
     int32_t rowstat_in_tiles;
     float ln_eps;
+    /* APAD_A_PLAIN with a channel-concatenated A operand that is never materialised (ABI 6): columns [0, k_split) of row m come from
+       a[(m % a_row_mod) * lda + k], columns [k_split, K) from a2[(m % a2_row_mod) * lda2 + k - k_split]; k_split % 64 == 0;
+       a_row_mod / a2_row_mod = 0: no modulo.  The UNet's up blocks: torch.cat([hidden, skip], 1) in front of a resnet
+       (modeling_audioldm2.py:1488) feeds its 1x1 shortcut convolution; a skip of the CFG-shared prefix holds one row set for both
+       halves of the batch (row modulo). */
+    const void* a2;
+    int64_t lda2;
+    int32_t k_split;
+    int32_t a_row_mod, a2_row_mod;
+    int32_t reserved_a2;
 } apad_gemm_desc;
 
 typedef struct apad_attn_desc {
@@ -258,6 +268,12 @@ int apad_layernorm(const void* x, const void* gamma, const void* beta, void* out
 int64_t apad_groupnorm_workspace_bytes(int32_t B, int32_t HW, int32_t G);
 int apad_groupnorm(const void* x, const void* gamma, const void* beta, void* out, void* workspace, int32_t B,
                    int32_t HW, int32_t C, int32_t G, float eps, int32_t silu, int32_t dtype, void* stream);
+/* GroupNorm (+ SiLU) over the channel concatenation [xa | xb] without materialising it (ABI 6): xa [Ba][HW][Ca], xb [Bb][HW][Cb],
+ * out [B][HW][Ca + Cb]; sample b reads rows of xa / xb at batch index b % Ba / b % Bb (a skip tensor of the CFG-shared prefix is
+ * stored once for both halves of the batch).  Ca % 8 == 0, Cb % 8 == 0; xb = NULL / Cb = 0: apad_groupnorm.  16-bit dtypes. */
+int apad_groupnorm2(const void* xa, const void* xb, const void* gamma, const void* beta, void* out, void* workspace, int32_t B,
+                    int32_t Ba, int32_t Bb, int32_t HW, int32_t Ca, int32_t Cb, int32_t G, float eps, int32_t silu, int32_t dtype,
+                    void* stream);
 
 /* rep [B][513][768] (dtype) -> out [B][(64/tp)*(8/fp)][768] (out_dtype): drop CLS, (avg + max)/2 */
 int apad_audiomae_pool(const void* rep, void* out, int32_t B, int32_t tp, int32_t fp, int32_t dtype,

@@ -28,7 +28,7 @@ def _knobs_do_not_leak():
     import importlib
     mods = {}
     for name, attrs in (("ap_adapter_amd.processors", ("USE_FUSED_XATTN",)), ("ap_adapter_amd.ops", ("XATTN_MAXL", "MLP_C", "RP_K", "FUSED_DTYPES")),
-                        ("ap_adapter_amd.unet", ("CFG_SHARED_PREFIX",))):
+                        ("ap_adapter_amd.unet", ("CFG_SHARED_PREFIX", "NO_CAT"))):
         try:
             m = importlib.import_module(name)
         except Exception:  # the CPU suite may run without the built library

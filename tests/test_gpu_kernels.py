@@ -351,6 +351,45 @@ def test_groupnorm(dev, dtype, B, HW, C_, silu):
         assert rel_err(out, ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", DTYPES16)
+@pytest.mark.parametrize("B,Ba,Bb,HW,Ca,Cb,silu", [(4, 4, 4, 4000, 128, 128, True), (4, 4, 2, 1000, 384, 256, True), (6, 3, 6, 252, 640, 384, False),
+                                                    (4, 4, 2, 64, 640, 640, True), (2, 2, 1, 1000, 256, 128, True)])
+def test_groupnorm_two_sources(dev, dtype, B, Ba, Bb, HW, Ca, Cb, silu):
+    """GroupNorm (+ SiLU) of the channel concatenation of two tensors that is never materialised, the smaller batch read modulo
+    (two-pass and one-pass kernels; groups that straddle the two sources: 640 = 384 + 256 has 20-channel groups) -- against fp32
+    torch on the concatenation and BIT-equal to the single-source kernel on torch.cat"""
+    from ap_adapter_amd import ops
+    xa, xb = q(R(Ba, HW, Ca, seed=91) + 0.3, dtype), q(R(Bb, HW, Cb, seed=92, std=2.0), dtype)
+    C_ = Ca + Cb
+    g, b = q(R(C_, seed=93) * 0.2 + 1.0, dtype), q(R(C_, seed=94) * 0.2, dtype)
+    cat = torch.cat([xa.repeat(B // Ba, 1, 1), xb.repeat(B // Bb, 1, 1)], -1)
+    ref = F.group_norm(cat.permute(0, 2, 1), 32, g, b, 1e-5).permute(0, 2, 1)
+    if silu:
+        ref = F.silu(q(ref, dtype))
+    D = lambda t: t.to(dev, dtype)
+    out = ops.group_norm2(D(xa), D(xb), D(g), D(b), 32, 1e-5, silu=silu)
+    assert rel_err(out, ref) < TOL[dtype]
+    assert torch.equal(out, ops.group_norm(D(cat), D(g), D(b), 32, 1e-5, silu=silu))
+
+
+@pytest.mark.parametrize("dtype", DTYPES16)
+@pytest.mark.parametrize("Ba,Bb,T,Ca,Cb,N", [(4, 4, 1000, 256, 128, 256), (4, 2, 252, 640, 384, 384), (2, 4, 64, 640, 640, 640), (64, 32, 1000, 256, 128, 256),
+                                               (8, 4, 4000, 128, 128, 128)])
+def test_linear_two_sources(dev, dtype, Ba, Bb, T, Ca, Cb, N):
+    """the up-block resnets' 1x1 shortcut over [hidden | skip] without the concatenation (tiled kernel below 16000 rows, big-tile
+    LDS-DMA kernel from there on; K-group shapes): against fp32 torch and BIT-equal to the Linear of torch.cat"""
+    from ap_adapter_amd import ops
+    B = max(Ba, Bb)
+    xa, xb = q(R(Ba, T, Ca, seed=95), dtype), q(R(Bb, T, Cb, seed=96), dtype)
+    w, b = q(R(N, Ca + Cb, seed=97, std=0.05), dtype), q(R(N, seed=98), dtype)
+    cat = torch.cat([xa.repeat(B // Ba, 1, 1), xb.repeat(B // Bb, 1, 1)], -1)
+    ref = F.linear(cat, w, b)
+    D = lambda t: t.to(dev, dtype)
+    out = ops.linear2(D(xa), D(xb), D(w), D(b))
+    assert rel_err(out, ref) < TOL[dtype]
+    assert torch.equal(out, ops.linear(D(cat), D(w), D(b)))
+
+
 @pytest.mark.parametrize("tp,fp", [(1, 1), (2, 2), (4, 4), (8, 8), (8, 1), (2, 8)])
 def test_audiomae_pool(dev, tp, fp):
     from ap_adapter_amd import ops

@@ -305,23 +305,32 @@ def _independent_of_batch(dev, full_pipe, La):
 
 
 @pytest.mark.parametrize("B", [4, 32])
-def test_cfg_shared_prefix_equals_the_duplicated_batch(dev, full_pipe, monkeypatch, B):
+def test_cfg_shared_prefix_and_two_source_resnets_equal_the_plain_step(dev, full_pipe, monkeypatch, B):
     """the CFG batch is [latents] * 2 (pipeline_audioldm2.py:1003): until the first conditioned attention its halves are the same
-    rows, so the denoise step enters the UNet un-duplicated and replicates the hidden states there (unet.cfg_expand).  Asserted:
-    conv_in really runs on B rows (2 B with the switch off) and the latents after two DDIM steps are BIT-equal either way."""
+    rows, so the denoise step enters the UNet un-duplicated and replicates the hidden states there (unet.cfg_expand); and the up
+    blocks' torch.cat([hidden, skip], 1) (modeling_audioldm2.py:1488) is never materialised (two-source GroupNorm / shortcut GEMM,
+    a skip of the shared prefix read modulo its batch).  Asserted: conv_in really runs on B rows (2 B with the switch off), no
+    torch.cat of activations with the second switch on, and the latents after two DDIM steps are BIT-equal in all four settings."""
     from ap_adapter_amd import ops, unet as U
     d = _full_inputs(full_pipe, B, 32, dev)
-    first = []
-    real = ops.conv3x3
+    first, cats = [], []
+    real, real_cat = ops.conv3x3, torch.cat
     monkeypatch.setattr(ops, "conv3x3", lambda x, w, b, Bc, *a, **kw: (first.append(Bc) if not first else None, real(x, w, b, Bc, *a, **kw))[1])
+    monkeypatch.setattr(U.torch, "cat", lambda ts, *a, **kw: (cats.append(1), real_cat(ts, *a, **kw))[1])
     out = {}
-    for share in (True, False):
-        monkeypatch.setattr(U, "CFG_SHARED_PREFIX", share)
-        del first[:]
-        with torch.no_grad():
-            out[share] = full_pipe.denoise(d["lat"], d["ehs"], d["pe"], d["mask"], 2, 9.5, use_graph=False)
-        assert first[0] == (B if share else 2 * B)
-    assert torch.isfinite(out[True]).all() and torch.equal(out[True], out[False])
+    for share in (False, True):
+        for nocat in (False, True):
+            monkeypatch.setattr(U, "CFG_SHARED_PREFIX", share)
+            monkeypatch.setattr(U, "NO_CAT", nocat)
+            del first[:], cats[:]
+            with torch.no_grad():
+                out[share, nocat] = full_pipe.denoise(d["lat"], d["ehs"], d["pe"], d["mask"], 2, 9.5, use_graph=False)
+            assert first[0] == (B if share else 2 * B)
+            assert (len(cats) == 0) == nocat, len(cats)
+    base = out[False, False]
+    assert torch.isfinite(base).all()
+    for k, v in out.items():
+        assert torch.equal(v, base), k
 
 
 def test_full_size_scale_zero_ignores_the_audio_tokens(dev, full_pipe):
