@@ -153,6 +153,36 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnSrc x, const float* par
     }
     __syncthreads();
     const int p0 = chunk * GN_CHUNK, p1 = min(p0 + GN_CHUNK, HW);
+    if (256 % vpr == 0) {
+        // a thread keeps ONE channel vector and walks the chunk's pixels: gamma / beta / the two groups' statistics are loaded once
+        // and the loop carries no integer division (the generic loop below spends as many instructions on idx % vpr, c0 / cg as on
+        // the normalisation: gn_apply at the 4000-pixel level measured 2.1 TB/s)
+        const int vc = tid % vpr, py = tid / vpr, PY = 256 / vpr, c0 = vc * 8;
+        float g[8], bt[8];
+        unpack8<DT>(*reinterpret_cast<const uint4*>(gamma + c0 * 2), g);
+        unpack8<DT>(*reinterpret_cast<const uint4*>(beta + c0 * 2), bt);
+        const int g0 = c0 / cg, g1 = (c0 + 4) / cg;
+        const float m0 = lm[g0], r0 = lr[g0], m1 = lm[g1], r1 = lr[g1];
+        const uint8_t* src = gn_vec(x, b, HW, 0, c0);
+        const int64_t pstride = (c0 < x.Ca ? x.Ca : x.Cb) * 2;
+        uint8_t* dst = out + ((int64_t)b * HW * C + c0) * 2;
+        for (int px = p0 + py; px < p1; px += PY) {
+            float v[8], y[8];
+            unpack8<DT>(*reinterpret_cast<const uint4*>(src + (int64_t)px * pstride), v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float mean = e < 4 ? m0 : m1, rstd = e < 4 ? r0 : r1;
+                float t = (v[e] - mean) * rstd * g[e] + bt[e];
+                if (SILU) {
+                    t = (float)(typename ET<DT>::elem)t;
+                    t = silu_f(t);
+                }
+                y[e] = t;
+            }
+            *reinterpret_cast<uint4*>(dst + (int64_t)px * C * 2) = pack8<DT>(y);
+        }
+        return;
+    }
     const int nv = (p1 - p0) * vpr;
     uint8_t* ob = out + (((int64_t)b * HW + p0) * C) * 2;
     for (int idx = tid; idx < nv; idx += 256) {

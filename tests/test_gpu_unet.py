@@ -316,7 +316,9 @@ def test_cfg_shared_prefix_and_two_source_resnets_equal_the_plain_step(dev, full
     first, cats = [], []
     real, real_cat = ops.conv3x3, torch.cat
     monkeypatch.setattr(ops, "conv3x3", lambda x, w, b, Bc, *a, **kw: (first.append(Bc) if not first else None, real(x, w, b, Bc, *a, **kw))[1])
-    monkeypatch.setattr(U.torch, "cat", lambda ts, *a, **kw: (cats.append(1), real_cat(ts, *a, **kw))[1])
+    # (channel concatenations only: the two-stream low-resolution section re-joins its batch halves with a dim-0 cat)
+    monkeypatch.setattr(U.torch, "cat", lambda ts, *a, **kw: (cats.append(1) if kw.get("dim", a[0] if a else 0) == -1 else None,
+                                                               real_cat(ts, *a, **kw))[1])
     out = {}
     for share in (False, True):
         for nocat in (False, True):
