@@ -960,8 +960,10 @@ template <int DT, int D> int launch_d(const AttnP& p, bool dual, dim3 grid, hipS
     if constexpr (D == 32 || D == 48 || D == 64) {
         // long single-segment launches without a key bias (the UNet's self-attention): two query tiles per wave
         static const int two_q = [] { const char* e = getenv("APAD_ATTN_2Q"); return e ? atoi(e) : 1; }();
-        static const int two_q_min = [] { const char* e = getenv("APAD_ATTN_2Q_MIN_N"); return e ? atoi(e) : 512; }();  // (A/B knob)
-        if (two_q && !dual && p.key_bias == nullptr && p.N >= two_q_min && p.L >= (two_q_min < 256 ? two_q_min : 256) && (D == 32 || two_q > 1)) {
+        // (A/B knob; round 3: 512 -> 200, i.e. the 252-token level's d = 48 self-attention too: step 44.87 -> 44.74 ms; in round 2,
+        //  before the batched fragment reads, it measured slower there; the gain is 0.1 ms)
+        static const int two_q_min = [] { const char* e = getenv("APAD_ATTN_2Q_MIN_N"); return e ? atoi(e) : 200; }();
+        if (two_q && !dual && p.key_bias == nullptr && p.N >= two_q_min && p.L >= (two_q_min < 256 ? two_q_min : 256) && (D == 32 || D == 48 || two_q > 1)) {
             if constexpr (D == 32) {
                 static const int nw8 = [] { const char* e = getenv("APAD_ATTN_NW8"); return e ? atoi(e) : 0; }();  // off: step 49.68 -> 50.12 ms (the 8-wave barrier costs more than the halved staging saves)
                 if (nw8) {
@@ -972,7 +974,9 @@ template <int DT, int D> int launch_d(const AttnP& p, bool dual, dim3 grid, hipS
             }
             dim3 g2((unsigned)(((p.N + 255) / 256) * 8 * ((p.B + 7) / 8) * p.H));  // (sample-major XCD order: attn2q_body)
             if constexpr (D == 32) {
-                // pre-scaled q: the softmax without per-score max / scale instructions (APAD_ATTN_DIRECT=0: A/B switch)
+                // pre-scaled q: the softmax without per-score max / scale instructions (APAD_ATTN_DIRECT=0: A/B switch).  d = 48 (the
+                // 252-token level) keeps the classic two-tile form: its direct form needs 256 VGPRs and measured slower in-step
+                // (44.82 vs 44.69 ms)
                 static const int direct = [] { const char* e = getenv("APAD_ATTN_DIRECT"); return e ? atoi(e) : 1; }();
                 if (direct && p.prescaled) {
                     hipLaunchKernelGGL((attn2q_kernel<DT, D, 4, true>), g2, dim3(256), 0, s, p);
