@@ -375,6 +375,172 @@ __global__ __launch_bounds__(512) void cgemm_kernel(CgP p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Small-tile form for the 3x3 convolutions of the 64-token level (M = 2048 / 4096 output pixels, K = 9 Cin = 3456 .. 11520, N = 640)
+// and of small batches: 64 x 64 x 64 tile, 4 waves (2 x 2 of 32 x 32), FOUR 16 KB LDS stages -- three k-tiles in flight per workgroup,
+// two workgroups per CU.  Those launches are a few hundred workgroups walking 54 .. 180 k-tiles each: the tiled kernel keeps ONE
+// k-tile in flight per workgroup (global load -> registers -> LDS -> barrier per k-tile, ~0.45 .. 0.75 us each), so its loop is a chain
+// of exposed load latencies; here the DMA ring keeps the loads of three k-tiles outstanding and the loop is paced by the CU's LDS fill
+// rate.  Same operand layout, zero padding through the buffer range check and sequential k order as the big-tile kernel above (a
+// row's result does not depend on which of the two forms its batch size selects).  One barrier per k-tile: [counted vmcnt -> barrier
+// -> DMA issue of tile t + 3 into the stage read in iteration t - 1 -> fragment reads -> 4 MFMAs].
+constexpr int SBM = 64, SBN = 64, SSTAGE = 2 * SBM * CBK * 2, SNST = 4, SSMEM = SNST * SSTAGE;  // 16 384 per stage, 65 536
+
+template <int DT>
+__global__ __launch_bounds__(256) void cconv_small_kernel(CgP p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    using E = ET<DT>;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    int mt, nt;
+    {
+        const int nN = p.n_tiles, nM = p.m_tiles;
+        const int b = blockIdx.x;
+        const int full = (nM / 8) * 8 * nN;
+        if (b < full) {
+            const int g = b / (8 * nN), rem = b - g * 8 * nN;
+            nt = rem >> 3;
+            mt = g * 8 + (rem & 7);
+        } else {
+            const int rem = b - full, tail = nM - (nM / 8) * 8;
+            nt = rem / tail;
+            mt = (nM / 8) * 8 + rem - nt * tail;
+        }
+    }
+    const int m0 = mt * SBM, n0 = nt * SBN;
+    const __amdgpu_buffer_rsrc_t ra = c_rsrc(p.a, p.a_bytes), rw = c_rsrc(p.w, p.w_bytes);
+    // DMA sources: wave w fills blocks 2w, 2w + 1 (8 rows each) of the A tile and of the W tile
+    uint32_t aoff[2], amask[2], boff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int R = (wave * 2 + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((R >> 1) & 7);
+        const int m = m0 + R;
+        const int hw = p.Hin * p.Win;
+        const int b = m / hw, rem = m - b * hw;
+        const int oy = rem / p.Win, ox = rem - oy * p.Win;
+        aoff[i] = (uint32_t)(((b * p.Hin + oy) * p.Win + ox) * p.Cin * 2 + c * 16);
+        amask[i] = 0;
+        if (m < p.M) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
+                if ((unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win) amask[i] |= 1u << t;
+            }
+        }
+        boff[i] = (uint32_t)((n0 + R) * p.ldw * 2 + c * 16);
+    }
+    const int nk = p.K / CBK, tiles_per_tap = p.Cin / CBK;
+    int rq_tap = 0, rq_cb = 0;
+    auto request = [&](int kt, int stage) {  // the four pieces of this wave for k-tile kt
+        const int ky = rq_tap / 3, kx = rq_tap - ky * 3;
+        const int delta = ((ky - 1) * p.Win + (kx - 1)) * p.Cin * 2;
+        const uint32_t bit = 1u << rq_tap;
+        const int soff = rq_cb * (CBK * 2);
+        if (++rq_cb == tiles_per_tap) {
+            rq_cb = 0;
+            ++rq_tap;
+        }
+        uint8_t* st = smem + stage * SSTAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const uint32_t av = (amask[i] & bit) ? aoff[i] + (uint32_t)delta : C_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(st + (wave * 2 + i) * 1024), 16, av, soff, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(st + SBM * CBK * 2 + (wave * 2 + i) * 1024), 16, boff[i], kt * (CBK * 2), 0, 0);
+    };
+    uint32_t fo[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fo[ks] = (uint32_t)(l31 * 128 + (((ks * 2 + half) ^ ((l31 >> 1) & 7)) << 4));
+    const uint32_t lds0 = (uint32_t)(size_t)(lds_ptr)smem;
+    const uint32_t abase = lds0 + (uint32_t)(wm * 32 * 128), bbase = lds0 + (uint32_t)(SBM * CBK * 2 + wn * 32 * 128);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+#pragma unroll
+    for (int t = 0; t < SNST - 1; ++t)
+        if (t < nk) request(t, t);
+    auto ktile = [&](int t, auto stage_tag) {
+        constexpr int S = decltype(stage_tag)::value;
+        // this wave's pieces of tile t have landed when at most the pieces of the (up to two) later tiles are outstanding
+        if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        C_BARRIER();  // everyone's pieces of tile t are in LDS, and everyone is past its reads of tile t - 1
+        if (t + SNST - 1 < nk) request(t + SNST - 1, (S + SNST - 1) % SNST);
+        u32x4 fa[4], fb[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const uint32_t aa = abase + (uint32_t)(S * SSTAGE) + fo[ks], bb = bbase + (uint32_t)(S * SSTAGE) + fo[ks];
+            asm volatile("ds_read_b128 %0, %1" : "=v"(fa[ks]) : "v"(aa));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(fb[ks]) : "v"(bb));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            acc = E::mfma32(__builtin_bit_cast(typename E::v8, fa[ks]), __builtin_bit_cast(typename E::v8, fb[ks]), acc);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#pragma unroll 1
+    for (int t = 0; t < nk; t += 4) {
+        ktile(t, std::integral_constant<int, 0>{});
+        if (t + 1 < nk) ktile(t + 1, std::integral_constant<int, 1>{});
+        if (t + 2 < nk) ktile(t + 2, std::integral_constant<int, 2>{});
+        if (t + 3 < nk) ktile(t + 3, std::integral_constant<int, 3>{});
+    }
+    __syncthreads();  // the stages are dead
+
+    constexpr int LD = SBN + 8;
+    typename E::elem* ct = reinterpret_cast<typename E::elem*>(smem);
+    const int64_t step = p.step_ptr ? (int64_t)*p.step_ptr : 0;
+    {
+        const int nl = wn * 32 + l31, n = n0 + nl;
+        const float bv = p.bias ? ld_elem<DT>(p.bias, n) : 0.f;
+        const float rg0 = p.rg ? ld_elem<DT>(p.rg, step * p.ld_rg + n) : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ml = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            ct[ml * LD + nl] = (typename E::elem)(acc[r] + bv + rg0);
+        }
+    }
+    __syncthreads();
+    constexpr int VPR = SBN / 8;
+#pragma unroll
+    for (int v = 0; v < SBM * VPR / 256; ++v) {
+        const int idx = tid + v * 256, rl = idx / VPR, vc = idx - rl * VPR;
+        const int m = m0 + rl, n = n0 + vc * 8;
+        if (m >= p.M) continue;
+        uint4 o = *reinterpret_cast<const uint4*>(&ct[rl * LD + vc * 8]);
+        if (p.residual) {
+            float f[8], rr[8];
+            unpack8<DT>(o, f);
+            const int64_t rm = p.res_mod > 0 ? m % p.res_mod : m;
+            unpack8<DT>(*reinterpret_cast<const uint4*>(p.residual + (rm * p.ldr + n) * 2), rr);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += rr[e];
+            o = pack8<DT>(f);
+        }
+        *reinterpret_cast<uint4*>(p.out + ((int64_t)m * p.ldo + n) * 2) = o;
+    }
+}
+
+template <int DT> int cs_launch(const CgP& p, hipStream_t s) {
+    auto kern = cconv_small_kernel<DT>;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SSMEM);
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.m_tiles * p.n_tiles)), dim3(256), SSMEM, s, p);
+    return apad_check_launch("apad_gemm(small-tile conv)");
+}
+
 template <int DT, bool CONV, int BN> int cg_launch(const CgP& p, hipStream_t s) {
     auto kern = cgemm_kernel<DT, CONV, BN>;
     constexpr int CSMEM = CgT<BN>::SMEM;
@@ -398,7 +564,10 @@ int apad_cgemm_try(const apad_gemm_desc* d, hipStream_t s) {
     if (d->dtype != APAD_BF16 && d->dtype != APAD_F16) return 1;
     if (d->epilogue != APAD_EPI_NONE || d->out_mode != APAD_OUT_ROWMAJOR || d->rowstat_out || d->rowstat_in) return 1;
     static const int bn_mode = [] { const char* e = getenv("APAD_CGEMM_BN"); return e ? atoi(e) : 0; }();  // A/B knob: 128 = never the square tile
-    if (d->N % 128 != 0 || d->K % CBK != 0 || d->M < min_rows || d->M >= (1LL << 30)) return 1;
+    static const int small_mode = [] { const char* e = getenv("APAD_CGEMM_SMALL"); return e ? atoi(e) : 1; }();  // A/B knob: 0 = off
+    // below the row threshold: the small-tile form for 3x3 convolutions with long reductions (the 64-token level)
+    const bool small = d->M < min_rows && small_mode && d->a_mode == APAD_A_CONV3X3 && d->K >= 2304 && d->N % SBN == 0;
+    if ((d->N % 128 != 0 && !small) || d->K % CBK != 0 || (d->M < min_rows && !small) || d->M >= (1LL << 30)) return 1;
     const bool sq = d->N % 256 == 0 && bn_mode != 128;
     if (d->rowgroup_bias && d->rows_per_group < d->M) return 1;  // only the table form (every row reads row *step_ptr)
     const bool conv = d->a_mode == APAD_A_CONV3X3;
@@ -430,9 +599,17 @@ int apad_cgemm_try(const apad_gemm_desc* d, hipStream_t s) {
     p.M = (int32_t)d->M; p.N = (int32_t)d->N; p.K = (int32_t)d->K; p.lda = (int32_t)d->lda; p.ldw = (int32_t)d->ldw;
     p.Hin = d->Hin; p.Win = d->Win; p.Cin = d->Cin; p.res_mod = d->residual_row_mod;
     p.m_tiles = (int32_t)((d->M + CBM - 1) / CBM); p.n_tiles = (int32_t)(d->N / (sq ? 256 : 128));
+    if (small) {
+        p.m_tiles = (int32_t)((d->M + SBM - 1) / SBM);
+        p.n_tiles = (int32_t)(d->N / SBN);
+    }
     p.a_bytes = (uint32_t)a_bytes; p.w_bytes = (uint32_t)w_bytes;
     p.a2 = conv ? nullptr : (const uint8_t*)d->a2; p.lda2 = (int32_t)d->lda2; p.ksplit = d->k_split; p.a_mod = conv ? 0 : d->a_row_mod;
     p.a2_mod = d->a2_row_mod; p.a2_bytes = (uint32_t)a2_bytes;
+    if (small) {
+        p.a2 = nullptr; p.a_mod = 0;
+        return d->dtype == APAD_BF16 ? cs_launch<APAD_BF16>(p, s) : cs_launch<APAD_F16>(p, s);
+    }
 #define CG_GO(DT_)                                                                                              \
     return sq ? (conv ? cg_launch<DT_, true, 256>(p, s) : cg_launch<DT_, false, 256>(p, s))                     \
               : (conv ? cg_launch<DT_, true, 128>(p, s) : cg_launch<DT_, false, 128>(p, s));

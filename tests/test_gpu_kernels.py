@@ -126,6 +126,27 @@ def test_conv3x3_big_tile_kernel(dev, dtype, B, H, W, Cin, Cout):
 
 
 @pytest.mark.parametrize("dtype", DTYPES16)
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 32, 2, 640, 640), (5, 32, 2, 1280, 640), (3, 63, 4, 384, 384), (1, 9, 7, 256, 64), (7, 13, 5, 320, 192)])
+def test_conv3x3_small_tile_ring_kernel(dev, dtype, B, H, W, Cin, Cout):
+    """csrc/cgemm.hip, small-tile form (64 x 64 tile, four-stage LDS-DMA ring): the long-reduction 3x3 convolutions below 16000 output
+    pixels (the 64-token level; K = 9 Cin >= 2304), ragged last tile, 1 .. 180 k-tiles, + bias + time-embedding table row + residual;
+    same k order as the tiled kernel"""
+    from ap_adapter_amd import ops
+    x = q(R(B, Cin, H, W, seed=14), dtype)
+    w = q(R(Cout, Cin, 3, 3, seed=15, std=0.03), dtype)
+    b = q(R(Cout, seed=16), dtype)
+    t = q(R(4, Cout, seed=17), dtype)
+    r = q(R(B, Cout, H, W, seed=18), dtype)
+    ref = q(_conv_ref(x, w, b) + t[1][None, :, None, None], dtype) + r
+    nhwc = lambda a: a.permute(0, 2, 3, 1).reshape(B, H * W, -1).contiguous().to(dev, dtype)
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(dev, dtype)
+    step = torch.tensor([1], dtype=torch.int32, device=dev)
+    out, Ho, Wo = ops.conv3x3(nhwc(x), wp, b.to(dev, dtype), B, H, W, residual=nhwc(r), rowgroup_bias=t.to(dev, dtype),
+                              rows_per_group=1 << 40, step_ptr=step)
+    assert rel_err(out.reshape(B, Ho, Wo, Cout).permute(0, 3, 1, 2), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES16)
 @pytest.mark.parametrize("M,N,K", [(40001, 128, 192), (33000, 384, 1024), (32768, 256, 64)])
 def test_gemm_big_tile_kernel(dev, dtype, M, N, K):
     """the same kernel on a plain A operand (1, 3, 16 k-tiles: prologue-only, one round of the three LDS stages, many)"""
