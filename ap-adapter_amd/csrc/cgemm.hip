@@ -125,7 +125,6 @@ __global__ __launch_bounds__(512) void cgemm_kernel(CgP p) {
     // ---- DMA sources.  One instruction of a wave fills one 1 KB block = 8 tile rows x 128 bytes; lane -> (row r = lane / 8,
     //      LDS slot lane % 8), and the slot holds source chunk slot ^ ((row >> 1) & 7): the swizzle the fragment reads undo. ----
     const __amdgpu_buffer_rsrc_t ra = c_rsrc(p.a, p.a_bytes), rw = c_rsrc(p.w, p.w_bytes);
-    const __amdgpu_buffer_rsrc_t ra2 = c_rsrc(CONV || p.a2 == nullptr ? p.a : p.a2, CONV || p.a2 == nullptr ? p.a_bytes : p.a2_bytes);
     uint32_t aoff2[4];  // plain, two sources: the row's offset in the second one
     uint32_t aoff[4];   // plain: byte offset of (row, chunk) at k = 0, or C_OOB; conv: of the CENTRE tap, channel 0
     uint32_t amask[4];  // conv: bit (3 ky + kx) = that tap lies inside the image (0 for rows past M)
@@ -189,10 +188,13 @@ __global__ __launch_bounds__(512) void cgemm_kernel(CgP p) {
     // piece q of k-tile kt (its sources prepared by next_tile_sources) -> LDS stage `stage`: q < 4 an A block, else a B block
     auto issue = [&](int q, int stage, int kt) {
         if (q < 4) {
-            if (!CONV && a_second)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra2, (lds_ptr)(smem + stage * STAGE + (wave * 4 + q) * 1024), 16, av[q], a_soff, 0, 0);
-            else
+            if constexpr (CONV) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(smem + stage * STAGE + (wave * 4 + q) * 1024), 16, av[q], a_soff, 0, 0);
+            } else {
+                // (the descriptor is rebuilt from scalar selects: two descriptors selected per call were kept in scratch)
+                const __amdgpu_buffer_rsrc_t rs = c_rsrc(a_second ? p.a2 : p.a, a_second ? p.a2_bytes : p.a_bytes);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(smem + stage * STAGE + (wave * 4 + q) * 1024), 16, av[q], a_soff, 0, 0);
+            }
         } else
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(smem + stage * STAGE + CA_BYTES + (wave * PB + q - 4) * 1024), 16,
                                                      boff[q - 4], kt * (CBK * 2), 0, 0);
