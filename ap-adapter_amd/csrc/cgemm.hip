@@ -59,6 +59,7 @@ struct CgP {
     int64_t ldo, ldr, ld_rg;
     int32_t M, N, K, lda, ldw;
     int32_t Hin, Win, Cin, res_mod;
+    int32_t Hout, Wout, stride, Hup, Wup;  // general convolution form (stride 2 / nearest-upsampled source)
     int32_t m_tiles, n_tiles;
     uint32_t a_bytes, w_bytes;
     // two-source plain A (apad_gemm_desc::a2): k-tiles from ksplit on come from a2
@@ -73,6 +74,31 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t c_rsrc(const void* p, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
+
+// General 3x3-convolution source mapping (stride 2: Downsample2D; nearest-upsampled source: Upsample2D with the interpolation folded
+// into the gather, modeling_audioldm2.py:1156 / :1509): the source pixel of tap (ky, kx) is not "centre + a uniform delta" any more,
+// so a row keeps three row offsets yo (byte offset of (b * Hin + sy(ky)) * Win * Cin * 2), three column offsets xo (sx(kx) * Cin * 2 +
+// chunk * 16) and validity bits ok (bit ky: row tap inside the (virtual) source grid; bit 3 + kx: column tap inside; 0 for rows past
+// M); a k-tile picks one of each (ky, kx are wave-uniform).  (Plain scalars / arrays with literal indices: a struct of arrays handed
+// to the lambdas by reference lived in scratch.)
+#define CG_ROW_GENERAL(yo, xo, ok, p, m, c)                                                                          \
+    do {                                                                                                              \
+        const int hw_ = (p).Hout * (p).Wout;                                                                          \
+        const int b_ = (m) / hw_, rem_ = (m) - b_ * hw_;                                                              \
+        const int oy_ = rem_ / (p).Wout, ox_ = rem_ - oy_ * (p).Wout;                                                 \
+        const int Hs_ = (p).Hup > 0 ? (p).Hup : (p).Hin, Ws_ = (p).Hup > 0 ? (p).Wup : (p).Win;                       \
+        (ok) = 0;                                                                                                     \
+        _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_) {                                                            \
+            const int uy_ = oy_ * (p).stride + k_ - 1, ux_ = ox_ * (p).stride + k_ - 1;                               \
+            const bool vy_ = (unsigned)uy_ < (unsigned)Hs_, vx_ = (unsigned)ux_ < (unsigned)Ws_;                      \
+            const int sy_ = vy_ ? ((p).Hup > 0 ? (int)(((int64_t)uy_ * (p).Hin) / (p).Hup) : uy_) : 0;                \
+            const int sx_ = vx_ ? ((p).Hup > 0 ? (int)(((int64_t)ux_ * (p).Win) / (p).Wup) : ux_) : 0;                \
+            (yo)[k_] = (uint32_t)((b_ * (p).Hin + sy_) * (p).Win * (p).Cin * 2);                                      \
+            (xo)[k_] = (uint32_t)(sx_ * (p).Cin * 2 + (c) * 16);                                                      \
+            if ((m) < (p).M) (ok) |= (vy_ ? 1u << k_ : 0u) | (vx_ ? 8u << k_ : 0u);                                   \
+        }                                                                                                             \
+    } while (0)
+__device__ __forceinline__ uint32_t cg_pick3(const uint32_t (&v)[3], int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2]); }
 
 #define C_FENCE() asm volatile("" ::: "memory")
 #define C_BARRIER()                          \
@@ -92,8 +118,9 @@ template <int N_> __device__ __forceinline__ void c_wait_vm() {
     else static_assert(N_ == 0, "add the count");
 }
 
-template <int DT, bool CONV, int BN>
+template <int DT, int MODE, int BN>  // MODE: 0 plain A, 1 3x3 convolution (stride 1), 2 general 3x3 convolution (stride 2 / up-sampled source)
 __global__ __launch_bounds__(512) void cgemm_kernel(CgP p) {
+    constexpr bool CONV = MODE != 0, GEN = MODE == 2;
     using T = CgT<BN>;
     constexpr int MI = T::MI, KSP = T::KSP, NPH = T::NPH, NST = T::NST, D = T::D, PB = T::PB, P = T::P, STAGE = T::STAGE, C_LD = T::C_LD;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -128,6 +155,7 @@ __global__ __launch_bounds__(512) void cgemm_kernel(CgP p) {
     uint32_t aoff2[4];  // plain, two sources: the row's offset in the second one
     uint32_t aoff[4];   // plain: byte offset of (row, chunk) at k = 0, or C_OOB; conv: of the CENTRE tap, channel 0
     uint32_t amask[4];  // conv: bit (3 ky + kx) = that tap lies inside the image (0 for rows past M)
+    uint32_t gyo[4][3], gxo[4][3], gok[4];  // (GEN only)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int R = (wave * 4 + i) * 8 + (lane >> 3);
@@ -135,7 +163,10 @@ __global__ __launch_bounds__(512) void cgemm_kernel(CgP p) {
         const int m = m0 + R;
         const bool valid = m < p.M;
         amask[i] = 0;
-        if (CONV) {
+        if constexpr (GEN) {
+            CG_ROW_GENERAL(gyo[i], gxo[i], gok[i], p, m, c);
+            aoff[i] = 0;
+        } else if (CONV) {
             const int hw = p.Hin * p.Win;
             const int b = m / hw, rem = m - b * hw;
             const int oy = rem / p.Win, ox = rem - oy * p.Win;
@@ -169,10 +200,16 @@ __global__ __launch_bounds__(512) void cgemm_kernel(CgP p) {
     auto next_tile_sources = [&](int kt) {  // per-lane A offsets + the scalar offset of k-tile kt
         if (CONV) {
             const int ky = rq_tap / 3, kx = rq_tap - ky * 3;
-            const int delta = ((ky - 1) * p.Win + (kx - 1)) * p.Cin * 2;  // wave-uniform, may be negative
-            const uint32_t bit = 1u << rq_tap;
+            if constexpr (GEN) {
+                const uint32_t need = (1u << ky) | (8u << kx);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) av[i] = (amask[i] & bit) ? aoff[i] + (uint32_t)delta : C_OOB;
+                for (int i = 0; i < 4; ++i) av[i] = (gok[i] & need) == need ? cg_pick3(gyo[i], ky) + cg_pick3(gxo[i], kx) : C_OOB;
+            } else {
+                const int delta = ((ky - 1) * p.Win + (kx - 1)) * p.Cin * 2;  // wave-uniform, may be negative
+                const uint32_t bit = 1u << rq_tap;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) av[i] = (amask[i] & bit) ? aoff[i] + (uint32_t)delta : C_OOB;
+            }
             a_soff = rq_cb * (CBK * 2);
             if (++rq_cb == tiles_per_tap) {
                 rq_cb = 0;
@@ -388,7 +425,7 @@ __global__ __launch_bounds__(512) void cgemm_kernel(CgP p) {
 // -> DMA issue of tile t + 3 into the stage read in iteration t - 1 -> fragment reads -> 4 MFMAs].
 constexpr int SBM = 64, SBN = 64, SSTAGE = 2 * SBM * CBK * 2, SNST = 4, SSMEM = SNST * SSTAGE;  // 16 384 per stage, 65 536
 
-template <int DT>
+template <int DT, bool GEN>
 __global__ __launch_bounds__(256) void cconv_small_kernel(CgP p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     using E = ET<DT>;
@@ -415,11 +452,13 @@ __global__ __launch_bounds__(256) void cconv_small_kernel(CgP p) {
     const __amdgpu_buffer_rsrc_t ra = c_rsrc(p.a, p.a_bytes), rw = c_rsrc(p.w, p.w_bytes);
     // DMA sources: wave w fills blocks 2w, 2w + 1 (8 rows each) of the A tile and of the W tile
     uint32_t aoff[2], amask[2], boff[2];
+    uint32_t gyo[2][3], gxo[2][3], gok[2];  // (GEN only)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int R = (wave * 2 + i) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((R >> 1) & 7);
         const int m = m0 + R;
+        if constexpr (GEN) CG_ROW_GENERAL(gyo[i], gxo[i], gok[i], p, m, c);
         const int hw = p.Hin * p.Win;
         const int b = m / hw, rem = m - b * hw;
         const int oy = rem / p.Win, ox = rem - oy * p.Win;
@@ -448,7 +487,9 @@ __global__ __launch_bounds__(256) void cconv_small_kernel(CgP p) {
         uint8_t* st = smem + stage * SSTAGE;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const uint32_t av = (amask[i] & bit) ? aoff[i] + (uint32_t)delta : C_OOB;
+            const uint32_t need = (1u << ky) | (8u << kx);
+            const uint32_t av = GEN ? ((gok[i] & need) == need ? cg_pick3(gyo[i], ky) + cg_pick3(gxo[i], kx) : C_OOB)
+                                    : ((amask[i] & bit) ? aoff[i] + (uint32_t)delta : C_OOB);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(st + (wave * 2 + i) * 1024), 16, av, soff, 0, 0);
         }
 #pragma unroll
@@ -532,8 +573,8 @@ __global__ __launch_bounds__(256) void cconv_small_kernel(CgP p) {
     }
 }
 
-template <int DT> int cs_launch(const CgP& p, hipStream_t s) {
-    auto kern = cconv_small_kernel<DT>;
+template <int DT, bool GEN> int cs_launch(const CgP& p, hipStream_t s) {
+    auto kern = cconv_small_kernel<DT, GEN>;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SSMEM);
@@ -543,8 +584,8 @@ template <int DT> int cs_launch(const CgP& p, hipStream_t s) {
     return apad_check_launch("apad_gemm(small-tile conv)");
 }
 
-template <int DT, bool CONV, int BN> int cg_launch(const CgP& p, hipStream_t s) {
-    auto kern = cgemm_kernel<DT, CONV, BN>;
+template <int DT, int MODE, int BN> int cg_launch(const CgP& p, hipStream_t s) {
+    auto kern = cgemm_kernel<DT, MODE, BN>;
     constexpr int CSMEM = CgT<BN>::SMEM;
     static bool attr = false;
     if (!attr) {
@@ -573,12 +614,14 @@ int apad_cgemm_try(const apad_gemm_desc* d, hipStream_t s) {
     const bool sq = d->N % 256 == 0 && bn_mode != 128;
     if (d->rowgroup_bias && d->rows_per_group < d->M) return 1;  // only the table form (every row reads row *step_ptr)
     const bool conv = d->a_mode == APAD_A_CONV3X3;
+    bool general = false;
     int64_t a_bytes;
     if (conv) {
-        if (d->stride != 1 || d->Hup != 0 || d->src_batch_mod != 0 || d->conv_asym_pad || d->Cin % CBK != 0 || d->Hout != d->Hin ||
-            d->Wout != d->Win)
-            return 1;
-        a_bytes = d->M * (int64_t)d->Cin * 2;
+        static const int gen_mode = [] { const char* e = getenv("APAD_CGEMM_GENCONV"); return e ? atoi(e) : 1; }();  // A/B knob: 0 = stride-1 only
+        general = d->stride != 1 || d->Hup != 0;
+        if ((d->stride != 1 && d->stride != 2) || d->src_batch_mod != 0 || d->conv_asym_pad || d->Cin % CBK != 0 || (general && !gen_mode)) return 1;
+        if (!general && (d->Hout != d->Hin || d->Wout != d->Win)) return 1;
+        a_bytes = (d->M / ((int64_t)d->Hout * d->Wout)) * d->Hin * d->Win * (int64_t)d->Cin * 2;
     } else if (d->a_mode == APAD_A_PLAIN) {
         if (d->lda % 8 != 0) return 1;
         if (d->a2 != nullptr && (d->k_split % CBK != 0 || d->lda2 % 8 != 0)) return 1;
@@ -600,6 +643,7 @@ int apad_cgemm_try(const apad_gemm_desc* d, hipStream_t s) {
     p.ldo = d->ldo; p.ldr = d->ldr; p.ld_rg = d->ld_rg;
     p.M = (int32_t)d->M; p.N = (int32_t)d->N; p.K = (int32_t)d->K; p.lda = (int32_t)d->lda; p.ldw = (int32_t)d->ldw;
     p.Hin = d->Hin; p.Win = d->Win; p.Cin = d->Cin; p.res_mod = d->residual_row_mod;
+    p.Hout = d->Hout; p.Wout = d->Wout; p.stride = d->stride; p.Hup = d->Hup; p.Wup = d->Wup;
     p.m_tiles = (int32_t)((d->M + CBM - 1) / CBM); p.n_tiles = (int32_t)(d->N / (sq ? 256 : 128));
     if (small) {
         p.m_tiles = (int32_t)((d->M + SBM - 1) / SBM);
@@ -610,11 +654,13 @@ int apad_cgemm_try(const apad_gemm_desc* d, hipStream_t s) {
     p.a2_mod = d->a2_row_mod; p.a2_bytes = (uint32_t)a2_bytes;
     if (small) {
         p.a2 = nullptr; p.a_mod = 0;
-        return d->dtype == APAD_BF16 ? cs_launch<APAD_BF16>(p, s) : cs_launch<APAD_F16>(p, s);
+        if (general) return d->dtype == APAD_BF16 ? cs_launch<APAD_BF16, true>(p, s) : cs_launch<APAD_F16, true>(p, s);
+        return d->dtype == APAD_BF16 ? cs_launch<APAD_BF16, false>(p, s) : cs_launch<APAD_F16, false>(p, s);
     }
 #define CG_GO(DT_)                                                                                              \
-    return sq ? (conv ? cg_launch<DT_, true, 256>(p, s) : cg_launch<DT_, false, 256>(p, s))                     \
-              : (conv ? cg_launch<DT_, true, 128>(p, s) : cg_launch<DT_, false, 128>(p, s));
+    if (general) return sq ? cg_launch<DT_, 2, 256>(p, s) : cg_launch<DT_, 2, 128>(p, s);                       \
+    return sq ? (conv ? cg_launch<DT_, 1, 256>(p, s) : cg_launch<DT_, 0, 256>(p, s))                           \
+              : (conv ? cg_launch<DT_, 1, 128>(p, s) : cg_launch<DT_, 0, 128>(p, s));
     if (d->dtype == APAD_BF16) { CG_GO(APAD_BF16) }
     CG_GO(APAD_F16)
 #undef CG_GO

@@ -147,6 +147,25 @@ def test_conv3x3_small_tile_ring_kernel(dev, dtype, B, H, W, Cin, Cout):
 
 
 @pytest.mark.parametrize("dtype", DTYPES16)
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,up", [
+    (9, 250, 30, 64, 128, 2, None), (5, 125, 8, 128, 256, 1, (250, 16)), (64, 32, 2, 384, 256, 1, (63, 4)), (3, 63, 4, 384, 384, 2, None),
+    (4, 32, 2, 640, 640, 1, (63, 4)), (2, 125, 9, 256, 128, 2, None)])
+def test_conv3x3_general_forms_on_the_dma_kernels(dev, dtype, B, H, W, Cin, Cout, stride, up):
+    """stride-2 (Downsample2D) and nearest-upsampled-source (Upsample2D, odd target sizes) 3x3 convolutions on the LDS-DMA kernels
+    (big-tile from 16000 output pixels, small-tile ring below for K >= 2304): per-row source offsets per tap, borders, ragged tiles"""
+    from ap_adapter_amd import ops
+    x = q(R(B, Cin, H, W, seed=14), dtype)
+    w = q(R(Cout, Cin, 3, 3, seed=15, std=0.04), dtype)
+    b = q(R(Cout, seed=16), dtype)
+    ref = _conv_ref(x, w, b, stride, up)
+    xn = x.permute(0, 2, 3, 1).reshape(B, H * W, Cin).contiguous().to(dev, dtype)
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(dev, dtype)
+    out, Ho, Wo = ops.conv3x3(xn, wp, b.to(dev, dtype), B, H, W, stride=stride, up=up)
+    assert (Ho, Wo) == tuple(ref.shape[2:])
+    assert rel_err(out.reshape(B, Ho, Wo, Cout).permute(0, 3, 1, 2), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES16)
 @pytest.mark.parametrize("M,N,K", [(40001, 128, 192), (33000, 384, 1024), (32768, 256, 64)])
 def test_gemm_big_tile_kernel(dev, dtype, M, N, K):
     """the same kernel on a plain A operand (1, 3, 16 k-tiles: prologue-only, one round of the three LDS stages, many)"""
