@@ -220,6 +220,9 @@ class Transformer2DModel(nn.Module):
         for blk in self.transformer_blocks:
             h = blk(h, ehs, emask)
         if h.shape[0] != x.shape[0]:  # the CFG batch was expanded inside (cfg_expand): the residual rows are the same for both halves
+            if h.dtype in ops.FUSED_DTYPES and not AG.on(h, x):  # read modulo its rows by the GEMM's epilogue: no copy
+                return ops.linear(h, _w2d(self.proj_out), self.proj_out.bias, residual=x.contiguous(),
+                                  residual_row_mod=x.shape[0] * x.shape[1])
             x = x.repeat(h.shape[0] // x.shape[0], 1, 1)
         if AG.on(h, x):
             return AG.linear(h, self.proj_out.weight, self.proj_out.bias, residual=x)
