@@ -114,6 +114,7 @@ SYMBOLS = {
     "apad_head_transpose": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "apad_head_transpose3": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "apad_layernorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _i32, _vp]),
+    "apad_layernorm_bwd_add": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _i32, _vp]),
     "apad_groupnorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp]),
     "apad_geglu": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "apad_geglu_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),

@@ -140,6 +140,38 @@ def layer_norm(x, g, b, eps):
     return _LayerNorm.apply(x, g, b, eps)
 
 
+class _LayerNormRes(torch.autograd.Function):
+    """(LayerNorm(x), x): the pre-norm sub-layers feed x to the LayerNorm AND to the residual add behind the branch
+    (BasicTransformerBlock: x = x + attn(norm(x))).  Handing the residual out of THIS node makes x single-use for the autograd
+    engine, and the backward adds the residual gradient inside the LayerNorm-backward launch (384 accumulation launches per
+    training step otherwise: the step at batch 4 is bound by its launch count)."""
+
+    @staticmethod
+    def forward(ctx, x, g, b, eps):
+        x = _c(x)
+        ctx.save_for_backward(x, g)
+        ctx.eps = eps
+        return ops.layer_norm(x, g, b, eps), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dres):
+        x, g = ctx.saved_tensors
+        if dy is None:
+            return dres, None, None, None
+        return ops.layer_norm_bwd(x, g, _c(dy), ctx.eps, dres=None if dres is None else _c(dres)), None, None, None
+
+
+import os as _os
+_LN_RES = _os.environ.get("APAD_TRAIN_LN_RES", "1") == "1"  # A/B switch (read once)
+
+
+def layer_norm_res(x, g, b, eps):
+    """-> (LayerNorm(x), x as the residual operand of the sub-layer's closing Linear)"""
+    if not _LN_RES:
+        return _LayerNorm.apply(x, g, b, eps), x
+    return _LayerNormRes.apply(x, g, b, eps)
+
+
 class _GroupNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, g, b, groups, eps, silu):

@@ -62,8 +62,10 @@ __device__ __forceinline__ void block_sum2(float& a, float& b, float* sh /* [2*4
 }
 
 // ---- LayerNorm backward (input gradient): one wave per row -----------------------------------------------------------
+// dres (optional): the gradient that reaches x past the LayerNorm (the residual connection of a pre-norm sub-layer): added here,
+// to the storage-rounded LayerNorm gradient, instead of by a separate accumulation kernel of the autograd engine
 template <int DT> __global__ __launch_bounds__(256) void ln_bwd_kernel(const uint8_t* x, const uint8_t* gamma, const uint8_t* dy,
-                                                                       uint8_t* dx, int64_t M, int C, float eps) {
+                                                                       const uint8_t* dres, uint8_t* dx, int64_t M, int C, float eps) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -96,6 +98,12 @@ template <int DT> __global__ __launch_bounds__(256) void ln_bwd_kernel(const uin
         ld8<DT>(gamma, c * 8, w);
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = rstd * (g[j] * w[j] - sg - (v[j] - mean) * rstd * sgx);
+        if (dres != nullptr) {
+            float r[8];
+            ld8<DT>(dres, r0 + c * 8, r);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (float)(typename ET<DT>::elem)o[j] + r[j];
+        }
         st8<DT>(dx, r0 + c * 8, o);
     }
 }
@@ -327,13 +335,19 @@ constexpr int REDUCE_BLOCKS = 1024;
         else hipLaunchKernelGGL((kern<APAD_F16>), grid, dim3(256), 0, s, __VA_ARGS__);          \
     } while (0)
 
-extern "C" int apad_layernorm_bwd(const void* x, const void* gamma, const void* dy, void* dx, int64_t M, int32_t C, float eps,
-                                  int32_t dtype, void* stream) {
+extern "C" int apad_layernorm_bwd_add(const void* x, const void* gamma, const void* dy, const void* dres, void* dx, int64_t M, int32_t C,
+                                      float eps, int32_t dtype, void* stream) {
     TRAIN_DT_CHECK("apad_layernorm_bwd");
     APAD_CHECK(x && gamma && dy && dx && M > 0 && C > 0 && C % 8 == 0, "apad_layernorm_bwd: bad operands (C %% 8 == 0 required)");
     hipStream_t s = (hipStream_t)stream;
-    LAUNCH_DT(ln_bwd_kernel, dim3((unsigned)((M + 3) / 4)), (const uint8_t*)x, (const uint8_t*)gamma, (const uint8_t*)dy, (uint8_t*)dx, M, C, eps);
+    LAUNCH_DT(ln_bwd_kernel, dim3((unsigned)((M + 3) / 4)), (const uint8_t*)x, (const uint8_t*)gamma, (const uint8_t*)dy, (const uint8_t*)dres,
+              (uint8_t*)dx, M, C, eps);
     return apad_check_launch("apad_layernorm_bwd");
+}
+
+extern "C" int apad_layernorm_bwd(const void* x, const void* gamma, const void* dy, void* dx, int64_t M, int32_t C, float eps,
+                                  int32_t dtype, void* stream) {
+    return apad_layernorm_bwd_add(x, gamma, dy, nullptr, dx, M, C, eps, dtype, stream);
 }
 
 extern "C" int apad_groupnorm_bwd(const void* x, const void* gamma, const void* beta, const void* dy, void* dx, int32_t B, int32_t HW,

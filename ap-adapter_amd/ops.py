@@ -679,12 +679,17 @@ def attention_bwd(q, k, v, out, dout, lse, heads, key_bias=None, dout_scale=1.0,
     return dq, dk, dv
 
 
-def layer_norm_bwd(x, gamma, dy, eps):
+def layer_norm_bwd(x, gamma, dy, eps, dres=None):
+    """dres: the gradient that reaches x past the LayerNorm (a pre-norm sub-layer's residual connection), added in the same launch"""
     _req(x, "layer_norm_bwd.x", gamma.dtype)
     Cc = x.shape[-1]
     dx = torch.empty_like(x)
-    L.check(L.lib().apad_layernorm_bwd(x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel() // Cc, Cc,
-                                       eps, _DT[x.dtype], _stream()), "apad_layernorm_bwd")
+    if dres is not None:
+        _req(dres, "layer_norm_bwd.dres", x.dtype)
+        if not dres.is_contiguous() or dres.shape != x.shape:
+            raise ValueError("layer_norm_bwd.dres: must be contiguous and shaped like x")
+    L.check(L.lib().apad_layernorm_bwd_add(x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), _ptr(dres), dx.data_ptr(), x.numel() // Cc, Cc,
+                                           eps, _DT[x.dtype], _stream()), "apad_layernorm_bwd")
     return dx
 
 

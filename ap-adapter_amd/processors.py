@@ -265,7 +265,10 @@ def _attn_call_train(self, attn, hidden_states, encoder_hidden_states, attention
     to_q / to_k / to_v -> attention -> to_out (+ residual), every node a HIP forward with a HIP backward."""
     _train_common(attn)
     B, N, _ = hidden_states.shape
-    hs = hidden_states if _ln is None else AG.layer_norm(hidden_states, *_ln)
+    if _ln is not None and _residual is hidden_states:
+        hs, _residual = AG.layer_norm_res(hidden_states, *_ln)  # (the residual gradient joins the LayerNorm backward launch)
+    else:
+        hs = hidden_states if _ln is None else AG.layer_norm(hidden_states, *_ln)
     src = hs if encoder_hidden_states is None else (encoder_hidden_states if encoder_hidden_states.dim() == 3
                                                     else encoder_hidden_states.unsqueeze(0))
     if encoder_hidden_states is None:  # self-attention: one input-gradient GEMM for the three projections
@@ -393,7 +396,10 @@ class IPAttnProcessor2_0(nn.Module):
         B = hidden_states.shape[0]
         nt = self.num_tokens
         txt, aud = ehs[:, :nt, :].contiguous(), ehs[:, nt:, :].contiguous()
-        hs = hidden_states if _ln is None else AG.layer_norm(hidden_states, *_ln)
+        if _ln is not None and _residual is hidden_states:
+            hs, _residual = AG.layer_norm_res(hidden_states, *_ln)  # (the residual gradient joins the LayerNorm backward launch)
+        else:
+            hs = hidden_states if _ln is None else AG.layer_norm(hidden_states, *_ln)
         q = AG.linear(hs, attn.to_q.weight)
         k_t, v_t = AG.linear(txt, attn.to_k.weight), AG.linear(txt, attn.to_v.weight)
         bias = None

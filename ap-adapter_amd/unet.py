@@ -152,8 +152,9 @@ class FeedForward(nn.Module):
         activation never reaches HBM); otherwise LayerNorm + GEGLU projection in one launch, then the 4C->C GEMM +
         residual."""
         if AG.on(x):  # training: un-fused, the GEGLU projection is kept for the backward
-            h = AG.geglu(AG.linear(AG.layer_norm(x, *ln), self.net[0].proj.weight, self.net[0].proj.bias))
-            return AG.linear(h, self.net[2].weight, self.net[2].bias, residual=x)
+            xn, xr = AG.layer_norm_res(x, *ln)  # (the residual gradient joins the LayerNorm backward launch)
+            h = AG.geglu(AG.linear(xn, self.net[0].proj.weight, self.net[0].proj.bias))
+            return AG.linear(h, self.net[2].weight, self.net[2].bias, residual=xr)
         if x.shape[-1] in ops.MLP_C and x.dtype in ops.FUSED_DTYPES and os.environ.get("APAD_FUSED_MLP", "1") != "0":
             return ops.geglu_mlp(x, self.net[0].proj.weight, self.net[0].proj.bias, self.net[2].weight, self.net[2].bias, ln=ln)
         h = ops.fused_linear(x, self.net[0].proj.weight, self.net[0].proj.bias, ln=ln, act="geglu")

@@ -359,6 +359,11 @@ int apad_head_transpose3(const void* x0, void* xt0, const void* x1, void* xt1, c
 
 int apad_layernorm_bwd(const void* x, const void* gamma, const void* dy, void* dx, int64_t M, int32_t C, float eps,
                        int32_t dtype, void* stream);
+/* the same with the gradient that reaches x past the LayerNorm added in (dres, may be NULL): the pre-norm sub-layers' residual
+ * connection (x feeds LayerNorm AND the residual add), whose two gradients the autograd engine would otherwise sum with a kernel of
+ * its own; dx = round(ln_bwd) + dres (ABI 6) */
+int apad_layernorm_bwd_add(const void* x, const void* gamma, const void* dy, const void* dres, void* dx, int64_t M, int32_t C, float eps,
+                           int32_t dtype, void* stream);
 int apad_groupnorm_bwd(const void* x, const void* gamma, const void* beta, const void* dy, void* dx, int32_t B, int32_t HW,
                        int32_t C, int32_t G, float eps, int32_t silu, int32_t dtype, void* stream);
 /* proj [M][2N] (value | gate) -> h [M][N] = value * gelu(gate), and its gradient dproj [M][2N] */
