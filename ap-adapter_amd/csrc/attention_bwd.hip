@@ -113,6 +113,20 @@ __device__ __forceinline__ void store_row(uint8_t* dst /* row base + head offset
         }
 }
 
+// Branch-free forms for the software-pipelined loops below: out-of-range rows are CLAMPED (their scores are masked to probability 0
+// where they matter, and accumulator rows d >= D are never stored), so every load is unconditional -- an exec-masked load makes the
+// compiler's wait-count pass wait for everything in flight, which would undo the prefetch.
+template <int DT> __device__ __forceinline__ typename ET<DT>::v8 row_frag_c(const uint8_t* base, int row, int limit, int C, int col) {
+    const int r = row < limit ? row : limit - 1;
+    return as_v8<DT>(*reinterpret_cast<const uint4*>(base + ((int64_t)r * C + col) * 2));
+}
+template <int DT, int D> __device__ __forceinline__ typename ET<DT>::v8 tr_frag_c(const uint8_t* base, int d, int pad, int c0, int half) {
+    const int dd = d < D ? d : D - 1;
+    const uint8_t* ptr = base + ((int64_t)dd * pad + c0 + 4 * half) * 2;
+    const uint2 lo = *reinterpret_cast<const uint2*>(ptr), hi = *reinterpret_cast<const uint2*>(ptr + 16);
+    return as_v8<DT>(make_uint4(lo.x, lo.y, hi.x, hi.y));
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 template <int DT, int D> __global__ __launch_bounds__(256) void dq_kernel(BwdP p) {
     using E = ET<DT>;
@@ -146,14 +160,32 @@ template <int DT, int D> __global__ __launch_bounds__(256) void dq_kernel(BwdP p
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    for (int k0 = 0; k0 < p.L; k0 += 32) {
+    // key loop, software-pipelined by hand (round 3): the K / V / K^T fragments of tile t + 1 are requested before tile t is
+    // computed (two register sets, the loop unrolled by two).  The first version loaded each fragment right in front of its MFMA:
+    // at the training batch of 4 the pass is a chain of exposed L2 latencies, not MFMA work.
+    struct Fr {
+        typename E::v8 kf[KC], vf[KC], ktf[TT][2];
+    };
+    const int last0 = ((p.L - 1) / 32) * 32;  // first key of the last tile
+    auto load = [&](Fr& f, int k0) {
+#pragma unroll
+        for (int s_ = 0; s_ < KC; ++s_) {
+            f.kf[s_] = row_frag_c<DT>(kb, k0 + l31, p.L, C, 16 * s_ + 8 * half);
+            f.vf[s_] = row_frag_c<DT>(vb, k0 + l31, p.L, C, 16 * s_ + 8 * half);
+        }
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) f.ktf[t][u] = tr_frag_c<DT, D>(ktb, 32 * t + l31, p.Lpad, k0 + 16 * u, half);
+    };
+    auto compute = [&](const Fr& f, int k0) {
         f32x16 st, dpt;
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[r] = dpt[r] = 0.f;
 #pragma unroll
-        for (int s = 0; s < KC; ++s) {
-            st = E::mfma32(row_frag<DT>(kb, k0 + l31, p.L, C, 16 * s + 8 * half), qf[s], st);
-            dpt = E::mfma32(row_frag<DT>(vb, k0 + l31, p.L, C, 16 * s + 8 * half), gf[s], dpt);
+        for (int s_ = 0; s_ < KC; ++s_) {
+            st = E::mfma32(f.kf[s_], qf[s_], st);
+            dpt = E::mfma32(f.vf[s_], gf[s_], dpt);
         }
         typename E::v8 dsf[2];
 #pragma unroll
@@ -167,8 +199,16 @@ template <int DT, int D> __global__ __launch_bounds__(256) void dq_kernel(BwdP p
 #pragma unroll
         for (int t = 0; t < TT; ++t)
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
-                acc[t] = E::mfma32(tr_frag<DT, D>(ktb, 32 * t + l31, p.Lpad, k0 + 16 * u, half), dsf[u], acc[t]);
+            for (int u = 0; u < 2; ++u) acc[t] = E::mfma32(f.ktf[t][u], dsf[u], acc[t]);
+    };
+    Fr fa, fb;
+    load(fa, 0);
+    for (int k0 = 0; k0 < p.L; k0 += 64) {
+        load(fb, k0 + 32 <= last0 ? k0 + 32 : last0);  // (unconditional: the last tile is re-requested)
+        compute(fa, k0);
+        if (k0 + 32 >= p.L) break;
+        load(fa, k0 + 64 <= last0 ? k0 + 64 : last0);
+        compute(fb, k0 + 32);
     }
     if (qvalid) store_row<DT, D>(p.dq + (qrow * C + h * D) * 2, acc, p.scale, half, p.accumulate_dq != 0);
 }
@@ -206,22 +246,46 @@ template <int DT, int D> __global__ __launch_bounds__(256) void dkv_kernel(BwdP 
 #pragma unroll
         for (int r = 0; r < 16; ++r) dk[t][r] = dv[t][r] = 0.f;
 
-    for (int q0 = 0; q0 < p.N; q0 += 32) {
+    // query loop, software-pipelined like the dQ pass: Q / dO / Q^T / dO^T fragments and the row statistics of tile t + 1 are
+    // requested before tile t is computed
+    struct Fr {
+        typename E::v8 qa[KC], ga[KC], gt[TT][2], qt[TT][2];
+        float4 l4[4], d4[4];
+    };
+    const int last0 = ((p.N - 1) / 32) * 32;
+    auto load = [&](Fr& f, int q0) {
+#pragma unroll
+        for (int s_ = 0; s_ < KC; ++s_) {
+            f.qa[s_] = row_frag_c<DT>(qb, q0 + l31, p.N, C, 16 * s_ + 8 * half);
+            f.ga[s_] = row_frag_c<DT>(gb, q0 + l31, p.N, C, 16 * s_ + 8 * half);
+        }
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                f.gt[t][u] = tr_frag_c<DT, D>(gtb, 32 * t + l31, p.Npad, q0 + 16 * u, half);
+                f.qt[t][u] = tr_frag_c<DT, D>(qtb, 32 * t + l31, p.Npad, q0 + 16 * u, half);
+            }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            // queries q0 + 8g + 4half + (0..3): the stats arrays are padded to Npad (multiple of 32), so the float4 is in bounds
+            f.l4[g] = *reinterpret_cast<const float4*>(lse + q0 + 8 * g + 4 * half);
+            f.d4[g] = *reinterpret_cast<const float4*>(del + q0 + 8 * g + 4 * half);
+        }
+    };
+    auto compute = [&](const Fr& f, int q0) {
         f32x16 sc, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[r] = dp[r] = 0.f;
 #pragma unroll
-        for (int s = 0; s < KC; ++s) {
-            sc = E::mfma32(row_frag<DT>(qb, q0 + l31, p.N, C, 16 * s + 8 * half), kf[s], sc);
-            dp = E::mfma32(row_frag<DT>(gb, q0 + l31, p.N, C, 16 * s + 8 * half), vf[s], dp);
+        for (int s_ = 0; s_ < KC; ++s_) {
+            sc = E::mfma32(f.qa[s_], kf[s_], sc);
+            dp = E::mfma32(f.ga[s_], vf[s_], dp);
         }
         typename E::v8 pf[2], dsf[2];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            // queries q0 + 8g + 4half + (0..3): the stats arrays are padded to Npad (multiple of 32), so the float4 is in bounds
-            const float4 l4 = *reinterpret_cast<const float4*>(lse + q0 + 8 * g + 4 * half);
-            const float4 d4 = *reinterpret_cast<const float4*>(del + q0 + 8 * g + 4 * half);
-            const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+            const float lv[4] = {f.l4[g].x, f.l4[g].y, f.l4[g].z, f.l4[g].w}, dl[4] = {f.d4[g].x, f.d4[g].y, f.d4[g].z, f.d4[g].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int r = 4 * g + j, qq = q0 + 8 * g + 4 * half + j;
@@ -236,9 +300,18 @@ template <int DT, int D> __global__ __launch_bounds__(256) void dkv_kernel(BwdP 
         for (int t = 0; t < TT; ++t)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                dv[t] = E::mfma32(tr_frag<DT, D>(gtb, 32 * t + l31, p.Npad, q0 + 16 * u, half), pf[u], dv[t]);
-                dk[t] = E::mfma32(tr_frag<DT, D>(qtb, 32 * t + l31, p.Npad, q0 + 16 * u, half), dsf[u], dk[t]);
+                dv[t] = E::mfma32(f.gt[t][u], pf[u], dv[t]);
+                dk[t] = E::mfma32(f.qt[t][u], dsf[u], dk[t]);
             }
+    };
+    Fr fa, fb;
+    load(fa, 0);
+    for (int q0 = 0; q0 < p.N; q0 += 64) {
+        load(fb, q0 + 32 <= last0 ? q0 + 32 : last0);
+        compute(fa, q0);
+        if (q0 + 32 >= p.N) break;
+        load(fa, q0 + 64 <= last0 ? q0 + 64 : last0);
+        compute(fb, q0 + 32);
     }
     if (kvalid) {
         store_row<DT, D>(p.dk + (krow * C + h * D) * 2, dk, p.scale, half, false);
