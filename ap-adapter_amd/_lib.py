@@ -121,6 +121,7 @@ SYMBOLS = {
     "apad_upsample_nearest_bwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "apad_zero_stuff2": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "apad_transpose_pad": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "apad_transpose_pad2": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "apad_reduce_workspace_bytes": (_i64, []),
     "apad_mse_loss_grad": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _i32, _vp]),
     "apad_step_advance_if_finite": (C.c_int, [_vp, _vp, _vp]),

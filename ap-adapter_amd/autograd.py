@@ -86,8 +86,11 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             if ctx.sink is not None:
                 acc, inv_scale = ctx.sink
-                acc.add_(ops.weight_grad(dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1]), fp32=True).reshape(acc.shape),
-                         alpha=inv_scale)
+                if inv_scale == 1.0 and acc.is_contiguous() and acc.dim() == 2:  # accumulated in the GEMM's epilogue
+                    ops.weight_grad(dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1]), fp32=True, acc=acc)
+                else:
+                    acc.add_(ops.weight_grad(dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1]), fp32=True).reshape(acc.shape),
+                             alpha=inv_scale)
             else:
                 dw = ops.weight_grad(dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])).reshape(w.shape)
         return dx, dw, None, (dy if ctx.has_res and ctx.needs_input_grad[3] else None)

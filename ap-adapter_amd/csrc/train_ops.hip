@@ -268,6 +268,34 @@ template <int DT> __global__ __launch_bounds__(256) void transpose_pad_kernel(co
     }
 }
 
+// two operands of ONE weight-gradient GEMM in one launch (blockIdx.z = operand), optionally widened to fp32 on the way (the
+// exact-f32 MFMA path takes fp32 operands): replaces two transposes + two cast kernels per adapter tensor and micro-step
+template <int DT, bool F32OUT>
+__global__ __launch_bounds__(256) void transpose_pad2_kernel(const uint8_t* x0, uint8_t* xt0, int C0, const uint8_t* x1, uint8_t* xt1, int C1, int M,
+                                                             int Mpad) {
+    using E = ET<DT>;
+    __shared__ typename E::elem tile[32][33];
+    const bool second = blockIdx.z == 1;
+    const int C = second ? C1 : C0;
+    const int c0 = blockIdx.y * 32, m0 = blockIdx.x * 32;
+    if (c0 >= C) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const typename E::elem* xin = reinterpret_cast<const typename E::elem*>(second ? x1 : x0);
+    uint8_t* xo = second ? xt1 : xt0;
+    for (int i = ty; i < 32; i += 8) {
+        const int m = m0 + i, c = c0 + tx;
+        tile[i][tx] = (m < M && c < C) ? xin[(int64_t)m * C + c] : (typename E::elem)0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, m = m0 + tx;
+        if (c < C && m < Mpad) {
+            if (F32OUT) reinterpret_cast<float*>(xo)[(int64_t)c * Mpad + m] = (float)tile[tx][i];
+            else reinterpret_cast<typename E::elem*>(xo)[(int64_t)c * Mpad + m] = tile[tx][i];
+        }
+    }
+}
+
 // ---- loss ------------------------------------------------------------------------------------------------------------
 // partial[blockIdx] = sum (pred - target)^2 over the block's slice; dpred = 2 (pred - target) / n  (F.mse_loss, mean)
 // grad_scale: static loss scale, applied in fp32 BEFORE dpred is rounded to the storage type (2 (p - t) / n is ~1e-5 at full
@@ -411,6 +439,21 @@ extern "C" int apad_transpose_pad(const void* x, void* xt, int32_t M, int32_t C,
     hipStream_t s = (hipStream_t)stream;
     LAUNCH_DT(transpose_pad_kernel, dim3((unsigned)(Mpad / 32), (unsigned)((C + 31) / 32)), (const uint8_t*)x, (uint8_t*)xt, M, C, Mpad);
     return apad_check_launch("apad_transpose_pad");
+}
+
+extern "C" int apad_transpose_pad2(const void* x0, void* xt0, int32_t C0, const void* x1, void* xt1, int32_t C1, int32_t M, int32_t Mpad,
+                                   int32_t dtype, int32_t out_f32, void* stream) {
+    APAD_CHECK(dtype == APAD_BF16 || dtype == APAD_F16, "apad_transpose_pad2: dtype %d not supported (16-bit inputs)", dtype);
+    APAD_CHECK(x0 && xt0 && x1 && xt1 && M > 0 && C0 > 0 && C1 > 0 && Mpad >= M && Mpad % 32 == 0, "apad_transpose_pad2: bad operands");
+    hipStream_t s = (hipStream_t)stream;
+    const int Cm = C0 > C1 ? C0 : C1;
+    dim3 grid((unsigned)(Mpad / 32), (unsigned)((Cm + 31) / 32), 2);
+#define TP2(DT_, F_) hipLaunchKernelGGL((transpose_pad2_kernel<DT_, F_>), grid, dim3(256), 0, s, (const uint8_t*)x0, (uint8_t*)xt0, C0, \
+                                        (const uint8_t*)x1, (uint8_t*)xt1, C1, M, Mpad)
+    if (dtype == APAD_BF16) { if (out_f32) TP2(APAD_BF16, true); else TP2(APAD_BF16, false); }
+    else { if (out_f32) TP2(APAD_F16, true); else TP2(APAD_F16, false); }
+#undef TP2
+    return apad_check_launch("apad_transpose_pad2");
 }
 
 extern "C" int64_t apad_reduce_workspace_bytes(void) { return (int64_t)REDUCE_BLOCKS * sizeof(float); }

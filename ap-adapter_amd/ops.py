@@ -741,17 +741,30 @@ def transpose_pad(x, Mpad):
     return xt
 
 
-def weight_grad(dy, x, fp32=False):
+def weight_grad(dy, x, fp32=False, acc=None):
     """dW [N, K] = dy[M, N]^T . x[M, K] (the adapter's to_k_ip / to_v_ip gradient), reduction over the M token rows.
     fp32: the product of the (storage-type) operands is formed on the exact-f32 MFMA path and returned in fp32 -- the reference
     computes the adapter gradients in fp32, and a per-micro-batch rounding of dW to bf16 would sit in front of the fp32
-    accumulation otherwise."""
+    accumulation otherwise.  acc (fp32 [N, K], with fp32=True): dW is ADDED to it in the GEMM's epilogue (residual = out = acc) and
+    None is returned -- two launches per adapter tensor (transposes + widening, GEMM + accumulation) instead of six."""
     M, N = dy.shape
     K = x.shape[-1]
     Mpad = round_up(M, 64)
-    dyt, xt = transpose_pad(dy.contiguous(), Mpad), transpose_pad(x.contiguous(), Mpad)
-    if fp32:
-        dyt, xt = dyt.float(), xt.float()  # widening copies (exact)
+    dy, x = dy.contiguous(), x.contiguous()
+    if fp32 and dy.dtype in FUSED_DTYPES:
+        dyt = torch.empty(N, Mpad, dtype=torch.float32, device=dy.device)
+        xt = torch.empty(K, Mpad, dtype=torch.float32, device=dy.device)
+        L.check(L.lib().apad_transpose_pad2(dy.data_ptr(), dyt.data_ptr(), N, x.data_ptr(), xt.data_ptr(), K, M, Mpad, _DT[dy.dtype], 1, _stream()),
+                "apad_transpose_pad2")
+    else:
+        dyt, xt = transpose_pad(dy, Mpad), transpose_pad(x, Mpad)
+        if fp32:
+            dyt, xt = dyt.float(), xt.float()  # widening copies (exact)
+    if acc is not None:
+        if not (fp32 and acc.dtype == torch.float32 and acc.is_contiguous() and tuple(acc.shape) == (N, K)):
+            raise ValueError("weight_grad(acc=...): needs fp32=True and a contiguous fp32 [N, K] accumulator")
+        gemm(dyt, xt, M=N, N=K, K=Mpad, lda=Mpad, out=acc, ldo=K, ldw=Mpad, residual=acc, ldr=K)
+        return None
     out = torch.empty(N, K, dtype=dyt.dtype, device=dy.device)
     gemm(dyt, xt, M=N, N=K, K=Mpad, lda=Mpad, out=out, ldo=K, ldw=Mpad)
     return out

@@ -377,6 +377,10 @@ int apad_zero_stuff2(const void* dy, void* z, int32_t B, int32_t H, int32_t W, i
                      int32_t dtype, void* stream);
 /* x [M][C] -> xt [C][Mpad] zero padded (Mpad % 32 == 0) */
 int apad_transpose_pad(const void* x, void* xt, int32_t M, int32_t C, int32_t Mpad, int32_t dtype, void* stream);
+/* both operands of one weight-gradient GEMM in ONE launch: x0 [M][C0] -> xt0 [C0][Mpad], x1 [M][C1] -> xt1 [C1][Mpad] (columns >= M zero),
+ * 16-bit inputs, outputs in the input type or widened to fp32 (out_f32 = 1: the exact-f32 MFMA path of the adapter gradients) (ABI 6) */
+int apad_transpose_pad2(const void* x0, void* xt0, int32_t C0, const void* x1, void* xt1, int32_t C1, int32_t M, int32_t Mpad,
+                        int32_t dtype, int32_t out_f32, void* stream);
 
 /* fp32 workspace size of the three reductions below */
 int64_t apad_reduce_workspace_bytes(void);
