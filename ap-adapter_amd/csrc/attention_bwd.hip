@@ -38,34 +38,6 @@ struct BwdP {
     int32_t accumulate_dq;
 };
 
-// delta[b][h][n] = dout_scale * sum_d dO[b][n][h*D+d] * O[b][n][h*D+d]
-template <int DT, int D> __global__ __launch_bounds__(256) void delta_kernel(BwdP p) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (b, n, h), n over the PADDED range: pad entries are written 0
-    const int64_t total = (int64_t)p.B * p.Npad * p.H;
-    if (idx >= total) return;
-    const int h = (int)(idx % p.H);
-    const int64_t bnp = idx / p.H;
-    const int n = (int)(bnp % p.Npad), b = (int)(bnp / p.Npad);
-    if (n >= p.N) {
-        p.delta[((int64_t)b * p.H + h) * p.Npad + n] = 0.f;
-        return;
-    }
-    const int64_t bn = (int64_t)b * p.N + n;
-    const int C = p.H * D;
-    const uint8_t* o = p.out + (bn * C + h * D) * 2;
-    const uint8_t* g = p.dout + (bn * C + h * D) * 2;
-    float acc = 0.f;
-#pragma unroll
-    for (int c = 0; c < D / 8; ++c) {
-        float a[8], e[8];
-        unpack8<DT>(*reinterpret_cast<const uint4*>(o + c * 16), a);
-        unpack8<DT>(*reinterpret_cast<const uint4*>(g + c * 16), e);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc += a[j] * e[j];
-    }
-    p.delta[((int64_t)b * p.H + h) * p.Npad + n] = acc * p.dout_scale;
-}
-
 // A-operand fragment (row = tile row l31, k = 8 contiguous elements) of a row-major [rows][C] matrix; rows >= limit read 0
 template <int DT> __device__ __forceinline__ typename ET<DT>::v8 row_frag(const uint8_t* base, int64_t row, int limit, int C, int col) {
     uint4 u = make_uint4(0u, 0u, 0u, 0u);
@@ -148,7 +120,22 @@ template <int DT, int D> __global__ __launch_bounds__(256) void dq_kernel(BwdP p
         gf[s] = as_v8<DT>(*reinterpret_cast<const uint4*>(p.dout + (qrow * C + h * D + 16 * s + 8 * half) * 2));
     }
     const int64_t stat = ((int64_t)b * p.H + h) * p.Npad + (qvalid ? qi : 0);
-    const float lse2 = p.lse[stat], delta = p.delta[stat];
+    const float lse2 = p.lse[stat];
+    // delta[q] = dout_scale * sum_d dO[q][d] O[q][d], formed here from the resident dO fragments (a lane holds half of its query's
+    // head dims: one half-wave exchange) and written for the dK/dV pass that follows on the stream -- pad entries 0 -- instead of by a
+    // launch of its own (the step at batch 4 is bound by its launch count: 256 launches)
+    float delta;
+    {
+        float dsum = 0.f;
+#pragma unroll
+        for (int s = 0; s < KC; ++s) {
+            const typename E::v8 of = as_v8<DT>(*reinterpret_cast<const uint4*>(p.out + (qrow * C + h * D + 16 * s + 8 * half) * 2));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dsum += (float)of[j] * (float)gf[s][j];
+        }
+        delta = half_sum(dsum) * p.dout_scale;
+        if (half == 0 && qi < p.Npad) p.delta[((int64_t)b * p.H + h) * p.Npad + qi] = qvalid ? delta : 0.f;
+    }
     const uint8_t* kb = p.k + ((int64_t)b * p.L * C + h * D) * 2;
     const uint8_t* vb = p.v + ((int64_t)b * p.L * C + h * D) * 2;
     const uint8_t* ktb = p.kt + ((int64_t)b * p.H + h) * D * p.Lpad * 2;
@@ -320,8 +307,6 @@ template <int DT, int D> __global__ __launch_bounds__(256) void dkv_kernel(BwdP 
 }
 
 template <int DT, int D> int launch_bwd(const BwdP& p, hipStream_t s) {
-    const int64_t total = (int64_t)p.B * p.Npad * p.H;
-    hipLaunchKernelGGL((delta_kernel<DT, D>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
     hipLaunchKernelGGL((dq_kernel<DT, D>), dim3((unsigned)((p.N + 127) / 128), (unsigned)(p.B * p.H)), dim3(256), 0, s, p);
     if (p.dk != nullptr)
         hipLaunchKernelGGL((dkv_kernel<DT, D>), dim3((unsigned)((p.L + 127) / 128), (unsigned)(p.B * p.H)), dim3(256), 0, s, p);
