@@ -76,6 +76,7 @@ class AttnBwdDesc(C.Structure):
 SYMBOLS = {
     "apad_last_error": (C.c_char_p, []),
     "apad_abi_version": (C.c_int, []),
+    "apad_set_gemm_ring": (C.c_int, [_i32]),
     "apad_sizeof_gemm_desc": (C.c_int, []),
     "apad_sizeof_attn_desc": (C.c_int, []),
     "apad_echo_gemm_desc": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(C.c_double), C.c_int]),

@@ -11,6 +11,7 @@
 // ds_read_b128 fragment reads); next K-tile's global loads are issued before the MFMAs of the current one.
 // Epilogue: accumulators -> LDS tile -> full-row 16 B stores (residual read with the same coalescing).
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 #include "f32_ops.h"
 
@@ -736,6 +737,300 @@ template <int DT, int EPI> int launch_dma(const GemmP& p, hipStream_t s) {
     return apad_check_launch("apad_gemm(dma)");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// LDS-DMA ring form of the 64x64 tile for latency-bound plain launches (round 3).  The tiled kernel above keeps one k-tile per K group
+// in flight -- global load -> registers -> LDS -> barrier -- so a launch of a few hundred workgroups with 4 .. 40 k-tiles each is a chain
+// of exposed load latencies.  Here both operands go HBM / L2 -> LDS by `buffer_load ... lds` into a FOUR-stage ring (three k-tiles in
+// flight per workgroup, two workgroups per CU), one barrier per k-tile, fragment reads in inline asm (see cgemm.hip for why).  Same LDS
+// layout (lds_off) as the tiled kernel, produced on the source side.  KSUM = 2 reproduces the K-group summation of the tiled kernel
+// for the shapes its (N, K) rule selects -- even k-tiles into one accumulator, odd ones into another, then even + odd -- so that a
+// row's result does not depend on which kernel ran; KSUM = 1: k-tiles in order.  Epilogue: the tiled kernel's, at MI = 1.
+// Where it is used: the TRAINING step (apad_set_gemm_ring(1), AdapterTrainer: ~2600 launches of <= 4000 rows per step on one stream);
+// in the denoise step the 64-token level runs on two streams and the ring's 66 KB of LDS per workgroup (tiled: 32 KB) costs their
+// co-residency: measured slower there (44.54 -> 44.83 ms), so inference keeps the tiled kernel.
+typedef __attribute__((address_space(3))) void* g_lds_ptr;
+constexpr int RSTAGE = 2 * 64 * BK * 2, RNST = 4, RSMEM = RNST * RSTAGE + 64 * 2 * 4;  // 16 384 per stage + the row statistics
+constexpr uint32_t R_OOB = 0x80000000u;
+
+template <int DT, int EPI, int OUTMODE, int KSUM>
+__global__ __launch_bounds__(256) void gemm_ring_kernel(GemmP p, uint32_t a_bytes, uint32_t a2_bytes, uint32_t w_bytes) {
+    constexpr int TM = 64, BM = 64, BN = 64, C_LD = TM + 8, WT = 32;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    float (*rstat)[2] = reinterpret_cast<float (*)[2]>(smem + RNST * RSTAGE);
+    using E = ET<DT>;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    constexpr int BN_OUT = (EPI == APAD_EPI_GEGLU) ? BN / 2 : BN;
+    constexpr int GH = BN / 2;
+    int mt, nt;
+    {
+        const int nN = p.n_tiles, nM = p.m_tiles;
+        const int b = blockIdx.x;
+        const int full = (nM / 8) * 8 * nN;
+        if (b < full) {
+            const int grp = b / (8 * nN), rem = b - grp * 8 * nN;
+            nt = rem >> 3;
+            mt = grp * 8 + (rem & 7);
+        } else {
+            const int rem = b - full, tail = nM - (nM / 8) * 8;
+            nt = rem / tail;
+            mt = (nM / 8) * 8 + rem - nt * tail;
+        }
+    }
+    const int64_t m0 = (int64_t)mt * BM;
+    const int64_t n0 = (int64_t)nt * BN_OUT;
+    auto wrow = [&](int nl) -> int64_t {
+        if (EPI == APAD_EPI_GEGLU) return nl < GH ? n0 + nl : p.N + n0 + (nl - GH);
+        return n0 + nl;
+    };
+    if (p.rs_in != nullptr && tid < BM) {
+        const int64_t m = m0 + tid;
+        float s1 = 0.f, s2 = 0.f;
+        if (m < p.M) {
+            const float* src = p.rs_in + m * p.rs_in_tiles * 2;
+            for (int t_ = 0; t_ < p.rs_in_tiles; ++t_) {
+                s1 += src[2 * t_];
+                s2 += src[2 * t_ + 1];
+            }
+        }
+        const float mean = s1 / (float)p.K;
+        const float var = fmaxf(s2 / (float)p.K - mean * mean, 0.f);
+        rstat[tid][0] = mean;
+        rstat[tid][1] = rsqrtf(var + p.ln_eps);
+    }
+    // ---- DMA sources: wave w fills blocks 2w, 2w + 1 (8 rows each) of the A tile and of the W tile; lane -> (row, LDS slot), the
+    //      slot holds source chunk slot ^ ((row >> 1) & 7) = lds_off's swizzle ----
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.w), 0, (int)w_bytes, 0x00020000);
+    uint32_t aoff[2], aoff2[2], boff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int R = (wave * 2 + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((R >> 1) & 7);
+        const int64_t m = m0 + R;
+        const bool valid = m < p.M;
+        aoff[i] = valid ? (uint32_t)((p.a_mod > 0 ? m % p.a_mod : m) * p.lda * 2 + c * 16) : R_OOB;
+        aoff2[i] = (valid && p.a2 != nullptr) ? (uint32_t)((p.a2_mod > 0 ? m % p.a2_mod : m) * p.lda2 * 2 + c * 16) : R_OOB;
+        boff[i] = (uint32_t)(wrow(R) * p.ldw * 2 + c * 16);
+    }
+    const int nk = (int)(p.K / BK);
+    auto request = [&](int kt, int stage) {
+        uint8_t* st = smem + stage * RSTAGE;
+        const bool second = p.a2 != nullptr && kt * BK >= p.ksplit;  // wave-uniform
+        const int soff = (second ? kt * BK - p.ksplit : kt * BK) * 2;
+        // (the descriptor is rebuilt from scalar selects: two descriptors selected per call were kept in scratch)
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(second ? p.a2 : p.a), 0,
+                                                                            (int)(second ? a2_bytes : a_bytes), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (g_lds_ptr)(st + (wave * 2 + i) * 1024), 16, second ? aoff2[i] : aoff[i], soff, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (g_lds_ptr)(st + 64 * BK * 2 + (wave * 2 + i) * 1024), 16, boff[i], kt * (BK * 2), 0, 0);
+    };
+    uint32_t fo[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fo[ks] = (uint32_t)(l31 * 128 + (((ks * 2 + half) ^ ((l31 >> 1) & 7)) << 4));
+    const uint32_t lds0 = (uint32_t)(size_t)(g_lds_ptr)smem;
+    const uint32_t abase = lds0 + (uint32_t)(wm * 32 * 128), bbase = lds0 + (uint32_t)(64 * BK * 2 + wn * 32 * 128);
+    f32x16 acc, acc1;  // (named, not an array: a lambda-captured one-element array of vectors went to scratch)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if constexpr (KSUM == 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+    }
+
+#pragma unroll
+    for (int t = 0; t < RNST - 1; ++t)
+        if (t < nk) request(t, t);
+    auto ktile = [&](int t, auto stage_tag) {
+        constexpr int S = decltype(stage_tag)::value;
+        if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // everyone's pieces of tile t are in LDS, everyone is past its reads of tile t - 1
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + RNST - 1 < nk) request(t + RNST - 1, (S + RNST - 1) % RNST);
+        u32x4 fa[4], fb[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const uint32_t aa = abase + (uint32_t)(S * RSTAGE) + fo[ks], bb = bbase + (uint32_t)(S * RSTAGE) + fo[ks];
+            asm volatile("ds_read_b128 %0, %1" : "=v"(fa[ks]) : "v"(aa));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(fb[ks]) : "v"(bb));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // (RNST = 4 is even: the stage index parity is the k-tile parity, i.e. the K group of the tiled kernel)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if constexpr (KSUM == 2 && (S & 1) == 1)
+                acc1 = E::mfma32(__builtin_bit_cast(typename E::v8, fa[ks]), __builtin_bit_cast(typename E::v8, fb[ks]), acc1);
+            else
+                acc = E::mfma32(__builtin_bit_cast(typename E::v8, fa[ks]), __builtin_bit_cast(typename E::v8, fb[ks]), acc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#pragma unroll 1
+    for (int t = 0; t < nk; t += 4) {
+        ktile(t, std::integral_constant<int, 0>{});
+        if (t + 1 < nk) ktile(t + 1, std::integral_constant<int, 1>{});
+        if (t + 2 < nk) ktile(t + 2, std::integral_constant<int, 2>{});
+        if (t + 3 < nk) ktile(t + 3, std::integral_constant<int, 3>{});
+    }
+    if constexpr (KSUM == 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += acc1[r];  // group 0 + group 1, as the tiled kernel's reduction
+    }
+    __syncthreads();  // the stages are dead (rstat lives behind them)
+
+    // ---- epilogue: the tiled kernel's (gemm_kernel), one MFMA tile per wave ----
+    typename E::elem* ct = reinterpret_cast<typename E::elem*>(smem);
+    const int64_t step = p.step_ptr ? (int64_t)*p.step_ptr : 0;
+    const bool one_group = p.rows_per_group >= p.M;
+    {
+        const int nl = wn * WT + l31;
+        const int64_t wr = wrow(nl);
+        const float bv = p.bias ? ld_elem<DT>(p.bias, wr) : 0.f;
+        const float rg0 = (p.rg && one_group) ? ld_elem<DT>(p.rg, step * p.ld_rg + wr) : 0.f;
+        const bool lnf = p.rs_in != nullptr;
+        const float lcs = lnf ? p.ln_cs[wr] : 0.f, lbb = lnf ? p.ln_bb[wr] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ml = wm * WT + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float v = acc[r] + bv + rg0;
+            if (lnf) v = rstat[ml][1] * (acc[r] - rstat[ml][0] * lcs) + lbb + rg0;
+            if (p.rg && !one_group) {
+                const int64_t m = m0 + ml;
+                if (m < p.M) v += ld_elem<DT>(p.rg, (m / p.rows_per_group + step) * p.ld_rg + wr);
+            }
+            if (EPI == APAD_EPI_SILU) v = silu_f(v);
+            if (EPI == APAD_EPI_GELU) v = gelu_erf_f(v);
+            ct[ml * C_LD + nl] = (typename E::elem)v;
+        }
+    }
+    __syncthreads();
+    const int Cq = (int)(p.N / 3);
+    const int qseg = (OUTMODE == APAD_OUT_QKV) ? (int)(n0 / Cq) : 0;
+    if (OUTMODE == APAD_OUT_ROWMAJOR || (OUTMODE == APAD_OUT_QKV && qseg < 2)) {
+        uint8_t* const obase = (OUTMODE == APAD_OUT_QKV && qseg == 1) ? p.out2 : p.out;
+        const int64_t ncol0 = (OUTMODE == APAD_OUT_QKV) ? (int64_t)qseg * Cq : 0;
+        constexpr int VPR = BN_OUT / 8;
+        if (p.rs_out != nullptr && VPR >= 8 && OUTMODE == APAD_OUT_ROWMAJOR) {
+            for (int idx = tid; idx < BM * VPR; idx += 256) {
+                const int rl = idx / VPR, vc = idx - rl * VPR;
+                const int64_t m = m0 + rl, n = n0 + vc * 8;
+                const bool ok = m < p.M && n < p.N;
+                float f[8];
+                unpack8<DT>(*reinterpret_cast<const uint4*>(&ct[rl * C_LD + vc * 8]), f);
+                if (p.residual && ok) {
+                    float rr[8];
+                    const int64_t rm = p.res_mod > 0 ? m % p.res_mod : m;
+                    unpack8<DT>(*reinterpret_cast<const uint4*>(p.residual + (rm * p.ldr + n) * 2), rr);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = (float)(typename E::elem)f[e] + rr[e];
+                }
+                const uint4 pk = pack8<DT>(f);
+                float s1 = 0.f, s2 = 0.f;
+                if (ok) {
+                    *reinterpret_cast<uint4*>(obase + (m * p.ldo + (n - ncol0)) * 2) = pk;
+                    float g[8];
+                    unpack8<DT>(pk, g);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        s1 += g[e];
+                        s2 = __builtin_fmaf(g[e], g[e], s2);
+                    }
+                }
+#pragma unroll
+                for (int o_ = 1; o_ < 8; o_ <<= 1) {
+                    s1 += __shfl_xor(s1, o_);
+                    s2 += __shfl_xor(s2, o_);
+                }
+                if (ok && (vc & 7) == 0) {
+                    float* dst = p.rs_out + (m * p.rs_out_tiles + (n >> 6)) * 2;
+                    dst[0] = s1;
+                    dst[1] = s2;
+                }
+            }
+        } else
+        for (int idx = tid; idx < BM * VPR; idx += 256) {
+            const int rl = idx / VPR, vc = idx - rl * VPR;
+            const int64_t m = m0 + rl, n = n0 + vc * 8;
+            if (m >= p.M || n >= p.N) continue;
+            float f[8];
+            unpack8<DT>(*reinterpret_cast<const uint4*>(&ct[rl * C_LD + vc * 8]), f);
+            if (EPI == APAD_EPI_GEGLU) {
+                float g[8];
+                unpack8<DT>(*reinterpret_cast<const uint4*>(&ct[rl * C_LD + GH + vc * 8]), g);
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const apad_f32x2 ge = gelu_erf_2((apad_f32x2){g[e], g[e + 1]});
+                    f[e] *= ge[0];
+                    f[e + 1] *= ge[1];
+                }
+            }
+            if (p.residual) {
+                float rr[8];
+                const int64_t rm = p.res_mod > 0 ? m % p.res_mod : m;
+                unpack8<DT>(*reinterpret_cast<const uint4*>(p.residual + (rm * p.ldr + n) * 2), rr);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = (float)(typename E::elem)f[e] + rr[e];
+            }
+            *reinterpret_cast<uint4*>(obase + (m * p.ldo + (n - ncol0)) * 2) = pack8<DT>(f);
+        }
+    } else {
+        typename E::elem* o = reinterpret_cast<typename E::elem*>(OUTMODE == APAD_OUT_QKV ? p.out3 : p.out);
+        const int64_t nsub = (OUTMODE == APAD_OUT_QKV) ? 2 * (int64_t)Cq : 0;
+        for (int idx = tid; idx < BM * BN; idx += 256) {
+            const int nl = idx / BM, rl = idx % BM;
+            const int64_t m = m0 + rl;
+            int64_t n = n0 + nl;
+            if (m >= p.M || n >= p.N) continue;
+            n -= nsub;
+            const int64_t b = m / p.L;
+            const int l = (int)(m - b * p.L);
+            const int h = (int)(n / p.head_dim), dd = (int)(n - (int64_t)h * p.head_dim);
+            o[((b * p.heads + h) * p.head_dim + dd) * p.Lpad + l] = ct[rl * C_LD + nl];
+        }
+    }
+}
+
+// the ring kernel's envelope: plain A, K % 64 == 0, all weight rows of the tiles in range, operands below 2 GB; returns 1 when it
+// does not apply
+template <int DT, int EPI, int OUTMODE>
+int launch_ring(const GemmP& p, bool kgroups, hipStream_t s) {
+    constexpr int BN_OUT = (EPI == APAD_EPI_GEGLU) ? 32 : 64;
+    if (p.K % 64 != 0 || p.N % BN_OUT != 0 || p.lda % 8 != 0 || p.M >= (1LL << 30)) return 1;
+    const int64_t rows_a = p.a_mod > 0 ? p.a_mod : p.M;
+    const int64_t a_bytes = ((rows_a - 1) * p.lda + (p.a2 ? p.ksplit : p.K)) * 2;
+    const int64_t a2_bytes = p.a2 ? (((p.a2_mod > 0 ? p.a2_mod : p.M) - 1) * p.lda2 + (p.K - p.ksplit)) * 2 : 0;
+    const int64_t w_bytes = ((int64_t)(p.wrows - 1) * p.ldw + p.K) * 2;
+    if (a_bytes >= (1LL << 31) || a2_bytes >= (1LL << 31) || w_bytes >= (1LL << 31)) return 1;
+    GemmP q = p;
+    q.n_tiles = (int)(p.N / BN_OUT);
+    q.m_tiles = (int)((p.M + 63) / 64);
+    dim3 grid((unsigned)(q.n_tiles * q.m_tiles));
+    auto go = [&](auto kern) {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RSMEM);
+            attr = true;
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(256), RSMEM, s, q, (uint32_t)a_bytes, (uint32_t)a2_bytes, (uint32_t)w_bytes);
+        return apad_check_launch("apad_gemm(ring)");
+    };
+    if (kgroups) return go(gemm_ring_kernel<DT, EPI, OUTMODE, 2>);
+    return go(gemm_ring_kernel<DT, EPI, OUTMODE, 1>);
+}
+
+// process-wide switch of the ring form (apad_set_gemm_ring): -1 = the APAD_GEMM_RING environment variable (default 0)
+int g_ring_mode = -1;
+
 template <int DT, int AMODE, int EPI, int OUTMODE, int TM, int NS = 1, int KG = 1>
 int launch_tm(const GemmP& p, hipStream_t s) {
     constexpr int BN_OUT = (EPI == APAD_EPI_GEGLU) ? TM / 2 : TM;
@@ -772,6 +1067,20 @@ int launch(const GemmP& p, hipStream_t s) {
         // lose more from the halved residency than they gain: 250x16 128->128 118.9 -> 132.6 us)
         if (p.K >= 2048 && blocks128 <= 1024 && !one_stage)
             return t128 ? launch_tm<DT, AMODE, EPI, OUTMODE, 128, 2>(p, s) : launch_tm<DT, AMODE, EPI, OUTMODE, 64, 2>(p, s);
+    }
+    if constexpr (AMODE == APAD_A_PLAIN && (EPI == APAD_EPI_NONE || EPI == APAD_EPI_GEGLU) && (OUTMODE == APAD_OUT_ROWMAJOR || OUTMODE == APAD_OUT_QKV) &&
+                  !(EPI == APAD_EPI_GEGLU && OUTMODE == APAD_OUT_QKV)) {
+        // latency-bound launches: the LDS-DMA ring form (apad_set_gemm_ring / APAD_GEMM_RING: 0 off, 1 = grids the 128-tile rule calls
+        // under-filled, 2 = every launch; below APAD_GEMM_RING_MAX_M = 16000 rows).  Bit-equal to the tiled kernels (same k-summation order, K groups included).
+        static const int ring_env = [] { const char* e = getenv("APAD_GEMM_RING"); return e ? atoi(e) : 0; }();
+        static const int kg_mode_r = [] { const char* e = getenv("APAD_GEMM_KG"); return e ? atoi(e) : 2; }();
+        static const int ring_max_m = [] { const char* e = getenv("APAD_GEMM_RING_MAX_M"); return e ? atoi(e) : 16000; }();
+        const int ring_mode = g_ring_mode >= 0 ? g_ring_mode : ring_env;
+        if (ring_mode && p.K >= 128 && p.M < ring_max_m && (!t128 || ring_mode >= 2)) {
+            const bool kgroups = EPI == APAD_EPI_NONE && kg_mode_r >= 2 && p.K >= 384 && p.N >= 640;
+            const int rc = launch_ring<DT, EPI, OUTMODE>(p, kgroups, s);
+            if (rc <= 0) return rc;
+        }
     }
     if constexpr (AMODE == APAD_A_PLAIN && EPI == APAD_EPI_NONE) {
         // K groups inside the workgroup for the skinny launches of the 640- / 384-wide levels.  The choice depends on (N, K) ONLY,
@@ -837,6 +1146,12 @@ template <int DT> int dispatch_amode(const GemmP& p, const apad_gemm_desc* d, hi
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
+
+extern "C" int apad_set_gemm_ring(int32_t mode) {
+    const int old = g_ring_mode;
+    g_ring_mode = mode;
+    return old;
+}
 
 extern "C" int apad_gemm(const apad_gemm_desc* d, void* stream) {
     APAD_CHECK(d != nullptr, "apad_gemm: null descriptor");

@@ -38,6 +38,12 @@ def round_up(x, m):
     return (x + m - 1) // m * m
 
 
+def set_gemm_ring(mode):
+    """process-wide kernel form of apad_gemm's latency-bound plain launches (apad_set_gemm_ring): 0 tiled, 1 / 2 LDS-DMA ring for
+    under-filled grids / every launch below 16000 rows, -1 the APAD_GEMM_RING environment variable.  Returns the previous setting."""
+    return int(L.lib().apad_set_gemm_ring(int(mode)))
+
+
 def gemm(a, w, *, M, N, K, lda, out, ldo, bias=None, residual=None, ldr=0, act=None, rowgroup_bias=None, ld_rg=0,
          rows_per_group=0, step_ptr=None, a_mode=L.A_PLAIN, out_mode=L.OUT_ROWMAJOR, conv=None, vt=None, ldw=None,
          residual_row_mod=0, asym_pad=False, rowstat_out=None, ln_fold=None, a2=None, lda2=0, k_split=0, a_row_mod=0, a2_row_mod=0):

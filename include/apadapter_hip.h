@@ -241,6 +241,10 @@ int apad_xattn_pack_kv(const void* k, const void* vt, void* packed, int32_t B, i
 
 const char* apad_last_error(void);
 int apad_abi_version(void);
+/* process-wide choice of apad_gemm's kernel for latency-bound plain launches (64 x 64 tiles): 0 = tiled, 1 / 2 = LDS-DMA ring form for
+ * under-filled grids / for every launch below 16000 rows, -1 = the APAD_GEMM_RING environment variable (default 0).  Same results bit for
+ * bit; the training step switches it on (one stream, ~2600 such launches per step).  Returns the previous setting.  (ABI 6) */
+int apad_set_gemm_ring(int32_t mode);
 /* size of the descriptor structs as compiled, for binding self-checks */
 int apad_sizeof_gemm_desc(void);
 int apad_sizeof_attn_desc(void);

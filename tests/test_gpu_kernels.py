@@ -175,6 +175,74 @@ def test_gemm_big_tile_kernel(dev, dtype, M, N, K):
     assert rel_err(out, q(F.linear(x, w, b), dtype) + r) < TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", DTYPES16)
+def test_gemm_ring_form_equals_the_tiled_kernel_bit_for_bit(dev, dtype):
+    """apad_set_gemm_ring(2): the LDS-DMA ring form of the 64 x 64 tile (the training step's launches) against the tiled kernel on the
+    same descriptors -- plain / bias / residual / row-modulo residual, GEGLU, the K-group shapes (N >= 640, K >= 384), row statistics
+    out and a folded LayerNorm in, the q | k | v^T output mode, two A sources; ragged M, 2 .. 40 k-tiles."""
+    from ap_adapter_amd import ops
+
+    def both(fn):
+        outs = []
+        for mode in (0, 2):
+            old = ops.set_gemm_ring(mode)
+            try:
+                outs.append(fn())
+            finally:
+                ops.set_gemm_ring(old)
+        return outs
+
+    def same(a, b):
+        a, b = (a, b) if isinstance(a, (list, tuple)) else ([a], [b])
+        return all(torch.equal(x, y) for x, y in zip(a, b))
+
+    D = lambda *s, seed, std=1.0: q(R(*s, seed=seed, std=std), dtype).to(dev, dtype)
+    for i, (M, N, K) in enumerate([(4000, 256, 256), (1008, 640, 640), (250, 1280, 1280), (2048, 640, 2560), (333, 64, 128), (4000, 384, 1152)]):
+        x, w, b, r = D(M, K, seed=10 + i), D(N, K, seed=20 + i, std=0.05), D(N, seed=30 + i), D(M, N, seed=40 + i)
+        a, c = both(lambda: ops.linear(x, w, b, residual=r))
+        assert torch.equal(a, c), (M, N, K)
+        assert rel_err(a.cpu(), q(F.linear(x.cpu().float(), w.cpu().float(), b.cpu().float()), dtype) + r.cpu().float()) < TOL[dtype]
+        a, c = both(lambda: ops.linear(x, w))
+        assert torch.equal(a, c), (M, N, K)
+        if M % 4 == 0:
+            a, c = both(lambda: ops.linear(x, w, b, residual=r[: M // 4], residual_row_mod=M // 4))
+            assert torch.equal(a, c), (M, N, K, "row-modulo residual")
+    # GEGLU (the un-fused feed-forward of the 640 / 1280 levels)
+    x, w, b = D(1008, 640, seed=50), D(2 * 2560, 640, seed=51, std=0.05), D(2 * 2560, seed=52)
+    a, c = both(lambda: ops.linear(x, w, b, act="geglu"))
+    assert torch.equal(a, c)
+    # row statistics out, then LayerNorm folded into the consumer
+    x, w1, b1, r = D(1000, 640, seed=53), D(640, 640, seed=54, std=0.05), D(640, seed=55), D(1000, 640, seed=56)
+    g, be, w2, b2 = D(640, seed=57), D(640, seed=58), D(1280, 640, seed=59, std=0.05), D(1280, seed=60)
+
+    def chain():
+        y = ops.linear(x, w1, b1, residual=r, rowstat=True)
+        outs = [y, ops.rowstat_of(y)]
+        if ops.ln_foldable(y, w2):
+            outs.append(ops.linear(y, w2, b2, ln=(g, be, 1e-5)))
+        return outs
+
+    a, c = both(chain)
+    assert len(a) == 3 and same(a, c)
+    # q | k | v^T (self-attention projections of the 640 level)
+    B, Lk, heads, C = 3, 250, 8, 640
+    x, wq = D(B, Lk, C, seed=61), D(3 * C, C, seed=62, std=0.05)
+    Lp = ops.round_up(Lk, 8)
+
+    def qkv():
+        qo, ko = torch.empty(B, Lk, C, dtype=dtype, device=dev), torch.empty(B, Lk, C, dtype=dtype, device=dev)
+        vt = torch.zeros(B, heads, C // heads, Lp, dtype=dtype, device=dev)
+        ops.linear_qkv(x, wq, B, Lk, heads, qo, ko, vt)
+        return [qo, ko, vt]
+
+    a, c = both(qkv)
+    assert same(a, c)
+    # two A sources (the up-block shortcut over [hidden | skip]), the skip read modulo
+    xa, xb, w, b = D(4, 250, 640, seed=63), D(2, 250, 320, seed=64), D(640, 960, seed=65, std=0.05), D(640, seed=66)
+    a, c = both(lambda: ops.linear2(xa, xb, w, b))
+    assert torch.equal(a, c)
+
+
 def test_conv3x3_cfg_duplication_and_temb(dev):
     from ap_adapter_amd import ops
     dtype = torch.bfloat16
