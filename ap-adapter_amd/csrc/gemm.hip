@@ -1077,9 +1077,12 @@ int launch(const GemmP& p, hipStream_t s) {
         static const int ring_max_m = [] { const char* e = getenv("APAD_GEMM_RING_MAX_M"); return e ? atoi(e) : 16000; }();
         const int ring_mode = g_ring_mode >= 0 ? g_ring_mode : ring_env;
         if (ring_mode && p.K >= 128 && p.M < ring_max_m && (!t128 || ring_mode >= 2)) {
+            static const int ring_kg = [] { const char* e = getenv("APAD_GEMM_RING_KG"); return e ? atoi(e) : 1; }();
             const bool kgroups = EPI == APAD_EPI_NONE && kg_mode_r >= 2 && p.K >= 384 && p.N >= 640;
-            const int rc = launch_ring<DT, EPI, OUTMODE>(p, kgroups, s);
-            if (rc <= 0) return rc;
+            if (!kgroups || ring_kg) {
+                const int rc = launch_ring<DT, EPI, OUTMODE>(p, kgroups, s);
+                if (rc <= 0) return rc;
+            }
         }
     }
     if constexpr (AMODE == APAD_A_PLAIN && EPI == APAD_EPI_NONE) {
