@@ -66,6 +66,12 @@ class XattnDesc(C.Structure):
                [(n, _f32) for n in ("ln_eps", "softmax_scale", "scale2", "reserved_f")]
 
 
+class XrowsDesc(C.Structure):
+    _fields_ = [(n, _vp) for n in ("x", "ln_gamma", "ln_beta", "wq_packed", "wo_packed", "bo", "k1", "vt1", "key_bias", "k2", "vt2", "out")] + \
+               [(n, _i32) for n in ("B", "N", "C", "heads", "L1", "Lpad1", "L2", "Lpad2", "dtype", "reserved")] + \
+               [(n, _f32) for n in ("ln_eps", "softmax_scale", "scale2", "reserved_f")]
+
+
 class AttnBwdDesc(C.Structure):
     _fields_ = [(n, _vp) for n in ("q", "k", "v", "qt", "kt", "out", "dout", "doutt", "lse", "key_bias", "delta", "dq", "dk", "dv")] + \
                [(n, _i32) for n in ("B", "N", "H", "D", "L", "Npad", "Lpad", "dtype")] + \
@@ -90,6 +96,8 @@ SYMBOLS = {
     "apad_sizeof_xattn_desc": (C.c_int, []),
     "apad_echo_xattn_desc": (C.c_int, [C.POINTER(XattnDesc), C.POINTER(C.c_double), C.c_int]),
     "apad_fused_cross_attention": (C.c_int, [C.POINTER(XattnDesc), _vp]),
+    "apad_sizeof_xrows_desc": (C.c_int, []),
+    "apad_cross_attention_rows": (C.c_int, [C.POINTER(XrowsDesc), _vp]),
     "apad_xattn_pack_weight": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "apad_xattn_packed_kv_bytes": (_i64, [_i32, _i32]),
     "apad_xattn_pack_kv": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp]),
@@ -171,7 +179,7 @@ def lib():
                     or h.apad_sizeof_rp_desc() != C.sizeof(RpDesc) \
                     or h.apad_sizeof_mlp_desc() != C.sizeof(MlpDesc) \
                     or h.apad_sizeof_attn_bwd_desc() != C.sizeof(AttnBwdDesc) \
-                    or h.apad_sizeof_xattn_desc() != C.sizeof(XattnDesc):
+                    or h.apad_sizeof_xattn_desc() != C.sizeof(XattnDesc) or h.apad_sizeof_xrows_desc() != C.sizeof(XrowsDesc):
                 raise RuntimeError("descriptor layout mismatch between include/apadapter_hip.h and _lib.py")
             _lib = h
     return _lib

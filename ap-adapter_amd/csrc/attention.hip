@@ -1008,6 +1008,392 @@ template <int DT> int launch_dt(const AttnP& p, int D, bool dual, dim3 grid, hip
     return -1;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// apad_cross_attention_rows: the fused cross-attention sub-layer (apad_fused_cross_attention's arithmetic) for the levels whose width
+// does not fit xattn.hip's weight-stationary registers -- C = 384 (252 tokens per sample, d = 48):
+//     out = x + to_out( A(q, K1, V1, bias) [+ scale2 * A(q, K2, V2)] ) + b_out,   q = to_q(LayerNorm(x))
+// One 256-thread workgroup owns 64 tokens of ONE sample (4 tiles per sample at 252 tokens: 256 workgroups for the CFG batch of 64 = one
+// per CU).  The tokens stay in LDS from the first read to the last write -- two [64][C] tiles, rows padded to an odd number of 16-byte
+// slots -- and the three kernels of the un-fused chain become four phases separated by workgroup barriers:
+//   1. LayerNorm: x -> X tile (8 lanes per row, statistics in registers, two passes)
+//   2. q^T = Wq . X^T -> Q tile.  Wave w owns output features 96 w .. 96 w + 95 (3 MFMA row tiles) for BOTH 32-token panels: every weight
+//      fragment is read ONCE per workgroup, straight from L2 into registers (fragment-major packing: one contiguous KB per wave-load, two
+//      k-steps ahead); the token fragments come from the X tile.  C layout = (lane: token, registers: 4 consecutive features) -> 8-byte
+//      LDS stores into the row-major Q tile
+//   3. attention: wave w runs heads 2 w, 2 w + 1 on both panels with attn_short_kernel's segment routine (K rows and V^T rows of the
+//      hoisted sets straight from L2, <= 64 keys per segment, each branch rounded before the blend); q fragments from the Q tile, the
+//      heads' outputs into the X tile (the normalised tokens are dead)
+//   4. out^T = Wo . O^T (+ bias) -> Q tile (rounded like the chain's to_out), then one coalesced pass adds the residual x and stores.
+// HBM traffic per launch: x once in, out once out (the chain: six activation passes).
+constexpr int XR_TM = 64;
+#ifndef XR_ABL
+#define XR_ABL 0  // timing ablations (tools/ab_build.sh; results are wrong): 1 = weight fragments loaded once, 2 = no attention phase, 4 = no projections, 8 = no LayerNorm arithmetic
+#endif
+struct XrP {
+    const uint8_t* x;
+    const uint8_t* gamma;
+    const uint8_t* beta;
+    const uint8_t* wq;  // packed: [C / 32 row tiles][C / 16 k-steps][64 lanes][8]
+    const uint8_t* wo;
+    const uint8_t* bo;
+    const uint8_t* k1;
+    const uint8_t* vt1;
+    const float* bias1;
+    const uint8_t* k2;
+    const uint8_t* vt2;
+    uint8_t* out;
+    int32_t B, N, L1, Lpad1, L2, Lpad2, tiles_per_sample;
+    float eps, scale_log2, scale2;
+};
+
+// short_segment with the fragment loads split from the arithmetic (xattn_rows_kernel issues the loads of BOTH segments of a head before
+// it computes either: one L2 round trip per head instead of four dependent ones).  NS = 32-key sub-tiles of the segment (compile time).
+template <int DT, int D, int NS> struct ShortFr {
+    typename ET<DT>::v8 kf[NS][D / 16];
+    typename ET<DT>::v8 vf[2 * NS][(D + 31) / 32];
+};
+template <int DT, int D, int NS>
+__device__ __forceinline__ void short_load(ShortFr<DT, D, NS>& f, const uint8_t* kbase, int64_t k_sl, const uint8_t* vbase, int L, int Lpad, int l31,
+                                           int half) {
+    constexpr int KC = D / 16, DTT = (D + 31) / 32;
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        const int key = u * 32 + l31;
+        const uint8_t* kp = kbase + ((int64_t)(key < L ? key : L - 1) * k_sl + half * 8) * 2;  // rows past L: masked in short_compute
+#pragma unroll
+        for (int cc = 0; cc < KC; ++cc) f.kf[u][cc] = as_v8<DT>(*reinterpret_cast<const uint4*>(kp + cc * 32));
+    }
+#pragma unroll
+    for (int st = 0; st < 2 * NS; ++st) {
+        const int kcol = st * 16 + 4 * half;
+#pragma unroll
+        for (int dt = 0; dt < DTT; ++dt) {
+            const int d = dt * 32 + l31;
+            uint2 v0 = make_uint2(0u, 0u), v1 = make_uint2(0u, 0u);
+            if (d < D && st * 16 < Lpad) {  // (Lpad is a multiple of 32: a visited 16-key step lies inside the padded row)
+                const uint8_t* vp = vbase + ((int64_t)d * Lpad + kcol) * 2;
+                v0 = *reinterpret_cast<const uint2*>(vp);
+                v1 = *reinterpret_cast<const uint2*>(vp + 16);
+            }
+            f.vf[st][dt] = as_v8<DT>(make_uint4(v0.x, v0.y, v1.x, v1.y));
+        }
+    }
+}
+template <int DT, int D, int NS>
+__device__ __forceinline__ void short_compute(const ShortFr<DT, D, NS>& f, int L, const float* bias, float c, const typename ET<DT>::v8* qf, f32x16* o,
+                                              float& inv_den, int half) {
+    using E = ET<DT>;
+    constexpr int KC = D / 16, DTT = (D + 31) / 32;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 s[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        s[u] = zero16;
+#pragma unroll
+        for (int cc = 0; cc < KC; ++cc) s[u] = E::mfma32(f.kf[u][cc], qf[cc], cc == 0 ? zero16 : s[u]);
+    }
+    float tmax = NEG_BIG;
+#pragma unroll
+    for (int u = 0; u < NS; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = u * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float v = s[u][r] * c;
+            if (bias) v += bias[key < L ? key : L - 1] * LOG2E;
+            v = key < L ? v : NEG_BIG;
+            s[u][r] = v;
+            tmax = fmaxf(tmax, v);
+        }
+    tmax = half_max(tmax);
+    float sum = 0.f;
+#pragma unroll
+    for (int u = 0; u < NS; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = (float)(typename E::elem)__builtin_amdgcn_exp2f(s[u][r] - tmax);  // (as short_segment: the sum of the ROUNDED probabilities)
+            s[u][r] = e;
+            sum += e;
+        }
+    sum = half_sum(sum);
+    inv_den = 1.0f / sum;
+#pragma unroll
+    for (int st = 0; st < 2 * NS; ++st) {
+        typename E::v8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (typename E::elem)s[st >> 1][(st & 1) * 8 + j];
+#pragma unroll
+        for (int dt = 0; dt < DTT; ++dt) o[dt] = E::mfma32(f.vf[st][dt], pf, o[dt]);
+    }
+}
+
+// the two projections of xattn_rows_kernel: dst^T[feature][token] = W . src^T (+ bias), wave w = features 32 NT w .. (+ 32 NT), both
+// 32-token panels; weight fragments from L2 (packed), three register sets rotating two k-steps ahead
+template <int DT, int NT>
+__device__ __forceinline__ void xr_ldw(typename ET<DT>::v8 (&wf)[NT], const uint8_t* wl, int KS, int kk) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) wf[j] = as_v8<DT>(*reinterpret_cast<const uint4*>(wl + ((int64_t)j * KS + kk) * 1024));
+}
+template <int DT, int NT, int ROWB, int PW>
+__device__ __forceinline__ void xr_step(f32x16 (&acc)[NT][PW], const typename ET<DT>::v8 (&wf)[NT], const uint8_t* sl, int kk) {
+    using E = ET<DT>;
+    typename E::v8 t[PW];
+#pragma unroll
+    for (int mt = 0; mt < PW; ++mt) t[mt] = as_v8<DT>(*reinterpret_cast<const uint4*>(sl + mt * 32 * ROWB + kk * 32));
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int mt = 0; mt < PW; ++mt) acc[j][mt] = E::mfma32(wf[j], t[mt], acc[j][mt]);
+}
+template <int DT, int C, int PW, int NSET>
+__device__ __forceinline__ void xr_project(const uint8_t* wpk, const uint8_t* src, uint8_t* dst, const uint8_t* bias, int wave, int lane) {
+    // PW = token panels per wave: 2 -> 4 waves (every weight fragment read once per workgroup), 1 -> 8 waves (waves w and w + 4 share
+    // the fragments through the CU's vector cache; twice the loads in flight, two waves per SIMD)
+    using E = ET<DT>;
+    constexpr int KS = C / 16, NT = C / 32 / 4, ROWB = C * 2 + 16;
+    const int p0 = PW == 1 ? (wave >> 2) : 0;
+    wave &= 3;
+    src += p0 * 32 * ROWB;
+    dst += p0 * 32 * ROWB;
+    static_assert(KS % NSET == 0, "the register sets of weight fragments rotate over the k-steps");
+    const int half = lane >> 5, l31 = lane & 31;
+    f32x16 acc[NT][PW];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int mt = 0; mt < PW; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][mt][r] = 0.f;
+    const uint8_t* wl = wpk + ((int64_t)(wave * NT) * KS) * 1024 + lane * 16;
+    const uint8_t* sl = src + l31 * ROWB + half * 16;
+    typename E::v8 wf[NSET][NT];  // NSET register sets of weight fragments: the fragment of k-step kk + NSET is requested when kk is consumed
+#pragma unroll
+    for (int i = 0; i < NSET; ++i) xr_ldw<DT, NT>(wf[i], wl, KS, i);
+#pragma unroll 1
+    for (int kk = 0; kk < KS; kk += NSET) {
+#pragma unroll
+        for (int i = 0; i < NSET; ++i) {
+            xr_step<DT, NT, ROWB, PW>(acc, wf[i], sl, kk + i);
+            if (!(XR_ABL & 1) && kk + i + NSET < KS) xr_ldw<DT, NT>(wf[i], wl, KS, kk + i + NSET);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int f0 = (wave * NT + j) * 32;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int f = f0 + 8 * g + 4 * half;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bias != nullptr) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[e] = ld_elem<DT>(bias, f + e);
+            }
+#pragma unroll
+            for (int mt = 0; mt < PW; ++mt) {
+                typename E::v4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = (typename E::elem)(acc[j][mt][4 * g + e] + bv[e]);
+                *reinterpret_cast<uint2*>(dst + (mt * 32 + l31) * ROWB + f * 2) = __builtin_bit_cast(uint2, y);
+            }
+        }
+    }
+}
+
+template <int DT, int C, int NS1, int NS2, int NW, int NSET>
+__global__ __launch_bounds__(NW * 64) void xattn_rows_kernel(XrP p) {
+    constexpr bool DUAL = NS2 > 0;
+    constexpr int PW = 8 / NW, NTH = NW * 64;
+    static_assert(NW == 4 || NW == 8, "4 waves x 2 token panels or 8 waves x 1");
+    using E = ET<DT>;
+    constexpr int H = 8, D = C / H, KC = D / 16, DTT = (D + 31) / 32;
+    constexpr int ROWB = C * 2 + 16;  // 49 (C = 384) sixteen-byte slots: odd -> conflict-free fragment reads over 32 rows
+    constexpr int CH = C / 64;        // 16-byte chunks per lane in the LayerNorm pass (8 lanes per row)
+    static_assert(C % 128 == 0 && D % 16 == 0, "4 waves x whole row tiles; whole k-steps per head");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t* const X = smem;
+    uint8_t* const Q = smem + XR_TM * ROWB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.x / p.tiles_per_sample, row0 = (blockIdx.x - b * p.tiles_per_sample) * XR_TM;
+    const int nrows = p.N - row0 < XR_TM ? p.N - row0 : XR_TM;
+    const uint8_t* const xb = p.x + ((int64_t)b * p.N + row0) * C * 2;
+
+    // ---- 1. LayerNorm -> X ----
+    {
+        const int sub = tid & 7;
+#pragma unroll
+        for (int it = 0; it < XR_TM / (NTH / 8); ++it) {
+            const int row = it * (NTH / 8) + (tid >> 3);
+            float v[CH][8];
+            const bool ok = row < nrows;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                uint4 u = make_uint4(0u, 0u, 0u, 0u);
+                if (ok) u = *reinterpret_cast<const uint4*>(xb + ((int64_t)row * C + (sub + 8 * i) * 8) * 2);
+                unpack8<DT>(u, v[i]);
+            }
+            if (p.gamma != nullptr && !(XR_ABL & 8)) {
+                float s1 = 0.f;
+#pragma unroll
+                for (int i = 0; i < CH; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) s1 += v[i][e];
+                s1 += __shfl_xor(s1, 1);
+                s1 += __shfl_xor(s1, 2);
+                s1 += __shfl_xor(s1, 4);
+                const float mean = s1 * (1.0f / C);
+                float s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < CH; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float dd = v[i][e] - mean;
+                        s2 = __builtin_fmaf(dd, dd, s2);
+                    }
+                s2 += __shfl_xor(s2, 1);
+                s2 += __shfl_xor(s2, 2);
+                s2 += __shfl_xor(s2, 4);
+                const float rstd = rsqrtf(s2 * (1.0f / C) + p.eps);
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    float g[8], be[8];
+                    unpack8<DT>(*reinterpret_cast<const uint4*>(p.gamma + (sub + 8 * i) * 16), g);
+                    unpack8<DT>(*reinterpret_cast<const uint4*>(p.beta + (sub + 8 * i) * 16), be);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[i][e] = ok ? (v[i][e] - mean) * rstd * g[e] + be[e] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < CH; ++i) *reinterpret_cast<uint4*>(X + row * ROWB + (sub + 8 * i) * 16) = pack8<DT>(v[i]);
+        }
+    }
+    __syncthreads();
+
+    // ---- 2. q = to_q(X) -> Q ----
+    if (!(XR_ABL & 4)) xr_project<DT, C, PW, NSET>(p.wq, X, Q, nullptr, wave, lane);
+
+    // ---- 3. attention, heads 2 w and 2 w + 1: Q -> X.  All K / V^T fragments of a head (both segments) are requested before any of its
+    //         arithmetic, and the first head's before the barrier: one exposed L2 round trip per wave ----
+    constexpr int NSB = DUAL ? NS2 : 1;
+    ShortFr<DT, D, NS1> f1;
+    ShortFr<DT, D, NSB> f2;
+    // (two sub-tiles in both segments: both fragment sets at once do not fit the 256 registers of two waves per SIMD -- that form keeps
+    //  attn_short_kernel's load-as-you-go segment routine)
+    constexpr bool SPLITF = DUAL && NS1 + NS2 > 3;
+#define XR_FETCH1(h_) short_load<DT, D, NS1>(f1, p.k1 + ((int64_t)b * p.L1 * C + (h_) * D) * 2, C, p.vt1 + ((int64_t)(b * H + (h_)) * D * p.Lpad1) * 2, p.L1, p.Lpad1, l31, half)
+#define XR_FETCH2(h_) short_load<DT, D, NSB>(f2, p.k2 + ((int64_t)b * p.L2 * C + (h_) * D) * 2, C, p.vt2 + ((int64_t)(b * H + (h_)) * D * p.Lpad2) * 2, p.L2, p.Lpad2, l31, half)
+    // (macros, not lambdas: a fragment struct captured by a lambda is kept in scratch by this compiler)
+    if (!(XR_ABL & 2) && !SPLITF) {
+        XR_FETCH1((wave & 3) * 2);
+        if (DUAL) XR_FETCH2((wave & 3) * 2);
+    }
+    __syncthreads();
+    const float* const bias1 = p.bias1 ? p.bias1 + (int64_t)b * p.L1 : nullptr;
+#pragma unroll
+    for (int hh = 0; hh < ((XR_ABL & 2) ? 0 : 2); ++hh) {
+        const int h = (wave & 3) * 2 + hh;
+        if (hh == 1 && !SPLITF) {
+            XR_FETCH1(h);
+            if (DUAL) XR_FETCH2(h);
+        }
+#pragma unroll
+        for (int pp = 0; pp < PW; ++pp) {
+            const int mt = PW == 1 ? (wave >> 2) : pp;
+            typename E::v8 qf[KC];
+            const uint8_t* qp = Q + (mt * 32 + l31) * ROWB + (h * D + half * 8) * 2;
+#pragma unroll
+            for (int cc = 0; cc < KC; ++cc) qf[cc] = as_v8<DT>(*reinterpret_cast<const uint4*>(qp + cc * 32));
+            f32x16 o[DTT];
+#pragma unroll
+            for (int dt = 0; dt < DTT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+            float inv = 1.f;
+            if constexpr (SPLITF)
+                short_segment<DT, D>(p.k1 + ((int64_t)b * p.L1 * C + h * D) * 2, C, p.vt1 + ((int64_t)(b * H + h) * D * p.Lpad1) * 2, p.L1, p.Lpad1, bias1,
+                                     p.scale_log2, qf, o, inv, l31, half);
+            else
+                short_compute<DT, D, NS1>(f1, p.L1, bias1, p.scale_log2, qf, o, inv, half);
+#pragma unroll
+            for (int dt = 0; dt < DTT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= inv;
+            if (DUAL) {
+                f32x16 o2[DTT];
+#pragma unroll
+                for (int dt = 0; dt < DTT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o2[dt][r] = 0.f;
+                float inv2 = 1.f;
+                if constexpr (SPLITF)
+                    short_segment<DT, D>(p.k2 + ((int64_t)b * p.L2 * C + h * D) * 2, C, p.vt2 + ((int64_t)(b * H + h) * D * p.Lpad2) * 2, p.L2, p.Lpad2,
+                                         nullptr, p.scale_log2, qf, o2, inv2, l31, half);
+                else
+                    short_compute<DT, D, NSB>(f2, p.L2, nullptr, p.scale_log2, qf, o2, inv2, half);
+                // (as attn_short_kernel: each branch, and scale * audio, rounded to the storage type before the add)
+#pragma unroll
+                for (int dt = 0; dt < DTT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float t = (float)(typename E::elem)o[dt][r];
+                        const float a = (float)(typename E::elem)(o2[dt][r] * inv2);
+                        o[dt][r] = t + (float)(typename E::elem)(p.scale2 * a);
+                    }
+            }
+#pragma unroll
+            for (int dt = 0; dt < DTT; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int dcol = dt * 32 + 8 * g + 4 * half;
+                    if (dcol < D) {
+                        typename E::v4 pk;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) pk[j] = (typename E::elem)o[dt][g * 4 + j];
+                        *reinterpret_cast<uint2*>(X + (mt * 32 + l31) * ROWB + (h * D + dcol) * 2) = __builtin_bit_cast(uint2, pk);
+                    }
+                }
+        }
+    }
+#undef XR_FETCH1
+#undef XR_FETCH2
+    __syncthreads();
+
+    // ---- 4. to_out(O) + bias -> Q, then + residual -> out ----
+    if (!(XR_ABL & 4)) xr_project<DT, C, PW, NSET>(p.wo, X, Q, p.bo, wave, lane);
+    __syncthreads();
+    uint8_t* const ob = p.out + ((int64_t)b * p.N + row0) * C * 2;
+    constexpr int CPR = C / 8;
+    for (int idx = tid; idx < XR_TM * CPR; idx += NTH) {
+        const int row = idx / CPR, ch = idx - row * CPR;
+        if (row >= nrows) break;
+        float y[8], r[8];
+        unpack8<DT>(*reinterpret_cast<const uint4*>(Q + row * ROWB + ch * 16), y);
+        unpack8<DT>(*reinterpret_cast<const uint4*>(xb + ((int64_t)row * C + ch * 8) * 2), r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] += r[e];
+        *reinterpret_cast<uint4*>(ob + ((int64_t)row * C + ch * 8) * 2) = pack8<DT>(y);
+    }
+}
+
+template <int DT, int C, int NW, int NSET> int xattn_rows_launch(const XrP& p, hipStream_t s) {
+    constexpr int LDS = 2 * XR_TM * (C * 2 + 16);
+    dim3 grid((unsigned)(p.B * p.tiles_per_sample));
+    auto go = [&](auto kern) {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            attr = true;
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(NW * 64), LDS, s, p);
+        return apad_check_launch("apad_cross_attention_rows");
+    };
+    // sub-tile counts of the two segments are compile-time (the fragment registers of an unused sub-tile would not fit beside the rest)
+    const int ns1 = p.L1 > 32 ? 2 : 1, ns2 = p.L2 == 0 ? 0 : (p.L2 > 32 ? 2 : 1);
+    if (ns1 == 1 && ns2 == 0) return go(xattn_rows_kernel<DT, C, 1, 0, NW, NSET>);
+    if (ns1 == 1 && ns2 == 1) return go(xattn_rows_kernel<DT, C, 1, 1, NW, NSET>);
+    if (ns2 == 0) return go(xattn_rows_kernel<DT, C, 2, 0, NW, NSET>);
+    return go(xattn_rows_kernel<DT, C, 2, 2, NW, NSET>);
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -1050,4 +1436,38 @@ extern "C" int apad_attention(const apad_attn_desc* d, void* stream) {
     dim3 grid((unsigned)(((d->N + 127) / 128) * (((d->H * d->B) + 7) / 8 * 8)));
     hipStream_t s = (hipStream_t)stream;
     return d->dtype == APAD_BF16 ? launch_dt<APAD_BF16>(p, d->D, dual, grid, s) : launch_dt<APAD_F16>(p, d->D, dual, grid, s);
+}
+
+extern "C" int apad_cross_attention_rows(const apad_xrows_desc* d, void* stream) {
+    APAD_CHECK(d != nullptr, "apad_cross_attention_rows: null descriptor");
+    APAD_CHECK(d->dtype == APAD_BF16 || d->dtype == APAD_F16, "apad_cross_attention_rows: dtype %d not supported (16-bit only)", d->dtype);
+    if (d->C != 384 || d->heads != 8) {
+        apad_set_error("apad_cross_attention_rows: C=%d heads=%d outside the kernel envelope (384, 8)", d->C, d->heads);
+        return -3;
+    }
+    APAD_CHECK(d->x && d->wq_packed && d->wo_packed && d->k1 && d->vt1 && d->out, "apad_cross_attention_rows: null operand");
+    APAD_CHECK((d->ln_gamma == nullptr) == (d->ln_beta == nullptr), "apad_cross_attention_rows: LayerNorm needs gamma and beta");
+    APAD_CHECK(d->B > 0 && d->N > 0, "apad_cross_attention_rows: empty problem B=%d N=%d", d->B, d->N);
+    APAD_CHECK(d->L1 >= 1 && d->L1 <= 64 && d->L2 >= 0 && d->L2 <= 64, "apad_cross_attention_rows: segment lengths %d / %d outside 1..64 / 0..64", d->L1,
+               d->L2);
+    APAD_CHECK(d->Lpad1 >= d->L1 && d->Lpad1 % 32 == 0, "apad_cross_attention_rows: Lpad1 must be >= L1 and a multiple of 32");
+    const bool dual = d->L2 > 0;
+    if (dual) {
+        APAD_CHECK(d->k2 && d->vt2, "apad_cross_attention_rows: segment 2 needs k2 / vt2");
+        APAD_CHECK(d->Lpad2 >= d->L2 && d->Lpad2 % 32 == 0, "apad_cross_attention_rows: Lpad2 must be >= L2 and a multiple of 32");
+    }
+    APAD_CHECK(al16(d->x) && al16(d->out) && al16(d->wq_packed) && al16(d->wo_packed) && al16(d->k1) && al16(d->vt1) && al16(d->k2) && al16(d->vt2) &&
+                   al16(d->ln_gamma) && al16(d->ln_beta),
+               "apad_cross_attention_rows: pointers must be 16-byte aligned");
+    XrP p;
+    p.x = (const uint8_t*)d->x; p.gamma = (const uint8_t*)d->ln_gamma; p.beta = (const uint8_t*)d->ln_beta;
+    p.wq = (const uint8_t*)d->wq_packed; p.wo = (const uint8_t*)d->wo_packed; p.bo = (const uint8_t*)d->bo;
+    p.k1 = (const uint8_t*)d->k1; p.vt1 = (const uint8_t*)d->vt1; p.bias1 = d->key_bias;
+    p.k2 = (const uint8_t*)d->k2; p.vt2 = (const uint8_t*)d->vt2; p.out = (uint8_t*)d->out;
+    p.B = d->B; p.N = d->N; p.L1 = d->L1; p.Lpad1 = d->Lpad1; p.L2 = d->L2; p.Lpad2 = d->Lpad2;
+    p.tiles_per_sample = (d->N + XR_TM - 1) / XR_TM;
+    p.eps = d->ln_eps; p.scale_log2 = d->softmax_scale * LOG2E; p.scale2 = d->scale2;
+    hipStream_t s = (hipStream_t)stream;
+    // (8 waves: 35.8 us at the bench geometry vs 42.5 with 4 waves x 2 panels; deeper weight prefetch -- 6 / 8 register sets -- within 1 us)
+    return d->dtype == APAD_BF16 ? xattn_rows_launch<APAD_BF16, 384, 8, 3>(p, s) : xattn_rows_launch<APAD_F16, 384, 8, 3>(p, s);
 }

@@ -92,6 +92,7 @@ extern "C" int apad_echo_attn_bwd_desc(const apad_attn_bwd_desc* d, double* out,
 }
 
 extern "C" int apad_sizeof_xattn_desc(void) { return (int)sizeof(apad_xattn_desc); }
+extern "C" int apad_sizeof_xrows_desc(void) { return (int)sizeof(apad_xrows_desc); }
 extern "C" int apad_echo_xattn_desc(const apad_xattn_desc* d, double* out, int cap) {
     int n = 0;
     PUTP(d->x); PUTP(d->ln_gamma); PUTP(d->ln_beta); PUTP(d->wq_packed); PUTP(d->wo_packed); PUTP(d->bo); PUTP(d->kv1_packed);

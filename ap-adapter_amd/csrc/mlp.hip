@@ -524,9 +524,14 @@ __global__ __launch_bounds__(512, 1) void mlp2_kernel(MlpP p) {
         }
     };
 
+#ifndef MLP2_ABL
+#define MLP2_ABL 0  // timing ablations (results are wrong): 1 = no global weight loads, 2 = no LDS weight stores, 4 = no per-chunk barrier, 8 = no GELU
+#endif
     for (int jc = 0; jc < G::NCHUNK; ++jc) {
-        load_w1(jc + 2 < G::NCHUNK ? jc + 2 : G::NCHUNK - 1);
-        load_w2(jc + 1 < G::NCHUNK ? jc + 1 : G::NCHUNK - 1);
+        if (!(MLP2_ABL & 1)) {
+            load_w1(jc + 2 < G::NCHUNK ? jc + 2 : G::NCHUNK - 1);
+            load_w2(jc + 1 < G::NCHUNK ? jc + 1 : G::NCHUNK - 1);
+        }
         float4 bcur[4];
         load_bias(jc, bcur);
         const float bv[8] = {bcur[0].x, bcur[0].y, bcur[0].z, bcur[0].w, bcur[1].x, bcur[1].y, bcur[1].z, bcur[1].w};
@@ -556,7 +561,7 @@ __global__ __launch_bounds__(512, 1) void mlp2_kernel(MlpP p) {
             const float v0 = acur[r] + bv[r];
             const float v1 = acur[r + 1] + bv[r + 1];
             const apad_f32x2 gt = {acur[8 + r] + bg[r], acur[9 + r] + bg[r + 1]};
-            const apad_f32x2 ge = gelu_erf_2(gt);
+            const apad_f32x2 ge = (MLP2_ABL & 8) ? gt : gelu_erf_2(gt);
             hb[r] = (typename E::elem)(v0 * ge[0]);
             hb[r + 1] = (typename E::elem)(v1 * ge[1]);
         };
@@ -589,9 +594,11 @@ __global__ __launch_bounds__(512, 1) void mlp2_kernel(MlpP p) {
         }
 #endif
         *reinterpret_cast<uint4*>(hxs + (jc & 1) * G::HX_BYTES + hxoff + hh * 1024) = as_u4<DT>(hb);
-        store_w1(w1s + (jc & 1) * G::W1_BYTES);
-        store_w2(w2s + ((jc + 1) % 3) * G::W2_BYTES);
-        __syncthreads();
+        if (!(MLP2_ABL & 2)) {
+            store_w1(w1s + (jc & 1) * G::W1_BYTES);
+            store_w2(w2s + ((jc + 1) % 3) * G::W2_BYTES);
+        }
+        if (!(MLP2_ABL & 4)) __syncthreads();
         acur = anxt;
     }
     gemm2((G::NCHUNK - 1) % 3, (G::NCHUNK - 1) & 1);

@@ -283,6 +283,52 @@ def fused_cross_attention(x, wq_packed, wo_packed, bo, kv1_packed, L1, heads, ln
     return out
 
 
+XROWS_C, XROWS_MAXL = (384,), 64  # envelope of apad_cross_attention_rows (8 heads; <= 64 keys per segment)
+
+
+def xrows_ok(C_, heads, L1, L2=0):
+    return C_ in XROWS_C and heads == XATTN_HEADS and 1 <= L1 <= XROWS_MAXL and 0 <= L2 <= XROWS_MAXL
+
+
+def xrows_pack_weight(w):
+    """[C, C] projection weight -> the fragment-major packing apad_cross_attention_rows reads: one contiguous KB per MFMA operand fragment
+    (row tile of 32 output features x k-step of 16): w.view(C/32, 32, C/16, 2, 8) -> [row tile][k-step][half][row][8]"""
+    N, K = w.shape
+    if N % 32 or K % 16:
+        raise ValueError(f"xrows_pack_weight: {tuple(w.shape)}")
+    return w.detach().reshape(N // 32, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().reshape(-1)
+
+
+def cross_attention_rows(x, wq_packed, wo_packed, bo, k1, vt1, heads, ln=None, key_bias=None, k2=None, vt2=None, scale2=0.0, out=None):
+    """The fused cross-attention sub-layer at the 384-wide level: out = x + to_out(A(q, k1, v1, bias) [+ scale2 * A(q, k2, v2)]) + bo,
+    q = to_q(LayerNorm(x)), one launch (csrc/attention.hip, xattn_rows_kernel).  x [B, N, C]; k* [B, L, C] row-major, vt* [B, heads, d,
+    Lpad] as ops.attention takes them; weights from xrows_pack_weight."""
+    _req(x, "cross_attention_rows.x", wq_packed.dtype)
+    B, N, Cc = x.shape
+    L1, L2 = k1.shape[1], (0 if k2 is None else k2.shape[1])
+    if not xrows_ok(Cc, heads, L1, L2) or x.dtype not in FUSED_DTYPES:
+        raise ValueError(f"cross_attention_rows: C={Cc} heads={heads} L1={L1} L2={L2} {x.dtype} outside the kernel envelope")
+    for t, n in ((x, "x"), (k1, "k1"), (vt1, "vt1"), (k2, "k2"), (vt2, "vt2")):
+        if t is not None and (not t.is_contiguous() or t.dtype != x.dtype):
+            raise ValueError(f"cross_attention_rows.{n}: must be contiguous {x.dtype}")
+    if k1.shape[0] != B or tuple(vt1.shape[:3]) != (B, heads, Cc // heads) or (k2 is not None and (k2.shape[0] != B or tuple(vt2.shape[:3]) != (B, heads, Cc // heads))):
+        raise ValueError("cross_attention_rows: key / value sets must have the batch of x")
+    if out is None:
+        out = torch.empty_like(x)
+    d = L.XrowsDesc()
+    d.x, d.wq_packed, d.wo_packed, d.bo, d.k1, d.vt1, d.out = (x.data_ptr(), wq_packed.data_ptr(), wo_packed.data_ptr(), _ptr(bo), k1.data_ptr(),
+                                                               vt1.data_ptr(), out.data_ptr())
+    if ln is not None:
+        d.ln_gamma, d.ln_beta, d.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), float(ln[2])
+    d.key_bias = _ptr(key_bias)
+    d.B, d.N, d.C, d.heads, d.L1, d.Lpad1 = B, N, Cc, heads, L1, vt1.shape[-1]
+    if L2 > 0:
+        d.k2, d.vt2, d.L2, d.Lpad2 = k2.data_ptr(), vt2.data_ptr(), L2, vt2.shape[-1]
+    d.dtype, d.softmax_scale, d.scale2 = _DT[x.dtype], 1.0 / math.sqrt(Cc // heads), float(scale2)
+    L.check(L.lib().apad_cross_attention_rows(C.byref(d), _stream()), "apad_cross_attention_rows")
+    return out
+
+
 MLP_C = (256,)  # envelope of apad_geglu_mlp
 
 

@@ -38,6 +38,25 @@ def _fused_xattn_ok(attn, hidden_states, residual, ln, L1, L2=0, masked=False):
             and hidden_states.is_contiguous() and hidden_states.dtype in ops.FUSED_DTYPES)
 
 
+USE_XATTN_ROWS = _os.environ.get("APAD_XATTN_ROWS", "1") == "1"  # the 384-wide level's single-launch route (A/B switch; tests)
+
+
+def _xrows_ok(attn, hidden_states, residual, ln, L1, L2=0):
+    """the 384-wide cross-attention sub-layers with <= 64 keys per segment: apad_cross_attention_rows (masked or not)"""
+    C_ = hidden_states.shape[-1]
+    return (USE_FUSED_XATTN and USE_XATTN_ROWS and residual is hidden_states and ln is not None and ops.xrows_ok(C_, attn.heads, L1, L2)
+            and tuple(attn.to_q.weight.shape) == (C_, C_) and hidden_states.is_contiguous() and hidden_states.dtype in ops.FUSED_DTYPES)
+
+
+def _xrows_weights(attn):
+    """fragment-packed to_q / to_out[0] of apad_cross_attention_rows, cached like _xattn_weights"""
+    key = _pkey(attn.to_q.weight, attn.to_out[0].weight)
+    if getattr(attn, "_xrows_key", None) != key:
+        attn._xrows_w = (ops.xrows_pack_weight(attn.to_q.weight), ops.xrows_pack_weight(attn.to_out[0].weight))
+        attn._xrows_key = key
+    return attn._xrows_w
+
+
 def _xattn_weights(attn):
     """fragment-packed to_q / to_out[0] weights of the fused kernel, cached on the Attention module and re-packed when a
     parameter is re-assigned, moved, cast or updated in place"""
@@ -244,6 +263,9 @@ class AttnProcessor2_0(nn.Module):
         if encoder_hidden_states is not None and fused and pk is not None:
             wq_p, wo_p = _xattn_weights(attn)
             return ops.fused_cross_attention(hidden_states, wq_p, wo_p, attn.to_out[0].bias, pk, Lk, heads, ln=_ln, key_bias=bias)
+        if encoder_hidden_states is not None and _xrows_ok(attn, hidden_states, _residual, _ln, Lk) and k.shape[0] == B:
+            wq_p, wo_p = _xrows_weights(attn)
+            return ops.cross_attention_rows(hidden_states, wq_p, wo_p, attn.to_out[0].bias, k, vt, heads, ln=_ln, key_bias=bias)
         if q is None:
             q = ops.fused_linear(hidden_states, attn.to_q.weight, ln=_ln)
         o = ops.attention(q, k, vt, Lk, heads, key_bias=bias, q_prescaled=prescaled)
@@ -381,6 +403,10 @@ class IPAttnProcessor2_0(nn.Module):
             wq_p, wo_p = _xattn_weights(attn)
             return ops.fused_cross_attention(hidden_states, wq_p, wo_p, attn.to_out[0].bias, pk_t, Lt, attn.heads, ln=_ln,
                                              key_bias=bias, kv2_packed=pk_a, L2=La, scale2=self.scale)
+        if _xrows_ok(attn, hidden_states, _residual, _ln, Lt, La) and k_t.shape[0] == B:
+            wq_p, wo_p = _xrows_weights(attn)
+            return ops.cross_attention_rows(hidden_states, wq_p, wo_p, attn.to_out[0].bias, k_t, vt_t, attn.heads, ln=_ln, key_bias=bias,
+                                            k2=k_a, vt2=vt_a, scale2=self.scale)
         q = ops.fused_linear(hidden_states, attn.to_q.weight, ln=_ln)
         o = ops.attention(q, k_t, vt_t, Lt, attn.heads, key_bias=bias, k2=k_a, vt2=vt_a, L2=La, scale2=self.scale)
         out = ops.fused_linear(o, attn.to_out[0].weight, attn.to_out[0].bias, residual=_residual, rowstat=True)

@@ -334,13 +334,14 @@ def fused_attn2_grid(dev, dtype, B2, ap_scale):
         for La in (8, 32, 128, 512):
             ehs = torch.randn(B2, 8 + La, 768, device=dev).to(dtype)
             calls = []
-            real = ops.fused_cross_attention
+            real, real_rows = ops.fused_cross_attention, ops.cross_attention_rows
             ops.fused_cross_attention = lambda *a, **kw: (calls.append(1), real(*a, **kw))[1]
+            ops.cross_attention_rows = lambda *a, **kw: (calls.append(1), real_rows(*a, **kw))[1]  # (the 384-wide level's one-launch kernel)
             try:
                 with torch.no_grad():
                     ms = time_kernel_graphed(lambda: attn(x, encoder_hidden_states=ehs, residual=x, ln=ln))
             finally:
-                ops.fused_cross_attention = real
+                ops.fused_cross_attention, ops.cross_attention_rows = real, real_rows
             flops = (4.0 * N * C_ * C_ + 4.0 * N * (8 + La) * C_) * B2
             nbytes = 2 * B2 * N * C_ * 2 + 2 * C_ * C_ * 2 + 2 * B2 * (8 + La) * C_ * 2
             grid[f"C{C_}_N{N}_La{La}"] = {"us": round(ms * 1e3, 2), "route": "one launch" if calls else "three launches",

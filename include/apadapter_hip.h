@@ -231,6 +231,35 @@ typedef struct apad_xattn_desc {
 int apad_sizeof_xattn_desc(void);
 int apad_echo_xattn_desc(const apad_xattn_desc* d, double* out, int cap);
 int apad_fused_cross_attention(const apad_xattn_desc* d, void* stream);
+
+/* The same sub-layer for the 384-wide level (252 tokens per sample, 8 heads of 48), where the weights do not fit the weight-stationary
+ * registers of apad_fused_cross_attention: 64-token row tiles stay in LDS through LayerNorm -> to_q -> attention -> to_out -> + residual
+ * (attention.hip, xattn_rows_kernel).  K / V sets as apad_attention takes them (k [B][L][C] row-major, vt [B][heads][d][Lpad] zero-padded);
+ * <= 64 keys per segment (longer segments: the un-fused chain).  The two weights FRAGMENT-PACKED:
+ *   packed[(rt * (C / 16) + ks) * 512 + lane * 8 + e] = W[rt * 32 + (lane & 31)][ks * 16 + (lane >> 5) * 8 + e]   (elements)
+ * i.e. W.view(C/32, 32, C/16, 2, 8).permute(0, 2, 3, 1, 4): every MFMA operand fragment is one contiguous KB.  Envelope: C = 384, 8 heads,
+ * 16-bit (else -3).  Replaces, per site, to_q + scaled_dot_product_attention (x 2 for the adapter) + to_out[0] of attention_processor.py:387-457
+ * / :256-289 plus the block's norm2 / norm3 and residual add (modeling_audioldm2 BasicTransformerBlock).  (ABI 6) */
+typedef struct apad_xrows_desc {
+    const void* x;         /* [B*N][C] un-normalised hidden states (also the residual)  */
+    const void* ln_gamma;  /* [C] or NULL                                               */
+    const void* ln_beta;
+    const void* wq_packed; /* attn.to_q.weight, fragment-packed                         */
+    const void* wo_packed; /* attn.to_out[0].weight, fragment-packed                    */
+    const void* bo;        /* [C] or NULL                                               */
+    const void* k1;        /* [B][L1][C]                                                */
+    const void* vt1;       /* [B][heads][C / heads][Lpad1]                              */
+    const float* key_bias; /* [B][L1] fp32 additive bias on segment 1, or NULL          */
+    const void* k2;        /* segment 2 (to_k_ip / to_v_ip of the audio tokens) or NULL */
+    const void* vt2;
+    void* out;             /* [B*N][C]; may alias x                                     */
+    int32_t B, N, C, heads;
+    int32_t L1, Lpad1, L2, Lpad2;
+    int32_t dtype, reserved;
+    float ln_eps, softmax_scale, scale2, reserved_f;
+} apad_xrows_desc;
+int apad_sizeof_xrows_desc(void);
+int apad_cross_attention_rows(const apad_xrows_desc* d, void* stream);
 /* w [256][ldw] (nn.Linear layout) -> packed [8 row slices][16 k-steps][64 lanes][8], 128 KB */
 int apad_xattn_pack_weight(const void* w, void* packed, int64_t ldw, int32_t dtype, void* stream);
 /* bytes of the packed form of one segment's K / V^T: B * 8 heads * ceil(L/32) * 4 KB */

@@ -762,6 +762,75 @@ def test_fused_cross_attention(dev, dtype, B, N, Lt, La, masked):
     assert rel_err(out, chain.float().cpu()) < TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", DTYPES16)
+@pytest.mark.parametrize("B,N,Lt,La,masked", [(2, 252, 8, 32, False), (3, 100, 8, 8, False), (2, 252, 16, 0, True), (1, 33, 8, 64, False),
+                                               (5, 64, 40, 0, False), (2, 130, 8, 33, False), (9, 252, 8, 32, True), (2, 31, 64, 50, True),
+                                               (64, 252, 8, 32, False), (2, 65, 1, 1, False)])
+def test_cross_attention_rows_384(dev, dtype, B, N, Lt, La, masked):
+    """the 384-wide level's single-launch form (apad_cross_attention_rows: 64-token row tiles in LDS through LayerNorm, to_q, attention,
+    to_out, residual): ragged last tiles, one- and two-segment forms, the masked forms of both, full CFG batch; against fp32 torch on
+    storage-rounded operands and against the three-kernel chain it replaces"""
+    from ap_adapter_amd import ops
+    C, H = 384, 8
+    x = q(R(B, N, C, seed=301), dtype)
+    g, be = q(1 + 0.1 * R(C, seed=302), dtype), q(0.1 * R(C, seed=303), dtype)
+    wq, wo, bo = q(R(C, C, seed=304, std=0.05), dtype), q(R(C, C, seed=305, std=0.05), dtype), q(R(C, seed=306, std=0.3), dtype)
+    wk, wv = q(R(C, 768, seed=307, std=0.04), dtype), q(R(C, 768, seed=308, std=0.04), dtype)
+    wki, wvi = q(R(C, 768, seed=309, std=0.04), dtype), q(R(C, 768, seed=310, std=0.04), dtype)
+    et = q(R(B, Lt, 768, seed=311), dtype)
+    ea = q(R(B, La, 768, seed=312), dtype) if La else None
+    bias = None
+    if masked:
+        bias = torch.zeros(B, Lt)
+        bias[1::2, -(Lt // 2):] = -10000.0
+    ref = _xattn_ref(x, g, be, wq, wo, bo, et, wk, wv, H, bias, ea, wki, wvi, 0.55)
+    D = lambda t: t.to(dev, dtype)
+    k1 = ops.linear(D(et), D(wk))
+    v1t = torch.zeros(B, H, C // H, ops.round_up(Lt, 32), device=dev, dtype=dtype)
+    ops.linear_vt(D(et), D(wv), B, Lt, H, v1t)
+    k2 = v2t = None
+    if La:
+        k2 = ops.linear(D(ea), D(wki))
+        v2t = torch.zeros(B, H, C // H, ops.round_up(La, 32), device=dev, dtype=dtype)
+        ops.linear_vt(D(ea), D(wvi), B, La, H, v2t)
+    wq_p, wo_p = ops.xrows_pack_weight(D(wq)), ops.xrows_pack_weight(D(wo))
+    bd = None if bias is None else bias.to(dev)
+    xd = D(x)
+    out = ops.cross_attention_rows(xd, wq_p, wo_p, D(bo), k1, v1t, H, ln=(D(g), D(be), 1e-5), key_bias=bd, k2=k2, vt2=v2t, scale2=0.55)
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < 1.5 * TOL[dtype]
+    qd = ops.fused_linear(xd, D(wq), ln=(D(g), D(be), 1e-5))
+    od = ops.attention(qd, k1, v1t, Lt, H, key_bias=bd, k2=k2, vt2=v2t, L2=La, scale2=0.55)
+    chain = ops.fused_linear(od, D(wo), D(bo), residual=xd)
+    assert rel_err(out, chain.float().cpu()) < TOL[dtype]
+    # in place (out aliases x), and without the bias of to_out
+    x2 = xd.clone()
+    ops.cross_attention_rows(x2, wq_p, wo_p, D(bo), k1, v1t, H, ln=(D(g), D(be), 1e-5), key_bias=bd, k2=k2, vt2=v2t, scale2=0.55, out=x2)
+    assert torch.equal(x2, out)
+    nb = ops.cross_attention_rows(xd, wq_p, wo_p, None, k1, v1t, H, ln=(D(g), D(be), 1e-5), key_bias=bd, k2=k2, vt2=v2t, scale2=0.55)
+    assert rel_err(nb, ref - bo) < 1.5 * TOL[dtype]
+
+
+def test_cross_attention_rows_outside_envelope(dev):
+    from ap_adapter_amd import ops
+    bf = torch.bfloat16
+    assert ops.xrows_ok(384, 8, 8, 32) and ops.xrows_ok(384, 8, 64, 64) and ops.xrows_ok(384, 8, 16)
+    assert not ops.xrows_ok(384, 8, 8, 128) and not ops.xrows_ok(640, 8, 8, 32) and not ops.xrows_ok(384, 4, 8, 32) and not ops.xrows_ok(384, 8, 65)
+    x = torch.zeros(1, 64, 640, device=dev, dtype=bf)
+    w = ops.xrows_pack_weight(torch.zeros(640, 640, device=dev, dtype=bf))
+    with pytest.raises(ValueError):
+        ops.cross_attention_rows(x, w, w, None, torch.zeros(1, 8, 640, device=dev, dtype=bf), torch.zeros(1, 8, 80, 32, device=dev, dtype=bf), 8)
+    x = torch.zeros(1, 64, 384, device=dev, dtype=bf)
+    w = ops.xrows_pack_weight(torch.zeros(384, 384, device=dev, dtype=bf))
+    with pytest.raises(ValueError):  # 128 audio keys: the chain's job
+        ops.cross_attention_rows(x, w, w, None, torch.zeros(1, 8, 384, device=dev, dtype=bf), torch.zeros(1, 8, 48, 32, device=dev, dtype=bf), 8,
+                                 k2=torch.zeros(1, 128, 384, device=dev, dtype=bf), vt2=torch.zeros(1, 8, 48, 128, device=dev, dtype=bf))
+    # the packing: fragment (row tile rt, k-step ks) = one contiguous KB, lane = (k half, row)
+    wt = torch.arange(384 * 384, dtype=torch.float32).reshape(384, 384).to(dev)
+    pk = ops.xrows_pack_weight(wt).reshape(12, 24, 2, 32, 8)
+    assert torch.equal(pk[5, 7, 1, 9], wt[5 * 32 + 9, 7 * 16 + 8: 7 * 16 + 16])
+
+
 def test_fused_cross_attention_outside_envelope(dev):
     from ap_adapter_amd import ops
     x = torch.zeros(1, 64, 384, device=dev, dtype=torch.bfloat16)

@@ -87,11 +87,18 @@ def test_audiomae_vs_oracle(dev, dtype, tol):
 N_FUSED_ATTN2_SITES = 20  # attention sites inside apad_fused_cross_attention's envelope at AudioLDM2-large geometry, La <= 64 or 128
 
 
-def _count_fused(monkeypatch):
+N_ROWS_ATTN2_SITES = 20  # ... and inside apad_cross_attention_rows' (the 384-wide level; La <= 64: the 128-key presets take the chain there)
+
+
+def _count_fused(monkeypatch, rows=None):
+    """counts apad_fused_cross_attention launches (returned list) and, into ``rows``, apad_cross_attention_rows launches"""
     from ap_adapter_amd import ops
     calls = []
     real = ops.fused_cross_attention
     monkeypatch.setattr(ops, "fused_cross_attention", lambda *a, **kw: (calls.append(1), real(*a, **kw))[1])
+    if rows is not None:
+        real_rows = ops.cross_attention_rows
+        monkeypatch.setattr(ops, "cross_attention_rows", lambda *a, **kw: (rows.append(1), real_rows(*a, **kw))[1])
     return calls
 
 
@@ -132,10 +139,13 @@ def _full_geometry_case(dev, dtype, La=32, scale=0.55, t=501, frames=250, routes
         outs = {}
         for route in routes:
             monkeypatch.setattr(P, "USE_FUSED_XATTN", route == "fused")
-            calls = _count_fused(monkeypatch)
+            rows = []
+            calls = _count_fused(monkeypatch, rows)
             outs[route] = run()
             expect = N_FUSED_ATTN2_SITES if (route == "fused" and dtype != torch.float32 and (La <= 64 or La == 128)) else 0
             assert len(calls) == expect, (route, len(calls), expect)
+            expect_rows = N_ROWS_ATTN2_SITES if (route == "fused" and dtype != torch.float32 and La <= 64) else 0
+            assert len(rows) == expect_rows, (route, len(rows), expect_rows)
             monkeypatch.undo()
     return outs, oracle
 
@@ -264,14 +274,16 @@ def _run(pipe, d, steps=2, gs=9.5):
 
 def test_full_size_default_route_is_the_one_launch_attn2(dev, full_pipe, monkeypatch):
     """the configuration bench.py times: batch 32, style preset (La = 32), default switches -> every forward sends the 20 sites of
-    the 1000-token level through apad_fused_cross_attention (asserted by counting; one eager step = one forward of the CFG batch)"""
+    the 1000-token level through apad_fused_cross_attention and the 20 of the 252-token level through apad_cross_attention_rows
+    (asserted by counting; one eager step = one forward of the CFG batch)"""
     from ap_adapter_amd import processors as P
-    assert P.USE_FUSED_XATTN is True
-    calls = _count_fused(monkeypatch)
+    assert P.USE_FUSED_XATTN is True and P.USE_XATTN_ROWS is True
+    rows = []
+    calls = _count_fused(monkeypatch, rows)
     d = _full_inputs(full_pipe, 32, 32, dev)
     with torch.no_grad():
         out = full_pipe.denoise(d["lat"], d["ehs"], d["pe"], d["mask"], 1, 9.5, use_graph=False)
-    assert len(calls) == N_FUSED_ATTN2_SITES and torch.isfinite(out).all()
+    assert len(calls) == N_FUSED_ATTN2_SITES and len(rows) == N_ROWS_ATTN2_SITES and torch.isfinite(out).all()
 
 
 @pytest.mark.parametrize("La,scale", [(8, 0.55), (32, 0.55), (128, 0.5), (512, 1.0)])

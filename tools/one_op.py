@@ -45,6 +45,31 @@ elif op == "xattn":
     pk1, pk2 = ops.xattn_pack_kv(k1, v1t, Lt), ops.xattn_pack_kv(k2, v2t, La)
     out = torch.empty_like(x)
     fn = lambda: ops.fused_cross_attention(x, wq_p, wo_p, bo, pk1, Lt, H, ln=(g, be, 1e-5), kv2_packed=pk2, L2=La, scale2=0.55, out=out)
+elif op in ("xrows", "xrows_chain"):
+    N, C, H, Lt, La = 252, 384, 8, 8, int(os.environ.get("LA", "32"))
+    x, g, be, wq, wo, bo = R(B2, N, C), R(C), R(C), R(C, C, std=0.02), R(C, C, std=0.02), R(C, std=0.02)
+    k1, k2 = R(B2, Lt, C, std=0.3), R(B2, La, C, std=0.3)
+    v1t = torch.zeros(B2, H, C // H, 32, device=dev, dtype=dt); v1t[..., :Lt].normal_(0, 0.3)
+    v2t = torch.zeros(B2, H, C // H, ops.round_up(La, 32), device=dev, dtype=dt); v2t[..., :La].normal_(0, 0.3)
+    wq_p, wo_p = ops.xrows_pack_weight(wq), ops.xrows_pack_weight(wo)
+    out = torch.empty_like(x)
+    if op == "xrows":
+        fn = lambda: ops.cross_attention_rows(x, wq_p, wo_p, bo, k1, v1t, H, ln=(g, be, 1e-5), k2=k2, vt2=v2t, scale2=0.55, out=out)
+    else:
+        def fn():
+            qd = ops.fused_linear(x, wq, ln=(g, be, 1e-5))
+            od = ops.attention(qd, k1, v1t, Lt, H, k2=k2, vt2=v2t, L2=La, scale2=0.55)
+            return ops.fused_linear(od, wo, bo, residual=x, out=out)
 for _ in range(iters):
     fn()
 torch.cuda.synchronize()
+if os.environ.get("TIME"):  # event timing of the op alone (isolated; the in-step figure is what counts)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 50
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"{op} {os.environ.get('APAD_LIB_PATH', 'product')}: {e0.elapsed_time(e1) / n * 1000:.1f} us")
+
