@@ -606,11 +606,15 @@ def test_rowpanel_geglu(dev, dtype, M, K, ln):
 
 
 @pytest.mark.parametrize("dtype", DTYPES16)
-@pytest.mark.parametrize("M,C", [(1000, 256), (300, 256), (33000, 256), (37, 256)])
+@pytest.mark.parametrize("M,C", [(1000, 256), (300, 256), (33000, 256), (37, 256), (16128, 384), (300, 384), (37, 384), (64, 384)])
 @pytest.mark.parametrize("ln", [False, True])
-def test_geglu_mlp(dev, dtype, M, C, ln):
-    """norm3 + GEGLU + FeedForward.net[2] + residual in one launch (both workgroup sizes, ragged last panel)"""
+def test_geglu_mlp(dev, dtype, M, C, ln, monkeypatch):
+    """norm3 + GEGLU + FeedForward.net[2] + residual in one launch (both workgroup sizes, ragged last panel); C = 384: the row-tile
+    kernel (apad_geglu_mlp_rows, fragment-packed weights cached per parameter; an opt-in route, see ops.MLP_ROWS_C)"""
     from ap_adapter_amd import ops
+    if C == 384:
+        monkeypatch.setattr(ops, "MLP_ROWS_C", (384,))
+        monkeypatch.setattr(ops, "MLP_C", (256, 384))
     x = q(R(M, C, seed=156), dtype)
     w1, b1 = q(R(8 * C, C, seed=157, std=0.08), dtype), q(R(8 * C, seed=158, std=0.5), dtype)
     w2, b2 = q(R(C, 4 * C, seed=159, std=0.04), dtype), q(R(C, seed=160, std=0.5), dtype)
@@ -630,10 +634,12 @@ def test_geglu_mlp(dev, dtype, M, C, ln):
 
 def test_geglu_mlp_outside_envelope_is_an_error(dev):
     from ap_adapter_amd import ops
-    x = torch.zeros(64, 384, device=dev, dtype=torch.bfloat16)
+    x = torch.zeros(64, 640, device=dev, dtype=torch.bfloat16)
     with pytest.raises(ValueError):
-        ops.geglu_mlp(x, torch.zeros(3072, 384, device=dev, dtype=torch.bfloat16), None,
-                      torch.zeros(384, 1536, device=dev, dtype=torch.bfloat16), None)
+        ops.geglu_mlp(x, torch.zeros(5120, 640, device=dev, dtype=torch.bfloat16), None,
+                      torch.zeros(640, 2560, device=dev, dtype=torch.bfloat16), None)
+    with pytest.raises(ValueError):  # fp32 storage: the un-fused exact-f32 chain's job
+        ops.geglu_mlp(torch.zeros(64, 384, device=dev), torch.zeros(3072, 384, device=dev), None, torch.zeros(384, 1536, device=dev), None)
 
 
 @pytest.mark.parametrize("dtype", DTYPES16)

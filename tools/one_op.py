@@ -45,6 +45,16 @@ elif op == "xattn":
     pk1, pk2 = ops.xattn_pack_kv(k1, v1t, Lt), ops.xattn_pack_kv(k2, v2t, La)
     out = torch.empty_like(x)
     fn = lambda: ops.fused_cross_attention(x, wq_p, wo_p, bo, pk1, Lt, H, ln=(g, be, 1e-5), kv2_packed=pk2, L2=La, scale2=0.55, out=out)
+elif op in ("mlp384", "mlp384_chain"):
+    M, C = B2 * 252, 384
+    x = R(M, C); g = R(C); be = R(C); w1 = R(8 * C, C, std=0.02); b1 = R(8 * C, std=0.02)
+    w2 = R(C, 4 * C, std=0.02); b2 = R(C, std=0.02); out = torch.empty(M, C, device=dev, dtype=dt)
+    if op == "mlp384":
+        fn = lambda: ops.geglu_mlp(x, w1, b1, w2, b2, ln=(g, be, 1e-5), out=out)
+    else:
+        def fn():
+            h = ops.fused_linear(x, w1, b1, ln=(g, be, 1e-5), act="geglu")
+            return ops.linear(h, w2, b2, residual=x, out=out)
 elif op in ("xrows", "xrows_chain"):
     N, C, H, Lt, La = 252, 384, 8, 8, int(os.environ.get("LA", "32"))
     x, g, be, wq, wo, bo = R(B2, N, C), R(C), R(C), R(C, C, std=0.02), R(C, C, std=0.02), R(C, std=0.02)
