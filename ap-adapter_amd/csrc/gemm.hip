@@ -1076,7 +1076,10 @@ int launch(const GemmP& p, hipStream_t s) {
         static const int kg_mode_r = [] { const char* e = getenv("APAD_GEMM_KG"); return e ? atoi(e) : 2; }();
         static const int ring_max_m = [] { const char* e = getenv("APAD_GEMM_RING_MAX_M"); return e ? atoi(e) : 16000; }();
         const int ring_mode = g_ring_mode >= 0 ? g_ring_mode : ring_env;
-        if (ring_mode && p.K >= 128 && p.M < ring_max_m && (!t128 || ring_mode >= 2)) {
+        static const int ring_max_wg = [] { const char* e = getenv("APAD_GEMM_RING_MAX_WG"); return e ? atoi(e) : (1 << 30); }();
+        static const int ring_min_wg = [] { const char* e = getenv("APAD_GEMM_RING_MIN_WG"); return e ? atoi(e) : 0; }();
+        const int64_t ring_wgs = ((p.M + 63) / 64) * (p.N / (EPI == APAD_EPI_GEGLU ? 32 : 64));
+        if (ring_mode && p.K >= 128 && p.M < ring_max_m && (!t128 || ring_mode >= 2) && ring_wgs <= ring_max_wg && ring_wgs >= ring_min_wg) {
             static const int ring_kg = [] { const char* e = getenv("APAD_GEMM_RING_KG"); return e ? atoi(e) : 1; }();
             const bool kgroups = EPI == APAD_EPI_NONE && kg_mode_r >= 2 && p.K >= 384 && p.N >= 640;
             if (!kgroups || ring_kg) {
