@@ -32,7 +32,7 @@ class GemmDesc(C.Structure):
                [(n, _i32) for n in ("taps", "dilation", "pad", "transposed", "a_pre_act")] + [("a_pre_slope", _f32)] + \
                [("conv_asym_pad", _i32), ("reserved_conv", _i32)] + \
                [(n, _vp) for n in ("rowstat_out", "rowstat_in", "ln_colsum", "ln_bias")] + [("rowstat_in_tiles", _i32), ("ln_eps", _f32)] + \
-               [("a2", _vp), ("lda2", _i64), ("k_split", _i32), ("a_row_mod", _i32), ("a2_row_mod", _i32), ("reserved_a2", _i32)]
+               [("a2", _vp), ("lda2", _i64), ("k_split", _i32), ("a_row_mod", _i32), ("a2_row_mod", _i32), ("reserved_a2", _i32), ("out4", _vp)]
 
 
 class AttnDesc(C.Structure):

@@ -11,6 +11,8 @@ Frozen weights need no weight gradient; their transposed / flipped copies for th
 """
 import weakref
 
+import os as _os
+
 import torch
 
 from . import ops
@@ -119,10 +121,41 @@ class _QKV(torch.autograd.Function):
         return ops.linear(torch.cat([_c(dq), _c(dk), _c(dv)], dim=-1), wst), None, None, None
 
 
-def qkv(x, wq, wk, wv):
+class _QKVT(_QKV):
+    """_QKV with ONE forward launch: q, k, v row-major and v^T (what the forward attention kernel reads) from apad_gemm's q | k | v^T
+    output mode with its optional row-major v (four launches -- three projections and a transpose -- otherwise; the step at batch 4 is
+    bound by its launch count).  v^T lives in a scratch buffer shared by shape: it is consumed by the attention launch that follows."""
+
+    @staticmethod
+    def forward(ctx, x, wq, wk, wv, heads):
+        from .processors import vt_buffer
+        x = _c(x)
+        B, N, Cc = x.shape
+        ctx.save_for_backward(wq, wk, wv)
+        w = _cached(wq, ("qkv", id(wk), id(wv), wk._version, wv._version), lambda t: torch.cat([t, wk.detach(), wv.detach()], 0).contiguous())
+        q, k, v = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        vt = vt_buffer("train_self", B, heads, Cc // heads, N, x.dtype, x.device)
+        ops.linear_qkv(x, w, B, N, heads, q, k, vt, v=v)
+        ctx.mark_non_differentiable(vt)
+        return q, k, v, vt
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv, _dvt):
+        return _QKV.backward(ctx, dq, dk, dv) + (None,)
+
+
+_QKV_FUSED = _os.environ.get("APAD_TRAIN_QKV_FUSED", "1") == "1"  # A/B switch (read once)
+
+
+def qkv(x, wq, wk, wv, heads=None):
+    """-> (q, k, v, vt or None)"""
     if wq.requires_grad or wk.requires_grad or wv.requires_grad:
-        return linear(x, wq), linear(x, wk), linear(x, wv)
-    return _QKV.apply(x, wq, wk, wv)
+        return linear(x, wq), linear(x, wk), linear(x, wv), None
+    C_ = x.shape[-1]
+    if (_QKV_FUSED and heads is not None and x.dtype in ops.FUSED_DTYPES and x.dim() == 3 and C_ % 128 == 0
+            and tuple(wq.shape) == tuple(wk.shape) == tuple(wv.shape) == (C_, C_)):
+        return _QKVT.apply(x, wq, wk, wv, heads)
+    return _QKV.apply(x, wq, wk, wv) + (None,)
 
 
 class _LayerNorm(torch.autograd.Function):
@@ -164,7 +197,6 @@ class _LayerNormRes(torch.autograd.Function):
         return ops.layer_norm_bwd(x, g, _c(dy), ctx.eps, dres=None if dres is None else _c(dres)), None, None, None
 
 
-import os as _os
 _LN_RES = _os.environ.get("APAD_TRAIN_LN_RES", "1") == "1"  # A/B switch (read once)
 
 
@@ -259,9 +291,10 @@ class _Attention(torch.autograd.Function):
     """o = softmax(q k^T / sqrt(d) + bias) v, all [B, tokens, C] row-major"""
 
     @staticmethod
-    def forward(ctx, q, k, v, heads, key_bias):
+    def forward(ctx, q, k, v, heads, key_bias, vt=None):
         q, k, v = _c(q), _c(k), _c(v)
-        vt = ops.head_transpose(v, heads)
+        if vt is None:
+            vt = ops.head_transpose(v, heads)
         o, lse = ops.attention_lse(q, k, vt, k.shape[1], heads, key_bias=key_bias)
         ctx.save_for_backward(q, k, v, o, lse, key_bias)
         ctx.heads = heads
@@ -272,11 +305,12 @@ class _Attention(torch.autograd.Function):
         q, k, v, o, lse, key_bias = ctx.saved_tensors
         need_kv = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         dq, dk, dv = ops.attention_bwd(q, k, v, o, _c(do), lse, ctx.heads, key_bias=key_bias, need_dkv=need_kv)
-        return dq, dk, dv, None, None
+        return dq, dk, dv, None, None, None
 
 
-def attention(q, k, v, heads, key_bias=None):
-    return _Attention.apply(q, k, v, heads, key_bias)
+def attention(q, k, v, heads, key_bias=None, vt=None):
+    """vt: v per-head transposed [B, heads, d, Lpad], when the projection already produced it (qkv)"""
+    return _Attention.apply(q, k, v, heads, key_bias, vt)
 
 
 class _IPAttention(torch.autograd.Function):

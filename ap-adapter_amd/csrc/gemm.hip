@@ -45,6 +45,7 @@ struct GemmP {
     uint8_t* out;
     uint8_t* out2;
     uint8_t* out3;
+    uint8_t* out4;  // APAD_OUT_QKV: optional row-major v
     const uint8_t* bias;
     const uint8_t* residual;
     const uint8_t* rg;
@@ -528,6 +529,13 @@ __global__ __launch_bounds__(256 * KG) void gemm_kernel(GemmP p) {
     } else {  // APAD_OUT_VT (or the v third of APAD_OUT_QKV): consecutive lanes -> consecutive tokens of one (head, dd) row
         typename E::elem* o = reinterpret_cast<typename E::elem*>(OUTMODE == APAD_OUT_QKV ? p.out3 : p.out);
         const int64_t nsub = (OUTMODE == APAD_OUT_QKV) ? 2 * (int64_t)Cq : 0;
+        if (OUTMODE == APAD_OUT_QKV && p.out4 != nullptr) {  // v row-major as well (the training step keeps both forms)
+            for (int idx = threadIdx.x; idx < BM * (BN / 8); idx += NT) {
+                const int rl = idx / (BN / 8), vc = idx - rl * (BN / 8);
+                const int64_t m = m0 + rl, n = n0 + vc * 8;
+                if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(p.out4 + (m * p.ldo + (n - nsub)) * 2) = *reinterpret_cast<const uint4*>(&ct[rl * C_LD + vc * 8]);
+            }
+        }
         for (int idx = threadIdx.x; idx < BM * BN; idx += NT) {
             const int nl = idx / BM, rl = idx % BM;
             const int64_t m = m0 + rl;
@@ -986,6 +994,13 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmP p, uint32_t a_byte
     } else {
         typename E::elem* o = reinterpret_cast<typename E::elem*>(OUTMODE == APAD_OUT_QKV ? p.out3 : p.out);
         const int64_t nsub = (OUTMODE == APAD_OUT_QKV) ? 2 * (int64_t)Cq : 0;
+        if (OUTMODE == APAD_OUT_QKV && p.out4 != nullptr) {
+            for (int idx = tid; idx < BM * (BN / 8); idx += 256) {
+                const int rl = idx / (BN / 8), vc = idx - rl * (BN / 8);
+                const int64_t m = m0 + rl, n = n0 + vc * 8;
+                if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(p.out4 + (m * p.ldo + (n - nsub)) * 2) = *reinterpret_cast<const uint4*>(&ct[rl * C_LD + vc * 8]);
+            }
+        }
         for (int idx = tid; idx < BM * BN; idx += 256) {
             const int nl = idx / BM, rl = idx % BM;
             const int64_t m = m0 + rl;
@@ -1175,6 +1190,7 @@ extern "C" int apad_gemm(const apad_gemm_desc* d, void* stream) {
     p.out = (uint8_t*)d->out;
     p.out2 = (uint8_t*)d->out2;
     p.out3 = (uint8_t*)d->out3;
+    p.out4 = (uint8_t*)d->out4;
     p.bias = (const uint8_t*)d->bias;
     p.residual = (const uint8_t*)d->residual;
     p.rg = (const uint8_t*)d->rowgroup_bias;
@@ -1211,6 +1227,7 @@ extern "C" int apad_gemm(const apad_gemm_desc* d, void* stream) {
         if (d->epilogue == APAD_EPI_GEGLU) APAD_CHECK(d->N % 64 == 0, "apad_gemm: GEGLU needs N %% 64 == 0");
     } else if (d->out_mode == APAD_OUT_QKV) {
         APAD_CHECK(d->out2 && d->out3 && al16(d->out2) && al16(d->out3), "apad_gemm: APAD_OUT_QKV needs 16-byte aligned out2 / out3");
+        APAD_CHECK(al16(d->out4), "apad_gemm: out4 must be 16-byte aligned");
         APAD_CHECK(d->heads > 0 && d->head_dim > 0 && d->L > 0 && d->Lpad >= d->L && d->N == 3LL * d->heads * d->head_dim &&
                        d->M % d->L == 0 && (d->N / 3) % 128 == 0 && d->ldo % 8 == 0,
                    "apad_gemm: fused q|k|v geometry inconsistent (needs C %% 128 == 0)");

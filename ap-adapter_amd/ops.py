@@ -390,9 +390,10 @@ def linear_vt(x, w, B, Lk, heads, out_vt, bias=None):
     return out_vt
 
 
-def linear_qkv(x, w_qkv, B, Lk, heads, q, k, vt, bias=None, ln=None):
+def linear_qkv(x, w_qkv, B, Lk, heads, q, k, vt, bias=None, ln=None, v=None):
     """Fused q|k|v projection on the tiled kernel (any K): x [B*Lk, K] @ w_qkv[3C, K]^T -> q, k [B*Lk, C] row-major and
-    vt [B, heads, d, Lpad] per-head transposed, one launch.  ln = (gamma, beta, eps): LayerNorm(x) folded in (needs rowstat_of(x))."""
+    vt [B, heads, d, Lpad] per-head transposed, one launch.  ln = (gamma, beta, eps): LayerNorm(x) folded in (needs rowstat_of(x)).
+    v: optional [B*Lk, C] row-major copy of the values (same rounded numbers as vt)."""
     _req(x, "linear_qkv.x", w_qkv.dtype)
     fold = None
     if ln is not None:
@@ -405,6 +406,7 @@ def linear_qkv(x, w_qkv, B, Lk, heads, q, k, vt, bias=None, ln=None):
     x2 = x.reshape(B * Lk, K)
     d = L.GemmDesc()
     d.a, d.w, d.out, d.out2, d.out3 = x2.data_ptr(), w_qkv.data_ptr(), q.data_ptr(), k.data_ptr(), vt.data_ptr()
+    d.out4 = _ptr(v)  # v row-major [B*Lk, C] as well (the training step's backward reads it)
     d.bias = _ptr(bias)
     d.M, d.N, d.K, d.lda, d.ldw, d.ldo = B * Lk, C3, K, x2.stride(0), w_qkv.stride(0), Cc
     d.a_mode, d.epilogue, d.out_mode, d.dtype = L.A_PLAIN, L.EPI_NONE, L.OUT_QKV, _DT[w_qkv.dtype]

@@ -294,12 +294,13 @@ def _attn_call_train(self, attn, hidden_states, encoder_hidden_states, attention
     src = hs if encoder_hidden_states is None else (encoder_hidden_states if encoder_hidden_states.dim() == 3
                                                     else encoder_hidden_states.unsqueeze(0))
     if encoder_hidden_states is None:  # self-attention: one input-gradient GEMM for the three projections
-        q, k, v = AG.qkv(hs, attn.to_q.weight, attn.to_k.weight, attn.to_v.weight)
+        q, k, v, vt = AG.qkv(hs, attn.to_q.weight, attn.to_k.weight, attn.to_v.weight, attn.heads)
     else:
         q = AG.linear(hs, attn.to_q.weight)
         k = AG.linear(src, attn.to_k.weight)
         v = AG.linear(src, attn.to_v.weight)
-    o = AG.attention(q, k, v, attn.heads, _key_bias(attention_mask, B, src.shape[1]))
+        vt = None
+    o = AG.attention(q, k, v, attn.heads, _key_bias(attention_mask, B, src.shape[1]), vt=vt)
     return AG.linear(o, attn.to_out[0].weight, attn.to_out[0].bias, residual=_residual)
 
 

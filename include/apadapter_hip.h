@@ -128,6 +128,8 @@ typedef struct apad_gemm_desc {
     int32_t k_split;
     int32_t a_row_mod, a2_row_mod;
     int32_t reserved_a2;
+    void* out4;                /* APAD_OUT_QKV: optional v ROW-MAJOR [M][C] (ldo) beside the v^T of out3 -- the training step keeps both forms;
+                                  NULL: not written (ABI 6) */
 } apad_gemm_desc;
 
 typedef struct apad_attn_desc {

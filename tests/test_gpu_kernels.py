@@ -232,11 +232,15 @@ def test_gemm_ring_form_equals_the_tiled_kernel_bit_for_bit(dev, dtype):
     def qkv():
         qo, ko = torch.empty(B, Lk, C, dtype=dtype, device=dev), torch.empty(B, Lk, C, dtype=dtype, device=dev)
         vt = torch.zeros(B, heads, C // heads, Lp, dtype=dtype, device=dev)
-        ops.linear_qkv(x, wq, B, Lk, heads, qo, ko, vt)
-        return [qo, ko, vt]
+        vo = torch.empty(B, Lk, C, dtype=dtype, device=dev)
+        ops.linear_qkv(x, wq, B, Lk, heads, qo, ko, vt, v=vo)  # (+ the optional row-major v of the training step)
+        return [qo, ko, vt, vo]
 
     a, c = both(qkv)
     assert same(a, c)
+    for qo, ko, vt, vo in (a, c):  # row-major v = the same rounded numbers as v^T
+        assert torch.equal(vo.view(B, Lk, heads, C // heads).permute(0, 2, 3, 1), vt[..., :Lk])
+        assert rel_err(vo.cpu(), F.linear(x.cpu().float(), wq.cpu().float()[2 * C:])) < TOL[dtype]
     # two A sources (the up-block shortcut over [hidden | skip]), the skip read modulo
     xa, xb, w, b = D(4, 250, 640, seed=63), D(2, 250, 320, seed=64), D(640, 960, seed=65, std=0.05), D(640, seed=66)
     a, c = both(lambda: ops.linear2(xa, xb, w, b))
