@@ -1126,6 +1126,68 @@ __device__ __forceinline__ void short_compute(const ShortFr<DT, D, NS>& f, int L
     }
 }
 
+// the same arithmetic with the fragments requested where they are used (no resident fragment set): segments of up to NS x 32 keys --
+// the 128 audio keys of the timbre / accompaniment presets -- whose K and V^T fragments (64 + 64 registers at NS = 4) do not fit beside
+// the rest of xattn_rows_kernel's attention phase
+template <int DT, int D, int NS>
+__device__ __forceinline__ void short_segment_ns(const uint8_t* kbase, int64_t k_sl, const uint8_t* vbase, int L, int Lpad, const float* bias, float c,
+                                                 const typename ET<DT>::v8* qf, f32x16* o, float& inv_den, int l31, int half) {
+    using E = ET<DT>;
+    constexpr int KC = D / 16, DTT = (D + 31) / 32;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 s[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        const int key = u * 32 + l31;
+        const uint8_t* kp = kbase + ((int64_t)(key < L ? key : L - 1) * k_sl + half * 8) * 2;
+        s[u] = zero16;
+#pragma unroll
+        for (int cc = 0; cc < KC; ++cc) s[u] = E::mfma32(as_v8<DT>(*reinterpret_cast<const uint4*>(kp + cc * 32)), qf[cc], cc == 0 ? zero16 : s[u]);
+    }
+    float tmax = NEG_BIG;
+#pragma unroll
+    for (int u = 0; u < NS; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = u * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float v = s[u][r] * c;
+            if (bias) v += bias[key < L ? key : L - 1] * LOG2E;
+            v = key < L ? v : NEG_BIG;
+            s[u][r] = v;
+            tmax = fmaxf(tmax, v);
+        }
+    tmax = half_max(tmax);
+    float sum = 0.f;
+#pragma unroll
+    for (int u = 0; u < NS; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = (float)(typename E::elem)__builtin_amdgcn_exp2f(s[u][r] - tmax);
+            s[u][r] = e;
+            sum += e;
+        }
+    sum = half_sum(sum);
+    inv_den = 1.0f / sum;
+#pragma unroll
+    for (int st = 0; st < 2 * NS; ++st) {
+        typename E::v8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (typename E::elem)s[st >> 1][(st & 1) * 8 + j];
+        const int kcol = st * 16 + 4 * half;
+#pragma unroll
+        for (int dt = 0; dt < DTT; ++dt) {
+            const int d = dt * 32 + l31;
+            uint2 v0 = make_uint2(0u, 0u), v1 = make_uint2(0u, 0u);
+            if (d < D && st * 16 < Lpad) {
+                const uint8_t* vp = vbase + ((int64_t)d * Lpad + kcol) * 2;
+                v0 = *reinterpret_cast<const uint2*>(vp);
+                v1 = *reinterpret_cast<const uint2*>(vp + 16);
+            }
+            o[dt] = E::mfma32(as_v8<DT>(make_uint4(v0.x, v0.y, v1.x, v1.y)), pf, o[dt]);
+        }
+    }
+}
+
 // the two projections of xattn_rows_kernel: dst^T[feature][token] = W . src^T (+ bias), wave w = features 32 NT w .. (+ 32 NT), both
 // 32-token panels; weight fragments from L2 (packed), three register sets rotating two k-steps ahead
 template <int DT, int NT>
@@ -1273,18 +1335,19 @@ __global__ __launch_bounds__(NW * 64) void xattn_rows_kernel(XrP p) {
 
     // ---- 3. attention, heads 2 w and 2 w + 1: Q -> X.  All K / V^T fragments of a head (both segments) are requested before any of its
     //         arithmetic, and the first head's before the barrier: one exposed L2 round trip per wave ----
-    constexpr int NSB = DUAL ? NS2 : 1;
+    constexpr bool BIG2 = NS2 > 2;  // the second segment's fragments are requested as they are used (short_segment_ns)
+    constexpr int NSB = (DUAL && !BIG2) ? NS2 : 1;
     ShortFr<DT, D, NS1> f1;
     ShortFr<DT, D, NSB> f2;
     // (two sub-tiles in both segments: both fragment sets at once do not fit the 256 registers of two waves per SIMD -- that form keeps
     //  attn_short_kernel's load-as-you-go segment routine)
-    constexpr bool SPLITF = DUAL && NS1 + NS2 > 3;
+    constexpr bool SPLITF = DUAL && !BIG2 && NS1 + NS2 > 3;
 #define XR_FETCH1(h_) short_load<DT, D, NS1>(f1, p.k1 + ((int64_t)b * p.L1 * C + (h_) * D) * 2, C, p.vt1 + ((int64_t)(b * H + (h_)) * D * p.Lpad1) * 2, p.L1, p.Lpad1, l31, half)
 #define XR_FETCH2(h_) short_load<DT, D, NSB>(f2, p.k2 + ((int64_t)b * p.L2 * C + (h_) * D) * 2, C, p.vt2 + ((int64_t)(b * H + (h_)) * D * p.Lpad2) * 2, p.L2, p.Lpad2, l31, half)
     // (macros, not lambdas: a fragment struct captured by a lambda is kept in scratch by this compiler)
     if (!(XR_ABL & 2) && !SPLITF) {
         XR_FETCH1((wave & 3) * 2);
-        if (DUAL) XR_FETCH2((wave & 3) * 2);
+        if (DUAL && !BIG2) XR_FETCH2((wave & 3) * 2);
     }
     __syncthreads();
     const float* const bias1 = p.bias1 ? p.bias1 + (int64_t)b * p.L1 : nullptr;
@@ -1293,7 +1356,7 @@ __global__ __launch_bounds__(NW * 64) void xattn_rows_kernel(XrP p) {
         const int h = (wave & 3) * 2 + hh;
         if (hh == 1 && !SPLITF) {
             XR_FETCH1(h);
-            if (DUAL) XR_FETCH2(h);
+            if (DUAL && !BIG2) XR_FETCH2(h);
         }
 #pragma unroll
         for (int pp = 0; pp < PW; ++pp) {
@@ -1324,7 +1387,10 @@ __global__ __launch_bounds__(NW * 64) void xattn_rows_kernel(XrP p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o2[dt][r] = 0.f;
                 float inv2 = 1.f;
-                if constexpr (SPLITF)
+                if constexpr (BIG2)
+                    short_segment_ns<DT, D, NS2>(p.k2 + ((int64_t)b * p.L2 * C + h * D) * 2, C, p.vt2 + ((int64_t)(b * H + h) * D * p.Lpad2) * 2, p.L2,
+                                                 p.Lpad2, nullptr, p.scale_log2, qf, o2, inv2, l31, half);
+                else if constexpr (SPLITF)
                     short_segment<DT, D>(p.k2 + ((int64_t)b * p.L2 * C + h * D) * 2, C, p.vt2 + ((int64_t)(b * H + h) * D * p.Lpad2) * 2, p.L2, p.Lpad2,
                                          nullptr, p.scale_log2, qf, o2, inv2, l31, half);
                 else
@@ -1387,7 +1453,8 @@ template <int DT, int C, int NW, int NSET> int xattn_rows_launch(const XrP& p, h
         return apad_check_launch("apad_cross_attention_rows");
     };
     // sub-tile counts of the two segments are compile-time (the fragment registers of an unused sub-tile would not fit beside the rest)
-    const int ns1 = p.L1 > 32 ? 2 : 1, ns2 = p.L2 == 0 ? 0 : (p.L2 > 32 ? 2 : 1);
+    const int ns1 = p.L1 > 32 ? 2 : 1, ns2 = (p.L2 + 31) / 32;
+    if (ns2 > 2) return go(xattn_rows_kernel<DT, C, 1, 4, NW, NSET>);  // (ns1 == 1: checked by the caller) 8 text + 65 .. 128 audio keys
     if (ns1 == 1 && ns2 == 0) return go(xattn_rows_kernel<DT, C, 1, 0, NW, NSET>);
     if (ns1 == 1 && ns2 == 1) return go(xattn_rows_kernel<DT, C, 1, 1, NW, NSET>);
     if (ns2 == 0) return go(xattn_rows_kernel<DT, C, 2, 0, NW, NSET>);
@@ -1448,8 +1515,8 @@ extern "C" int apad_cross_attention_rows(const apad_xrows_desc* d, void* stream)
     APAD_CHECK(d->x && d->wq_packed && d->wo_packed && d->k1 && d->vt1 && d->out, "apad_cross_attention_rows: null operand");
     APAD_CHECK((d->ln_gamma == nullptr) == (d->ln_beta == nullptr), "apad_cross_attention_rows: LayerNorm needs gamma and beta");
     APAD_CHECK(d->B > 0 && d->N > 0, "apad_cross_attention_rows: empty problem B=%d N=%d", d->B, d->N);
-    APAD_CHECK(d->L1 >= 1 && d->L1 <= 64 && d->L2 >= 0 && d->L2 <= 64, "apad_cross_attention_rows: segment lengths %d / %d outside 1..64 / 0..64", d->L1,
-               d->L2);
+    APAD_CHECK(d->L1 >= 1 && d->L1 <= 64 && d->L2 >= 0 && (d->L2 <= 64 || (d->L2 <= 128 && d->L1 <= 32)),
+               "apad_cross_attention_rows: segment lengths %d / %d outside 1..64 / 0..64 (0..128 beside <= 32 keys in segment 1)", d->L1, d->L2);
     APAD_CHECK(d->Lpad1 >= d->L1 && d->Lpad1 % 32 == 0, "apad_cross_attention_rows: Lpad1 must be >= L1 and a multiple of 32");
     const bool dual = d->L2 > 0;
     if (dual) {

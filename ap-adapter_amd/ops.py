@@ -283,11 +283,13 @@ def fused_cross_attention(x, wq_packed, wo_packed, bo, kv1_packed, L1, heads, ln
     return out
 
 
-XROWS_C, XROWS_MAXL = (384,), 64  # envelope of apad_cross_attention_rows (8 heads; <= 64 keys per segment)
+XROWS_C, XROWS_MAXL = (384,), 64  # envelope of apad_cross_attention_rows (8 heads; <= 64 keys per segment, ...
+XROWS_MAXL2 = 128                 # ... <= 128 in the second segment beside <= 32 in the first: the adapter's 8 text + 128 audio keys)
 
 
 def xrows_ok(C_, heads, L1, L2=0):
-    return C_ in XROWS_C and heads == XATTN_HEADS and 1 <= L1 <= XROWS_MAXL and 0 <= L2 <= XROWS_MAXL
+    return (C_ in XROWS_C and heads == XATTN_HEADS and 1 <= L1 <= XROWS_MAXL
+            and (0 <= L2 <= XROWS_MAXL or (L2 <= XROWS_MAXL2 and L1 <= 32)))
 
 
 def xrows_pack_weight(w):

@@ -237,7 +237,8 @@ int apad_fused_cross_attention(const apad_xattn_desc* d, void* stream);
 /* The same sub-layer for the 384-wide level (252 tokens per sample, 8 heads of 48), where the weights do not fit the weight-stationary
  * registers of apad_fused_cross_attention: 64-token row tiles stay in LDS through LayerNorm -> to_q -> attention -> to_out -> + residual
  * (attention.hip, xattn_rows_kernel).  K / V sets as apad_attention takes them (k [B][L][C] row-major, vt [B][heads][d][Lpad] zero-padded);
- * <= 64 keys per segment (longer segments: the un-fused chain).  The two weights FRAGMENT-PACKED:
+ * <= 64 keys per segment, or <= 128 in segment 2 beside <= 32 in segment 1 (8 text + 128 audio keys: the timbre / accompaniment presets);
+ * longer segments: the un-fused chain.  The two weights FRAGMENT-PACKED:
  *   packed[(rt * (C / 16) + ks) * 512 + lane * 8 + e] = W[rt * 32 + (lane & 31)][ks * 16 + (lane >> 5) * 8 + e]   (elements)
  * i.e. W.view(C/32, 32, C/16, 2, 8).permute(0, 2, 3, 1, 4): every MFMA operand fragment is one contiguous KB.  Envelope: C = 384, 8 heads,
  * 16-bit (else -3).  Replaces, per site, to_q + scaled_dot_product_attention (x 2 for the adapter) + to_out[0] of attention_processor.py:387-457

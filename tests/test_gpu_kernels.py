@@ -775,10 +775,12 @@ def test_fused_cross_attention(dev, dtype, B, N, Lt, La, masked):
 @pytest.mark.parametrize("dtype", DTYPES16)
 @pytest.mark.parametrize("B,N,Lt,La,masked", [(2, 252, 8, 32, False), (3, 100, 8, 8, False), (2, 252, 16, 0, True), (1, 33, 8, 64, False),
                                                (5, 64, 40, 0, False), (2, 130, 8, 33, False), (9, 252, 8, 32, True), (2, 31, 64, 50, True),
-                                               (64, 252, 8, 32, False), (2, 65, 1, 1, False)])
+                                               (64, 252, 8, 32, False), (2, 65, 1, 1, False), (2, 252, 8, 128, False), (3, 100, 8, 70, True),
+                                               (64, 252, 8, 128, False), (2, 60, 32, 97, False)])
 def test_cross_attention_rows_384(dev, dtype, B, N, Lt, La, masked):
     """the 384-wide level's single-launch form (apad_cross_attention_rows: 64-token row tiles in LDS through LayerNorm, to_q, attention,
-    to_out, residual): ragged last tiles, one- and two-segment forms, the masked forms of both, full CFG batch; against fp32 torch on
+    to_out, residual): ragged last tiles, one- and two-segment forms, the masked forms of both, the 8 + 128-key form of the timbre /
+    accompaniment presets (second segment's fragments requested as they are used), full CFG batch; against fp32 torch on
     storage-rounded operands and against the three-kernel chain it replaces"""
     from ap_adapter_amd import ops
     C, H = 384, 8
@@ -825,16 +827,17 @@ def test_cross_attention_rows_outside_envelope(dev):
     from ap_adapter_amd import ops
     bf = torch.bfloat16
     assert ops.xrows_ok(384, 8, 8, 32) and ops.xrows_ok(384, 8, 64, 64) and ops.xrows_ok(384, 8, 16)
-    assert not ops.xrows_ok(384, 8, 8, 128) and not ops.xrows_ok(640, 8, 8, 32) and not ops.xrows_ok(384, 4, 8, 32) and not ops.xrows_ok(384, 8, 65)
+    assert ops.xrows_ok(384, 8, 8, 128) and ops.xrows_ok(384, 8, 32, 128) and not ops.xrows_ok(384, 8, 40, 128) and not ops.xrows_ok(384, 8, 8, 129)
+    assert not ops.xrows_ok(640, 8, 8, 32) and not ops.xrows_ok(384, 4, 8, 32) and not ops.xrows_ok(384, 8, 65)
     x = torch.zeros(1, 64, 640, device=dev, dtype=bf)
     w = ops.xrows_pack_weight(torch.zeros(640, 640, device=dev, dtype=bf))
     with pytest.raises(ValueError):
         ops.cross_attention_rows(x, w, w, None, torch.zeros(1, 8, 640, device=dev, dtype=bf), torch.zeros(1, 8, 80, 32, device=dev, dtype=bf), 8)
     x = torch.zeros(1, 64, 384, device=dev, dtype=bf)
     w = ops.xrows_pack_weight(torch.zeros(384, 384, device=dev, dtype=bf))
-    with pytest.raises(ValueError):  # 128 audio keys: the chain's job
+    with pytest.raises(ValueError):  # 512 audio keys: the chain's job
         ops.cross_attention_rows(x, w, w, None, torch.zeros(1, 8, 384, device=dev, dtype=bf), torch.zeros(1, 8, 48, 32, device=dev, dtype=bf), 8,
-                                 k2=torch.zeros(1, 128, 384, device=dev, dtype=bf), vt2=torch.zeros(1, 8, 48, 128, device=dev, dtype=bf))
+                                 k2=torch.zeros(1, 512, 384, device=dev, dtype=bf), vt2=torch.zeros(1, 8, 48, 512, device=dev, dtype=bf))
     # the packing: fragment (row tile rt, k-step ks) = one contiguous KB, lane = (k half, row)
     wt = torch.arange(384 * 384, dtype=torch.float32).reshape(384, 384).to(dev)
     pk = ops.xrows_pack_weight(wt).reshape(12, 24, 2, 32, 8)
