@@ -1025,7 +1025,6 @@ template <int DT> int launch_dt(const AttnP& p, int D, bool dual, dim3 grid, hip
 //      heads' outputs into the X tile (the normalised tokens are dead)
 //   4. out^T = Wo . O^T (+ bias) -> Q tile (rounded like the chain's to_out), then one coalesced pass adds the residual x and stores.
 // HBM traffic per launch: x once in, out once out (the chain: six activation passes).
-constexpr int XR_TM = 64;
 #ifndef XR_ABL
 #define XR_ABL 0  // timing ablations (tools/ab_build.sh; results are wrong): 1 = weight fragments loaded once, 2 = no attention phase, 4 = no projections, 8 = no LayerNorm arithmetic
 #endif
@@ -1263,8 +1262,9 @@ __device__ __forceinline__ void xr_project(const uint8_t* wpk, const uint8_t* sr
 template <int DT, int C, int NS1, int NS2, int NW, int NSET>
 __global__ __launch_bounds__(NW * 64) void xattn_rows_kernel(XrP p) {
     constexpr bool DUAL = NS2 > 0;
-    constexpr int PW = 8 / NW, NTH = NW * 64;
-    static_assert(NW == 4 || NW == 8, "4 waves x 2 token panels or 8 waves x 1");
+    // one 32-token panel per wave quartet: 8 waves = 64 tokens (C = 384), 4 waves = 32 tokens (C = 640: two 64-token tiles would not fit the LDS)
+    constexpr int PW = 1, NTH = NW * 64, XR_TM = NW * 8;
+    static_assert(NW == 4 || NW == 8, "one or two wave quartets");
     using E = ET<DT>;
     constexpr int H = 8, D = C / H, KC = D / 16, DTT = (D + 31) / 32;
     constexpr int ROWB = C * 2 + 16;  // 49 (C = 384) sixteen-byte slots: odd -> conflict-free fragment reads over 32 rows
@@ -1441,7 +1441,7 @@ __global__ __launch_bounds__(NW * 64) void xattn_rows_kernel(XrP p) {
 }
 
 template <int DT, int C, int NW, int NSET> int xattn_rows_launch(const XrP& p, hipStream_t s) {
-    constexpr int LDS = 2 * XR_TM * (C * 2 + 16);
+    constexpr int LDS = 2 * (NW * 8) * (C * 2 + 16);
     dim3 grid((unsigned)(p.B * p.tiles_per_sample));
     auto go = [&](auto kern) {
         static bool attr = false;
@@ -1508,8 +1508,8 @@ extern "C" int apad_attention(const apad_attn_desc* d, void* stream) {
 extern "C" int apad_cross_attention_rows(const apad_xrows_desc* d, void* stream) {
     APAD_CHECK(d != nullptr, "apad_cross_attention_rows: null descriptor");
     APAD_CHECK(d->dtype == APAD_BF16 || d->dtype == APAD_F16, "apad_cross_attention_rows: dtype %d not supported (16-bit only)", d->dtype);
-    if (d->C != 384 || d->heads != 8) {
-        apad_set_error("apad_cross_attention_rows: C=%d heads=%d outside the kernel envelope (384, 8)", d->C, d->heads);
+    if ((d->C != 384 && d->C != 640) || d->heads != 8) {
+        apad_set_error("apad_cross_attention_rows: C=%d heads=%d outside the kernel envelope (384 / 640, 8)", d->C, d->heads);
         return -3;
     }
     APAD_CHECK(d->x && d->wq_packed && d->wo_packed && d->k1 && d->vt1 && d->out, "apad_cross_attention_rows: null operand");
@@ -1532,9 +1532,11 @@ extern "C" int apad_cross_attention_rows(const apad_xrows_desc* d, void* stream)
     p.k1 = (const uint8_t*)d->k1; p.vt1 = (const uint8_t*)d->vt1; p.bias1 = d->key_bias;
     p.k2 = (const uint8_t*)d->k2; p.vt2 = (const uint8_t*)d->vt2; p.out = (uint8_t*)d->out;
     p.B = d->B; p.N = d->N; p.L1 = d->L1; p.Lpad1 = d->Lpad1; p.L2 = d->L2; p.Lpad2 = d->Lpad2;
-    p.tiles_per_sample = (d->N + XR_TM - 1) / XR_TM;
+    const int tm = d->C == 384 ? 64 : 32;  // tokens per workgroup (xattn_rows_kernel: 8 / 4 waves)
+    p.tiles_per_sample = (d->N + tm - 1) / tm;
     p.eps = d->ln_eps; p.scale_log2 = d->softmax_scale * LOG2E; p.scale2 = d->scale2;
     hipStream_t s = (hipStream_t)stream;
     // (8 waves: 35.8 us at the bench geometry vs 42.5 with 4 waves x 2 panels; deeper weight prefetch -- 6 / 8 register sets -- within 1 us)
+    if (d->C == 640) return d->dtype == APAD_BF16 ? xattn_rows_launch<APAD_BF16, 640, 4, 4>(p, s) : xattn_rows_launch<APAD_F16, 640, 4, 4>(p, s);
     return d->dtype == APAD_BF16 ? xattn_rows_launch<APAD_BF16, 384, 8, 3>(p, s) : xattn_rows_launch<APAD_F16, 384, 8, 3>(p, s);
 }

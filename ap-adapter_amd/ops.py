@@ -283,7 +283,11 @@ def fused_cross_attention(x, wq_packed, wo_packed, bo, kv1_packed, L1, heads, ln
     return out
 
 
-XROWS_C, XROWS_MAXL = (384,), 64  # envelope of apad_cross_attention_rows (8 heads; <= 64 keys per segment, ...
+# envelope of apad_cross_attention_rows: 8 heads; C = 384 routed by default.  C = 640 (32-token tiles, 4 waves) is built and tested but
+# OFF: isolated it beats the chain (31.4 vs 47.1 us at 32 samples) but the 64-token level runs its two batch halves on two streams,
+# where three small launches overlap with the other stream better than one 64-workgroup kernel holding 83 KB of LDS per CU: step
+# 43.78 -> 44.08 ms (APAD_XROWS_C=384,640 switches it on).  <= 64 keys per segment, ...
+XROWS_C, XROWS_MAXL = tuple(int(c) for c in _os.environ.get("APAD_XROWS_C", "384").split(",") if c), 64
 XROWS_MAXL2 = 128                 # ... <= 128 in the second segment beside <= 32 in the first: the adapter's 8 text + 128 audio keys)
 
 

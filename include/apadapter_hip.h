@@ -240,8 +240,8 @@ int apad_fused_cross_attention(const apad_xattn_desc* d, void* stream);
  * <= 64 keys per segment, or <= 128 in segment 2 beside <= 32 in segment 1 (8 text + 128 audio keys: the timbre / accompaniment presets);
  * longer segments: the un-fused chain.  The two weights FRAGMENT-PACKED:
  *   packed[(rt * (C / 16) + ks) * 512 + lane * 8 + e] = W[rt * 32 + (lane & 31)][ks * 16 + (lane >> 5) * 8 + e]   (elements)
- * i.e. W.view(C/32, 32, C/16, 2, 8).permute(0, 2, 3, 1, 4): every MFMA operand fragment is one contiguous KB.  Envelope: C = 384, 8 heads,
- * 16-bit (else -3).  Replaces, per site, to_q + scaled_dot_product_attention (x 2 for the adapter) + to_out[0] of attention_processor.py:387-457
+ * i.e. W.view(C/32, 32, C/16, 2, 8).permute(0, 2, 3, 1, 4): every MFMA operand fragment is one contiguous KB.  Envelope: C = 384 (64-token
+ * tiles) or 640 (32-token tiles; the Python side routes it only on request), 8 heads, 16-bit (else -3).  Replaces, per site, to_q + scaled_dot_product_attention (x 2 for the adapter) + to_out[0] of attention_processor.py:387-457
  * / :256-289 plus the block's norm2 / norm3 and residual add (modeling_audioldm2 BasicTransformerBlock).  (ABI 6) */
 typedef struct apad_xrows_desc {
     const void* x;         /* [B*N][C] un-normalised hidden states (also the residual)  */

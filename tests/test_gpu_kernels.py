@@ -773,17 +773,20 @@ def test_fused_cross_attention(dev, dtype, B, N, Lt, La, masked):
 
 
 @pytest.mark.parametrize("dtype", DTYPES16)
-@pytest.mark.parametrize("B,N,Lt,La,masked", [(2, 252, 8, 32, False), (3, 100, 8, 8, False), (2, 252, 16, 0, True), (1, 33, 8, 64, False),
-                                               (5, 64, 40, 0, False), (2, 130, 8, 33, False), (9, 252, 8, 32, True), (2, 31, 64, 50, True),
-                                               (64, 252, 8, 32, False), (2, 65, 1, 1, False), (2, 252, 8, 128, False), (3, 100, 8, 70, True),
-                                               (64, 252, 8, 128, False), (2, 60, 32, 97, False)])
-def test_cross_attention_rows_384(dev, dtype, B, N, Lt, La, masked):
-    """the 384-wide level's single-launch form (apad_cross_attention_rows: 64-token row tiles in LDS through LayerNorm, to_q, attention,
-    to_out, residual): ragged last tiles, one- and two-segment forms, the masked forms of both, the 8 + 128-key form of the timbre /
+@pytest.mark.parametrize("B,N,Lt,La,masked,C", [
+    (2, 252, 8, 32, False, 384), (3, 100, 8, 8, False, 384), (2, 252, 16, 0, True, 384), (1, 33, 8, 64, False, 384), (5, 64, 40, 0,
+    False, 384), (2, 130, 8, 33, False, 384), (9, 252, 8, 32, True, 384), (2, 31, 64, 50, True, 384), (64, 252, 8, 32, False, 384),
+    (2, 65, 1, 1, False, 384), (2, 252, 8, 128, False, 384), (3, 100, 8, 70, True, 384), (64, 252, 8, 128, False, 384), (2, 60, 32,
+    97, False, 384), (2, 64, 8, 32, False, 640), (32, 64, 8, 32, True, 640), (3, 64, 16, 0, True, 640), (2, 64, 8, 128, False, 640),
+    (2, 50, 40, 64, False, 640), (5, 97, 8, 8, False, 640)])
+def test_cross_attention_rows(dev, dtype, B, N, Lt, La, masked, C, monkeypatch):
+    """the 384- and 640-wide levels' single-launch form (apad_cross_attention_rows: 64- / 32-token row tiles in LDS through LayerNorm, to_q,
+    attention, to_out, residual): ragged last tiles, one- and two-segment forms, the masked forms of both, the 8 + 128-key form of the timbre /
     accompaniment presets (second segment's fragments requested as they are used), full CFG batch; against fp32 torch on
     storage-rounded operands and against the three-kernel chain it replaces"""
     from ap_adapter_amd import ops
-    C, H = 384, 8
+    monkeypatch.setattr(ops, "XROWS_C", (384, 640))  # (640: an opt-in route, see ops.XROWS_C)
+    H = 8
     x = q(R(B, N, C, seed=301), dtype)
     g, be = q(1 + 0.1 * R(C, seed=302), dtype), q(0.1 * R(C, seed=303), dtype)
     wq, wo, bo = q(R(C, C, seed=304, std=0.05), dtype), q(R(C, C, seed=305, std=0.05), dtype), q(R(C, seed=306, std=0.3), dtype)
@@ -823,16 +826,19 @@ def test_cross_attention_rows_384(dev, dtype, B, N, Lt, La, masked):
     assert rel_err(nb, ref - bo) < 1.5 * TOL[dtype]
 
 
-def test_cross_attention_rows_outside_envelope(dev):
+def test_cross_attention_rows_outside_envelope(dev, monkeypatch):
     from ap_adapter_amd import ops
+    assert ops.XROWS_C == (384,)
+    monkeypatch.setattr(ops, "XROWS_C", (384, 640))
     bf = torch.bfloat16
     assert ops.xrows_ok(384, 8, 8, 32) and ops.xrows_ok(384, 8, 64, 64) and ops.xrows_ok(384, 8, 16)
     assert ops.xrows_ok(384, 8, 8, 128) and ops.xrows_ok(384, 8, 32, 128) and not ops.xrows_ok(384, 8, 40, 128) and not ops.xrows_ok(384, 8, 8, 129)
-    assert not ops.xrows_ok(640, 8, 8, 32) and not ops.xrows_ok(384, 4, 8, 32) and not ops.xrows_ok(384, 8, 65)
-    x = torch.zeros(1, 64, 640, device=dev, dtype=bf)
-    w = ops.xrows_pack_weight(torch.zeros(640, 640, device=dev, dtype=bf))
+    assert ops.xrows_ok(640, 8, 8, 32) and not ops.xrows_ok(1280, 8, 8, 32) and not ops.xrows_ok(256, 8, 8, 32)
+    assert not ops.xrows_ok(384, 4, 8, 32) and not ops.xrows_ok(384, 8, 65)
+    x = torch.zeros(1, 64, 512, device=dev, dtype=bf)
+    w = ops.xrows_pack_weight(torch.zeros(512, 512, device=dev, dtype=bf))
     with pytest.raises(ValueError):
-        ops.cross_attention_rows(x, w, w, None, torch.zeros(1, 8, 640, device=dev, dtype=bf), torch.zeros(1, 8, 80, 32, device=dev, dtype=bf), 8)
+        ops.cross_attention_rows(x, w, w, None, torch.zeros(1, 8, 512, device=dev, dtype=bf), torch.zeros(1, 8, 64, 32, device=dev, dtype=bf), 8)
     x = torch.zeros(1, 64, 384, device=dev, dtype=bf)
     w = ops.xrows_pack_weight(torch.zeros(384, 384, device=dev, dtype=bf))
     with pytest.raises(ValueError):  # 512 audio keys: the chain's job

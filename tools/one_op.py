@@ -56,7 +56,9 @@ elif op in ("mlp384", "mlp384_chain"):
             h = ops.fused_linear(x, w1, b1, ln=(g, be, 1e-5), act="geglu")
             return ops.linear(h, w2, b2, residual=x, out=out)
 elif op in ("xrows", "xrows_chain"):
-    N, C, H, Lt, La = 252, 384, 8, 8, int(os.environ.get("LA", "32"))
+    C = int(os.environ.get("XC", "384"))
+    N, H, Lt, La = (252 if C == 384 else 64), 8, 8, int(os.environ.get("LA", "32"))
+    B2 = int(os.environ.get("XB", B2))
     x, g, be, wq, wo, bo = R(B2, N, C), R(C), R(C), R(C, C, std=0.02), R(C, C, std=0.02), R(C, std=0.02)
     k1, k2 = R(B2, Lt, C, std=0.3), R(B2, La, C, std=0.3)
     v1t = torch.zeros(B2, H, C // H, 32, device=dev, dtype=dt); v1t[..., :Lt].normal_(0, 0.3)
