@@ -75,7 +75,7 @@ class XrowsDesc(C.Structure):
 class AttnBwdDesc(C.Structure):
     _fields_ = [(n, _vp) for n in ("q", "k", "v", "qt", "kt", "out", "dout", "doutt", "lse", "key_bias", "delta", "dq", "dk", "dv")] + \
                [(n, _i32) for n in ("B", "N", "H", "D", "L", "Npad", "Lpad", "dtype")] + \
-               [("softmax_scale", _f32), ("dout_scale", _f32), ("accumulate_dq", _i32), ("reserved", _i32)]
+               [("softmax_scale", _f32), ("dout_scale", _f32), ("accumulate_dq", _i32), ("ld_grad", _i32)]
 
 
 # name -> (restype, argtypes); every symbol include/apadapter_hip.h declares

@@ -102,6 +102,22 @@ def linear(x, w, b=None, residual=None):
     return _Linear.apply(x, w, b, residual)
 
 
+_BWD_PACKED = _os.environ.get("APAD_TRAIN_BWD_PACKED", "1") == "1"  # A/B switch (read once)
+
+
+def _packed_grads(dq, dk, dv):
+    """[dq | dk | dv] as one [.., 3C] tensor: the buffer apad_attention_bwd wrote them into as column blocks (ops.attention_bwd(packed=True))
+    when the three are such views, their concatenation otherwise"""
+    base = dq._base
+    C_ = dq.shape[-1]
+    if (base is not None and dk._base is base and dv._base is base and base.is_contiguous() and base.shape[-1] == 3 * C_
+            and base.shape[:-1] == dq.shape[:-1] and dq.stride() == dk.stride() == dv.stride() == base.stride()
+            and dq.storage_offset() == base.storage_offset() and dk.storage_offset() == base.storage_offset() + C_
+            and dv.storage_offset() == base.storage_offset() + 2 * C_):
+        return base
+    return torch.cat([_c(dq), _c(dk), _c(dv)], dim=-1)
+
+
 class _QKV(torch.autograd.Function):
     """q, k, v = x Wq^T, x Wk^T, x Wv^T with FROZEN weights (the UNet's self-attention): three forward GEMMs, but ONE input-gradient
     GEMM -- dx = [dq | dk | dv] . [Wq; Wk; Wv] -- instead of three GEMMs and two accumulation kernels (the training step at batch 4 is
@@ -118,7 +134,7 @@ class _QKV(torch.autograd.Function):
         wq, wk, wv = ctx.saved_tensors
         wst = _cached(wq, ("qkvT", id(wk), id(wv), wk._version, wv._version),
                       lambda t: torch.cat([t, wk.detach(), wv.detach()], 0).t().contiguous())  # [C, 3C]
-        return ops.linear(torch.cat([_c(dq), _c(dk), _c(dv)], dim=-1), wst), None, None, None
+        return ops.linear(_packed_grads(dq, dk, dv), wst), None, None, None
 
 
 class _QKVT(_QKV):
@@ -304,7 +320,9 @@ class _Attention(torch.autograd.Function):
     def backward(ctx, do):
         q, k, v, o, lse, key_bias = ctx.saved_tensors
         need_kv = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
-        dq, dk, dv = ops.attention_bwd(q, k, v, o, _c(do), lse, ctx.heads, key_bias=key_bias, need_dkv=need_kv)
+        # (self-attention whose q, k, v all take gradients: dq | dk | dv as column blocks of one buffer, see _QKV.backward)
+        packed = _BWD_PACKED and all(ctx.needs_input_grad[:3]) and q.shape == k.shape
+        dq, dk, dv = ops.attention_bwd(q, k, v, o, _c(do), lse, ctx.heads, key_bias=key_bias, need_dkv=need_kv, packed=packed)
         return dq, dk, dv, None, None, None
 
 

@@ -36,6 +36,7 @@ struct BwdP {
     int32_t B, N, H, L, Npad, Lpad;
     float scale, scale_log2, dout_scale;
     int32_t accumulate_dq;
+    int32_t ldg;  // row stride (elements) of dq / dk / dv: H * D, or 3 H D when the three are column blocks of one [rows][3C] buffer
 };
 
 // A-operand fragment (row = tile row l31, k = 8 contiguous elements) of a row-major [rows][C] matrix; rows >= limit read 0
@@ -197,7 +198,7 @@ template <int DT, int D> __global__ __launch_bounds__(256) void dq_kernel(BwdP p
         load(fa, k0 + 64 <= last0 ? k0 + 64 : last0);
         compute(fb, k0 + 32);
     }
-    if (qvalid) store_row<DT, D>(p.dq + (qrow * C + h * D) * 2, acc, p.scale, half, p.accumulate_dq != 0);
+    if (qvalid) store_row<DT, D>(p.dq + (qrow * p.ldg + h * D) * 2, acc, p.scale, half, p.accumulate_dq != 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -301,8 +302,8 @@ template <int DT, int D> __global__ __launch_bounds__(256) void dkv_kernel(BwdP 
         compute(fb, q0 + 32);
     }
     if (kvalid) {
-        store_row<DT, D>(p.dk + (krow * C + h * D) * 2, dk, p.scale, half, false);
-        store_row<DT, D>(p.dv + (krow * C + h * D) * 2, dv, p.dout_scale, half, false);
+        store_row<DT, D>(p.dk + (krow * p.ldg + h * D) * 2, dk, p.scale, half, false);
+        store_row<DT, D>(p.dv + (krow * p.ldg + h * D) * 2, dv, p.dout_scale, half, false);
     }
 }
 
@@ -399,6 +400,8 @@ extern "C" int apad_attention_bwd(const apad_attn_bwd_desc* d, void* stream) {
     p.B = d->B; p.N = d->N; p.H = d->H; p.L = d->L; p.Npad = d->Npad; p.Lpad = d->Lpad;
     p.scale = d->softmax_scale; p.scale_log2 = d->softmax_scale * LOG2E_B; p.dout_scale = d->dout_scale;
     p.accumulate_dq = d->accumulate_dq;
+    p.ldg = d->ld_grad > 0 ? d->ld_grad : d->H * d->D;
+    APAD_CHECK(p.ldg >= d->H * d->D && p.ldg % 8 == 0, "apad_attention_bwd: ld_grad must be >= H * D and a multiple of 8");
     hipStream_t s = (hipStream_t)stream;
     return d->dtype == APAD_BF16 ? launch_bwd_dt<APAD_BF16>(p, d->D, s) : launch_bwd_dt<APAD_F16>(p, d->D, s);
 }

@@ -88,7 +88,7 @@ extern "C" int apad_echo_attn_bwd_desc(const apad_attn_bwd_desc* d, double* out,
     PUTP(d->q); PUTP(d->k); PUTP(d->v); PUTP(d->qt); PUTP(d->kt); PUTP(d->out); PUTP(d->dout); PUTP(d->doutt); PUTP(d->lse);
     PUTP(d->key_bias); PUTP(d->delta); PUTP(d->dq); PUTP(d->dk); PUTP(d->dv);
     PUT(d->B); PUT(d->N); PUT(d->H); PUT(d->D); PUT(d->L); PUT(d->Npad); PUT(d->Lpad); PUT(d->dtype);
-    PUT(d->softmax_scale); PUT(d->dout_scale); PUT(d->accumulate_dq); PUT(d->reserved);
+    PUT(d->softmax_scale); PUT(d->dout_scale); PUT(d->accumulate_dq); PUT(d->ld_grad);
     return n;
 }
 

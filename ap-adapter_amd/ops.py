@@ -723,8 +723,10 @@ def head_transpose_many(xs, heads, pad):
     return outs
 
 
-def attention_bwd(q, k, v, out, dout, lse, heads, key_bias=None, dout_scale=1.0, need_dkv=True, dq=None):
-    """gradients of one softmax segment; dq given -> accumulated into.  Returns (dq, dk, dv)."""
+def attention_bwd(q, k, v, out, dout, lse, heads, key_bias=None, dout_scale=1.0, need_dkv=True, dq=None, packed=False):
+    """gradients of one softmax segment; dq given -> accumulated into.  Returns (dq, dk, dv).
+    packed (self-attention, 16-bit): the three gradients are the column blocks of ONE [B, N, 3C] buffer (views of it are returned), so
+    the input-gradient GEMM of the q|k|v projection reads them without a torch.cat."""
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (out, "out"), (dout, "dout")):
         _req(t, "attention_bwd." + n, q.dtype)
         if not t.is_contiguous():
@@ -747,12 +749,18 @@ def attention_bwd(q, k, v, out, dout, lse, heads, key_bias=None, dout_scale=1.0,
     delta = torch.empty(B, heads, Npad, dtype=torch.float32, device=q.device)
     d.delta = delta.data_ptr()
     acc = dq is not None
-    if dq is None:
+    packed = packed and need_dkv and not f32 and dq is None and N == Lk
+    dk = dv = None
+    if packed:
+        buf = torch.empty(B, N, 3 * Cc, dtype=q.dtype, device=q.device)
+        dq, dk, dv = buf[..., :Cc], buf[..., Cc:2 * Cc], buf[..., 2 * Cc:]
+        d.ld_grad = 3 * Cc
+    elif dq is None:
         dq = torch.empty_like(q)
     d.dq = dq.data_ptr()
-    dk = dv = None
     if need_dkv:
-        dk, dv = torch.empty_like(k), torch.empty_like(v)
+        if not packed:
+            dk, dv = torch.empty_like(k), torch.empty_like(v)
         d.dk, d.dv = dk.data_ptr(), dv.data_ptr()
         if not f32:
             if not same:

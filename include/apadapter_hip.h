@@ -387,7 +387,8 @@ typedef struct apad_attn_bwd_desc {
     float softmax_scale;
     float dout_scale;      /* the segment saw dout_scale * dout (ap_scale for the audio branch, :454)    */
     int32_t accumulate_dq; /* 1: dq += (second segment of the decoupled cross-attention)                */
-    int32_t reserved;
+    int32_t ld_grad;       /* row stride (elements) of dq / dk / dv; 0 = H*D.  3*H*D: the three are column blocks of ONE [B*N][3C]
+                              buffer (self-attention: the input-gradient GEMM of q|k|v reads it without a concatenation).  16-bit only */
 } apad_attn_bwd_desc;
 int apad_sizeof_attn_bwd_desc(void);
 int apad_echo_attn_bwd_desc(const apad_attn_bwd_desc* d, double* out, int cap);
