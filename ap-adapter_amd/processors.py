@@ -69,7 +69,11 @@ def _xattn_weights(attn):
 
 def vt_buffer(slot, B, heads, d, Lk, dtype, device):
     """Zero-padded V^T scratch [B, heads, d, round_up(Lk,32)].  The pad columns are never written (apad_gemm
-    APAD_OUT_VT stores l < Lk only), so buffers are shared by shape across attention sites."""
+    APAD_OUT_VT stores l < Lk only), so buffers are shared by shape across attention sites.
+    The pool is keyed by (slot, shape, dtype, device, stream) and is never evicted on purpose: a captured hipGraph holds the raw
+    addresses of the buffers its kernels were recorded with, so freeing an entry behind a live graph would hand its memory to someone
+    else.  Its size is bounded by the distinct attention geometries of the loaded models (a dozen entries, < 100 MB at batch 64);
+    ``clear_vt_pool()`` drops it when no captured graph is alive (e.g. between pipelines in one process)."""
     Lpad = ops.round_up(Lk, 32)
     # per stream: the denoise step may run the two CFG halves concurrently on two streams
     key = (slot, B, heads, d, Lpad, dtype, device, torch.cuda.current_stream().cuda_stream)
@@ -78,6 +82,11 @@ def vt_buffer(slot, B, heads, d, Lk, dtype, device):
         buf = torch.zeros(B, heads, d, Lpad, dtype=dtype, device=device)
         _vt_pool[key] = buf
     return buf
+
+
+def clear_vt_pool():
+    """Drop the V^T scratch pool.  Only when no captured hipGraph that used it is still going to be replayed."""
+    _vt_pool.clear()
 
 
 def _pkey(*params):
