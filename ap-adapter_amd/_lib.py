@@ -72,6 +72,16 @@ class XrowsDesc(C.Structure):
                [(n, _f32) for n in ("ln_eps", "softmax_scale", "scale2", "reserved_f")]
 
 
+class HsAttnDesc(C.Structure):
+    _fields_ = [(n, _vp) for n in ("x", "w_packed", "w_bias", "k1", "vt1", "key_bias", "k2", "vt2", "out")] + \
+               [(n, _i32) for n in ("B", "N", "C", "heads", "L1", "Lpad1", "L2", "Lpad2", "self_attention", "q_prescaled", "dtype", "normalize")] + \
+               [(n, _f32) for n in ("ln_eps", "softmax_scale", "scale2", "reserved_f")]
+
+
+class HsOutDesc(C.Structure):
+    _fields_ = [(n, _vp) for n in ("o", "w_packed", "bias", "residual", "out", "rowstat_out")] + [(n, _i32) for n in ("B", "N", "C", "dtype")]
+
+
 class AttnBwdDesc(C.Structure):
     _fields_ = [(n, _vp) for n in ("q", "k", "v", "qt", "kt", "out", "dout", "doutt", "lse", "key_bias", "delta", "dq", "dk", "dv")] + \
                [(n, _i32) for n in ("B", "N", "H", "D", "L", "Npad", "Lpad", "dtype")] + \
@@ -99,6 +109,10 @@ SYMBOLS = {
     "apad_geglu_mlp_rows": (C.c_int, [C.POINTER(MlpDesc), _vp]),
     "apad_sizeof_xrows_desc": (C.c_int, []),
     "apad_cross_attention_rows": (C.c_int, [C.POINTER(XrowsDesc), _vp]),
+    "apad_sizeof_hs_attn_desc": (C.c_int, []),
+    "apad_hs_attention": (C.c_int, [C.POINTER(HsAttnDesc), _vp]),
+    "apad_sizeof_hs_out_desc": (C.c_int, []),
+    "apad_hs_out": (C.c_int, [C.POINTER(HsOutDesc), _vp]),
     "apad_xattn_pack_weight": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "apad_xattn_packed_kv_bytes": (_i64, [_i32, _i32]),
     "apad_xattn_pack_kv": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp]),
@@ -174,13 +188,14 @@ def lib():
                 fn = getattr(h, name)  # AttributeError if the ABI lost a symbol
                 fn.restype = res
                 fn.argtypes = args
-            if h.apad_abi_version() != 6:
+            if h.apad_abi_version() != 7:
                 raise RuntimeError("libapadapter_hip.so ABI version mismatch")
             if h.apad_sizeof_gemm_desc() != C.sizeof(GemmDesc) or h.apad_sizeof_attn_desc() != C.sizeof(AttnDesc) \
                     or h.apad_sizeof_rp_desc() != C.sizeof(RpDesc) \
                     or h.apad_sizeof_mlp_desc() != C.sizeof(MlpDesc) \
                     or h.apad_sizeof_attn_bwd_desc() != C.sizeof(AttnBwdDesc) \
-                    or h.apad_sizeof_xattn_desc() != C.sizeof(XattnDesc) or h.apad_sizeof_xrows_desc() != C.sizeof(XrowsDesc):
+                    or h.apad_sizeof_xattn_desc() != C.sizeof(XattnDesc) or h.apad_sizeof_xrows_desc() != C.sizeof(XrowsDesc) \
+                    or h.apad_sizeof_hs_attn_desc() != C.sizeof(HsAttnDesc) or h.apad_sizeof_hs_out_desc() != C.sizeof(HsOutDesc):
                 raise RuntimeError("descriptor layout mismatch between include/apadapter_hip.h and _lib.py")
             _lib = h
     return _lib

@@ -138,6 +138,8 @@ def linear(x, w, bias=None, residual=None, act=None, out=None, rowgroup_bias=Non
          rowstat_out=rs_out, ln_fold=fold)
     if rs_out is not None:
         out._apad_rowstat = rs_out
+    elif hasattr(out, "_apad_rowstat"):  # (a reused ``out=`` buffer must not keep the statistics of what it held before)
+        del out._apad_rowstat
     return out
 
 
@@ -332,6 +334,125 @@ def cross_attention_rows(x, wq_packed, wo_packed, bo, k1, vt1, heads, ln=None, k
         d.k2, d.vt2, d.L2, d.Lpad2 = k2.data_ptr(), vt2.data_ptr(), L2, vt2.shape[-1]
     d.dtype, d.softmax_scale, d.scale2 = _DT[x.dtype], 1.0 / math.sqrt(Cc // heads), float(scale2)
     L.check(L.lib().apad_cross_attention_rows(C.byref(d), _stream()), "apad_cross_attention_rows")
+    return out
+
+
+# ---- the 64-token level's attention sub-layers (csrc/hsattn.hip): head-sliced LayerNorm + projections + attention, then to_out + residual ----
+HS_C, HS_HEADS, HS_MAXN = 640, 8, 64
+HS_ATTN = _os.environ.get("APAD_HS_ATTN", "1") == "1"  # A/B switch (read once): 0 = the LN-folded q|k|v GEMM -> attention -> to_out chain
+
+
+def hs_ok(x, heads, n_q_rows):
+    """envelope of apad_hs_attention / apad_hs_out: [B, <= 64, 640], 8 heads, 16-bit, a square to_q"""
+    return (HS_ATTN and x.dim() == 3 and x.shape[-1] == HS_C and x.shape[1] <= HS_MAXN and heads == HS_HEADS and n_q_rows == HS_C
+            and x.dtype in FUSED_DTYPES and x.is_contiguous())
+
+
+def hs_cross_lengths_ok(L1, L2=0):
+    return 1 <= L1 <= 64 and (0 <= L2 <= 64 or (L2 <= 128 and L1 <= 32))
+
+
+def _hs_frag(w):
+    """[..., 160 rows (5 tiles x 32), 640] -> [..., tile, k-step, half, row, 8]: one contiguous KB per MFMA operand fragment"""
+    lead = w.shape[:-2]
+    n = len(lead)
+    w = w.reshape(*lead, 5, 32, 40, 2, 8)
+    return w.permute(*range(n), n, n + 2, n + 3, n + 1, n + 4)
+
+
+def hs_pack_rows(w, ln=None, bias=None, scale=1.0):
+    """[640, 640] projection weight (to_q of a cross-attention, to_out[0]) -> (fragment packing per 160-row quarter, fp32 bias [640] or None).
+    ln = (gamma, beta, eps): the LayerNorm in front of the projection is folded in -- W * gamma (rounded once) and W . beta + bias as an
+    fp32 bias, the algebra of ``_ln_folded``; ``scale`` multiplies both (the softmax scale of a pre-scaled q)."""
+    wf = w.detach().float()
+    bb = None if bias is None else bias.detach().float()
+    if ln is not None:
+        bb = wf @ ln[1].detach().float() + (0.0 if bb is None else bb)
+        wf = wf * ln[0].detach().float()
+    if scale != 1.0:
+        wf = wf * scale
+        bb = None if bb is None else bb * scale
+    pk = _hs_frag(wf.to(w.dtype).reshape(4, 160, HS_C)).contiguous().reshape(-1)
+    return pk, (None if bb is None else bb.contiguous())
+
+
+def hs_pack_qkv(wq, wk, wv, ln=None, q_scale=1.0):
+    """to_q / to_k / to_v [640, 640] of a self-attention -> ([4 head pairs][15 row tiles: 5 q, 5 k, 5 v][40][64][8] packing, fp32 bias
+    [4][480] in the same row order or None); the LayerNorm folded in as in hs_pack_rows, the to_q rows scaled by ``q_scale``"""
+    ws = [w.detach().float() for w in (wq, wk, wv)]
+    bb = None
+    if ln is not None:
+        beta, gamma = ln[1].detach().float(), ln[0].detach().float()
+        bb = [w @ beta for w in ws]
+        ws = [w * gamma for w in ws]
+    if q_scale != 1.0:
+        ws[0] = ws[0] * q_scale
+        if bb is not None:
+            bb[0] = bb[0] * q_scale
+    w = torch.stack(ws, 0).to(wq.dtype).reshape(3, 4, 160, HS_C).permute(1, 0, 2, 3)  # [pair][which][160][640]
+    pk = _hs_frag(w).contiguous().reshape(-1)
+    if bb is not None:
+        bb = torch.stack(bb, 0).reshape(3, 4, 160).permute(1, 0, 2).contiguous().reshape(-1)
+    return pk, bb
+
+
+def hs_attention(x, w_packed, w_bias, *, self_attention, normalize=True, ln_eps=1e-5, k1=None, vt1=None, key_bias=None, k2=None, vt2=None,
+                 scale2=0.0, q_prescaled=False, out=None):
+    """O = heads' softmax attention of the 64-token level in ONE launch (apad_hs_attention): rows of x normalised (the LayerNorm's affine
+    part lives in w_packed / w_bias: hs_pack_qkv / hs_pack_rows), q|k|v (self) or q (cross: k*, vt* = the hoisted sets in ops.attention's
+    layout) projected per head pair, both heads attended, O [B, N, 640] written.  to_out + residual: ``hs_out``."""
+    _req(x, "hs_attention.x", w_packed.dtype)
+    B, N, Cc = x.shape
+    if Cc != HS_C or N > HS_MAXN or x.dtype not in FUSED_DTYPES or not x.is_contiguous():
+        raise ValueError(f"hs_attention: x {tuple(x.shape)} {x.dtype} outside the kernel envelope")
+    d = L.HsAttnDesc()
+    d.x, d.w_packed, d.w_bias = x.data_ptr(), w_packed.data_ptr(), _ptr(w_bias)
+    if w_bias is not None and w_bias.dtype != torch.float32:
+        raise ValueError("hs_attention.w_bias: must be fp32")
+    if not self_attention:
+        L1, L2 = k1.shape[1], (0 if k2 is None else k2.shape[1])
+        if not hs_cross_lengths_ok(L1, L2):
+            raise ValueError(f"hs_attention: segment lengths {L1} / {L2} outside the kernel envelope")
+        for t, n in ((k1, "k1"), (vt1, "vt1"), (k2, "k2"), (vt2, "vt2")):
+            if t is not None and (not t.is_contiguous() or t.dtype != x.dtype):
+                raise ValueError(f"hs_attention.{n}: must be contiguous {x.dtype}")
+        if k1.shape[0] != B or tuple(vt1.shape[:3]) != (B, HS_HEADS, 80) or (k2 is not None and (k2.shape[0] != B or tuple(vt2.shape[:3]) != (B, HS_HEADS, 80))):
+            raise ValueError("hs_attention: key / value sets must have the batch of x")
+        d.k1, d.vt1, d.key_bias, d.L1, d.Lpad1 = k1.data_ptr(), vt1.data_ptr(), _ptr(key_bias), L1, vt1.shape[-1]
+        if L2 > 0:
+            d.k2, d.vt2, d.L2, d.Lpad2 = k2.data_ptr(), vt2.data_ptr(), L2, vt2.shape[-1]
+    if out is None:
+        out = torch.empty_like(x)
+    d.out = out.data_ptr()
+    d.B, d.N, d.C, d.heads = B, N, Cc, HS_HEADS
+    d.self_attention, d.q_prescaled, d.dtype, d.normalize = int(bool(self_attention)), int(bool(q_prescaled)), _DT[x.dtype], int(bool(normalize))
+    d.ln_eps, d.softmax_scale, d.scale2 = float(ln_eps), 1.0 / math.sqrt(80.0), float(scale2)
+    L.check(L.lib().apad_hs_attention(C.byref(d), _stream()), "apad_hs_attention")
+    return out
+
+
+def hs_out(o, wo_packed, bias, residual, rowstat=False, out=None):
+    """out = (residual +) (o @ Wo^T + bias) for [B, <= 64, 640] (apad_hs_out; Wo from hs_pack_rows).  rowstat: the per-32-column row statistics a
+    folded LayerNorm in the NEXT Linear reads (retrieved with rowstat_of)."""
+    _req(o, "hs_out.o", wo_packed.dtype)
+    B, N, Cc = o.shape
+    if Cc != HS_C or N > HS_MAXN or o.dtype not in FUSED_DTYPES or not o.is_contiguous():
+        raise ValueError(f"hs_out: o {tuple(o.shape)} outside the kernel envelope")
+    if residual is not None:
+        _req(residual, "hs_out.residual", o.dtype)
+        if not residual.is_contiguous() or residual.shape != o.shape:
+            raise ValueError(f"hs_out: residual {tuple(residual.shape)} must be contiguous with the shape of o")
+    if out is None:
+        out = torch.empty_like(o)
+    rs = torch.empty(B * N, 20, 2, dtype=torch.float32, device=o.device) if (rowstat and LN_FOLD) else None
+    d = L.HsOutDesc()
+    d.o, d.w_packed, d.bias, d.residual, d.out, d.rowstat_out = o.data_ptr(), wo_packed.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), _ptr(rs)
+    d.B, d.N, d.C, d.dtype = B, N, Cc, _DT[o.dtype]
+    L.check(L.lib().apad_hs_out(C.byref(d), _stream()), "apad_hs_out")
+    if rs is not None:
+        out._apad_rowstat = rs
+    elif hasattr(out, "_apad_rowstat"):
+        del out._apad_rowstat
     return out
 
 

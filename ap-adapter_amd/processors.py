@@ -67,6 +67,38 @@ def _xattn_weights(attn):
     return attn._xattn_w
 
 
+def _hs_route(attn, hidden_states, residual, ln):
+    """the 64-token level's two-launch route (csrc/hsattn.hip): [B, <= 64, 640], 8 heads, a bias-free square to_q; entered with or without
+    the block's LayerNorm / residual (the reference call has neither)"""
+    return (ops.hs_ok(hidden_states, attn.heads, attn.to_q.weight.shape[0]) and attn.to_q.bias is None and attn.to_out[0].weight.shape[0] == ops.HS_C
+            and (residual is None or (residual.shape == hidden_states.shape and residual.is_contiguous())))
+
+
+def _hs_weights(attn, ln, self_attention):
+    """(packed projection weights, their fp32 bias, packed to_out[0]) of apad_hs_attention / apad_hs_out, cached on the Attention module and
+    re-packed when a parameter (the LayerNorm's included: it is folded into the projection) is re-assigned, moved, cast or updated in place"""
+    ps = (attn.to_q.weight, attn.to_out[0].weight) + ((attn.to_k.weight, attn.to_v.weight) if self_attention else ()) + (tuple(ln[:2]) if ln is not None else ())
+    key = (_pkey(*ps), self_attention, None if ln is None else float(ln[2]))
+    if getattr(attn, "_hs_key", None) != key:
+        if self_attention:  # (the to_q rows carry log2(e) / sqrt(d): q is the softmax's base-2 exponent operand as projected)
+            d = attn.to_q.weight.shape[0] // attn.heads
+            pk, bb = ops.hs_pack_qkv(attn.to_q.weight, attn.to_k.weight, attn.to_v.weight, ln=ln, q_scale=ops.LOG2E / d ** 0.5)
+        else:
+            pk, bb = ops.hs_pack_rows(attn.to_q.weight, ln=ln)
+        attn._hs_w = (pk, bb, ops.hs_pack_rows(attn.to_out[0].weight)[0])
+        attn._hs_key = key
+    return attn._hs_w
+
+
+def _hs_sublayer(attn, hidden_states, residual, ln, **kv):
+    """LayerNorm? -> projections -> attention (apad_hs_attention), then to_out + bias (+ residual) (apad_hs_out)"""
+    self_attention = "k1" not in kv
+    pk, bb, wo = _hs_weights(attn, ln, self_attention)
+    o = ops.hs_attention(hidden_states, pk, bb, self_attention=self_attention, normalize=ln is not None, ln_eps=(ln[2] if ln is not None else 0.0),
+                         q_prescaled=self_attention, **kv)
+    return ops.hs_out(o, wo, attn.to_out[0].bias, residual, rowstat=True)
+
+
 def vt_buffer(slot, B, heads, d, Lk, dtype, device):
     """Zero-padded V^T scratch [B, heads, d, round_up(Lk,32)].  The pad columns are never written (apad_gemm
     APAD_OUT_VT stores l < Lk only), so buffers are shared by shape across attention sites.
@@ -145,6 +177,25 @@ def _key_bias(attention_mask, B, Lk):
     return m.reshape(B, Lk).float().contiguous()
 
 
+def _as_tokens(hidden_states, residual):
+    """the 4-D entry of the reference's processors (attention_processor.py:232-236, :363-367): [B, C, H, W] -> [B, H*W, C] (a transposed copy:
+    the kernels want channel-contiguous rows); returns (tokens, residual in the same layout, the 4-D shape or None)"""
+    if hidden_states.ndim != 4:
+        return hidden_states, residual, None
+    Bc, Cc, H, W = hidden_states.shape
+    tok = hidden_states.reshape(Bc, Cc, H * W).transpose(1, 2).contiguous()
+    if residual is hidden_states:
+        residual = tok
+    elif residual is not None:
+        residual = residual.reshape(Bc, Cc, H * W).transpose(1, 2).contiguous()
+    return tok, residual, (Bc, Cc, H, W)
+
+
+def _as_image(out, shape4):
+    """... and back (:290-291, :461-462)"""
+    return out if shape4 is None else out.transpose(-1, -2).reshape(*shape4)
+
+
 class AttnProcessor2_0(nn.Module):
     """Plain scaled-dot-product attention (reference :199-294).  Accepts dummy hidden_size / cross_attention_dim
     like the reference so it can live in AttnProcsLayers."""
@@ -214,13 +265,21 @@ class AttnProcessor2_0(nn.Module):
         reference's."""
         if attn.spatial_norm is not None or attn.group_norm is not None or attn.norm_cross:
             raise NotImplementedError("spatial_norm / group_norm / norm_cross are not on the AudioLDM2 path")
+        if hidden_states.ndim == 4:
+            tok, res, shape4 = _as_tokens(hidden_states, _residual)
+            return _as_image(self(attn, tok, encoder_hidden_states, attention_mask, temb, _residual=res, _ln=_ln), shape4)
         if hidden_states.ndim != 3:
-            raise ValueError("hidden_states must be [batch, tokens, channels]")
+            raise ValueError("hidden_states must be [batch, tokens, channels] or [batch, channels, height, width]")
         B, N, C_ = hidden_states.shape
         heads = attn.heads
         if AG.on(hidden_states, encoder_hidden_states):
             return self._call_train(attn, hidden_states, encoder_hidden_states, attention_mask, _residual, _ln)
         prescaled = False
+        if attn.residual_connection or attn.rescale_output_factor != 1.0:
+            raise NotImplementedError("residual_connection / rescale_output_factor are not on the AudioLDM2 path")
+        hs_route = _hs_route(attn, hidden_states, _residual, _ln)
+        if encoder_hidden_states is None and hs_route:
+            return _hs_sublayer(attn, hidden_states, _residual, _ln)
         if encoder_hidden_states is None:
             Lk = N
             if ops.rp_ok(hidden_states) and attn.to_q.weight.shape[0] == C_:
@@ -275,15 +334,12 @@ class AttnProcessor2_0(nn.Module):
         if encoder_hidden_states is not None and _xrows_ok(attn, hidden_states, _residual, _ln, Lk) and k.shape[0] == B:
             wq_p, wo_p = _xrows_weights(attn)
             return ops.cross_attention_rows(hidden_states, wq_p, wo_p, attn.to_out[0].bias, k, vt, heads, ln=_ln, key_bias=bias)
+        if encoder_hidden_states is not None and hs_route and ops.hs_cross_lengths_ok(Lk) and k.shape[0] == B:
+            return _hs_sublayer(attn, hidden_states, _residual, _ln, k1=k, vt1=vt, key_bias=bias)
         if q is None:
             q = ops.fused_linear(hidden_states, attn.to_q.weight, ln=_ln)
         o = ops.attention(q, k, vt, Lk, heads, key_bias=bias, q_prescaled=prescaled)
-        out = ops.fused_linear(o, attn.to_out[0].weight, attn.to_out[0].bias, residual=_residual, rowstat=True)
-        if attn.residual_connection:
-            raise NotImplementedError("residual_connection=True is not on the AudioLDM2 path")
-        if attn.rescale_output_factor != 1.0:
-            raise NotImplementedError("rescale_output_factor != 1 is not on the AudioLDM2 path")
-        return out
+        return ops.fused_linear(o, attn.to_out[0].weight, attn.to_out[0].bias, residual=_residual, rowstat=True)
 
 
 def _train_common(attn):
@@ -378,8 +434,11 @@ class IPAttnProcessor2_0(nn.Module):
             raise ValueError("`scale` of IPAttnProcessor2_0 is set through the `scale` attribute, not the call kwarg")
         if attn.spatial_norm is not None or attn.group_norm is not None or attn.norm_cross:
             raise NotImplementedError("spatial_norm / group_norm / norm_cross are not on the AudioLDM2 path")
+        if hidden_states.ndim == 4:
+            tok, res, shape4 = _as_tokens(hidden_states, _residual)
+            return _as_image(self(attn, tok, encoder_hidden_states, attention_mask, temb, _residual=res, _ln=_ln), shape4)
         if hidden_states.ndim != 3:
-            raise ValueError("hidden_states must be [batch, tokens, channels]")
+            raise ValueError("hidden_states must be [batch, tokens, channels] or [batch, channels, height, width]")
         if encoder_hidden_states is None:
             raise ValueError("IPAttnProcessor2_0 needs encoder_hidden_states = [text tokens | audio tokens]")
         ehs = encoder_hidden_states
@@ -417,12 +476,13 @@ class IPAttnProcessor2_0(nn.Module):
             wq_p, wo_p = _xrows_weights(attn)
             return ops.cross_attention_rows(hidden_states, wq_p, wo_p, attn.to_out[0].bias, k_t, vt_t, attn.heads, ln=_ln, key_bias=bias,
                                             k2=k_a, vt2=vt_a, scale2=self.scale)
-        q = ops.fused_linear(hidden_states, attn.to_q.weight, ln=_ln)
-        o = ops.attention(q, k_t, vt_t, Lt, attn.heads, key_bias=bias, k2=k_a, vt2=vt_a, L2=La, scale2=self.scale)
-        out = ops.fused_linear(o, attn.to_out[0].weight, attn.to_out[0].bias, residual=_residual, rowstat=True)
         if attn.residual_connection or attn.rescale_output_factor != 1.0:
             raise NotImplementedError("residual_connection / rescale_output_factor are not on the AudioLDM2 path")
-        return out
+        if _hs_route(attn, hidden_states, _residual, _ln) and ops.hs_cross_lengths_ok(Lt, La) and k_t.shape[0] == B:
+            return _hs_sublayer(attn, hidden_states, _residual, _ln, k1=k_t, vt1=vt_t, key_bias=bias, k2=k_a, vt2=vt_a, scale2=self.scale)
+        q = ops.fused_linear(hidden_states, attn.to_q.weight, ln=_ln)
+        o = ops.attention(q, k_t, vt_t, Lt, attn.heads, key_bias=bias, k2=k_a, vt2=vt_a, L2=La, scale2=self.scale)
+        return ops.fused_linear(o, attn.to_out[0].weight, attn.to_out[0].bias, residual=_residual, rowstat=True)
 
 
     def _call_train(self, attn, hidden_states, ehs, attention_mask, _residual, _ln):

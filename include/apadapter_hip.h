@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define APAD_ABI_VERSION 6
+#define APAD_ABI_VERSION 7
 
 /* element types of activations / weights */
 enum { APAD_BF16 = 0, APAD_F16 = 1, APAD_F32 = 2 };
@@ -263,6 +263,49 @@ typedef struct apad_xrows_desc {
 } apad_xrows_desc;
 int apad_sizeof_xrows_desc(void);
 int apad_cross_attention_rows(const apad_xrows_desc* d, void* stream);
+/* The attention sub-layers of the 64-token level (C = 640, 8 heads of 80, <= 64 tokens per sample) in TWO launches (hsattn.hip; ABI 7):
+ *   apad_hs_attention  workgroup = (sample, head pair): LayerNorm(x) (normalisation here, affine part folded into the weights) -> the pair's q|k|v (self-attention) or q (cross-attention over the
+ *                      hoisted K / V^T sets of apad_attention's layout) -> softmax attention of its two heads (one segment, a masked
+ *                      segment, or the adapter's text + scale2 * audio pair) -> O[:, pair's 160 columns]
+ *   apad_hs_out        workgroup = (sample, output-column quarter): out = residual + (O . Wo^T + bias), plus the per-32-column (sum, sum of
+ *                      squares) row statistics [B*N][20][2] a folded LayerNorm (apad_gemm_desc.rowstat_in, 20 tiles) reads
+ * Every workgroup streams a disjoint quarter of the weights once against its sample's tokens in LDS.  Weights FRAGMENT-PACKED per
+ * quarter (one contiguous KB per MFMA operand fragment):
+ *   self-attention  w_packed[((p * 15 + t) * 40 + ks) * 512 + lane * 8 + e] = Wqkv[(t / 5) * 640 + p * 160 + (t % 5) * 32 + (lane & 31)][ks * 16 + (lane >> 5) * 8 + e]
+ *                   with Wqkv = [to_q ; to_k ; to_v] stacked (1920 x 640; q_prescaled = 1: the to_q rows carry log2(e) / sqrt(80))
+ *   cross / to_out  w_packed[((p * 5 + t) * 40 + ks) * 512 + lane * 8 + e]  = W[p * 160 + t * 32 + (lane & 31)][ks * 16 + (lane >> 5) * 8 + e]
+ * Replaces, per site, norm1 / norm2 + to_q / to_k / to_v + scaled_dot_product_attention (x 2 for the adapter) (attention_processor.py:256-276,
+ * :387-454) and to_out[0] + the block's residual add (:279, :457; modeling_audioldm2 BasicTransformerBlock).  Outside the envelope: -3. */
+typedef struct apad_hs_attn_desc {
+    const void* x;         /* [B*N][640] hidden states                                                */
+    const void* w_packed;  /* see above                                                               */
+    const float* w_bias;   /* [4][NTILE * 32] fp32 in the packed row order (W . ln_beta + bias), or NULL */
+    const void* k1;        /* cross: [B][L1][640]; self: NULL                                         */
+    const void* vt1;       /* cross: [B][8][80][Lpad1]                                                */
+    const float* key_bias; /* cross: [B][L1] fp32 additive bias on segment 1, or NULL                 */
+    const void* k2;        /* cross: segment 2 (to_k_ip / to_v_ip of the audio tokens) or NULL        */
+    const void* vt2;
+    void* out;             /* O [B*N][640]                                                            */
+    int32_t B, N, C, heads;
+    int32_t L1, Lpad1, L2, Lpad2;
+    int32_t self_attention, q_prescaled, dtype;
+    int32_t normalize;     /* 1: rows are normalised ((x - mean) * rstd, eps = ln_eps) before the projection; the LayerNorm's gamma is
+                              folded into w_packed and W . beta into w_bias by the caller (apad_gemm's folded-LayerNorm algebra)  */
+    float ln_eps, softmax_scale, scale2, reserved_f;
+} apad_hs_attn_desc;
+int apad_sizeof_hs_attn_desc(void);
+int apad_hs_attention(const apad_hs_attn_desc* d, void* stream);
+typedef struct apad_hs_out_desc {
+    const void* o;         /* [B*N][640] attention output (all heads)                                 */
+    const void* w_packed;  /* to_out[0].weight, packed as above                                       */
+    const void* bias;      /* [640] or NULL                                                           */
+    const void* residual;  /* [B*N][640] or NULL                                                      */
+    void* out;             /* [B*N][640]; may alias residual                                          */
+    float* rowstat_out;    /* [B*N][20][2] fp32 or NULL                                               */
+    int32_t B, N, C, dtype;
+} apad_hs_out_desc;
+int apad_sizeof_hs_out_desc(void);
+int apad_hs_out(const apad_hs_out_desc* d, void* stream);
 /* w [256][ldw] (nn.Linear layout) -> packed [8 row slices][16 k-steps][64 lanes][8], 128 KB */
 int apad_xattn_pack_weight(const void* w, void* packed, int64_t ldw, int32_t dtype, void* stream);
 /* bytes of the packed form of one segment's K / V^T: B * 8 heads * ceil(L/32) * 4 KB */

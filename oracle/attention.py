@@ -44,9 +44,23 @@ def prepare_attention_mask(mask, target_length, batch_size, heads):
     return mask.view(batch_size, heads, -1, mask.shape[-1])
 
 
+def _tokens_of(hs):
+    """the 4-D entry of both processors (:232-236, :363-367): [B, C, H, W] -> [B, H*W, C]; returns (tokens, shape or None)"""
+    if hs.dim() == 4:
+        b, c, h, w = hs.shape
+        return hs.view(b, c, h * w).transpose(1, 2), (b, c, h, w)
+    return hs, None
+
+
+def _image_of(out, shape4):
+    """... and back (:290-291, :461-462): transpose(-1, -2).reshape(B, C, H, W)"""
+    return out if shape4 is None else out.transpose(-1, -2).reshape(*shape4)
+
+
 def attn_processor_2_0(hs, ehs, wq, wk, wv, wo, bo, heads, attention_mask=None):
-    """AttnProcessor2_0 (:214-294).  hs [B,N,C]; ehs [B,L,X] or None (self-attention); attention_mask is the
+    """AttnProcessor2_0 (:214-294).  hs [B,N,C] (or [B,C,H,W]); ehs [B,L,X] or None (self-attention); attention_mask is the
     additive bias [B,1,L] the UNet builds (modeling_audioldm2.py:741-747) or None."""
+    hs, shape4 = _tokens_of(hs)
     b = hs.shape[0]
     src = hs if ehs is None else ehs
     bias = prepare_attention_mask(attention_mask, src.shape[1], b, heads)
@@ -54,7 +68,7 @@ def attn_processor_2_0(hs, ehs, wq, wk, wv, wo, bo, heads, attention_mask=None):
     k = _heads(F.linear(src, wk), heads)
     v = _heads(F.linear(src, wv), heads)
     o = _merge(sdpa(q, k, v, bias))
-    return F.linear(o, wo, bo)
+    return _image_of(F.linear(o, wo, bo), shape4)
 
 
 def ip_attn_processor_2_0(hs, ehs, wq, wk, wv, wo, bo, wk_ip, wv_ip, heads, num_tokens, scale,
@@ -62,6 +76,7 @@ def ip_attn_processor_2_0(hs, ehs, wq, wk, wv, wo, bo, wk_ip, wv_ip, heads, num_
     """IPAttnProcessor2_0 (:347-470): text branch over ehs[:, :num_tokens] with the frozen to_k/to_v (:400-431),
     audio branch over ehs[:, num_tokens:] with to_k_ip/to_v_ip (:435-445), blend text + scale*audio (:454),
     to_out[0] with bias (:457).  The masked branch keeps only the first q_len mask columns (:424-428)."""
+    hs, shape4 = _tokens_of(hs)
     b, n, _ = hs.shape
     if ehs.dim() < 3:
         ehs = ehs.unsqueeze(0)
@@ -76,4 +91,4 @@ def ip_attn_processor_2_0(hs, ehs, wq, wk, wv, wo, bo, wk_ip, wv_ip, heads, num_
     k_a = _heads(F.linear(aud, wk_ip), heads)
     v_a = _heads(F.linear(aud, wv_ip), heads)
     o_a = _merge(sdpa(q, k_a, v_a, None))
-    return F.linear(o_t + scale * o_a, wo, bo)
+    return _image_of(F.linear(o_t + scale * o_a, wo, bo), shape4)

@@ -22,7 +22,7 @@ sys.path.insert(0, HERE)
 sys.dont_write_bytecode = True
 sys.path.insert(0, "/root/reference")
 
-from cases import CASES, BLOCK_CASES, LN_EPS, make_inputs  # noqa: E402
+from cases import CASES, BLOCK_CASES, R4_BLOCK_CASES, R4_CASES, LN_EPS, make_inputs  # noqa: E402
 from APadapter.ap_adapter.attention_processor import AttnProcessor2_0, IPAttnProcessor2_0  # noqa: E402
 from safetensors.torch import save_file  # noqa: E402
 
@@ -87,6 +87,21 @@ def run_case(case, dtype):
     return out
 
 
+def main_r4():
+    """round 4's additions only (attn_r4.safetensors); attn_processors / attn_blocks stay byte-identical"""
+    tensors = {}
+    for case in R4_BLOCK_CASES + R4_CASES:
+        tensors[case["name"] + ".fp32"] = run_case(case, torch.float32).contiguous()
+        if case.get("bf16"):
+            tensors[case["name"] + ".bf16"] = run_case(case, torch.bfloat16).contiguous()
+        print(case["name"], tuple(tensors[case["name"] + ".fp32"].shape))
+    meta = {"generator": "tests/golden/make_golden.py --r4", "torch": torch.__version__,
+            "reference": "fundwotsai2001/AP-adapter @ 2024-10-22, APadapter/ap_adapter/attention_processor.py",
+            "cases": json.dumps([c["name"] for c in R4_BLOCK_CASES + R4_CASES])}
+    save_file(tensors, os.path.join(HERE, "attn_r4.safetensors"), metadata=meta)
+    print("wrote attn_r4.safetensors", os.path.getsize(os.path.join(HERE, "attn_r4.safetensors")), "bytes")
+
+
 def main():
     tensors = {}
     for case in CASES:
@@ -112,6 +127,9 @@ def main():
 
 
 if __name__ == "__main__":
+    if "--r4" in sys.argv:
+        main_r4()
+        sys.exit(0)
     main()
 
 

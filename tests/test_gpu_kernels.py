@@ -864,6 +864,128 @@ def test_fused_cross_attention_outside_envelope(dev):
     assert not ops.xattn_lengths_ok(8, 128, True) and not ops.xattn_lengths_ok(8, 96) and not ops.xattn_lengths_ok(16, 128) and not ops.xattn_lengths_ok(8, 512)
 
 
+# ---- the 64-token level's attention sub-layers: apad_hs_attention (head-sliced) + apad_hs_out ----
+def _hs_self_ref(x, g, be, wq, wk, wv, wo, bo, heads, residual=True):
+    B, N, C = x.shape
+    hs = x if g is None else F.layer_norm(x, (C,), g, be, 1e-5)
+    sp = lambda t: t.reshape(B, N, heads, C // heads).transpose(1, 2)
+    o = F.scaled_dot_product_attention(sp(F.linear(hs, wq)), sp(F.linear(hs, wk)), sp(F.linear(hs, wv))).transpose(1, 2).reshape(B, N, C)
+    y = F.linear(o, wo, bo)
+    return x + y if residual else y
+
+
+@pytest.mark.parametrize("dtype", DTYPES16)
+@pytest.mark.parametrize("B,N", [(2, 64), (5, 64), (3, 16), (2, 40), (1, 33), (64, 64), (3, 1)])
+def test_hs_self_attention_sublayer(dev, dtype, B, N):
+    """LayerNorm -> q|k|v -> softmax attention -> to_out + bias + residual of the 64-token level in two launches (workgroup = (sample, head
+    pair), then (sample, column quarter)): full and ragged samples (a shorter clip's 16 / 40 tokens, one token), odd batches, the CFG batch;
+    against fp32 torch on storage-rounded operands and against the chain it replaces; a sample's rows must not depend on its batch;
+    the row statistics hs_out leaves are those of the stored rows"""
+    from ap_adapter_amd import ops
+    C, H = 640, 8
+    x = q(R(B, N, C, seed=401), dtype)
+    g, be = q(1 + 0.1 * R(C, seed=402), dtype), q(0.1 * R(C, seed=403), dtype)
+    wq, wk, wv = (q(R(C, C, seed=404 + i, std=0.05), dtype) for i in range(3))
+    wo, bo = q(R(C, C, seed=407, std=0.05), dtype), q(R(C, seed=408, std=0.3), dtype)
+    ref = _hs_self_ref(x, g, be, wq, wk, wv, wo, bo, H)
+    D = lambda t: t.to(dev, dtype)
+    xd, ln = D(x), (D(g), D(be), 1e-5)
+    pk, bb = ops.hs_pack_qkv(D(wq), D(wk), D(wv), ln=ln, q_scale=ops.LOG2E / math.sqrt(C // H))
+    wo_p, _ = ops.hs_pack_rows(D(wo))
+    o = ops.hs_attention(xd, pk, bb, self_attention=True, ln_eps=1e-5, q_prescaled=True)
+    out = ops.hs_out(o, wo_p, D(bo), xd, rowstat=True)
+    assert out.shape == ref.shape and rel_err(out, ref) < 1.5 * TOL[dtype]
+    rs = ops.rowstat_of(out)
+    xs = out.float().cpu().reshape(B * N, C)
+    assert tuple(rs.shape) == (B * N, 20, 2)
+    assert rel_err(rs[..., 0].sum(1), xs.sum(1)) < 1e-5 and rel_err(rs[..., 1].sum(1), (xs * xs).sum(1)) < 1e-5
+    # the chain: LayerNorm -> q | k | v^T -> apad_attention -> to_out + residual
+    hs_n = ops.layer_norm(xd, *ln)
+    qd, kd = ops.linear(hs_n, D(wq)), ops.linear(hs_n, D(wk))
+    vt = torch.zeros(B, H, C // H, ops.round_up(N, 32), device=dev, dtype=dtype)
+    ops.linear_vt(hs_n, D(wv), B, N, H, vt)
+    chain = ops.linear(ops.attention(qd, kd, vt, N, H), D(wo), D(bo), residual=xd)
+    assert rel_err(out, chain.float().cpu()) < TOL[dtype]
+    # batch independence: sample i alone == row i of the batch, bit for bit
+    i = B // 2
+    o1 = ops.hs_out(ops.hs_attention(xd[i:i + 1].contiguous(), pk, bb, self_attention=True, ln_eps=1e-5, q_prescaled=True), wo_p, D(bo), xd[i:i + 1].contiguous())
+    assert torch.equal(o1[0], out[i])
+    # without LayerNorm / residual / bias (the reference's bare processor call)
+    pk0, bb0 = ops.hs_pack_qkv(D(wq), D(wk), D(wv), q_scale=ops.LOG2E / math.sqrt(C // H))
+    assert bb0 is None
+    bare = ops.hs_out(ops.hs_attention(xd, pk0, None, self_attention=True, normalize=False, q_prescaled=True), wo_p, None, None)
+    assert rel_err(bare, _hs_self_ref(x, None, None, wq, wk, wv, wo, None, H, residual=False)) < 1.5 * TOL[dtype]
+    # in place over the residual
+    x2 = xd.clone()
+    ops.hs_out(o, wo_p, D(bo), x2, out=x2)
+    assert torch.equal(x2, out)
+
+
+@pytest.mark.parametrize("dtype", DTYPES16)
+@pytest.mark.parametrize("B,N,Lt,La,masked", [(2, 64, 8, 32, False), (3, 64, 8, 8, False), (2, 64, 16, 0, True), (5, 16, 8, 64, False), (2, 64, 40, 0, True),
+                                               (2, 40, 8, 33, False), (64, 64, 8, 32, False), (2, 64, 40, 50, True), (3, 64, 8, 128, False), (2, 64, 32, 100, False)])
+def test_hs_cross_attention_sublayer(dev, dtype, B, N, Lt, La, masked):
+    """the cross-attention form: q of the head pair projected in the launch, K / V^T the hoisted sets in apad_attention's layout -- the
+    adapter's text + scale * audio pair at every pooling rate it covers (8 / 32 / 64 / 128 audio keys), the masked T5 segment (one and two
+    key sub-tiles), ragged samples, the CFG batch"""
+    from ap_adapter_amd import ops
+    C, H = 640, 8
+    x = q(R(B, N, C, seed=421), dtype)
+    g, be = q(1 + 0.1 * R(C, seed=422), dtype), q(0.1 * R(C, seed=423), dtype)
+    wq, wo, bo = q(R(C, C, seed=424, std=0.05), dtype), q(R(C, C, seed=425, std=0.05), dtype), q(R(C, seed=426, std=0.3), dtype)
+    wk, wv = q(R(C, 768, seed=427, std=0.04), dtype), q(R(C, 768, seed=428, std=0.04), dtype)
+    wki, wvi = q(R(C, 768, seed=429, std=0.04), dtype), q(R(C, 768, seed=430, std=0.04), dtype)
+    et = q(R(B, Lt, 768, seed=431), dtype)
+    ea = q(R(B, La, 768, seed=432), dtype) if La else None
+    bias = None
+    if masked:
+        bias = torch.zeros(B, Lt)
+        bias[1::2, -(Lt // 2):] = -10000.0
+    ref = _xattn_ref(x, g, be, wq, wo, bo, et, wk, wv, H, bias, ea, wki, wvi, 0.55)
+    D = lambda t: t.to(dev, dtype)
+    k1 = ops.linear(D(et), D(wk))
+    v1t = torch.zeros(B, H, C // H, ops.round_up(Lt, 32), device=dev, dtype=dtype)
+    ops.linear_vt(D(et), D(wv), B, Lt, H, v1t)
+    k2 = v2t = None
+    if La:
+        k2 = ops.linear(D(ea), D(wki))
+        v2t = torch.zeros(B, H, C // H, ops.round_up(La, 32), device=dev, dtype=dtype)
+        ops.linear_vt(D(ea), D(wvi), B, La, H, v2t)
+    xd, ln = D(x), (D(g), D(be), 1e-5)
+    bd = None if bias is None else bias.to(dev)
+    wq_p, qb = ops.hs_pack_rows(D(wq), ln=ln)
+    wo_p, _ = ops.hs_pack_rows(D(wo))
+    o = ops.hs_attention(xd, wq_p, qb, self_attention=False, ln_eps=1e-5, k1=k1, vt1=v1t, key_bias=bd, k2=k2, vt2=v2t, scale2=0.55)
+    out = ops.hs_out(o, wo_p, D(bo), xd)
+    assert out.shape == ref.shape and rel_err(out, ref) < 1.5 * TOL[dtype]
+    qd = ops.linear(ops.layer_norm(xd, *ln), D(wq))
+    chain = ops.linear(ops.attention(qd, k1, v1t, Lt, H, key_bias=bd, k2=k2, vt2=v2t, L2=La, scale2=0.55), D(wo), D(bo), residual=xd)
+    assert rel_err(out, chain.float().cpu()) < TOL[dtype]
+
+
+def test_hs_attention_outside_envelope(dev):
+    from ap_adapter_amd import ops
+    bf = torch.bfloat16
+    assert ops.HS_ATTN
+    x = torch.zeros(2, 64, 640, device=dev, dtype=bf)
+    assert ops.hs_ok(x, 8, 640) and not ops.hs_ok(x, 4, 640) and not ops.hs_ok(x.float(), 8, 640) and not ops.hs_ok(torch.zeros(2, 65, 640, device=dev, dtype=bf), 8, 640)
+    assert not ops.hs_ok(torch.zeros(2, 64, 384, device=dev, dtype=bf), 8, 384)
+    assert ops.hs_cross_lengths_ok(8, 32) and ops.hs_cross_lengths_ok(64, 64) and ops.hs_cross_lengths_ok(8, 128) and not ops.hs_cross_lengths_ok(8, 512) and not ops.hs_cross_lengths_ok(40, 128)
+    w = torch.zeros(640, 640, device=dev, dtype=bf)
+    pk, _ = ops.hs_pack_rows(w)
+    with pytest.raises(ValueError):
+        ops.hs_attention(torch.zeros(2, 65, 640, device=dev, dtype=bf), pk, None, self_attention=True)
+    with pytest.raises(ValueError):  # 512 audio keys: the chain's job
+        ops.hs_attention(x, pk, None, self_attention=False, k1=torch.zeros(2, 8, 640, device=dev, dtype=bf), vt1=torch.zeros(2, 8, 80, 32, device=dev, dtype=bf),
+                         k2=torch.zeros(2, 512, 640, device=dev, dtype=bf), vt2=torch.zeros(2, 8, 80, 512, device=dev, dtype=bf))
+    # the packing: quarter p, row tile t, k-step ks = one contiguous KB, lane = (k half, row)
+    wt = torch.arange(640 * 640, dtype=torch.float32).reshape(640, 640).to(dev)
+    pk = ops.hs_pack_rows(wt)[0].reshape(4, 5, 40, 2, 32, 8)
+    assert torch.equal(pk[2, 3, 7, 1, 9], wt[2 * 160 + 3 * 32 + 9, 7 * 16 + 8: 7 * 16 + 16])
+    pq = ops.hs_pack_qkv(wt, wt + 1e6, wt + 2e6)[0].reshape(4, 3, 5, 40, 2, 32, 8)
+    assert torch.equal(pq[1, 2, 4, 39, 0, 31], wt[160 + 4 * 32 + 31, 39 * 16: 39 * 16 + 8] + 2e6)
+
+
 # ---- LayerNorm folded into the Linear behind it (the 640-wide level: no row-panel kernel covers K = 640) ----
 @pytest.mark.parametrize("dtype", DTYPES16)
 @pytest.mark.parametrize("M,C_,mean_shift", [(2048, 640, 0.0), (300, 640, 3.0), (4096, 640, -8.0), (130, 768, 1.0)])

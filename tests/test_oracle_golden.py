@@ -6,11 +6,13 @@ import pytest
 import torch
 from safetensors.torch import load_file
 
-from cases import BLOCK_CASES, CASES, LN_EPS, make_inputs
+from cases import BLOCK_CASES, CASES, LN_EPS, R4_BLOCK_CASES, R4_CASES, make_inputs
 from oracle.attention import attn_processor_2_0, ip_attn_processor_2_0
 
 GOLD = load_file(os.path.join(os.path.dirname(__file__), "golden", "attn_processors.safetensors"))
 GOLD_BLK = load_file(os.path.join(os.path.dirname(__file__), "golden", "attn_blocks.safetensors"))
+GOLD.update({k: v for k, v in load_file(os.path.join(os.path.dirname(__file__), "golden", "attn_r4.safetensors")).items() if not k.startswith("blk_")})
+GOLD_BLK.update({k: v for k, v in load_file(os.path.join(os.path.dirname(__file__), "golden", "attn_r4.safetensors")).items() if k.startswith("blk_")})
 
 
 def run_oracle(c, t, **over):
@@ -22,7 +24,7 @@ def run_oracle(c, t, **over):
     return attn_processor_2_0(a["hs"], a["ehs"], a["wq"], a["wk"], a["wv"], a["wo"], a["bo"], c["heads"], a["mask_bias"])
 
 
-@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+@pytest.mark.parametrize("case", CASES + R4_CASES, ids=[c["name"] for c in CASES + R4_CASES])
 def test_oracle_matches_reference_fp32(case):
     out = run_oracle(case, make_inputs(case))
     ref = GOLD[case["name"] + ".fp32"]
@@ -31,11 +33,11 @@ def test_oracle_matches_reference_fp32(case):
 
 
 def test_every_case_has_a_golden_vector():
-    assert {c["name"] + ".fp32" for c in CASES} <= set(GOLD.keys())
-    assert {c["name"] + ".fp32" for c in BLOCK_CASES} <= set(GOLD_BLK.keys())
+    assert {c["name"] + ".fp32" for c in CASES + R4_CASES} <= set(GOLD.keys())
+    assert {c["name"] + ".fp32" for c in BLOCK_CASES + R4_BLOCK_CASES} <= set(GOLD_BLK.keys())
 
 
-@pytest.mark.parametrize("case", BLOCK_CASES, ids=[c["name"] for c in BLOCK_CASES])
+@pytest.mark.parametrize("case", BLOCK_CASES + R4_BLOCK_CASES, ids=[c["name"] for c in BLOCK_CASES + R4_BLOCK_CASES])
 def test_oracle_block_entry_matches_reference_fp32(case):
     """the attn2 sub-layer as diffusers' BasicTransformerBlock runs it (norm2 -> processor -> + x): the oracle's processors behind
     the oracle's LayerNorm restatement against x + reference_processor(LayerNorm(x)) computed by the reference itself"""
