@@ -40,6 +40,10 @@ constexpr float NEG_BIG = -1.0e30f;
 #ifndef HS_NSET
 #define HS_NSET 8  // register sets of weight fragments = k-steps a fragment is requested ahead of its use (per wave: NSET x NT KB in flight)
 #endif
+#ifndef HS_PRE
+#define HS_PRE 2  // of those, the sets requested BEFORE the sample's rows are normalised (the rest right after: a wave that is still pushing 16 KB
+                  // of weight requests into the memory pipe cannot start on rows that have long arrived)
+#endif
 #ifndef HS_ABL
 #define HS_ABL 0  // timing ablations (tools/ab_build.sh; results are wrong): 1 = weight fragments loaded once, 2 = no attention phase, 4 = no projection MFMAs
 #endif
@@ -72,7 +76,7 @@ constexpr int HS_C = 640, HS_H = 8, HS_D = 80, HS_TM = 64, HS_KS = HS_C / 16, HS
 constexpr int XROWB = HS_C * 2 + 16;   // X / O tile row stride: 81 sixteen-byte slots (odd: conflict-free ds_read_b128 over 32 rows)
 constexpr int QROWB = HS_PW * 2 + 16;  // Q / K tile row stride: 21 slots
 constexpr int VROWB = HS_TM * 2 + 8;   // V^T tile row stride: 34 dwords (conflict-free 8-byte reads over 32 rows)
-constexpr int X_BYTES = HS_TM * XROWB, Q_BYTES = HS_TM * QROWB, V_BYTES = HS_PW * VROWB;
+constexpr int X_BYTES = HS_TM * XROWB, Q_BYTES = HS_TM * QROWB, V_BYTES = HS_PW * VROWB, HS_BIAS_BYTES = 15 * 32 * 4;
 
 struct HsP {
     const uint8_t* x;
@@ -84,25 +88,27 @@ struct HsP {
     const uint8_t* k2;
     const uint8_t* vt2;
     uint8_t* out;
-    int32_t B, N, L1, Lpad1, L2, Lpad2, normalize;
+    int32_t B, N, L1, Lpad1, L2, Lpad2, normalize, xm;
     float eps, scale_log2, scale2;
 };
 
-// One sample's rows into the X tile: 8 lanes per row, 64 rows per pass of 512 threads.  NORM: (x - mean) * rstd, i.e. the LayerNorm
-// WITHOUT its affine part -- gamma is folded into the packed weights and W . beta into their fp32 bias (ops.hs_pack_*; the same algebra as
-// apad_gemm's folded LayerNorm, which this level's chain already uses): 20 parameter loads, 160 unpacks and 80 FMAs per lane less in
-// the prologue every workgroup of a sample repeats.  The row stays packed in registers between the passes.
-template <int DT, bool NORM>
-__device__ __forceinline__ void hs_rows_to_lds(const uint8_t* xb, float eps, int nrows, uint8_t* X, int tid) {
-    constexpr int CH = HS_C / 64;
+// One sample's rows into the X tile: 8 lanes per row, 64 rows per pass of 512 threads, in two steps so that the caller can put its weight
+// requests BETWEEN them (vmcnt retires in order: rows requested behind 16 KB of weight fragments per wave would wait for those too).
+// NORM: (x - mean) * rstd, i.e. the LayerNorm WITHOUT its affine part -- gamma is folded into the packed weights and W . beta into their
+// fp32 bias (ops.hs_pack_*; the same algebra as apad_gemm's folded LayerNorm, which this level's chain already uses): 20 parameter loads,
+// 160 unpacks and 80 FMAs per lane less in the prologue every workgroup of a sample repeats.  The row stays packed in registers.
+constexpr int HS_CH = HS_C / 64;
+__device__ __forceinline__ void hs_rows_load(uint4 (&u)[HS_CH], const uint8_t* xb, int nrows, int tid) {
     const int sub = tid & 7, row = tid >> 3;
-    uint4 u[CH];
-    const bool ok = row < nrows;
+    const int rr = row < nrows ? row : nrows - 1;  // (branch-free: a row past the sample re-reads its last row and is zeroed below)
 #pragma unroll
-    for (int i = 0; i < CH; ++i) {
-        u[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (ok) u[i] = *reinterpret_cast<const uint4*>(xb + ((int64_t)row * HS_C + (sub + 8 * i) * 8) * 2);
-    }
+    for (int i = 0; i < HS_CH; ++i) u[i] = *reinterpret_cast<const uint4*>(xb + ((int64_t)rr * HS_C + (sub + 8 * i) * 8) * 2);
+}
+template <int DT, bool NORM>
+__device__ __forceinline__ void hs_rows_store(const uint4 (&u)[HS_CH], float eps, int nrows, uint8_t* X, int tid) {
+    constexpr int CH = HS_CH;
+    const int sub = tid & 7, row = tid >> 3;
+    const bool ok = row < nrows;
     if (NORM) {
         float s1 = 0.f;
 #pragma unroll
@@ -142,15 +148,16 @@ __device__ __forceinline__ void hs_rows_to_lds(const uint8_t* xb, float eps, int
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < CH; ++i) *reinterpret_cast<uint4*>(X + row * XROWB + (sub + 8 * i) * 16) = u[i];
+        for (int i = 0; i < CH; ++i) *reinterpret_cast<uint4*>(X + row * XROWB + (sub + 8 * i) * 16) = ok ? u[i] : make_uint4(0u, 0u, 0u, 0u);
     }
 }
 
-// acc[j][mt] += W_tile_j . X_panel_mt^T over the 40 k-steps; wf holds the first NSET k-steps' fragments on entry (requested by the caller
-// before the LayerNorm); the fragment of k-step kk + NSET is requested right behind the MFMAs that consumed k-step kk, and the token
-// fragments of k-step kk + 1 are read from LDS in front of the MFMAs of kk.  The order is PINNED with sched_group_barrier: left alone,
-// hipcc sinks all 2 NSET loads of an unrolled body behind its last MFMA (prefetch distance 0: every body waits a full L2 round trip).
-template <int DT, int NT, int NSET>
+// acc[j][mt] += W_tile_j . X_panel_mt^T over the 40 k-steps (SWAP1: slot 1 with the operands exchanged, acc[1][mt] = X_panel_mt . W_tile_1^T, so
+// that its C layout is (lane: feature, registers: tokens) -- a V tile lands transposed without a transposing store).  wf holds the first NSET
+// k-steps' fragments on entry; the fragment of k-step kk + NSET is requested right behind the MFMAs that consumed k-step kk, and the token
+// fragments of k-step kk + 1 are read from LDS in front of the MFMAs of kk.  The order is PINNED with sched_group_barrier: left alone, hipcc
+// sinks all 2 NSET loads of an unrolled body behind its last MFMA (prefetch distance 0: every body waits a full L2 round trip).
+template <int DT, int NT, int NSET, bool SWAP1>
 __device__ __forceinline__ void hs_project(const hs_gptr (&wb)[NT], uint32_t loff, const uint8_t* xs, typename ET<DT>::v8 (&wf)[NSET][NT], f32x16 (&acc)[NT][2]) {
     using E = ET<DT>;
     static_assert(HS_KS % NSET == 0, "the register sets of weight fragments rotate over the k-steps");
@@ -161,8 +168,13 @@ __device__ __forceinline__ void hs_project(const hs_gptr (&wb)[NT], uint32_t lof
 #define HS_MM(i_, s_)                                                                               \
     _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                \
         if (!(HS_ABL & 4)) {                                                                        \
-            acc[j][0] = E::mfma32(wf[i_][j], t[s_][0], acc[j][0]);                                  \
-            acc[j][1] = E::mfma32(wf[i_][j], t[s_][1], acc[j][1]);                                  \
+            if (SWAP1 && j == 1) {                                                                  \
+                acc[j][0] = E::mfma32(t[s_][0], wf[i_][j], acc[j][0]);                              \
+                acc[j][1] = E::mfma32(t[s_][1], wf[i_][j], acc[j][1]);                              \
+            } else {                                                                                \
+                acc[j][0] = E::mfma32(wf[i_][j], t[s_][0], acc[j][0]);                              \
+                acc[j][1] = E::mfma32(wf[i_][j], t[s_][1], acc[j][1]);                              \
+            }                                                                                       \
         }                                                                                           \
     }
     HS_LDT(0, 0);
@@ -193,6 +205,28 @@ __device__ __forceinline__ void hs_project(const hs_gptr (&wb)[NT], uint32_t lof
 #undef HS_MM
 }
 
+// workgroup id -> (sample, quarter).  Workgroup i runs on XCD i % 8 (observed, speed only) and every launch has to pull its working set
+// through its XCD's memory-side port (~1 TB/s per XCD: what the prologue of these kernels waits for), so the map decides how many bytes that
+// is: with m sample classes on the XCD axis an XCD sees 1 / m of the samples' rows and m / 2 of the four weight quarters.  m = 2 (id = 4 b + q):
+// one quarter, half of the rows; m = 8: all four quarters, an eighth of the rows.  Rows are 80 KB per sample, a quarter is 600 KB (q|k|v) or
+// 200 KB (q / to_out): m = 4 for self-attention, 8 for the others.
+__device__ __forceinline__ void hs_decode(int id, int m, int& b, int& q) {
+    const int x = id & 7, r = id >> 3;
+    const int pl = 8 / m, ph = 4 / pl;  // quarter classes on the XCD axis / on the remaining axis
+    q = (r % ph) * pl + (x % pl);
+    b = (r / ph) * m + (x / pl);
+}
+inline int hs_grid(int B, int m) { return 4 * m * ((B + m - 1) / m); }
+
+// a [64][160] tile of 16-bit values in LDS (row stride QROWB) -> rows of a [.][640] tensor at column col0: 20 sixteen-byte chunks per row,
+// consecutive lanes = consecutive chunks (whole 64-byte sectors per quad)
+__device__ __forceinline__ void hs_tile_to_rows(const uint8_t* T, uint8_t* dst_rows, int col0, int nrows, int tid) {
+    for (int idx = tid; idx < HS_TM * 20; idx += 512) {
+        const int row = idx / 20, ch = idx - row * 20;
+        if (row < nrows) *reinterpret_cast<uint4*>(dst_rows + ((int64_t)row * HS_C + col0 + ch * 8) * 2) = *reinterpret_cast<const uint4*>(T + row * QROWB + ch * 16);
+    }
+}
+
 template <int DT, bool SELF, bool NORM, int NS1, int NS2, int NSET>
 __global__ __launch_bounds__(512) void hs_attn_kernel(HsP p) {
     using E = ET<DT>;
@@ -202,16 +236,22 @@ __global__ __launch_bounds__(512) void hs_attn_kernel(HsP p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* const X = smem;
     uint8_t* const Q = smem + X_BYTES;
-    uint8_t* const K = Q + Q_BYTES;   // (self-attention only)
-    uint8_t* const VT = K + Q_BYTES;  // (self-attention only)
+    uint8_t* const BIAS = Q + Q_BYTES;  // [NTILE * 32] fp32
+    uint8_t* const K = BIAS + HS_BIAS_BYTES;  // (self-attention only)
+    uint8_t* const VT = K + Q_BYTES;          // (self-attention only)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.x >> 2, pr = blockIdx.x & 3;
+    int b, pr;
+    hs_decode(blockIdx.x, p.xm, b, pr);
+    if (b >= p.B) return;  // (the grid is padded to whole XCD rounds)
     const int N = p.N;
 
     HS_STAMP(0, 0);
-    // ---- 0. the weight stream starts now: wave w owns row tiles w (and w + 8) of the pair's packed block ----
+    // ---- 0. the sample's rows are requested first, the weight stream right behind them: wave w owns row tiles w (and w + 8) of the pair's block ----
+    uint4 xr[HS_CH];
+    hs_rows_load(xr, p.x + (int64_t)b * N * HS_C * 2, N, tid);
     const bool proj = SELF || wave < NTILE;
+    const bool vslot = SELF && wave >= 2 && wave < 7;  // slot 1 of waves 2 .. 6 = tiles 10 .. 14 = the pair's V rows
     hs_gptr wb[NT];
     typename E::v8 wf[NSET][NT];
     const uint32_t loff = (uint32_t)lane * 16u;
@@ -222,16 +262,25 @@ __global__ __launch_bounds__(512) void hs_attn_kernel(HsP p) {
         const int tl = tile[j] < NTILE ? tile[j] : NTILE - 1;  // (wave 7's second tile does not exist: it repeats the last one and drops the result)
         wb[j] = sgpr_ptr(p.w + ((int64_t)(pr * NTILE + tl) * HS_KS) * 1024);
     }
+    constexpr int PRE = HS_PRE < NSET ? HS_PRE : NSET;
     if (proj) {
 #pragma unroll
-        for (int i = 0; i < NSET; ++i)
+        for (int i = 0; i < PRE; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j) wf[i][j] = __builtin_bit_cast(typename E::v8, hs_ld16(wb[j] + i * 1024, loff));
     }
+    if (tid < NTILE * 8 && p.wbias != nullptr)  // the pair's fp32 bias -> LDS (read by the projection epilogue)
+        *reinterpret_cast<float4*>(BIAS + tid * 16) = *reinterpret_cast<const float4*>(p.wbias + pr * NTILE * 32 + tid * 4);
+    HS_STAMP(0, 1);
 
     // ---- 1. LayerNorm -> X ----
-    HS_STAMP(0, 1);
-    hs_rows_to_lds<DT, NORM>(p.x + (int64_t)b * N * HS_C * 2, p.eps, N, X, tid);
+    hs_rows_store<DT, NORM>(xr, p.eps, N, X, tid);
+    if (proj) {
+#pragma unroll
+        for (int i = PRE; i < NSET; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wf[i][j] = __builtin_bit_cast(typename E::v8, hs_ld16(wb[j] + i * 1024, loff));
+    }
     HS_STAMP(0, 2);
     __syncthreads();
     HS_STAMP(0, 3);
@@ -245,46 +294,45 @@ __global__ __launch_bounds__(512) void hs_attn_kernel(HsP p) {
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][mt][r] = 0.f;
-        hs_project<DT, NT, NSET>(wb, loff, X + l31 * XROWB + half * 16, wf, acc);
+        if (vslot)
+            hs_project<DT, NT, NSET, SELF>(wb, loff, X + l31 * XROWB + half * 16, wf, acc);
+        else
+            hs_project<DT, NT, NSET, false>(wb, loff, X + l31 * XROWB + half * 16, wf, acc);
         HS_STAMP(0, 4);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int t = tile[j];
-            if (p.wbias != nullptr && t < NTILE) {  // W . beta (+ bias): fp32, before the rounding
-                const float* bp = p.wbias + (pr * NTILE + t) * 32 + 4 * half;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 bv = *reinterpret_cast<const float4*>(bp + 8 * g);
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
-                        acc[j][mt][4 * g + 0] += bv.x;
-                        acc[j][mt][4 * g + 1] += bv.y;
-                        acc[j][mt][4 * g + 2] += bv.z;
-                        acc[j][mt][4 * g + 3] += bv.w;
-                    }
-                }
-            }
-            if (t < 10 && t < NTILE) {  // q / k: C layout = (lane: token, registers: 4 consecutive features) -> 8-byte stores into the row-major tile
+            if (t >= NTILE) continue;
+            const float* bp = p.wbias != nullptr ? reinterpret_cast<const float*>(BIAS) + t * 32 : nullptr;  // W . beta (+ bias): fp32 (staged in LDS), added before the rounding
+            if (t < 10) {  // q / k: C layout = (lane: token, registers: 4 consecutive features) -> 8-byte stores into the row-major tile
                 uint8_t* const dst = t < 5 ? Q : K;
                 const int f0 = (t < 5 ? t : t - 5) * 32;
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
+                for (int g = 0; g < 4; ++g) {
+                    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (bp != nullptr) bv = *reinterpret_cast<const float4*>(bp + 8 * g + 4 * half);
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
                         typename E::v4 y;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) y[e] = (typename E::elem)acc[j][mt][4 * g + e];
+                        y[0] = (typename E::elem)(acc[j][mt][4 * g + 0] + bv.x);
+                        y[1] = (typename E::elem)(acc[j][mt][4 * g + 1] + bv.y);
+                        y[2] = (typename E::elem)(acc[j][mt][4 * g + 2] + bv.z);
+                        y[3] = (typename E::elem)(acc[j][mt][4 * g + 3] + bv.w);
                         *reinterpret_cast<uint2*>(dst + (mt * 32 + l31) * QROWB + (f0 + 8 * g + 4 * half) * 2) = __builtin_bit_cast(uint2, y);
                     }
-            } else if (SELF && t < NTILE) {  // v: the same C layout written transposed, V^T[feature][token] (2-byte stores, 64 contiguous bytes per half-wave)
-                const int f0 = (t - 10) * 32;
+                }
+            } else if (SELF) {  // v (operands exchanged): C layout = (lane: feature, registers: 4 consecutive tokens) -> 8-byte stores into V^T[feature][token]
+                const int f = (t - 10) * 32 + l31;
+                const float bv = bp != nullptr ? bp[l31] : 0.f;
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
+                for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
+                    for (int g = 0; g < 4; ++g) {
+                        typename E::v4 y;
 #pragma unroll
-                        for (int mt = 0; mt < 2; ++mt)
-                            *reinterpret_cast<typename E::elem*>(VT + (f0 + 8 * g + 4 * half + e) * VROWB + (mt * 32 + l31) * 2) = (typename E::elem)acc[j][mt][4 * g + e];
+                        for (int e = 0; e < 4; ++e) y[e] = (typename E::elem)(acc[j][mt][4 * g + e] + bv);
+                        *reinterpret_cast<uint2*>(VT + f * VROWB + (mt * 32 + 8 * g + 4 * half) * 2) = __builtin_bit_cast(uint2, y);
+                    }
             }
         }
     }
@@ -294,9 +342,10 @@ __global__ __launch_bounds__(512) void hs_attn_kernel(HsP p) {
     constexpr bool BIG2 = NS2 > 2;  // the second segment's fragments are requested as they are used (short_segment_ns)
     constexpr bool SPLITF = DUAL && !BIG2 && NS1 + NS2 > 3;  // both resident sets would not fit: the second segment loads as it goes too
     constexpr int NSB = (DUAL && !BIG2 && !SPLITF) ? NS2 : 1;
+    const bool att = wave < 4 && !(HS_ABL & 2);
     ShortFr<DT, D, NS1> f1;
     ShortFr<DT, D, NSB> f2;
-    if (!SELF && wave < 4 && !(HS_ABL & 2)) {
+    if (!SELF && att) {
         short_load<DT, D, NS1>(f1, p.k1 + ((int64_t)b * p.L1 * HS_C + hg * D) * 2, HS_C, p.vt1 + ((int64_t)(b * HS_H + hg) * D * p.Lpad1) * 2, p.L1, p.Lpad1, l31, half);
         if (DUAL && !BIG2 && !SPLITF)
             short_load<DT, D, NSB>(f2, p.k2 + ((int64_t)b * p.L2 * HS_C + hg * D) * 2, HS_C, p.vt2 + ((int64_t)(b * HS_H + hg) * D * p.Lpad2) * 2, p.L2, p.Lpad2, l31, half);
@@ -304,57 +353,50 @@ __global__ __launch_bounds__(512) void hs_attn_kernel(HsP p) {
     HS_STAMP(0, 5);
     __syncthreads();
     HS_STAMP(0, 6);
-    if (wave >= 4 || (HS_ABL & 2)) {
-        HS_STAMP(0, 9);
-        return;
-    }
-    if (SELF) short_load<DT, D, NS1>(f1, K + h * D * 2, QROWB / 2, VT + h * D * VROWB, N, VROWB / 2, l31, half);
-    typename E::v8 qf[KC];
-    {
-        const uint8_t* qp = Q + (mt * 32 + l31) * QROWB + (h * D + half * 8) * 2;
+    if (att) {
+        if (SELF) short_load<DT, D, NS1>(f1, K + h * D * 2, QROWB / 2, VT + h * D * VROWB, N, VROWB / 2, l31, half);
+        typename E::v8 qf[KC];
+        {
+            const uint8_t* qp = Q + (mt * 32 + l31) * QROWB + (h * D + half * 8) * 2;
 #pragma unroll
-        for (int cc = 0; cc < KC; ++cc) qf[cc] = as_v8<DT>(*reinterpret_cast<const uint4*>(qp + cc * 32));
-    }
-    f32x16 o[DTT];
-#pragma unroll
-    for (int dt = 0; dt < DTT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-    float inv = 1.f;
-    const float* const bias1 = (!SELF && p.bias1) ? p.bias1 + (int64_t)b * p.L1 : nullptr;
-    short_compute<DT, D, NS1>(f1, SELF ? N : p.L1, bias1, p.scale_log2, qf, o, inv, half);
-#pragma unroll
-    for (int dt = 0; dt < DTT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] *= inv;
-    if (DUAL) {
-        f32x16 o2[DTT];
+            for (int cc = 0; cc < KC; ++cc) qf[cc] = as_v8<DT>(*reinterpret_cast<const uint4*>(qp + cc * 32));
+        }
+        f32x16 o[DTT];
 #pragma unroll
         for (int dt = 0; dt < DTT; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o2[dt][r] = 0.f;
-        float inv2 = 1.f;
-        if constexpr (BIG2 || SPLITF)
-            short_segment_ns<DT, D, (NS2 > 0 ? NS2 : 1)>(p.k2 + ((int64_t)b * p.L2 * HS_C + hg * D) * 2, HS_C, p.vt2 + ((int64_t)(b * HS_H + hg) * D * p.Lpad2) * 2, p.L2, p.Lpad2,
-                                                          nullptr, p.scale_log2, qf, o2, inv2, l31, half);
-        else
-            short_compute<DT, D, NSB>(f2, p.L2, nullptr, p.scale_log2, qf, o2, inv2, half);
-        // (as attn_short_kernel: each branch, and scale * audio, rounded to the storage type before the add)
+            for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+        float inv = 1.f;
+        const float* const bias1 = (!SELF && p.bias1) ? p.bias1 + (int64_t)b * p.L1 : nullptr;
+        short_compute<DT, D, NS1>(f1, SELF ? N : p.L1, bias1, p.scale_log2, qf, o, inv, half);
 #pragma unroll
         for (int dt = 0; dt < DTT; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float t = (float)(typename E::elem)o[dt][r];
-                const float a = (float)(typename E::elem)(o2[dt][r] * inv2);
-                o[dt][r] = t + (float)(typename E::elem)(p.scale2 * a);
-            }
-    }
-
-    HS_STAMP(0, 7);
-    // ---- 4. O(pair) -> HBM: lane = token, 8 bytes per (d-tile, group); the two halves of a wave write 16 contiguous bytes of a row ----
-    const int row = mt * 32 + l31;
-    if (row < N) {
-        uint8_t* const ob = p.out + (((int64_t)b * N + row) * HS_C + hg * D) * 2;
+            for (int r = 0; r < 16; ++r) o[dt][r] *= inv;
+        if (DUAL) {
+            f32x16 o2[DTT];
+#pragma unroll
+            for (int dt = 0; dt < DTT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o2[dt][r] = 0.f;
+            float inv2 = 1.f;
+            if constexpr (BIG2 || SPLITF)
+                short_segment_ns<DT, D, (NS2 > 0 ? NS2 : 1)>(p.k2 + ((int64_t)b * p.L2 * HS_C + hg * D) * 2, HS_C, p.vt2 + ((int64_t)(b * HS_H + hg) * D * p.Lpad2) * 2, p.L2,
+                                                              p.Lpad2, nullptr, p.scale_log2, qf, o2, inv2, l31, half);
+            else
+                short_compute<DT, D, NSB>(f2, p.L2, nullptr, p.scale_log2, qf, o2, inv2, half);
+            // (as attn_short_kernel: each branch, and scale * audio, rounded to the storage type before the add)
+#pragma unroll
+            for (int dt = 0; dt < DTT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float t = (float)(typename E::elem)o[dt][r];
+                    const float a = (float)(typename E::elem)(o2[dt][r] * inv2);
+                    o[dt][r] = t + (float)(typename E::elem)(p.scale2 * a);
+                }
+        }
+        HS_STAMP(0, 7);
+        // O(head, panel) over this wave's own q values in the Q tile (nobody else reads them)
 #pragma unroll
         for (int dt = 0; dt < DTT; ++dt)
 #pragma unroll
@@ -364,10 +406,13 @@ __global__ __launch_bounds__(512) void hs_attn_kernel(HsP p) {
                     typename E::v4 pk;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) pk[j] = (typename E::elem)o[dt][g * 4 + j];
-                    *reinterpret_cast<uint2*>(ob + dcol * 2) = __builtin_bit_cast(uint2, pk);
+                    *reinterpret_cast<uint2*>(Q + (mt * 32 + l31) * QROWB + (h * D + dcol) * 2) = __builtin_bit_cast(uint2, pk);
                 }
             }
     }
+    __syncthreads();
+    // ---- 4. O(pair) [64][160] -> HBM, whole 16-byte chunks ----
+    hs_tile_to_rows(Q, p.out + (int64_t)b * N * HS_C * 2, pr * HS_PW, N, tid);
     HS_STAMP(0, 9);
 }
 
@@ -378,8 +423,14 @@ struct HoP {
     const uint8_t* res;
     uint8_t* out;
     float* rs_out;  // [B * N][20][2] (sum, sum of squares) of the stored row per 32-column tile, or nullptr
-    int32_t B, N;
+    int32_t B, N, xm;
 };
+
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));  // quad_perm [2,3,0,1]
+    return v;
+}
 
 template <int DT, int NSET>
 __global__ __launch_bounds__(512) void hs_out_kernel(HoP p) {
@@ -387,67 +438,101 @@ __global__ __launch_bounds__(512) void hs_out_kernel(HoP p) {
     constexpr int NTILE = 5;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* const X = smem;
+    uint8_t* const T = smem + X_BYTES;  // [64][160] to_out (+ bias), rounded
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.x >> 2, cq = blockIdx.x & 3;
+    int b, cq;
+    hs_decode(blockIdx.x, p.xm, b, cq);
+    if (b >= p.B) return;
     const int N = p.N;
     HS_STAMP(1, 0);
+    // the O rows first, then this wave's weight stream, then what the epilogue needs (bias in the C layout, the residual chunks of the
+    // final coalesced pass): everything is in flight before the first wait
+    uint4 xr[HS_CH];
+    hs_rows_load(xr, p.o + (int64_t)b * N * HS_C * 2, N, tid);
     const bool proj = wave < NTILE;
     hs_gptr wb[1];
     typename E::v8 wf[NSET][1];
     const uint32_t loff = (uint32_t)lane * 16u;
     wb[0] = sgpr_ptr(p.w + ((int64_t)(cq * NTILE + (proj ? wave : 0)) * HS_KS) * 1024);
-    const int c0 = cq * HS_PW + wave * 32;  // first output column of this wave's tile
-    uint2 rx[2][4];
+    uint2 bq[4];
+    constexpr int PRE = HS_PRE < NSET ? HS_PRE : NSET;
     if (proj) {
 #pragma unroll
-        for (int i = 0; i < NSET; ++i) wf[i][0] = __builtin_bit_cast(typename E::v8, hs_ld16(wb[0] + i * 1024, loff));
-        // the residual values of this wave's outputs, in the C layout (lane: token, 4 consecutive columns per group)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int row = mt * 32 + l31;
-                rx[mt][g] = make_uint2(0u, 0u);
-                if (row < N && p.res != nullptr) rx[mt][g] = *reinterpret_cast<const uint2*>(p.res + (((int64_t)b * N + row) * HS_C + c0 + 8 * g + 4 * half) * 2);
-            }
+        for (int i = 0; i < PRE; ++i) wf[i][0] = __builtin_bit_cast(typename E::v8, hs_ld16(wb[0] + i * 1024, loff));
     }
     HS_STAMP(1, 1);
-    hs_rows_to_lds<DT, false>(p.o + (int64_t)b * N * HS_C * 2, 0.f, N, X, tid);
+    hs_rows_store<DT, false>(xr, 0.f, N, X, tid);
+    if (proj) {
+#pragma unroll
+        for (int i = PRE; i < NSET; ++i) wf[i][0] = __builtin_bit_cast(typename E::v8, hs_ld16(wb[0] + i * 1024, loff));
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bq[g] = p.bo != nullptr ? *reinterpret_cast<const uint2*>(p.bo + (cq * HS_PW + wave * 32 + 8 * g + 4 * half) * 2) : make_uint2(0u, 0u);
+    }
+    constexpr int NPASS = (HS_TM * 20 + 511) / 512;
+    uint4 rres[NPASS];
+#pragma unroll
+    for (int it = 0; it < NPASS; ++it) {
+        const int idx = tid + it * 512, row = idx / 20, ch = idx - row * 20;
+        rres[it] = make_uint4(0u, 0u, 0u, 0u);
+        if (p.res != nullptr && row < N) rres[it] = *reinterpret_cast<const uint4*>(p.res + (((int64_t)b * N + row) * HS_C + cq * HS_PW + ch * 8) * 2);
+    }
     HS_STAMP(1, 2);
     __syncthreads();
     HS_STAMP(1, 3);
-    if (!proj) return;
-    f32x16 acc[1][2];
+    if (proj) {
+        f32x16 acc[1][2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][mt][r] = 0.f;
-    hs_project<DT, 1, NSET>(wb, loff, X + l31 * XROWB + half * 16, wf, acc);
-    HS_STAMP(1, 4);
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int row = mt * 32 + l31;
-        float s1 = 0.f, s2 = 0.f;
+            for (int r = 0; r < 16; ++r) acc[0][mt][r] = 0.f;
+        hs_project<DT, 1, NSET, false>(wb, loff, X + l31 * XROWB + half * 16, wf, acc);
+        HS_STAMP(1, 4);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int col = c0 + 8 * g + 4 * half;
-            typename E::v4 rr = __builtin_bit_cast(typename E::v4, rx[mt][g]), y;
+            const typename E::v4 bv = __builtin_bit_cast(typename E::v4, bq[g]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float bv = p.bo != nullptr ? ld_elem<DT>(p.bo, col + e) : 0.f;
-                const float lin = (float)(typename E::elem)(acc[0][mt][4 * g + e] + bv);  // to_out rounded, then the residual add rounded (the chain's two roundings)
-                y[e] = (typename E::elem)(lin + (float)rr[e]);                              // (no residual: + 0 of an already rounded value is exact)
-                const float yf = (float)y[e];
-                s1 += yf;
-                s2 = __builtin_fmaf(yf, yf, s2);
+            for (int mt = 0; mt < 2; ++mt) {
+                typename E::v4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = (typename E::elem)(acc[0][mt][4 * g + e] + (float)bv[e]);  // to_out + bias, rounded (the chain's first rounding)
+                *reinterpret_cast<uint2*>(T + (mt * 32 + l31) * QROWB + (wave * 32 + 8 * g + 4 * half) * 2) = __builtin_bit_cast(uint2, y);
             }
-            if (row < N) *reinterpret_cast<uint2*>(p.out + (((int64_t)b * N + row) * HS_C + col) * 2) = __builtin_bit_cast(uint2, y);
         }
+    }
+    __syncthreads();
+    // + residual (the second rounding), whole 16-byte chunks: lanes 4 k .. 4 k + 3 hold one 32-column tile of one row -> its statistics by two DPP steps
+#pragma unroll
+    for (int it = 0; it < NPASS; ++it) {
+        const int idx = tid + it * 512, row = idx / 20, ch = idx - row * 20;
+        float y[8], r[8];
+        float s1 = 0.f, s2 = 0.f;
+        if (idx < HS_TM * 20) {
+            unpack8<DT>(*reinterpret_cast<const uint4*>(T + row * QROWB + ch * 16), y);
+            unpack8<DT>(rres[it], r);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = r[e] = 0.f;
+        }
+        const uint4 pk = [&] {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] += r[e];
+            return pack8<DT>(y);
+        }();
         if (p.rs_out != nullptr) {
-            s1 = half_sum(s1);
-            s2 = half_sum(s2);
-            if (half == 0 && row < N) *reinterpret_cast<float2*>(p.rs_out + (((int64_t)b * N + row) * 20 + cq * NTILE + wave) * 2) = make_float2(s1, s2);
+            float z[8];
+            unpack8<DT>(pk, z);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                s1 += z[e];
+                s2 = __builtin_fmaf(z[e], z[e], s2);
+            }
+            s1 = quad_sum(s1);
+            s2 = quad_sum(s2);
+        }
+        if (idx < HS_TM * 20 && row < N) {
+            *reinterpret_cast<uint4*>(p.out + (((int64_t)b * N + row) * HS_C + cq * HS_PW + ch * 8) * 2) = pk;
+            if (p.rs_out != nullptr && (lane & 3) == 0) *reinterpret_cast<float2*>(p.rs_out + (((int64_t)b * N + row) * 20 + cq * NTILE + (ch >> 2)) * 2) = make_float2(s1, s2);
         }
     }
     HS_STAMP(1, 9);
@@ -470,12 +555,12 @@ template <class K> int hs_ensure_lds(K kern, int bytes, bool (&done)[16], std::m
 
 template <int DT, bool SELF, bool NORM, int NS1, int NS2> int hs_attn_go2(const HsP& p, hipStream_t s) {
     constexpr int NSET = HS_NSET;
-    constexpr int LDS = SELF ? X_BYTES + 2 * Q_BYTES + V_BYTES : X_BYTES + Q_BYTES;
+    constexpr int LDS = SELF ? X_BYTES + 2 * Q_BYTES + V_BYTES + HS_BIAS_BYTES : X_BYTES + Q_BYTES + HS_BIAS_BYTES;
     static bool done[16] = {};
     static std::mutex mu;
     auto kern = hs_attn_kernel<DT, SELF, NORM, NS1, NS2, NSET>;
     if (hs_ensure_lds(kern, LDS, done, mu) != 0) return -1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * 4)), dim3(512), LDS, s, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)hs_grid(p.B, p.xm)), dim3(512), LDS, s, p);
     return apad_check_launch("apad_hs_attention");
 }
 template <int DT, bool SELF, int NS1, int NS2> int hs_attn_go(const HsP& p, hipStream_t s) {
@@ -498,12 +583,17 @@ template <int DT> int hs_out_launch(const HoP& p, hipStream_t s) {
     static bool done[16] = {};
     static std::mutex mu;
     auto kern = hs_out_kernel<DT, NSET>;
-    if (hs_ensure_lds(kern, X_BYTES, done, mu) != 0) return -1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * 4)), dim3(512), X_BYTES, s, p);
+    if (hs_ensure_lds(kern, X_BYTES + Q_BYTES, done, mu) != 0) return -1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)hs_grid(p.B, p.xm)), dim3(512), X_BYTES + Q_BYTES, s, p);
     return apad_check_launch("apad_hs_out");
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline int hs_env_xm(const char* name, int dflt) {
+    const char* e = getenv(name);
+    const int v = e ? atoi(e) : dflt;
+    return (v == 2 || v == 4 || v == 8) ? v : dflt;
+}
 
 }  // namespace
 
@@ -546,6 +636,8 @@ extern "C" int apad_hs_attention(const apad_hs_attn_desc* d, void* stream) {
     p.out = (uint8_t*)d->out;
     p.B = d->B; p.N = d->N; p.L1 = d->L1; p.Lpad1 = d->Lpad1; p.L2 = d->L2; p.Lpad2 = d->Lpad2;
     p.eps = d->ln_eps; p.scale_log2 = d->q_prescaled ? 1.0f : d->softmax_scale * LOG2E; p.scale2 = d->scale2;
+    static const int xm_self = hs_env_xm("APAD_HS_XM_SELF", 8), xm_cross = hs_env_xm("APAD_HS_XM_CROSS", 8);  // (A/B knobs, read once)
+    p.xm = self ? xm_self : xm_cross;
     hipStream_t s = (hipStream_t)stream;
     return d->dtype == APAD_BF16 ? hs_attn_launch<APAD_BF16>(p, self, s) : hs_attn_launch<APAD_F16>(p, self, s);
 }
@@ -564,6 +656,8 @@ extern "C" int apad_hs_out(const apad_hs_out_desc* d, void* stream) {
     HoP p;
     p.o = (const uint8_t*)d->o; p.w = (const uint8_t*)d->w_packed; p.bo = (const uint8_t*)d->bias; p.res = (const uint8_t*)d->residual;
     p.out = (uint8_t*)d->out; p.rs_out = d->rowstat_out; p.B = d->B; p.N = d->N;
+    static const int xm_out = hs_env_xm("APAD_HS_XM_OUT", 8);
+    p.xm = xm_out;
     hipStream_t s = (hipStream_t)stream;
     return d->dtype == APAD_BF16 ? hs_out_launch<APAD_BF16>(p, s) : hs_out_launch<APAD_F16>(p, s);
 }
