@@ -157,8 +157,11 @@ __device__ __forceinline__ void hs_rows_store(const uint4 (&u)[HS_CH], float eps
 // k-steps' fragments on entry; the fragment of k-step kk + NSET is requested right behind the MFMAs that consumed k-step kk, and the token
 // fragments of k-step kk + 1 are read from LDS in front of the MFMAs of kk.  The order is PINNED with sched_group_barrier: left alone, hipcc
 // sinks all 2 NSET loads of an unrolled body behind its last MFMA (prefetch distance 0: every body waits a full L2 round trip).
-template <int DT, int NT, int NSET, bool SWAP1>
-__device__ __forceinline__ void hs_project(const hs_gptr (&wb)[NT], uint32_t loff, const uint8_t* xs, typename ET<DT>::v8 (&wf)[NSET][NT], f32x16 (&acc)[NT][2]) {
+// CHAIN: a wave that runs several tile sets back to back (the GEGLU projection) requests the first NSET k-steps of the NEXT set (wbn) behind the
+// last NSET k-steps of this one, so the stream does not drain under the epilogue in between.
+template <int DT, int NT, int NSET, bool SWAP1, bool CHAIN = false>
+__device__ __forceinline__ void hs_project(const hs_gptr (&wb)[NT], uint32_t loff, const uint8_t* xs, typename ET<DT>::v8 (&wf)[NSET][NT], f32x16 (&acc)[NT][2],
+                                           const hs_gptr* wbn = nullptr) {
     using E = ET<DT>;
     static_assert(HS_KS % NSET == 0, "the register sets of weight fragments rotate over the k-steps");
     typename E::v8 t[2][2];  // [k-step parity][panel]
@@ -200,6 +203,18 @@ __device__ __forceinline__ void hs_project(const hs_gptr (&wb)[NT], uint32_t lof
     for (int i = 0; i < NSET; ++i) {
         if (i + 1 < NSET) { HS_LDT(HS_KS - NSET + i + 1, (i + 1) & 1); }
         HS_MM(i, i & 1);
+        if (CHAIN) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wf[i][j] = __builtin_bit_cast(typename E::v8, hs_ld16(wbn[j] + i * 1024, loff));
+        }
+    }
+    if (CHAIN) {
+#pragma unroll
+        for (int i = 0; i < NSET; ++i) {
+            if (i + 1 < NSET) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * NT, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, NT, 0);
+        }
     }
 #undef HS_LDT
 #undef HS_MM
@@ -416,6 +431,103 @@ __global__ __launch_bounds__(512) void hs_attn_kernel(HsP p) {
     HS_STAMP(0, 9);
 }
 
+// ---- the feed-forward's first half at the same level: H = value * gelu(gate), [value | gate] = Linear(LayerNorm(x)) (diffusers GEGLU: proj 640 -> 5120) ----
+// workgroup = (sample, hidden quarter): the 640 hidden units of the quarter are 20 tiles of 32, each a (value, gate) pair of weight row tiles;
+// wave w runs hidden tiles w, w + 8 (, w + 16 for w < 4: the two waves of a SIMD together always 5) one after the other against the X tile, the weight
+// stream of the next tile requested under the tail of the current one; value and gate rounded like the chain's Linear output, the product rounded once;
+// H rows leave through a per-wave [64][32] LDS scratch as 64-byte row segments.
+struct HgP {
+    const uint8_t* x;
+    const uint8_t* w;    // packed [4 quarters][20 hidden tiles][2: value, gate][40 k-steps][64 lanes][8] (gamma folded in)
+    const float* wbias;  // [4][20][2][32] fp32: W . beta + bias
+    uint8_t* out;        // H [B * N][2560]
+    int32_t B, N, normalize, xm;
+    float eps;
+};
+constexpr int HG_TILES = 20, HG_SROWB = 32 * 2 + 16, HG_STG = HS_TM * HG_SROWB, HG_BIAS_BYTES = HG_TILES * 2 * 32 * 4;
+
+template <int DT, bool NORM, int NSET>
+__global__ __launch_bounds__(512) void hs_geglu_kernel(HgP p) {
+    using E = ET<DT>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t* const X = smem;
+    uint8_t* const BIAS = smem + X_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint8_t* const STG = BIAS + HG_BIAS_BYTES + wave * HG_STG;
+    const int half = lane >> 5, l31 = lane & 31;
+    int b, hq;
+    hs_decode(blockIdx.x, p.xm, b, hq);
+    if (b >= p.B) return;
+    const int N = p.N;
+    uint4 xr[HS_CH];
+    hs_rows_load(xr, p.x + (int64_t)b * N * HS_C * 2, N, tid);
+    const int ntl = wave < 4 ? 3 : 2;
+    const uint32_t loff = (uint32_t)lane * 16u;
+    auto tile_base = [&](int t, int j) { return sgpr_ptr(p.w + ((int64_t)((hq * HG_TILES + t) * 2 + j) * HS_KS) * 1024); };
+    hs_gptr wb[2] = {tile_base(wave, 0), tile_base(wave, 1)};
+    typename E::v8 wf[NSET][2];
+    constexpr int PRE = HS_PRE < NSET ? HS_PRE : NSET;
+#pragma unroll
+    for (int i = 0; i < PRE; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) wf[i][j] = __builtin_bit_cast(typename E::v8, hs_ld16(wb[j] + i * 1024, loff));
+    if (tid < HG_TILES * 2 * 8 && p.wbias != nullptr)
+        *reinterpret_cast<float4*>(BIAS + tid * 16) = *reinterpret_cast<const float4*>(p.wbias + hq * HG_TILES * 2 * 32 + tid * 4);
+    hs_rows_store<DT, NORM>(xr, p.eps, N, X, tid);
+#pragma unroll
+    for (int i = PRE; i < NSET; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) wf[i][j] = __builtin_bit_cast(typename E::v8, hs_ld16(wb[j] + i * 1024, loff));
+    __syncthreads();
+    uint8_t* const hb = p.out + ((int64_t)b * N * 4 * HS_C + hq * HS_C) * 2;
+#pragma unroll 1
+    for (int it = 0; it < ntl; ++it) {
+        const int t = wave + 8 * it;
+        const int tn = it + 1 < ntl ? t + 8 : t;  // (after the last tile: its own first fragments once more, unused)
+        const hs_gptr wbn[2] = {tile_base(tn, 0), tile_base(tn, 1)};
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][mt][r] = 0.f;
+        hs_project<DT, 2, NSET, false, true>(wb, loff, X + l31 * XROWB + half * 16, wf, acc, wbn);
+        wb[0] = wbn[0];
+        wb[1] = wbn[1];
+        const float* bp = reinterpret_cast<const float*>(BIAS) + t * 64;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), bg = bv;
+            if (p.wbias != nullptr) {
+                bv = *reinterpret_cast<const float4*>(bp + 8 * g + 4 * half);
+                bg = *reinterpret_cast<const float4*>(bp + 32 + 8 * g + 4 * half);
+            }
+            const float bva[4] = {bv.x, bv.y, bv.z, bv.w}, bga[4] = {bg.x, bg.y, bg.z, bg.w};
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                typename E::v4 y;
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    // (value and gate rounded to the storage type like the chain's Linear output; the product rounded once)
+                    const apad_f32x2 gg = {(float)(typename E::elem)(acc[1][mt][4 * g + e] + bga[e]), (float)(typename E::elem)(acc[1][mt][4 * g + e + 1] + bga[e + 1])};
+                    const apad_f32x2 ge = gelu_erf_2(gg);
+                    y[e] = (typename E::elem)((float)(typename E::elem)(acc[0][mt][4 * g + e] + bva[e]) * ge[0]);
+                    y[e + 1] = (typename E::elem)((float)(typename E::elem)(acc[0][mt][4 * g + e + 1] + bva[e + 1]) * ge[1]);
+                }
+                *reinterpret_cast<uint2*>(STG + (mt * 32 + l31) * HG_SROWB + (8 * g + 4 * half) * 2) = __builtin_bit_cast(uint2, y);
+            }
+        }
+        // this wave's [64][32] tile -> H: 4 lanes per row, 64 contiguous bytes per row and instruction
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const int row = q4 * 16 + (lane >> 2), ch = lane & 3;
+            const uint4 v = *reinterpret_cast<const uint4*>(STG + row * HG_SROWB + ch * 16);
+            if (row < N) *reinterpret_cast<uint4*>(hb + ((int64_t)row * 4 * HS_C + t * 32 + ch * 8) * 2) = v;
+        }
+    }
+}
+
 struct HoP {
     const uint8_t* o;
     const uint8_t* w;  // packed [4 quarters][5 row tiles][40 k-steps][64 lanes][8]
@@ -538,6 +650,197 @@ __global__ __launch_bounds__(512) void hs_out_kernel(HoP p) {
     HS_STAMP(1, 9);
 }
 
+// ---- the feed-forward's second half: out = x + (H . W2^T + b2), H [64][2560] per sample, workgroup = (sample, output-column quarter) ----
+// K = 2560 does not fit LDS: H streams through two [64][320] LDS buffers (8 chunks of 20 k-steps; chunk c + 1 is fetched into registers while chunk c
+// is multiplied, stored behind it, one barrier per chunk).  The 8 waves split every chunk by K-QUARTER x TILE GROUP -- wave (kq, tg) runs k-steps
+// 5 kq .. 5 kq + 4 of the chunk for row tiles {0, 1, 2} (tg 0) or {3, 4} (tg 1) on both token panels -- so every packed weight fragment is loaded exactly
+// once per workgroup (5 k-steps = one chunk ahead) and the two waves of a SIMD (w, w + 4) together always issue 50 MFMAs per chunk.  The four K-quarter
+// partials of an output tile are summed in a FIXED order (kq 0 + 1 + 2 + 3, through LDS), then bias, rounding, + residual and the row statistics exactly
+// as in hs_out_kernel.
+struct HfP {
+    const uint8_t* h;    // [B * N][2560]
+    const uint8_t* w;    // packed [4 quarters][5 row tiles][160 k-steps][64 lanes][8]
+    const uint8_t* bo;
+    const uint8_t* res;
+    uint8_t* out;
+    float* rs_out;
+    int32_t B, N, xm;
+};
+constexpr int HF_K = 4 * HS_C, HF_KS = HF_K / 16, HF_CK = 20, HF_NCH = HF_KS / HF_CK, HF_ROWB = HF_CK * 32 + 16, HF_BUF = HS_TM * HF_ROWB;
+constexpr int HF_RED = 3 * 10 * 4096;  // fp32 partials of the K-quarters 1 .. 3: [kq - 1][tile * 2 + panel][4 register groups][64 lanes][4]
+constexpr int HF_LDS = (2 * HF_BUF > HF_RED ? 2 * HF_BUF : HF_RED) + Q_BYTES;
+
+template <int DT, int NTW>
+__device__ __forceinline__ void hf_body(const HfP& p, uint8_t* smem, int b, int cq, int tid, int lane, int wave) {
+    using E = ET<DT>;
+    const int half = lane >> 5, l31 = lane & 31, kq = wave & 3, t0 = (wave >> 2) * 3;
+    const int N = p.N;
+    uint8_t* const T = smem + (HF_LDS - Q_BYTES);
+    const uint32_t loff = (uint32_t)lane * 16u;
+    hs_gptr wb[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) wb[j] = sgpr_ptr(p.w + ((int64_t)((cq * 5 + t0 + j) * HF_KS + kq * 5)) * 1024);
+    // H chunk staging: 64 rows x 40 sixteen-byte pieces = 5 per thread
+    const uint8_t* const hb = p.h + (int64_t)b * N * HF_K * 2;
+    int srow[5], sch[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int idx = tid + i * 512;
+        srow[i] = idx / 40;
+        sch[i] = idx - srow[i] * 40;
+    }
+    uint4 hr[5];
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int rr = srow[i] < N ? srow[i] : N - 1;
+            hr[i] = *reinterpret_cast<const uint4*>(hb + ((int64_t)rr * HF_K + c * (HF_CK * 16) + sch[i] * 8) * 2);
+        }
+    };
+    auto store_chunk = [&](int c) {
+        uint8_t* const dst = smem + (c & 1) * HF_BUF;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) *reinterpret_cast<uint4*>(dst + srow[i] * HF_ROWB + sch[i] * 16) = srow[i] < N ? hr[i] : make_uint4(0u, 0u, 0u, 0u);
+    };
+    load_chunk(0);
+    typename E::v8 wf[5][NTW];
+#pragma unroll
+    for (int s_ = 0; s_ < 5; ++s_)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) wf[s_][j] = __builtin_bit_cast(typename E::v8, hs_ld16(wb[j] + s_ * 1024, loff));
+    uint2 bq[NTW][4];
+    if (kq == 0) {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                bq[j][g] = p.bo != nullptr ? *reinterpret_cast<const uint2*>(p.bo + (cq * HS_PW + (t0 + j) * 32 + 8 * g + 4 * half) * 2) : make_uint2(0u, 0u);
+    }
+    constexpr int NPASS = (HS_TM * 20 + 511) / 512;
+    uint4 rres[NPASS];
+#pragma unroll
+    for (int it = 0; it < NPASS; ++it) {
+        const int idx = tid + it * 512, row = idx / 20, ch = idx - row * 20;
+        rres[it] = make_uint4(0u, 0u, 0u, 0u);
+        if (p.res != nullptr && row < N) rres[it] = *reinterpret_cast<const uint4*>(p.res + (((int64_t)b * N + row) * HS_C + cq * HS_PW + ch * 8) * 2);
+    }
+    store_chunk(0);
+    __syncthreads();
+    f32x16 acc[NTW][2];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][mt][r] = 0.f;
+#pragma unroll 1
+    for (int c = 0; c < HF_NCH; ++c) {
+        const bool more = c + 1 < HF_NCH;
+        const int cn = more ? c + 1 : c;  // (last chunk: re-reads itself, unused -- keeps the loop branch-free)
+        load_chunk(cn);
+        const uint8_t* xs = smem + (c & 1) * HF_BUF + l31 * HF_ROWB + half * 16 + kq * 5 * 32;
+#pragma unroll
+        for (int s_ = 0; s_ < 5; ++s_) {
+            const typename E::v8 ta = as_v8<DT>(*reinterpret_cast<const uint4*>(xs + s_ * 32));
+            const typename E::v8 tb = as_v8<DT>(*reinterpret_cast<const uint4*>(xs + 32 * HF_ROWB + s_ * 32));
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                acc[j][0] = E::mfma32(wf[s_][j], ta, acc[j][0]);
+                acc[j][1] = E::mfma32(wf[s_][j], tb, acc[j][1]);
+            }
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) wf[s_][j] = __builtin_bit_cast(typename E::v8, hs_ld16(wb[j] + (cn * HF_CK + s_) * 1024, loff));
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < 5; ++s_) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * NTW, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, NTW, 0);
+        }
+        store_chunk(c + 1);  // (c + 1 == HF_NCH lands in the buffer nobody reads any more)
+        __syncthreads();
+    }
+    // ---- K-quarter partials -> one sum per tile, fixed order ----
+    if (kq != 0) {
+        float* const R = reinterpret_cast<float*>(smem) + (kq - 1) * 10 * 1024;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(R + (((t0 + j) * 2 + mt) * 4 + g) * 256 + lane * 4) =
+                        make_float4(acc[j][mt][4 * g], acc[j][mt][4 * g + 1], acc[j][mt][4 * g + 2], acc[j][mt][4 * g + 3]);
+    }
+    __syncthreads();
+    if (kq == 0) {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const typename E::v4 bv = __builtin_bit_cast(typename E::v4, bq[j][g]);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    float v[4] = {acc[j][mt][4 * g], acc[j][mt][4 * g + 1], acc[j][mt][4 * g + 2], acc[j][mt][4 * g + 3]};
+#pragma unroll
+                    for (int k_ = 0; k_ < 3; ++k_) {
+                        const float4 o = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(smem) + k_ * 10 * 1024 + (((t0 + j) * 2 + mt) * 4 + g) * 256 + lane * 4);
+                        v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+                    }
+                    typename E::v4 y;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = (typename E::elem)(v[e] + (float)bv[e]);
+                    *reinterpret_cast<uint2*>(T + (mt * 32 + l31) * QROWB + ((t0 + j) * 32 + 8 * g + 4 * half) * 2) = __builtin_bit_cast(uint2, y);
+                }
+            }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NPASS; ++it) {
+        const int idx = tid + it * 512, row = idx / 20, ch = idx - row * 20;
+        float y[8], r[8];
+        float s1 = 0.f, s2 = 0.f;
+        if (idx < HS_TM * 20) {
+            unpack8<DT>(*reinterpret_cast<const uint4*>(T + row * QROWB + ch * 16), y);
+            unpack8<DT>(rres[it], r);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = r[e] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] += r[e];
+        const uint4 pk = pack8<DT>(y);
+        if (p.rs_out != nullptr) {
+            float z[8];
+            unpack8<DT>(pk, z);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                s1 += z[e];
+                s2 = __builtin_fmaf(z[e], z[e], s2);
+            }
+            s1 = quad_sum(s1);
+            s2 = quad_sum(s2);
+        }
+        if (idx < HS_TM * 20 && row < N) {
+            *reinterpret_cast<uint4*>(p.out + (((int64_t)b * N + row) * HS_C + cq * HS_PW + ch * 8) * 2) = pk;
+            if (p.rs_out != nullptr && (lane & 3) == 0) *reinterpret_cast<float2*>(p.rs_out + (((int64_t)b * N + row) * 20 + cq * 5 + (ch >> 2)) * 2) = make_float2(s1, s2);
+        }
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(512) void hs_ff2_kernel(HfP p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int b, cq;
+    hs_decode(blockIdx.x, p.xm, b, cq);
+    if (b >= p.B) return;
+    if (wave < 4)
+        hf_body<DT, 3>(p, smem, b, cq, tid, lane, wave);
+    else
+        hf_body<DT, 2>(p, smem, b, cq, tid, lane, wave);
+}
+
 // dynamic LDS above 64 KB needs the attribute once per (kernel, device)
 template <class K> int hs_ensure_lds(K kern, int bytes, bool (&done)[16], std::mutex& mu) {
     int dev = 0;
@@ -586,6 +889,25 @@ template <int DT> int hs_out_launch(const HoP& p, hipStream_t s) {
     if (hs_ensure_lds(kern, X_BYTES + Q_BYTES, done, mu) != 0) return -1;
     hipLaunchKernelGGL(kern, dim3((unsigned)hs_grid(p.B, p.xm)), dim3(512), X_BYTES + Q_BYTES, s, p);
     return apad_check_launch("apad_hs_out");
+}
+
+template <int DT, bool NORM> int hs_geglu_go(const HgP& p, hipStream_t s) {
+    constexpr int LDS = X_BYTES + HG_BIAS_BYTES + 8 * HG_STG;
+    static bool done[16] = {};
+    static std::mutex mu;
+    auto kern = hs_geglu_kernel<DT, NORM, HS_NSET>;
+    if (hs_ensure_lds(kern, LDS, done, mu) != 0) return -1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)hs_grid(p.B, p.xm)), dim3(512), LDS, s, p);
+    return apad_check_launch("apad_hs_geglu");
+}
+
+template <int DT> int hs_ff2_launch(const HfP& p, hipStream_t s) {
+    static bool done[16] = {};
+    static std::mutex mu;
+    auto kern = hs_ff2_kernel<DT>;
+    if (hs_ensure_lds(kern, HF_LDS, done, mu) != 0) return -1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)hs_grid(p.B, p.xm)), dim3(512), HF_LDS, s, p);
+    return apad_check_launch("apad_hs_ff2");
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -640,6 +962,44 @@ extern "C" int apad_hs_attention(const apad_hs_attn_desc* d, void* stream) {
     p.xm = self ? xm_self : xm_cross;
     hipStream_t s = (hipStream_t)stream;
     return d->dtype == APAD_BF16 ? hs_attn_launch<APAD_BF16>(p, self, s) : hs_attn_launch<APAD_F16>(p, self, s);
+}
+
+extern "C" int apad_hs_geglu(const void* x, const void* w_packed, const float* w_bias, void* out, int32_t B, int32_t N, int32_t C, int32_t normalize, float ln_eps,
+                             int32_t dtype, void* stream) {
+    APAD_CHECK(dtype == APAD_BF16 || dtype == APAD_F16, "apad_hs_geglu: dtype %d not supported (16-bit only)", dtype);
+    if (C != HS_C || N < 1 || N > HS_TM) {
+        apad_set_error("apad_hs_geglu: C=%d N=%d outside the kernel envelope (640, 1..64)", C, N);
+        return -3;
+    }
+    APAD_CHECK(x && w_packed && out && B > 0, "apad_hs_geglu: null operand / empty batch");
+    APAD_CHECK(al16(x) && al16(w_packed) && al16(out) && al16(w_bias), "apad_hs_geglu: pointers must be 16-byte aligned");
+    HgP p;
+    p.x = (const uint8_t*)x; p.w = (const uint8_t*)w_packed; p.wbias = w_bias; p.out = (uint8_t*)out;
+    p.B = B; p.N = N; p.normalize = normalize ? 1 : 0; p.eps = ln_eps;
+    static const int xm = hs_env_xm("APAD_HS_XM_GEGLU", 2);
+    p.xm = xm;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == APAD_BF16) return p.normalize ? hs_geglu_go<APAD_BF16, true>(p, s) : hs_geglu_go<APAD_BF16, false>(p, s);
+    return p.normalize ? hs_geglu_go<APAD_F16, true>(p, s) : hs_geglu_go<APAD_F16, false>(p, s);
+}
+
+extern "C" int apad_hs_ff2(const apad_hs_out_desc* d, void* stream) {
+    APAD_CHECK(d != nullptr, "apad_hs_ff2: null descriptor");
+    APAD_CHECK(d->dtype == APAD_BF16 || d->dtype == APAD_F16, "apad_hs_ff2: dtype %d not supported (16-bit only)", d->dtype);
+    if (d->C != HS_C || d->N < 1 || d->N > HS_TM) {
+        apad_set_error("apad_hs_ff2: C=%d N=%d outside the kernel envelope (640, 1..64)", d->C, d->N);
+        return -3;
+    }
+    APAD_CHECK(d->o && d->w_packed && d->out && d->B > 0, "apad_hs_ff2: null operand / empty batch");
+    APAD_CHECK(al16(d->o) && al16(d->w_packed) && al16(d->residual) && al16(d->out) && (reinterpret_cast<uintptr_t>(d->rowstat_out) & 7) == 0,
+               "apad_hs_ff2: pointers must be 16-byte aligned (rowstat_out: 8)");
+    HfP p;
+    p.h = (const uint8_t*)d->o; p.w = (const uint8_t*)d->w_packed; p.bo = (const uint8_t*)d->bias; p.res = (const uint8_t*)d->residual;
+    p.out = (uint8_t*)d->out; p.rs_out = d->rowstat_out; p.B = d->B; p.N = d->N;
+    static const int xm = hs_env_xm("APAD_HS_XM_FF2", 8);
+    p.xm = xm;
+    hipStream_t s = (hipStream_t)stream;
+    return d->dtype == APAD_BF16 ? hs_ff2_launch<APAD_BF16>(p, s) : hs_ff2_launch<APAD_F16>(p, s);
 }
 
 extern "C" int apad_hs_out(const apad_hs_out_desc* d, void* stream) {

@@ -348,6 +348,15 @@ def hs_ok(x, heads, n_q_rows):
             and x.dtype in FUSED_DTYPES and x.is_contiguous())
 
 
+HS_FF2 = _os.environ.get("APAD_HS_FF2", "1") == "1"  # A/B switch: its second Linear through apad_hs_ff2 (0: the tiled GEMM)
+HS_FF = _os.environ.get("APAD_HS_FF", "1") == "1"  # A/B switch: the feed-forward of that level through apad_hs_geglu (+ apad_hs_ff2)
+
+
+def hs_rows_ok(x):
+    """[B, <= 64, 640] contiguous 16-bit rows: what the row-tile kernels of csrc/hsattn.hip take"""
+    return x.dim() == 3 and x.shape[-1] == HS_C and x.shape[1] <= HS_MAXN and x.dtype in FUSED_DTYPES and x.is_contiguous()
+
+
 def hs_cross_lengths_ok(L1, L2=0):
     return 1 <= L1 <= 64 and (0 <= L2 <= 64 or (L2 <= 128 and L1 <= 32))
 
@@ -394,6 +403,61 @@ def hs_pack_qkv(wq, wk, wv, ln=None, q_scale=1.0):
     if bb is not None:
         bb = torch.stack(bb, 0).reshape(3, 4, 160).permute(1, 0, 2).contiguous().reshape(-1)
     return pk, bb
+
+
+def hs_pack_geglu(w1, b1, ln=None):
+    """GEGLU projection [5120, 640] (+ bias [5120]) -> ([4 hidden quarters][20 tiles][value, gate][40][64][8] packing, fp32 bias [4][20][2][32]);
+    ln = (gamma, beta, eps) folded in as in hs_pack_rows"""
+    wf = w1.detach().float()
+    bb = torch.zeros(wf.shape[0], device=wf.device) if b1 is None else b1.detach().float()
+    if ln is not None:
+        bb = wf @ ln[1].detach().float() + bb
+        wf = wf * ln[0].detach().float()
+    w = wf.to(w1.dtype).reshape(2, 4, 20, 32, 40, 2, 8).permute(1, 2, 0, 4, 5, 3, 6)  # [q][t][which][ks][half][row][8]
+    return w.contiguous().reshape(-1), bb.reshape(2, 4, 20, 32).permute(1, 2, 0, 3).contiguous().reshape(-1)
+
+
+def hs_geglu(x, w_packed, w_bias, normalize=True, ln_eps=1e-5, out=None):
+    """H [B, N, 2560] = value * gelu(gate), [value | gate] = Linear(LayerNorm(x)) of the 64-token level's feed-forward in one launch (apad_hs_geglu;
+    weights from hs_pack_geglu)"""
+    _req(x, "hs_geglu.x", w_packed.dtype)
+    B, N, Cc = x.shape
+    if Cc != HS_C or N > HS_MAXN or x.dtype not in FUSED_DTYPES or not x.is_contiguous():
+        raise ValueError(f"hs_geglu: x {tuple(x.shape)} {x.dtype} outside the kernel envelope")
+    if out is None:
+        out = torch.empty(B, N, 4 * Cc, dtype=x.dtype, device=x.device)
+    L.check(L.lib().apad_hs_geglu(x.data_ptr(), w_packed.data_ptr(), _ptr(w_bias), out.data_ptr(), B, N, Cc, int(bool(normalize)), float(ln_eps),
+                                  _DT[x.dtype], _stream()), "apad_hs_geglu")
+    return out
+
+
+def hs_pack_ff2(w2):
+    """FF2 weight [640, 2560] -> fragment packing per 160-row output quarter: [4][5 tiles][160 k-steps][half][row][8]"""
+    return w2.detach().reshape(4, 5, 32, 160, 2, 8).permute(0, 1, 3, 4, 2, 5).contiguous().reshape(-1)
+
+
+def hs_ff2(h, w2_packed, bias, residual, rowstat=False, out=None):
+    """out = (residual +) (h @ W2^T + bias) for h [B, <= 64, 2560] -> [B, N, 640] (apad_hs_ff2; W2 from hs_pack_ff2); rowstat as hs_out"""
+    _req(h, "hs_ff2.h", w2_packed.dtype)
+    B, N, K = h.shape
+    if K != 4 * HS_C or N > HS_MAXN or h.dtype not in FUSED_DTYPES or not h.is_contiguous():
+        raise ValueError(f"hs_ff2: h {tuple(h.shape)} outside the kernel envelope")
+    if residual is not None:
+        _req(residual, "hs_ff2.residual", h.dtype)
+        if not residual.is_contiguous() or tuple(residual.shape) != (B, N, HS_C):
+            raise ValueError(f"hs_ff2: residual {tuple(residual.shape)} must be contiguous [B, N, 640]")
+    if out is None:
+        out = torch.empty(B, N, HS_C, dtype=h.dtype, device=h.device)
+    rs = torch.empty(B * N, 20, 2, dtype=torch.float32, device=h.device) if (rowstat and LN_FOLD) else None
+    d = L.HsOutDesc()
+    d.o, d.w_packed, d.bias, d.residual, d.out, d.rowstat_out = h.data_ptr(), w2_packed.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), _ptr(rs)
+    d.B, d.N, d.C, d.dtype = B, N, HS_C, _DT[h.dtype]
+    L.check(L.lib().apad_hs_ff2(C.byref(d), _stream()), "apad_hs_ff2")
+    if rs is not None:
+        out._apad_rowstat = rs
+    elif hasattr(out, "_apad_rowstat"):
+        del out._apad_rowstat
+    return out
 
 
 def hs_attention(x, w_packed, w_bias, *, self_attention, normalize=True, ln_eps=1e-5, k1=None, vt1=None, key_bias=None, k2=None, vt2=None,

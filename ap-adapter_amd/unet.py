@@ -147,6 +147,15 @@ class FeedForward(nn.Module):
         super().__init__()
         self.net = nn.ModuleList([GEGLU(dim, dim * 4), nn.Dropout(0.0), nn.Linear(dim * 4, dim)])
 
+    def _hs_weights(self, ln):
+        """fragment-packed GEGLU projection (norm3 folded in) of apad_hs_geglu, re-packed when a parameter is re-assigned, moved, cast or updated"""
+        ps = (self.net[0].proj.weight, self.net[0].proj.bias, ln[0], ln[1], self.net[2].weight)
+        key = tuple((id(p), p.data_ptr(), p._version, p.dtype, p.device) for p in ps) + (float(ln[2]),)
+        if getattr(self, "_hs_key", None) != key:
+            self._hs_w = ops.hs_pack_geglu(self.net[0].proj.weight, self.net[0].proj.bias, ln=ln) + (ops.hs_pack_ff2(self.net[2].weight),)
+            self._hs_key = key
+        return self._hs_w
+
     def forward(self, x, ln):
         """x un-normalised; ln = norm3.  C in ops.MLP_C: the whole feed-forward + residual in one launch (the 4C-wide
         activation never reaches HBM); otherwise LayerNorm + GEGLU projection in one launch, then the 4C->C GEMM +
@@ -155,6 +164,13 @@ class FeedForward(nn.Module):
             xn, xr = AG.layer_norm_res(x, *ln)  # (the residual gradient joins the LayerNorm backward launch)
             h = AG.geglu(AG.linear(xn, self.net[0].proj.weight, self.net[0].proj.bias))
             return AG.linear(h, self.net[2].weight, self.net[2].bias, residual=xr)
+        if ops.HS_FF and ops.HS_ATTN and ops.hs_rows_ok(x) and self.net[0].proj.weight.shape[0] == 8 * ops.HS_C:
+            # the 64-token level: LayerNorm + GEGLU projection in ONE launch, workgroup = (sample, hidden quarter) (csrc/hsattn.hip)
+            pk, bb, w2p = self._hs_weights(ln)
+            h = ops.hs_geglu(x, pk, bb, ln_eps=ln[2])
+            if ops.HS_FF2:
+                return ops.hs_ff2(h, w2p, self.net[2].bias, x, rowstat=True)
+            return ops.linear(h, self.net[2].weight, self.net[2].bias, residual=x, rowstat=True)
         if x.shape[-1] in ops.MLP_C and x.dtype in ops.FUSED_DTYPES and os.environ.get("APAD_FUSED_MLP", "1") != "0":
             return ops.geglu_mlp(x, self.net[0].proj.weight, self.net[0].proj.bias, self.net[2].weight, self.net[2].bias, ln=ln)
         h = ops.fused_linear(x, self.net[0].proj.weight, self.net[0].proj.bias, ln=ln, act="geglu")

@@ -306,6 +306,16 @@ typedef struct apad_hs_out_desc {
 } apad_hs_out_desc;
 int apad_sizeof_hs_out_desc(void);
 int apad_hs_out(const apad_hs_out_desc* d, void* stream);
+/* the feed-forward's second Linear at that level with the same descriptor: o = H [B*N][2560], w_packed = W2 [640][2560] packed per output quarter
+ *   w_packed[((q * 5 + t) * 160 + ks) * 512 + lane * 8 + e] = W2[q * 160 + t * 32 + (lane & 31)][ks * 16 + (lane >> 5) * 8 + e]
+ * out = residual + (H . W2^T + bias); the four K-quarters of a workgroup are summed in a fixed order */
+int apad_hs_ff2(const apad_hs_out_desc* d, void* stream);
+/* The feed-forward's GEGLU projection at the same level (diffusers GEGLU behind norm3: H = value * gelu(gate), [value | gate] = Linear(640 -> 5120)),
+ * workgroup = (sample, hidden quarter), rows normalised in the launch (normalize = 1; gamma / beta folded into w_packed / w_bias like above):
+ *   w_packed[(((q * 20 + t) * 2 + j) * 40 + ks) * 512 + lane * 8 + e] = W[j * 2560 + q * 640 + t * 32 + (lane & 31)][ks * 16 + (lane >> 5) * 8 + e]
+ *   w_bias[((q * 20 + t) * 2 + j) * 32 + r] (fp32) = (W . beta + b)[j * 2560 + q * 640 + t * 32 + r]          x [B*N][640] -> out H [B*N][2560]      (ABI 7) */
+int apad_hs_geglu(const void* x, const void* w_packed, const float* w_bias, void* out, int32_t B, int32_t N, int32_t C, int32_t normalize, float ln_eps,
+                  int32_t dtype, void* stream);
 /* w [256][ldw] (nn.Linear layout) -> packed [8 row slices][16 k-steps][64 lanes][8], 128 KB */
 int apad_xattn_pack_weight(const void* w, void* packed, int64_t ldw, int32_t dtype, void* stream);
 /* bytes of the packed form of one segment's K / V^T: B * 8 heads * ceil(L/32) * 4 KB */

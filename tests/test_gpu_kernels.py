@@ -963,6 +963,70 @@ def test_hs_cross_attention_sublayer(dev, dtype, B, N, Lt, La, masked):
     assert rel_err(out, chain.float().cpu()) < TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", DTYPES16)
+@pytest.mark.parametrize("B,N", [(2, 64), (5, 64), (3, 16), (2, 40), (64, 64), (1, 1)])
+def test_hs_geglu(dev, dtype, B, N):
+    """LayerNorm + GEGLU projection (640 -> 5120 -> 2560) of the 64-token level's feed-forward in one launch (workgroup = (sample, hidden
+    quarter), three / two hidden tiles per wave back to back) against fp32 torch on storage-rounded operands and the chain's launch"""
+    from ap_adapter_amd import ops
+    C = 640
+    x = q(R(B, N, C, seed=441) + 0.5, dtype)
+    g, be = q(1 + 0.1 * R(C, seed=442), dtype), q(0.1 * R(C, seed=443), dtype)
+    w1, b1 = q(R(8 * C, C, seed=444, std=0.05), dtype), q(R(8 * C, seed=445, std=0.2), dtype)
+    y = F.linear(F.layer_norm(x, (C,), g, be, 1e-5), w1, b1)
+    a, gt = y.chunk(2, dim=-1)
+    ref = a * F.gelu(gt)
+    D = lambda t: t.to(dev, dtype)
+    xd, ln = D(x), (D(g), D(be), 1e-5)
+    pk, bb = ops.hs_pack_geglu(D(w1), D(b1), ln=ln)
+    h = ops.hs_geglu(xd, pk, bb, ln_eps=1e-5)
+    assert h.shape == ref.shape and rel_err(h, ref) < 1.5 * TOL[dtype]
+    chain = ops.linear(ops.layer_norm(xd, *ln), D(w1), D(b1), act="geglu")
+    assert rel_err(h, chain.float().cpu()) < TOL[dtype]
+    i = B // 2  # a sample's rows do not depend on its batch
+    assert torch.equal(ops.hs_geglu(xd[i:i + 1].contiguous(), pk, bb, ln_eps=1e-5)[0], h[i])
+    # the packing: quarter qq, hidden tile t, value / gate j
+    wt = torch.arange(5120 * 640, dtype=torch.float32).reshape(5120, 640).to(dev)
+    pw, pb = ops.hs_pack_geglu(wt, torch.arange(5120, dtype=torch.float32).to(dev))
+    pw = pw.reshape(4, 20, 2, 40, 2, 32, 8)
+    assert torch.equal(pw[3, 17, 1, 5, 1, 30], wt[2560 + 3 * 640 + 17 * 32 + 30, 5 * 16 + 8: 5 * 16 + 16])
+    assert float(pb.reshape(4, 20, 2, 32)[2, 9, 1, 7]) == 2560 + 2 * 640 + 9 * 32 + 7
+
+
+@pytest.mark.parametrize("dtype", DTYPES16)
+@pytest.mark.parametrize("B,N", [(2, 64), (5, 64), (3, 16), (2, 40), (64, 64), (1, 1)])
+def test_hs_ff2(dev, dtype, B, N):
+    """out = x + (H @ W2^T + b2) with H [B, N, 2560] streamed through LDS in eight chunks and the K-quarters of a workgroup summed in a fixed order;
+    against fp32 torch and the tiled GEMM; row statistics of the stored rows; batch independence; no residual / bias; in place"""
+    from ap_adapter_amd import ops
+    C = 640
+    h = q(R(B, N, 4 * C, seed=451), dtype)
+    x = q(R(B, N, C, seed=452), dtype)
+    w2, b2 = q(R(C, 4 * C, seed=453, std=0.03), dtype), q(R(C, seed=454, std=0.3), dtype)
+    ref = x + F.linear(h, w2, b2)
+    D = lambda t: t.to(dev, dtype)
+    hd, xd = D(h), D(x)
+    wp = ops.hs_pack_ff2(D(w2))
+    out = ops.hs_ff2(hd, wp, D(b2), xd, rowstat=True)
+    assert out.shape == ref.shape and rel_err(out, ref) < TOL[dtype]
+    rs = ops.rowstat_of(out)
+    xs = out.float().cpu().reshape(B * N, C)
+    assert tuple(rs.shape) == (B * N, 20, 2)
+    assert rel_err(rs[..., 0].sum(1), xs.sum(1)) < 1e-5 and rel_err(rs[..., 1].sum(1), (xs * xs).sum(1)) < 1e-5
+    chain = ops.linear(hd, D(w2), D(b2), residual=xd)
+    assert rel_err(out, chain.float().cpu()) < TOL[dtype]
+    i = B // 2
+    assert torch.equal(ops.hs_ff2(hd[i:i + 1].contiguous(), wp, D(b2), xd[i:i + 1].contiguous())[0], out[i])
+    bare = ops.hs_ff2(hd, wp, None, None)
+    assert rel_err(bare, F.linear(h, w2)) < TOL[dtype]
+    x2 = xd.clone()
+    ops.hs_ff2(hd, wp, D(b2), x2, out=x2)
+    assert torch.equal(x2, out)
+    wt = torch.arange(640 * 2560, dtype=torch.float32).reshape(640, 2560).to(dev)
+    pk = ops.hs_pack_ff2(wt).reshape(4, 5, 160, 2, 32, 8)
+    assert torch.equal(pk[1, 4, 159, 1, 3], wt[160 + 4 * 32 + 3, 159 * 16 + 8: 159 * 16 + 16])
+
+
 def test_hs_attention_outside_envelope(dev):
     from ap_adapter_amd import ops
     bf = torch.bfloat16

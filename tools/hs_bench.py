@@ -65,3 +65,15 @@ for B in (64, 32):
             return ops.linear(oo, wo, bo, residual=xp, rowstat=True)
         tcx = timeit(xchain)
         print(f"cross B={B} keys {Lt}+{La}: hs_attention {tx:6.1f} us  both {txb:6.1f} us   chain {tcx:6.1f} us", flush=True)
+    # feed-forward: LN + GEGLU (hs_geglu) / FF2, against the chain's two launches
+    w1, b1, w2, b2 = R(8 * C, C, std=0.03), R(8 * C, std=0.1), R(C, 4 * C, std=0.02), R(C, std=0.1)
+    pg, bg = ops.hs_pack_geglu(w1, b1, ln=ln)
+    hh = torch.empty(B, N, 4 * C, device=dev, dtype=dt)
+    tg = timeit(lambda: ops.hs_geglu(x, pg, bg, ln_eps=1e-5, out=hh))
+    tgc = timeit(lambda: ops.fused_linear(xp, w1, b1, ln=ln, act="geglu", out=hh))
+    tf2 = timeit(lambda: ops.linear(hh, w2, b2, residual=x, rowstat=True, out=out))
+    w2p = ops.hs_pack_ff2(w2)
+    tf2h = timeit(lambda: ops.hs_ff2(hh, w2p, b2, x, rowstat=True, out=out))
+    tffh = timeit(lambda: ops.hs_ff2(ops.hs_geglu(x, pg, bg, ln_eps=1e-5, out=hh), w2p, b2, x, rowstat=True, out=out))
+    print(f"ff    B={B}: hs_ff2 {tf2h:6.1f} us ({2.0 * B * N * C * 4 * C / tf2h / 1e6:6.0f} TF/s)   hs_geglu + hs_ff2 {tffh:6.1f} us", flush=True)
+    print(f"ff    B={B}: hs_geglu {tg:6.1f} us ({2.0 * B * N * C * 8 * C / tg / 1e6:6.0f} TF/s)   chain LN-folded GEGLU GEMM {tgc:6.1f} us   FF2 GEMM {tf2:6.1f} us", flush=True)
