@@ -106,7 +106,6 @@ SYMBOLS = {
     "apad_sizeof_xattn_desc": (C.c_int, []),
     "apad_echo_xattn_desc": (C.c_int, [C.POINTER(XattnDesc), C.POINTER(C.c_double), C.c_int]),
     "apad_fused_cross_attention": (C.c_int, [C.POINTER(XattnDesc), _vp]),
-    "apad_geglu_mlp_rows": (C.c_int, [C.POINTER(MlpDesc), _vp]),
     "apad_sizeof_xrows_desc": (C.c_int, []),
     "apad_cross_attention_rows": (C.c_int, [C.POINTER(XrowsDesc), _vp]),
     "apad_sizeof_hs_attn_desc": (C.c_int, []),

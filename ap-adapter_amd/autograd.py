@@ -26,13 +26,18 @@ def on(*tensors):
 _wcache = {}
 
 
-def _cached(w, tag, make):
+def _psig(*ps):
+    """identity + storage + version + type + place of companion weights (the signature of a stacked copy, not its key)"""
+    return tuple((id(p), p.data_ptr(), p._version, p.dtype, p.device) for p in ps)
+
+
+def _cached(w, tag, make, extra=()):
     """per-weight derived tensor (transposed / flipped copy), rebuilt when the weight is re-assigned or updated.  Only FROZEN
     weights are cached: the optimizer kernel updates trainable ones through raw pointers, which no version counter sees."""
     if w.requires_grad:
         return make(w.detach())
-    key = (id(w), tag)
-    sig = (w.data_ptr(), w._version, w.dtype, w.device)
+    key = (id(w), tag)  # ONE entry per (weight, kind): a changed companion (``extra``) overwrites it instead of piling up keys
+    sig = (w.data_ptr(), w._version, w.dtype, w.device) + tuple(extra)
     hit = _wcache.get(key)
     # the entry must belong to THIS tensor object: ids (and allocator addresses) are recycled once a model is freed, and a recycled
     # id with an equal signature would otherwise serve another model's derived weight
@@ -132,8 +137,7 @@ class _QKV(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dq, dk, dv):
         wq, wk, wv = ctx.saved_tensors
-        wst = _cached(wq, ("qkvT", id(wk), id(wv), wk._version, wv._version),
-                      lambda t: torch.cat([t, wk.detach(), wv.detach()], 0).t().contiguous())  # [C, 3C]
+        wst = _cached(wq, "qkvT", lambda t: torch.cat([t, wk.detach(), wv.detach()], 0).t().contiguous(), extra=_psig(wk, wv))  # [C, 3C]
         return ops.linear(_packed_grads(dq, dk, dv), wst), None, None, None
 
 
@@ -148,7 +152,7 @@ class _QKVT(_QKV):
         x = _c(x)
         B, N, Cc = x.shape
         ctx.save_for_backward(wq, wk, wv)
-        w = _cached(wq, ("qkv", id(wk), id(wv), wk._version, wv._version), lambda t: torch.cat([t, wk.detach(), wv.detach()], 0).contiguous())
+        w = _cached(wq, "qkv", lambda t: torch.cat([t, wk.detach(), wv.detach()], 0).contiguous(), extra=_psig(wk, wv))
         q, k, v = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
         vt = vt_buffer("train_self", B, heads, Cc // heads, N, x.dtype, x.device)
         ops.linear_qkv(x, w, B, N, heads, q, k, vt, v=v)

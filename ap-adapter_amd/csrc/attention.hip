@@ -1304,11 +1304,8 @@ template <int DT, int C, int NW, int NSET> int xattn_rows_launch(const XrP& p, h
     constexpr int LDS = 2 * (NW * 8) * (C * 2 + 16);
     dim3 grid((unsigned)(p.B * p.tiles_per_sample));
     auto go = [&](auto kern) {
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-            attr = true;
-        }
+        static unsigned devs = 0;
+        if (apad_ensure_dyn_lds(reinterpret_cast<const void*>(kern), LDS, &devs) != 0) return -1;
         hipLaunchKernelGGL(kern, grid, dim3(NW * 64), LDS, s, p);
         return apad_check_launch("apad_cross_attention_rows");
     };
@@ -1368,8 +1365,8 @@ extern "C" int apad_attention(const apad_attn_desc* d, void* stream) {
 extern "C" int apad_cross_attention_rows(const apad_xrows_desc* d, void* stream) {
     APAD_CHECK(d != nullptr, "apad_cross_attention_rows: null descriptor");
     APAD_CHECK(d->dtype == APAD_BF16 || d->dtype == APAD_F16, "apad_cross_attention_rows: dtype %d not supported (16-bit only)", d->dtype);
-    if ((d->C != 384 && d->C != 640) || d->heads != 8) {
-        apad_set_error("apad_cross_attention_rows: C=%d heads=%d outside the kernel envelope (384 / 640, 8)", d->C, d->heads);
+    if (d->C != 384 || d->heads != 8) {  // (the 64-token level, C = 640: apad_hs_attention + apad_hs_out, hsattn.hip)
+        apad_set_error("apad_cross_attention_rows: C=%d heads=%d outside the kernel envelope (384, 8)", d->C, d->heads);
         return -3;
     }
     APAD_CHECK(d->x && d->wq_packed && d->wo_packed && d->k1 && d->vt1 && d->out, "apad_cross_attention_rows: null operand");
@@ -1392,11 +1389,10 @@ extern "C" int apad_cross_attention_rows(const apad_xrows_desc* d, void* stream)
     p.k1 = (const uint8_t*)d->k1; p.vt1 = (const uint8_t*)d->vt1; p.bias1 = d->key_bias;
     p.k2 = (const uint8_t*)d->k2; p.vt2 = (const uint8_t*)d->vt2; p.out = (uint8_t*)d->out;
     p.B = d->B; p.N = d->N; p.L1 = d->L1; p.Lpad1 = d->Lpad1; p.L2 = d->L2; p.Lpad2 = d->Lpad2;
-    const int tm = d->C == 384 ? 64 : 32;  // tokens per workgroup (xattn_rows_kernel: 8 / 4 waves)
+    const int tm = 64;  // tokens per workgroup (xattn_rows_kernel, 8 waves)
     p.tiles_per_sample = (d->N + tm - 1) / tm;
     p.eps = d->ln_eps; p.scale_log2 = d->softmax_scale * LOG2E; p.scale2 = d->scale2;
     hipStream_t s = (hipStream_t)stream;
     // (8 waves: 35.8 us at the bench geometry vs 42.5 with 4 waves x 2 panels; deeper weight prefetch -- 6 / 8 register sets -- within 1 us)
-    if (d->C == 640) return d->dtype == APAD_BF16 ? xattn_rows_launch<APAD_BF16, 640, 4, 4>(p, s) : xattn_rows_launch<APAD_F16, 640, 4, 4>(p, s);
     return d->dtype == APAD_BF16 ? xattn_rows_launch<APAD_BF16, 384, 8, 3>(p, s) : xattn_rows_launch<APAD_F16, 384, 8, 3>(p, s);
 }

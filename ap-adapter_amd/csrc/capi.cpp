@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <mutex>
 #include "common.h"
 
 static thread_local char g_err[512] = "";
@@ -23,6 +24,22 @@ int apad_check_launch(const char* what) {
 }
 
 extern "C" const char* apad_last_error(void) { return g_err; }
+int apad_ensure_dyn_lds(const void* kern, int bytes, unsigned* devmask) {
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 31) dev = 0;
+    std::lock_guard<std::mutex> g(mu);
+    if (!((*devmask >> dev) & 1u)) {
+        const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) {
+            apad_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d) failed on device %d: %s", bytes, dev, hipGetErrorString(e));
+            return -1;
+        }
+        *devmask |= 1u << dev;
+    }
+    return 0;
+}
+
 extern "C" int apad_abi_version(void) { return APAD_ABI_VERSION; }
 extern "C" int apad_sizeof_gemm_desc(void) { return (int)sizeof(apad_gemm_desc); }
 extern "C" int apad_sizeof_attn_desc(void) { return (int)sizeof(apad_attn_desc); }

@@ -575,11 +575,8 @@ __global__ __launch_bounds__(256) void cconv_small_kernel(CgP p) {
 
 template <int DT, bool GEN> int cs_launch(const CgP& p, hipStream_t s) {
     auto kern = cconv_small_kernel<DT, GEN>;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SSMEM);
-        attr = true;
-    }
+    static unsigned devs = 0;
+    if (apad_ensure_dyn_lds(reinterpret_cast<const void*>(kern), SSMEM, &devs) != 0) return -1;
     hipLaunchKernelGGL(kern, dim3((unsigned)(p.m_tiles * p.n_tiles)), dim3(256), SSMEM, s, p);
     return apad_check_launch("apad_gemm(small-tile conv)");
 }
@@ -587,11 +584,8 @@ template <int DT, bool GEN> int cs_launch(const CgP& p, hipStream_t s) {
 template <int DT, int MODE, int BN> int cg_launch(const CgP& p, hipStream_t s) {
     auto kern = cgemm_kernel<DT, MODE, BN>;
     constexpr int CSMEM = CgT<BN>::SMEM;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CSMEM);
-        attr = true;
-    }
+    static unsigned devs = 0;
+    if (apad_ensure_dyn_lds(reinterpret_cast<const void*>(kern), CSMEM, &devs) != 0) return -1;
     hipLaunchKernelGGL(kern, dim3((unsigned)(p.m_tiles * p.n_tiles)), dim3(512), CSMEM, s, p);
     return apad_check_launch("apad_gemm(big tile)");
 }

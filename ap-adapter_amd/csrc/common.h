@@ -130,5 +130,8 @@ void apad_set_error(const char* fmt, ...);
         }                                \
     } while (0)
 int apad_check_launch(const char* what);
+// dynamic LDS above 64 KB needs hipFuncAttributeMaxDynamicSharedMemorySize once per (kernel, DEVICE): *devmask = the devices it has been set on
+// (one static word per kernel at the call site); thread-safe, the return code of hipFuncSetAttribute is checked.  0 = ok, -1 = error set
+int apad_ensure_dyn_lds(const void* kern, int bytes, unsigned* devmask);
 // big-tile GEMM / implicit convolution (cgemm.hip): 1 = not applicable, 0 = launched, < 0 = error
 int apad_cgemm_try(const apad_gemm_desc* d, hipStream_t s);

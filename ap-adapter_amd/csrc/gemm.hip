@@ -550,201 +550,6 @@ __global__ __launch_bounds__(256 * KG) void gemm_kernel(GemmP p) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// LDS-DMA pipelined variant for plain (row-major A) problems with K % 64 == 0: both operand tiles go HBM/L2 -> LDS with
-// global_load_lds (no staging registers), three 32 KB stages in flight, ONE raw s_barrier per K-tile and a counted
-// s_waitcnt vmcnt(8) so that the loads of the next tile stay outstanding across the barrier.  The XOR swizzle of the
-// tile is applied on the SOURCE address (the DMA writes lane-linear).  Fragment reads are double-buffered by hand.
-// ---------------------------------------------------------------------------------------------------------------
-#define APAD_GLDS16(src, dst)                                                                                   \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),                      \
-                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
-
-template <int DT, int EPI>
-__global__ __launch_bounds__(256) void gemm_dma_kernel(GemmP p) {
-    constexpr int TM = 128, BM = 128, BN = 128, A_BYTES = 16384, STAGE = 32768, C_LD = BN + 8, WT = 64;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    using E = ET<DT>;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wu = __builtin_amdgcn_readfirstlane(wave);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int half = lane >> 5, l31 = lane & 31;
-    constexpr int BN_OUT = (EPI == APAD_EPI_GEGLU) ? BN / 2 : BN;
-    constexpr int GH = BN / 2;
-    int mt, nt;
-    {
-        const int nN = p.n_tiles, nM = p.m_tiles;
-        const int b = blockIdx.x;
-        const int full = (nM / 8) * 8 * nN;
-        if (b < full) {
-            const int grp = b / (8 * nN), rem = b - grp * 8 * nN;
-            nt = rem >> 3;
-            mt = grp * 8 + (rem & 7);
-        } else {
-            const int rem = b - full, tail = nM - (nM / 8) * 8;
-            nt = rem / tail;
-            mt = (nM / 8) * 8 + rem - nt * tail;
-        }
-    }
-    const int64_t m0 = (int64_t)mt * BM;
-    const int64_t n0 = (int64_t)nt * BN_OUT;
-    auto wrow = [&](int nl) -> int64_t {
-        if (EPI == APAD_EPI_GEGLU) return nl < GH ? n0 + nl : p.N + n0 + (nl - GH);
-        return n0 + nl;
-    };
-    auto wrow_valid = [&](int nl) -> bool {
-        if (EPI == APAD_EPI_GEGLU) return (nl < GH ? n0 + nl : n0 + nl - GH) < p.N;
-        return n0 + nl < p.N;
-    };
-
-    // per-lane DMA sources: wave w, slot i covers tile rows (w*4+i)*8 .. +7; lane -> (row, LDS chunk); the source chunk
-    // is the LDS chunk XOR-ed with the row swizzle (lds_off), so fragment reads use the same lds_off as the tiled kernel
-    const uint8_t* asrc[4];
-    const uint8_t* bsrc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int rl = (wave * 4 + i) * 8 + (lane >> 3);
-        const int csrc = (lane & 7) ^ ((rl >> 1) & 7);
-        int64_t m = m0 + rl;
-        m = m < p.M ? m : p.M - 1;
-        asrc[i] = p.a + (m * p.lda + csrc * 8) * 2;
-        int64_t wr = wrow_valid(rl) ? wrow(rl) : 0;  // clamped rows produce columns the epilogue discards
-        bsrc[i] = p.w + (wr * p.ldw + csrc * 8) * 2;
-    }
-    const int nk = (int)(p.K / BK);
-    auto issue = [&](int kt) {
-        uint8_t* st = smem + (kt % 3) * STAGE + wu * 4096;
-        const int koff = kt * BK * 2;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            APAD_GLDS16(asrc[i] + koff, st + i * 1024);
-            APAD_GLDS16(bsrc[i] + koff, st + A_BYTES + i * 1024);
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    issue(0);
-    if (nk > 1) issue(1);
-    for (int kt = 0; kt < nk; ++kt) {
-        // tile kt has landed (its 8 loads are older than tile kt+1's 8) -> barrier -> everyone is also done reading the
-        // stage that tile kt+2 is about to overwrite
-        if (kt + 1 < nk)
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk) issue(kt + 2);
-        const uint8_t* sa = smem + (kt % 3) * STAGE;
-        const uint8_t* sb = sa + A_BYTES;
-        typename E::v8 af[2][2], bf[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            af[0][i] = as_v8<DT>(*reinterpret_cast<const uint4*>(sa + lds_off(wm * WT + i * 32 + l31, half)));
-            bf[0][i] = as_v8<DT>(*reinterpret_cast<const uint4*>(sb + lds_off(wn * WT + i * 32 + l31, half)));
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int cur = ks & 1, nxt = cur ^ 1;
-            if (ks + 1 < 4) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    af[nxt][i] = as_v8<DT>(*reinterpret_cast<const uint4*>(sa + lds_off(wm * WT + i * 32 + l31, (ks + 1) * 2 + half)));
-                    bf[nxt][i] = as_v8<DT>(*reinterpret_cast<const uint4*>(sb + lds_off(wn * WT + i * 32 + l31, (ks + 1) * 2 + half)));
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                asm volatile("" : "+v"(af[cur][i]) : : "memory");
-                asm volatile("" : "+v"(bf[cur][i]) : : "memory");
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = E::mfma32(af[cur][i], bf[cur][j], acc[i][j]);
-        }
-    }
-    __syncthreads();  // all fragment reads done before the epilogue reuses stage 0
-
-    // ---- epilogue (same as gemm_kernel, row-major output) ----
-    typename E::elem* ct = reinterpret_cast<typename E::elem*>(smem);
-    int64_t step = p.step_ptr ? (int64_t)*p.step_ptr : 0;
-    const bool one_group = p.rows_per_group >= p.M;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int nl = wn * WT + j * 32 + l31;
-        const bool nvalid = wrow_valid(nl);
-        const int64_t wr = nvalid ? wrow(nl) : 0;
-        const float bv = (p.bias && nvalid) ? ld_elem<DT>(p.bias, wr) : 0.f;
-        const float rg0 = (p.rg && one_group && nvalid) ? ld_elem<DT>(p.rg, step * p.ld_rg + wr) : 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ml = wm * WT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                float v = acc[i][j][r] + bv + rg0;
-                if (p.rg && !one_group) {
-                    int64_t m = m0 + ml;
-                    if (m < p.M && nvalid) v += ld_elem<DT>(p.rg, (m / p.rows_per_group + step) * p.ld_rg + wr);
-                }
-                if (EPI == APAD_EPI_SILU) v = silu_f(v);
-                if (EPI == APAD_EPI_GELU) v = gelu_erf_f(v);
-                if (EPI == APAD_EPI_TANH) v = tanhf(v);
-                ct[ml * C_LD + nl] = (typename E::elem)v;
-            }
-        }
-    }
-    __syncthreads();
-    constexpr int VPR = BN_OUT / 8;
-    for (int idx = tid; idx < BM * VPR; idx += 256) {
-        const int rl = idx / VPR, vc = idx - rl * VPR;
-        const int64_t m = m0 + rl, n = n0 + vc * 8;
-        if (m >= p.M || n >= p.N) continue;
-        float f[8];
-        unpack8<DT>(*reinterpret_cast<const uint4*>(&ct[rl * C_LD + vc * 8]), f);
-        if (EPI == APAD_EPI_GEGLU) {
-            float g[8];
-            unpack8<DT>(*reinterpret_cast<const uint4*>(&ct[rl * C_LD + GH + vc * 8]), g);
-#pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                const apad_f32x2 ge = gelu_erf_2((apad_f32x2){g[e], g[e + 1]});
-                f[e] *= ge[0];
-                f[e + 1] *= ge[1];
-            }
-        }
-        if (p.residual) {
-            float rr[8];
-            const int64_t rm = p.res_mod > 0 ? m % p.res_mod : m;
-            unpack8<DT>(*reinterpret_cast<const uint4*>(p.residual + (rm * p.ldr + n) * 2), rr);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = (float)(typename E::elem)f[e] + rr[e];
-        }
-        *reinterpret_cast<uint4*>(p.out + (m * p.ldo + n) * 2) = pack8<DT>(f);
-    }
-}
-
-template <int DT, int EPI> int launch_dma(const GemmP& p, hipStream_t s) {
-    constexpr int BN_OUT = (EPI == APAD_EPI_GEGLU) ? 64 : 128;
-    GemmP q = p;
-    q.n_tiles = (int)((p.N + BN_OUT - 1) / BN_OUT);
-    q.m_tiles = (int)((p.M + 127) / 128);
-    auto kern = gemm_dma_kernel<DT, EPI>;
-    constexpr int LDS = 3 * 32768;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr = true;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(q.n_tiles * q.m_tiles)), dim3(256), LDS, s, q);
-    return apad_check_launch("apad_gemm(dma)");
-}
-
 // ---------------------------------------------------------------------------------------------------------------------------------
 // LDS-DMA ring form of the 64x64 tile for latency-bound plain launches (round 3).  The tiled kernel above keeps one k-tile per K group
 // in flight -- global load -> registers -> LDS -> barrier -- so a launch of a few hundred workgroups with 4 .. 40 k-tiles each is a chain
@@ -1031,11 +836,8 @@ int launch_ring(const GemmP& p, bool kgroups, hipStream_t s) {
     q.m_tiles = (int)((p.M + 63) / 64);
     dim3 grid((unsigned)(q.n_tiles * q.m_tiles));
     auto go = [&](auto kern) {
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RSMEM);
-            attr = true;
-        }
+        static unsigned devs = 0;
+        if (apad_ensure_dyn_lds(reinterpret_cast<const void*>(kern), RSMEM, &devs) != 0) return -1;
         hipLaunchKernelGGL(kern, grid, dim3(256), RSMEM, s, q, (uint32_t)a_bytes, (uint32_t)a2_bytes, (uint32_t)w_bytes);
         return apad_check_launch("apad_gemm(ring)");
     };
@@ -1062,10 +864,6 @@ int launch(const GemmP& p, hipStream_t s) {
     // 128-tiles unless they would leave the chip under-filled (< ~2 workgroups per CU)
     constexpr int BN_OUT = (EPI == APAD_EPI_GEGLU) ? 64 : 128;
     const int64_t blocks128 = ((p.N + BN_OUT - 1) / BN_OUT) * ((p.M + 127) / 128);
-    static const int dma_mode = [] { const char* e = getenv("APAD_GEMM_DMA"); return e ? atoi(e) : 0; }();  // off by default: measured slower than the register-staged kernel (1 workgroup/CU)
-    if constexpr (AMODE == APAD_A_PLAIN && OUTMODE == APAD_OUT_ROWMAJOR) {
-        if (dma_mode && p.K % 64 == 0 && p.K >= 128 && blocks128 >= 256 && p.a2 == nullptr && p.a_mod == 0) return launch_dma<DT, EPI>(p, s);
-    }
     // long reductions amortise the under-fill: with K >= 1024 the 128-tile wins from ~1.25 workgroups per CU (measured:
     // conv 63x4 384->384 76.5 -> 71.5 us, FF2 M=16128 K=1536 38.5 -> 37.1 us), short-K launches prefer the 64-tile
     static const int t128_min = [] { const char* e = getenv("APAD_GEMM_T128_MIN"); return e ? atoi(e) : 512; }();  // (A/B knob)

@@ -26,7 +26,6 @@
 // bytes through the 64 B/clk path than the weights themselves); the launch boundary is the cheaper all-to-all (1.5 us, 20 KB per
 // workgroup each way).  A row's result never depends on its batch: one workgroup = one sample, fixed summation order.
 #include <stdlib.h>
-#include <mutex>
 #include "common.h"
 
 namespace {
@@ -841,28 +840,12 @@ __global__ __launch_bounds__(512) void hs_ff2_kernel(HfP p) {
         hf_body<DT, 2>(p, smem, b, cq, tid, lane, wave);
 }
 
-// dynamic LDS above 64 KB needs the attribute once per (kernel, device)
-template <class K> int hs_ensure_lds(K kern, int bytes, bool (&done)[16], std::mutex& mu) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
-    std::lock_guard<std::mutex> g(mu);
-    if (!done[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
-            apad_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d) failed", bytes);
-            return -1;
-        }
-        done[dev] = true;
-    }
-    return 0;
-}
-
 template <int DT, bool SELF, bool NORM, int NS1, int NS2> int hs_attn_go2(const HsP& p, hipStream_t s) {
     constexpr int NSET = HS_NSET;
     constexpr int LDS = SELF ? X_BYTES + 2 * Q_BYTES + V_BYTES + HS_BIAS_BYTES : X_BYTES + Q_BYTES + HS_BIAS_BYTES;
-    static bool done[16] = {};
-    static std::mutex mu;
+    static unsigned devs = 0;
     auto kern = hs_attn_kernel<DT, SELF, NORM, NS1, NS2, NSET>;
-    if (hs_ensure_lds(kern, LDS, done, mu) != 0) return -1;
+    if (apad_ensure_dyn_lds(reinterpret_cast<const void*>(kern), LDS, &devs) != 0) return -1;
     hipLaunchKernelGGL(kern, dim3((unsigned)hs_grid(p.B, p.xm)), dim3(512), LDS, s, p);
     return apad_check_launch("apad_hs_attention");
 }
@@ -883,29 +866,26 @@ template <int DT> int hs_attn_launch(const HsP& p, bool self, hipStream_t s) {
 
 template <int DT> int hs_out_launch(const HoP& p, hipStream_t s) {
     constexpr int NSET = HS_NSET;
-    static bool done[16] = {};
-    static std::mutex mu;
+    static unsigned devs = 0;
     auto kern = hs_out_kernel<DT, NSET>;
-    if (hs_ensure_lds(kern, X_BYTES + Q_BYTES, done, mu) != 0) return -1;
+    if (apad_ensure_dyn_lds(reinterpret_cast<const void*>(kern), X_BYTES + Q_BYTES, &devs) != 0) return -1;
     hipLaunchKernelGGL(kern, dim3((unsigned)hs_grid(p.B, p.xm)), dim3(512), X_BYTES + Q_BYTES, s, p);
     return apad_check_launch("apad_hs_out");
 }
 
 template <int DT, bool NORM> int hs_geglu_go(const HgP& p, hipStream_t s) {
     constexpr int LDS = X_BYTES + HG_BIAS_BYTES + 8 * HG_STG;
-    static bool done[16] = {};
-    static std::mutex mu;
+    static unsigned devs = 0;
     auto kern = hs_geglu_kernel<DT, NORM, HS_NSET>;
-    if (hs_ensure_lds(kern, LDS, done, mu) != 0) return -1;
+    if (apad_ensure_dyn_lds(reinterpret_cast<const void*>(kern), LDS, &devs) != 0) return -1;
     hipLaunchKernelGGL(kern, dim3((unsigned)hs_grid(p.B, p.xm)), dim3(512), LDS, s, p);
     return apad_check_launch("apad_hs_geglu");
 }
 
 template <int DT> int hs_ff2_launch(const HfP& p, hipStream_t s) {
-    static bool done[16] = {};
-    static std::mutex mu;
+    static unsigned devs = 0;
     auto kern = hs_ff2_kernel<DT>;
-    if (hs_ensure_lds(kern, HF_LDS, done, mu) != 0) return -1;
+    if (apad_ensure_dyn_lds(reinterpret_cast<const void*>(kern), HF_LDS, &devs) != 0) return -1;
     hipLaunchKernelGGL(kern, dim3((unsigned)hs_grid(p.B, p.xm)), dim3(512), HF_LDS, s, p);
     return apad_check_launch("apad_hs_ff2");
 }

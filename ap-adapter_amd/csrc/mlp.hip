@@ -625,11 +625,8 @@ __global__ __launch_bounds__(512, 1) void mlp2_kernel(MlpP p) {
 template <int DT, int KC, bool LN> int mlp2_launch(const MlpP& p, hipStream_t s) {
     using G = Mlp2Cfg<KC>;
     auto kern = mlp2_kernel<DT, KC, LN>;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-        attr = true;
-    }
+    static unsigned devs = 0;
+    if (apad_ensure_dyn_lds(reinterpret_cast<const void*>(kern), G::LDS, &devs) != 0) return -1;
     hipLaunchKernelGGL(kern, dim3((unsigned)((p.M + 127) / 128)), dim3(512), G::LDS, s, p);
     return apad_check_launch("apad_geglu_mlp");
 }
@@ -638,11 +635,8 @@ template <int DT, int KC, int NWV, bool LN> int mlp_launch(const MlpP& p, hipStr
     using G = MlpCfg<KC>;
     const size_t lds = 2 * G::STAGE + NWV * SCR_BYTES + (2 * G::HID + G::C) * sizeof(float);
     auto kern = mlp_kernel<DT, KC, NWV, LN>;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    static unsigned devs = 0;
+    if (apad_ensure_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds, &devs) != 0) return -1;
     const int64_t rows_per_wg = NWV * 32;
     hipLaunchKernelGGL(kern, dim3((unsigned)((p.M + rows_per_wg - 1) / rows_per_wg)), dim3(NWV * 64), lds, s, p);
     return apad_check_launch("apad_geglu_mlp");
@@ -652,7 +646,10 @@ template <int DT, int KC> int mlp_dispatch(const MlpP& p, bool ln, hipStream_t s
     // 4 waves (128 tokens) per workgroup when that still fills the chip, else 2 waves
     const bool big = (p.M + 127) / 128 >= 256;
     static const int v2 = [] { const char* e = getenv("APAD_MLP_V2"); return e ? atoi(e) : 1; }();
-    if (big && v2) return ln ? mlp2_launch<DT, KC, true>(p, s) : mlp2_launch<DT, KC, false>(p, s);
+    // (mlp2 from half a chip's worth of 128-token workgroups: the CFG-shared prefix runs this level at 32 x 1000 = 32000 rows = 250 workgroups;
+    //  the one-wave-per-SIMD kernel below stays for the small launches, where its 64-token workgroups fill more CUs)
+    static const int v2_min = [] { const char* e = getenv("APAD_MLP_V2_MIN_WG"); return e ? atoi(e) : 128; }();
+    if (v2 && (p.M + 127) / 128 >= v2_min) return ln ? mlp2_launch<DT, KC, true>(p, s) : mlp2_launch<DT, KC, false>(p, s);
     if (big) return ln ? mlp_launch<DT, KC, 4, true>(p, s) : mlp_launch<DT, KC, 4, false>(p, s);
     return ln ? mlp_launch<DT, KC, 2, true>(p, s) : mlp_launch<DT, KC, 2, false>(p, s);
 }

@@ -657,11 +657,8 @@ template <int DT> __global__ void xa_pack_kv_kernel(const uint8_t* k, const uint
 
 template <int DT, int NS1, int NS2, int G1 = 0, int G2 = 0, bool BIAS1 = false> int xa_launch(const XaP& p, hipStream_t s) {
     auto kern = xattn_kernel<DT, NS1, NS2, G1, G2, BIAS1>;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS);
-        attr = true;
-    }
+    static unsigned devs = 0;
+    if (apad_ensure_dyn_lds(reinterpret_cast<const void*>(kern), XA_LDS, &devs) != 0) return -1;
     // persistent: one workgroup per CU (a multiple of 8 so that virtual id % 8 stays the XCD), fewer when there are fewer tiles
     static const int ncu = [] {
         int dev = 0, n = 0;

@@ -285,11 +285,8 @@ def fused_cross_attention(x, wq_packed, wo_packed, bo, kv1_packed, L1, heads, ln
     return out
 
 
-# envelope of apad_cross_attention_rows: 8 heads; C = 384 routed by default.  C = 640 (32-token tiles, 4 waves) is built and tested but
-# OFF: isolated it beats the chain (31.4 vs 47.1 us at 32 samples) but the 64-token level runs its two batch halves on two streams,
-# where three small launches overlap with the other stream better than one 64-workgroup kernel holding 83 KB of LDS per CU: step
-# 43.78 -> 44.08 ms (APAD_XROWS_C=384,640 switches it on).  <= 64 keys per segment, ...
-XROWS_C, XROWS_MAXL = tuple(int(c) for c in _os.environ.get("APAD_XROWS_C", "384").split(",") if c), 64
+# envelope of apad_cross_attention_rows: 8 heads, C = 384, <= 64 keys per segment (...
+XROWS_C, XROWS_MAXL = (384,), 64
 XROWS_MAXL2 = 128                 # ... <= 128 in the second segment beside <= 32 in the first: the adapter's 8 text + 128 audio keys)
 
 
@@ -520,11 +517,7 @@ def hs_out(o, wo_packed, bias, residual, rowstat=False, out=None):
     return out
 
 
-# apad_geglu_mlp_rows (csrc/mlp_rows.hip), OFF by default: correct, but every 64-token workgroup streams both weight matrices (3.5 MB)
-# from L2 -- 0.9 GB per launch at 16128 rows -- and measures 118 us against 101 us for the two-launch chain it would replace (in-step
-# 44.25 -> 46.08 ms).  APAD_MLP_ROWS_C=384 switches it on (tests, A/B)
-MLP_ROWS_C = tuple(int(c) for c in _os.environ.get("APAD_MLP_ROWS_C", "").split(",") if c)
-MLP_C = (256,) + MLP_ROWS_C  # envelope of apad_geglu_mlp / apad_geglu_mlp_rows
+MLP_C = (256,)  # envelope of apad_geglu_mlp
 
 
 def geglu_mlp(x, w1, b1, w2, b2, ln=None, out=None):
@@ -539,34 +532,12 @@ def geglu_mlp(x, w1, b1, w2, b2, ln=None, out=None):
     if out is None:
         out = torch.empty_like(x)
     d = L.MlpDesc()
-    rows = Cc in MLP_ROWS_C  # the row-tile kernel (csrc/mlp_rows.hip): weights fragment-packed, cached per parameter
-    if rows:
-        w1, w2 = _packed_weight(w1), _packed_weight(w2)
     d.x, d.w1, d.b1, d.w2, d.b2, d.out = x.data_ptr(), w1.data_ptr(), _ptr(b1), w2.data_ptr(), _ptr(b2), out.data_ptr()
     if ln is not None:
         d.ln_gamma, d.ln_beta, d.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), float(ln[2])
     d.M, d.C, d.dtype = x.numel() // Cc, Cc, _DT[x.dtype]
-    if rows:
-        L.check(L.lib().apad_geglu_mlp_rows(C.byref(d), _stream()), "apad_geglu_mlp_rows")
-    else:
-        L.check(L.lib().apad_geglu_mlp(C.byref(d), _stream()), "apad_geglu_mlp")
+    L.check(L.lib().apad_geglu_mlp(C.byref(d), _stream()), "apad_geglu_mlp")
     return out
-
-
-_pack_cache = {}
-
-
-def _packed_weight(w):
-    """xrows_pack_weight(w), cached per parameter and re-packed when it is re-assigned, moved, cast or updated in place"""
-    sig = (id(w), w.data_ptr(), w._version, w.dtype, w.device)
-    hit = _pack_cache.get(id(w))
-    if hit is None or hit[0] != sig or hit[2]() is not w:
-        if len(_pack_cache) > 1024:
-            for k in [k for k, v in _pack_cache.items() if v[2]() is None]:
-                del _pack_cache[k]
-        hit = (sig, xrows_pack_weight(w), _weakref.ref(w))
-        _pack_cache[id(w)] = hit
-    return hit[1]
 
 
 def linear_vt(x, w, B, Lk, heads, out_vt, bias=None):

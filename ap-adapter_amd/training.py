@@ -32,6 +32,69 @@ def add_noise(latents, noise, timesteps, alphas_cumprod):
     return a * latents.float() + s * noise.float()
 
 
+# ---- learning-rate schedules (train_apadapter_v2.py:809-815 -> diffusers.optimization.get_scheduler, 0.21.2) ----
+SCHEDULES = ("constant", "constant_with_warmup", "linear", "cosine", "cosine_with_restarts", "polynomial", "piecewise_constant")
+
+
+def get_scheduler(name, num_warmup_steps=0, num_training_steps=None, num_cycles=1, power=1.0, step_rules=None, lr_init=None, lr_end=1e-7):
+    """The multiplier ``f(step)`` of diffusers' ``get_scheduler(name, optimizer, ...)`` (a torch LambdaLR there; the optimizer
+    kernel here takes the learning rate as an argument, so the schedule is a plain function of the scheduler step).  Same names,
+    same formulas: constant, constant_with_warmup, linear, cosine (half cosine per ``num_cycles`` of 0.5), cosine_with_restarts
+    (hard restarts), polynomial (down to lr_end / lr_init, needs ``lr_init``), piecewise_constant (``step_rules`` = "1:10,0.1:20,0.01")."""
+    import math
+    if name not in SCHEDULES:
+        raise ValueError(f"unknown lr scheduler {name!r}: one of {SCHEDULES}")
+    W, T = int(num_warmup_steps), num_training_steps
+    if name in ("linear", "cosine", "cosine_with_restarts", "polynomial") and T is None:
+        raise ValueError(f"{name} requires `num_training_steps`, please provide that argument.")
+    if name == "constant":
+        return lambda step: 1.0
+    if name == "constant_with_warmup":
+        return lambda step: float(step) / float(max(1.0, W)) if step < W else 1.0
+    if name == "piecewise_constant":
+        rules = (step_rules or "").split(",")
+        table = [(int(r.split(":")[1]), float(r.split(":")[0])) for r in rules[:-1]]
+        last = float(rules[-1])
+
+        def piecewise(step):
+            for end, mult in table:
+                if step < end:
+                    return mult
+            return last
+        return piecewise
+    warm = lambda step: float(step) / float(max(1, W))
+    if name == "linear":
+        return lambda step: warm(step) if step < W else max(0.0, float(T - step) / float(max(1, T - W)))
+    if name == "cosine":
+        nc = 0.5  # (diffusers' get_scheduler does not forward num_cycles to the plain cosine schedule: always half a cosine)
+
+        def cosine(step):
+            if step < W:
+                return warm(step)
+            prog = float(step - W) / float(max(1, T - W))
+            return max(0.0, 0.5 * (1.0 + math.cos(math.pi * float(nc) * 2.0 * prog)))
+        return cosine
+    if name == "cosine_with_restarts":
+        def restarts(step):
+            if step < W:
+                return warm(step)
+            prog = float(step - W) / float(max(1, T - W))
+            if prog >= 1.0:
+                return 0.0
+            return max(0.0, 0.5 * (1.0 + math.cos(math.pi * ((float(num_cycles) * prog) % 1.0))))
+        return restarts
+    if lr_init is None or not lr_init > lr_end:
+        raise ValueError(f"polynomial needs lr_init > lr_end ({lr_end})")
+
+    def poly(step):
+        if step < W:
+            return warm(step)
+        if step > T:
+            return lr_end / lr_init
+        return ((lr_init - lr_end) * (1 - (step - W) / (T - W)) ** power + lr_end) / lr_init
+    return poly
+
+
 # kernel form of the training step's latency-bound GEMMs (ops.set_gemm_ring; measured 60.0 -> 50.4 ms per cfg-5 step): -1 = leave the
 # process setting alone
 TRAIN_GEMM_RING = int(os.environ.get("APAD_TRAIN_GEMM_RING", "2"))
@@ -39,7 +102,14 @@ TRAIN_GEMM_RING = int(os.environ.get("APAD_TRAIN_GEMM_RING", "2"))
 
 class AdapterTrainer:
     def __init__(self, unet, lr=1e-4, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8, max_grad_norm=1.0,
-                 gradient_accumulation_steps=1, loss_scale=None):
+                 gradient_accumulation_steps=1, loss_scale=None, lr_scheduler="constant", lr_warmup_steps=0, max_train_steps=None,
+                 lr_num_cycles=1, lr_power=1.0, scheduler_steps_per_update=1, dynamic_loss_scale=None, scale_growth_interval=2000):
+        """lr_scheduler / lr_warmup_steps / max_train_steps / lr_num_cycles: the reference's arguments (train_apadapter_v2.py:125-140); like
+        it, warm-up, length and cycles are multiplied by gradient_accumulation_steps before they reach the schedule (:812-814), and the
+        schedule advances ``scheduler_steps_per_update`` per optimizer step -- 1 here; accelerate's prepared scheduler advances once per
+        PROCESS (pass the world size to reproduce a multi-GPU reference run's curve).  dynamic_loss_scale (default: on for f16 with the
+        default scale): the GradScaler behind accelerate's fp16 mode -- halve on an overflowed step, double after
+        ``scale_growth_interval`` clean ones."""
         self.unet = unet
         unet.requires_grad_(False)  # :604 (processors are submodules of the UNet: re-enabled below)
         self.params = adapter_parameters(unet)
@@ -71,7 +141,15 @@ class AdapterTrainer:
         self.step_t = torch.zeros(1, dtype=torch.int32, device=dev)
         self.norm_t = torch.zeros(1, dtype=torch.float32, device=dev)
         self._ws = ops._reduce_ws(dev)
-        self.lr, self.betas, self.weight_decay, self.eps = lr, betas, weight_decay, eps
+        self.base_lr, self.betas, self.weight_decay, self.eps = lr, betas, weight_decay, eps
+        acc = gradient_accumulation_steps
+        self._lr_mult = get_scheduler(lr_scheduler, lr_warmup_steps * acc, None if max_train_steps is None else max_train_steps * acc,
+                                      lr_num_cycles * acc, lr_power, lr_init=lr)
+        self._sched_step, self._sched_per_update = 0, int(scheduler_steps_per_update)
+        self.dynamic_loss_scale = (dtype == torch.float16 and loss_scale is None) if dynamic_loss_scale is None else bool(dynamic_loss_scale)
+        self.scale_growth_interval, self._good_steps, self._scale_epoch = int(scale_growth_interval), 0, 0
+        self._applied_host = torch.zeros(1, dtype=torch.int32).pin_memory() if dev.type == "cuda" else torch.zeros(1, dtype=torch.int32)
+        self._applied_evt, self._applied_expect, self._applied_seen = None, 0, 0
         self.max_grad_norm = max_grad_norm
         self.accum = gradient_accumulation_steps
         self._micro = 0
@@ -129,8 +207,21 @@ class AdapterTrainer:
         with torch.cuda.graph(graph):
             loss = run()
         self._micro = micro0
+        cap = {"graph": graph, "loss": loss, "epoch": self._scale_epoch}
+
+        def recapture():  # the loss scale changed (dynamic_loss_scale): it is a kernel argument of the captured launches
+            g0, m0 = self.grad.clone(), self._micro
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                l_ = run()
+            self.grad.copy_(g0)
+            self._micro = m0
+            cap.update(graph=g, loss=l_, epoch=self._scale_epoch)
 
         def replay(noisy_latents, timesteps, generated_prompt_embeds, prompt_embeds, attention_mask, target):
+            if cap["epoch"] != self._scale_epoch:
+                recapture()
+            graph, loss = cap["graph"], cap["loss"]
             st["noisy"].copy_(noisy_latents)
             st["t"].copy_(timesteps)
             st["gen"].copy_(generated_prompt_embeds)
@@ -144,8 +235,38 @@ class AdapterTrainer:
         replay.graph = graph
         return replay
 
+    @property
+    def lr(self):
+        """the learning rate the NEXT optimizer step applies (``lr_scheduler.get_last_lr()[0]``, train_apadapter_v2.py:1025)"""
+        return self.base_lr * self._lr_mult(self._sched_step)
+
+    def _set_loss_scale(self, scale):
+        self.loss_scale = float(scale)
+        for p, off in zip(self.params, self.offsets):
+            p._apad_grad_sink = (self.grad[off:off + p.numel()].view(p.shape), 1.0 / self.loss_scale)
+        self._scale_epoch += 1  # (captured micro-steps hold the scale as a kernel argument: they re-capture on their next replay)
+
+    def _update_loss_scale(self):
+        """GradScaler.update() without a host sync: the device counter of APPLIED updates is copied to pinned memory behind every
+        optimizer step and read one step later, when the copy has long landed -- the scale backs off one step after the overflow"""
+        if self._applied_evt is not None and self._applied_evt.query():
+            applied = int(self._applied_host[0])
+            skipped = (self._applied_expect - applied) - self._applied_seen
+            if skipped > 0:
+                self._applied_seen += skipped
+                self._good_steps = 0
+                self._set_loss_scale(max(self.loss_scale * 0.5, 1.0))
+            else:
+                self._good_steps += 1
+                if self._good_steps >= self.scale_growth_interval:
+                    self._good_steps = 0
+                    self._set_loss_scale(self.loss_scale * 2.0)
+            self._applied_evt = None
+
     # ---- optimizer step on the accumulation boundary ----
     def optimizer_step(self):
+        if self.dynamic_loss_scale:
+            self._update_loss_scale()
         average_flat_gradient_(self.grad, self._micro)  # the ONE collective of the step (86.5 MB fp32 for -large)
         gn = None
         if (self.max_grad_norm and self.max_grad_norm > 0) or self.loss_scale != 1.0:
@@ -158,14 +279,19 @@ class AdapterTrainer:
             torch.autograd.graph.increment_version(p)
         self._micro = 0
         self.global_step += 1
+        self._sched_step += self._sched_per_update  # lr_scheduler.step() (:978)
+        if self.dynamic_loss_scale and self._applied_evt is None and self.step_t.is_cuda:
+            self._applied_expect = self.global_step
+            self._applied_host.copy_(self.step_t, non_blocking=True)
+            self._applied_evt = torch.cuda.Event()
+            self._applied_evt.record()
 
     @property
     def skipped_steps(self):
         """optimizer steps skipped on the device because the (loss-scaled) gradient norm was not finite: ``global_step`` counts every
         boundary like the reference's (train_apadapter_v2.py:961-963 advances on ``sync_gradients`` whether or not the GradScaler
-        skipped), the device counter only the applied updates.  Reading it synchronises; poll it at logging cadence.  The f16 loss
-        scale is STATIC (a kernel argument inside the captured micro-step): a run whose skipped_steps keeps growing needs a smaller
-        ``loss_scale=`` -- accelerate's GradScaler would have halved it."""
+        skipped), the device counter only the applied updates.  Reading it synchronises; poll it at logging cadence.  With
+        ``dynamic_loss_scale`` the scale halves behind an overflowed step like accelerate's GradScaler (one step late, no sync)."""
         return self.global_step - int(self.step_t.item())
 
     def train_step(self, latents, noise, timesteps, generated_prompt_embeds, prompt_embeds, attention_mask):
@@ -195,7 +321,8 @@ class AdapterTrainer:
     # ---- checkpoint / resume of the trainable state (reference: accelerator.save_state, :988-1011) ----
     def state_dict(self):
         return {"master": self.master.cpu(), "exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(),
-                "step": int(self.step_t.item()), "global_step": self.global_step}
+                "step": int(self.step_t.item()), "global_step": self.global_step, "scheduler_step": self._sched_step,
+                "loss_scale": self.loss_scale}
 
     def load_state_dict(self, sd):
         self.master.copy_(sd["master"])
@@ -204,6 +331,10 @@ class AdapterTrainer:
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.step_t.fill_(sd["step"])
         self.global_step = sd["global_step"]
+        self._sched_step = sd.get("scheduler_step", sd["global_step"] * self._sched_per_update)
+        if "loss_scale" in sd and sd["loss_scale"] != self.loss_scale:
+            self._set_loss_scale(sd["loss_scale"])
+        self._applied_evt, self._applied_seen = None, sd["global_step"] - sd["step"]
 
 
 # ---------------------------------------------------------------------------------------------------------------------

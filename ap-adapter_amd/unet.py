@@ -184,14 +184,15 @@ def cfg_expand(x, cond):
     replicated here, in front of the first conditioned attention: conv_in, the first down block, the first resnet and the whole
     unconditioned (double-self-attention) transformer of the second one run once per clip instead of twice -- same values, row for
     row, as the duplicated batch (the kernels' per-row arithmetic does not depend on the batch size)."""
-    if cond is None or cond.dim() != 3 or cond.shape[0] <= x.shape[0]:
-        return x
+    if not _CFG_EXPAND[0] or cond is None or cond.dim() != 3 or cond.shape[0] <= x.shape[0]:
+        return x  # (outside a shared-prefix forward a batch mismatch is the caller's error and surfaces in the kernels' checks)
     if cond.shape[0] % x.shape[0] != 0:
         raise ValueError(f"condition batch {cond.shape[0]} is not a multiple of the hidden-state batch {x.shape[0]}")
     return x.repeat(cond.shape[0] // x.shape[0], *([1] * (x.dim() - 1)))
 
 
 CFG_SHARED_PREFIX = os.environ.get("APAD_CFG_SHARED_PREFIX", "1") == "1"  # A/B switch (read once)
+_CFG_EXPAND = [False]  # set by forward_nhwc for the duration of a shared-prefix forward: only then does cfg_expand replicate rows
 NO_CAT = os.environ.get("APAD_NO_CAT", "1") == "1"  # up blocks: two-source GroupNorm / shortcut instead of torch.cat (A/B switch)
 
 
@@ -496,7 +497,14 @@ class AudioLDM2UNet2DConditionModel(nn.Module):
             return (out,)
         return UNet2DConditionOutput(sample=out)
 
-    def forward_nhwc(self, x, H, W, timestep, ehs, ehs1=None, emask=None, emask1=None, batch_repeat=1):
+    def forward_nhwc(self, *args, **kwargs):
+        prev = _CFG_EXPAND[0]
+        try:
+            return self._forward_nhwc(*args, **kwargs)
+        finally:
+            _CFG_EXPAND[0] = prev
+
+    def _forward_nhwc(self, x, H, W, timestep, ehs, ehs1=None, emask=None, emask1=None, batch_repeat=1):
         """x [Bsrc, H*W, Cin] token-major; the effective batch is Bsrc*batch_repeat (CFG duplication is done by the
         first convolution's gather instead of a cat).  timestep None -> use the precomputed tables."""
         cfg = self.config
@@ -505,8 +513,11 @@ class AudioLDM2UNet2DConditionModel(nn.Module):
         B = Bs * batch_repeat
         # CFG duplication deferred to the first conditioned attention (cfg_expand): inference only, and only when a condition of
         # the full batch exists to trigger it (APAD_CFG_SHARED_PREFIX=0: duplicate in conv_in's gather, the A/B reference)
+        # (table mode only: with explicit per-sample timesteps the two halves of the batch may sit at different steps, and the prefix
+        #  would read the time projection of the first half for both)
         share = (batch_repeat > 1 and CFG_SHARED_PREFIX and not AG.on(x) and ehs is not None and ehs.dim() == 3 and ehs.shape[0] == B
-                 and (ehs1 is None or ehs1.shape[0] == B))
+                 and (ehs1 is None or ehs1.shape[0] == B) and timestep is None)
+        _CFG_EXPAND[0] = share
         # mask (1 keep / 0 drop) -> additive bias [B,1,L]  (:741-747).  Built in fp32, the type apad_attention takes its
         # key bias in: the reference's cast to the hidden dtype would only add one bf16 -> fp32 conversion launch in
         # front of every masked attention site (44 per captured step)

@@ -348,12 +348,6 @@ int apad_attention(const apad_attn_desc* d, void* stream);
 int apad_rowpanel_gemm(const apad_rp_desc* d, void* stream);
 /* returns -3 when C is outside {256, 384}; callers then use apad_rowpanel_gemm / apad_gemm for the two halves */
 int apad_geglu_mlp(const apad_mlp_desc* d, void* stream);
-/* The same feed-forward for C = 384 (the 252-token level), where the x panel + output accumulators do not fit apad_geglu_mlp's registers:
- * 64-token row tiles in LDS, the hidden activation 128 units at a time, both weights streamed from L2 as MFMA fragments (mlp_rows.hip).
- * SAME descriptor, but w1 / w2 are FRAGMENT-PACKED as apad_cross_attention_rows' weights are:
- *   packed[(rt * (K / 16) + ks) * 512 + lane * 8 + e] = W[rt * 32 + (lane & 31)][ks * 16 + (lane >> 5) * 8 + e]   (W = [rows][K])
- * Replaces FeedForward.net (GEGLU proj + Linear) + norm3 + the residual add of a BasicTransformerBlock.  C != 384: -3.  (ABI 6) */
-int apad_geglu_mlp_rows(const apad_mlp_desc* d, void* stream);
 
 int apad_layernorm(const void* x, const void* gamma, const void* beta, void* out, int64_t M, int32_t C,
                    int64_t ldx, int64_t ldo, float eps, int32_t dtype, void* stream);

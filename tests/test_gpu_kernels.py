@@ -610,15 +610,12 @@ def test_rowpanel_geglu(dev, dtype, M, K, ln):
 
 
 @pytest.mark.parametrize("dtype", DTYPES16)
-@pytest.mark.parametrize("M,C", [(1000, 256), (300, 256), (33000, 256), (37, 256), (16128, 384), (300, 384), (37, 384), (64, 384)])
+@pytest.mark.parametrize("M,C", [(1000, 256), (300, 256), (33000, 256), (37, 256), (16500, 256), (32000, 256)])
 @pytest.mark.parametrize("ln", [False, True])
-def test_geglu_mlp(dev, dtype, M, C, ln, monkeypatch):
-    """norm3 + GEGLU + FeedForward.net[2] + residual in one launch (both workgroup sizes, ragged last panel); C = 384: the row-tile
-    kernel (apad_geglu_mlp_rows, fragment-packed weights cached per parameter; an opt-in route, see ops.MLP_ROWS_C)"""
+def test_geglu_mlp(dev, dtype, M, C, ln):
+    """norm3 + GEGLU + FeedForward.net[2] + residual in one launch (the three workgroup forms -- 64- / 128-token one wave per SIMD, the
+    two-waves-per-SIMD kernel from 128 workgroups -- and a ragged last panel)"""
     from ap_adapter_amd import ops
-    if C == 384:
-        monkeypatch.setattr(ops, "MLP_ROWS_C", (384,))
-        monkeypatch.setattr(ops, "MLP_C", (256, 384))
     x = q(R(M, C, seed=156), dtype)
     w1, b1 = q(R(8 * C, C, seed=157, std=0.08), dtype), q(R(8 * C, seed=158, std=0.5), dtype)
     w2, b2 = q(R(C, 4 * C, seed=159, std=0.04), dtype), q(R(C, seed=160, std=0.5), dtype)
@@ -777,15 +774,13 @@ def test_fused_cross_attention(dev, dtype, B, N, Lt, La, masked):
     (2, 252, 8, 32, False, 384), (3, 100, 8, 8, False, 384), (2, 252, 16, 0, True, 384), (1, 33, 8, 64, False, 384), (5, 64, 40, 0,
     False, 384), (2, 130, 8, 33, False, 384), (9, 252, 8, 32, True, 384), (2, 31, 64, 50, True, 384), (64, 252, 8, 32, False, 384),
     (2, 65, 1, 1, False, 384), (2, 252, 8, 128, False, 384), (3, 100, 8, 70, True, 384), (64, 252, 8, 128, False, 384), (2, 60, 32,
-    97, False, 384), (2, 64, 8, 32, False, 640), (32, 64, 8, 32, True, 640), (3, 64, 16, 0, True, 640), (2, 64, 8, 128, False, 640),
-    (2, 50, 40, 64, False, 640), (5, 97, 8, 8, False, 640)])
+    97, False, 384)])
 def test_cross_attention_rows(dev, dtype, B, N, Lt, La, masked, C, monkeypatch):
     """the 384- and 640-wide levels' single-launch form (apad_cross_attention_rows: 64- / 32-token row tiles in LDS through LayerNorm, to_q,
     attention, to_out, residual): ragged last tiles, one- and two-segment forms, the masked forms of both, the 8 + 128-key form of the timbre /
     accompaniment presets (second segment's fragments requested as they are used), full CFG batch; against fp32 torch on
     storage-rounded operands and against the three-kernel chain it replaces"""
     from ap_adapter_amd import ops
-    monkeypatch.setattr(ops, "XROWS_C", (384, 640))  # (640: an opt-in route, see ops.XROWS_C)
     H = 8
     x = q(R(B, N, C, seed=301), dtype)
     g, be = q(1 + 0.1 * R(C, seed=302), dtype), q(0.1 * R(C, seed=303), dtype)
@@ -829,11 +824,10 @@ def test_cross_attention_rows(dev, dtype, B, N, Lt, La, masked, C, monkeypatch):
 def test_cross_attention_rows_outside_envelope(dev, monkeypatch):
     from ap_adapter_amd import ops
     assert ops.XROWS_C == (384,)
-    monkeypatch.setattr(ops, "XROWS_C", (384, 640))
     bf = torch.bfloat16
     assert ops.xrows_ok(384, 8, 8, 32) and ops.xrows_ok(384, 8, 64, 64) and ops.xrows_ok(384, 8, 16)
     assert ops.xrows_ok(384, 8, 8, 128) and ops.xrows_ok(384, 8, 32, 128) and not ops.xrows_ok(384, 8, 40, 128) and not ops.xrows_ok(384, 8, 8, 129)
-    assert ops.xrows_ok(640, 8, 8, 32) and not ops.xrows_ok(1280, 8, 8, 32) and not ops.xrows_ok(256, 8, 8, 32)
+    assert not ops.xrows_ok(640, 8, 8, 32) and not ops.xrows_ok(1280, 8, 8, 32) and not ops.xrows_ok(256, 8, 8, 32)
     assert not ops.xrows_ok(384, 4, 8, 32) and not ops.xrows_ok(384, 8, 65)
     x = torch.zeros(1, 64, 512, device=dev, dtype=bf)
     w = ops.xrows_pack_weight(torch.zeros(512, 512, device=dev, dtype=bf))

@@ -214,6 +214,56 @@ def test_trainer_f16_loss_scale_and_overflow_skip(dev):
     assert torch.equal(tr.master, before) and int(tr.step_t.item()) == 1 and torch.isfinite(tr.exp_avg).all()
 
 
+def test_trainer_lr_schedule_and_backing_off_loss_scale(dev):
+    """the reference's --lr_scheduler / --lr_warmup_steps (train_apadapter_v2.py:809-815) and the GradScaler behind accelerate's fp16 mode
+    (:958): warm-up starts at lr 0 (the first update changes nothing), the scale halves behind an overflowed step WITHOUT a host sync in the
+    step (read one step late from pinned memory), a captured micro-step re-captures with the new scale and still accumulates the same
+    unscaled gradient"""
+    import ap_adapter_amd as A
+    u, cfg, sd, procs = _small_unet(dev, torch.float16)
+    tr = A.AdapterTrainer(u, lr=1e-3, lr_scheduler="constant_with_warmup", lr_warmup_steps=2, gradient_accumulation_steps=1)
+    assert tr.dynamic_loss_scale and tr.loss_scale == 65536.0 and tr.lr == 0.0
+    lat, noise, t, ehs, ehs1, m1 = _batch(2, 8, torch.float16)
+    args = tuple(x.to(dev) for x in (lat, t, ehs, ehs1, m1, noise))
+    replay = tr.capture_micro_step(2, lat.shape[2], lat.shape[3], ehs.shape[1], ehs1.shape[1])
+    def step():  # (the flag copy behind a step has landed by the next one in a real run; make that certain here)
+        tr.optimizer_step()
+        torch.cuda.synchronize()
+
+    replay(*args)
+    g_ref = tr.grad.clone()
+    before = tr.master.clone()
+    step()                                                # lr 0: AdamW (decay included) moves nothing
+    assert torch.equal(tr.master, before) and tr.lr == 5e-4
+    replay(*args)
+    step()
+    assert not torch.equal(tr.master, before) and tr.lr == 1e-3
+    tr.grad.fill_(float("inf"))                           # an overflowed step ...
+    tr._micro = 1
+    step()
+    assert tr.loss_scale == 65536.0                       # ... is noticed behind the NEXT boundary
+    replay(*args)
+    step()
+    assert tr.loss_scale == 32768.0 and tr.skipped_steps == 1 and tr.global_step == 4
+    tr.grad.zero_()
+    tr._micro = 0
+    replay(*args)                                         # re-captured with the halved scale: same unscaled gradient (weights moved a little)
+    assert 1 - float(F.cosine_similarity(tr.grad.double(), g_ref.double(), dim=0)) < 2e-2
+    sd_ = tr.state_dict()
+    assert sd_["loss_scale"] == 32768.0 and sd_["scheduler_step"] == 4
+    # growth: scale_growth_interval clean boundaries double it
+    u2, *_ = _small_unet(dev, torch.float16)
+    tr2 = A.AdapterTrainer(u2, lr=1e-4, scale_growth_interval=2)
+    for _ in range(4):
+        tr2.micro_step(*args)
+        tr2.optimizer_step()
+        torch.cuda.synchronize()
+    assert tr2.loss_scale == 131072.0 and tr2.skipped_steps == 0
+    # bf16 runs unscaled and static
+    u3, *_ = _small_unet(dev, torch.bfloat16)
+    assert not A.AdapterTrainer(u3).dynamic_loss_scale
+
+
 def test_grad_norm_and_adamw_match_the_oracle(dev):
     """clip coefficient + AdamW over a flat buffer, 3 steps, against oracle/train.py (itself pinned to torch.optim.AdamW)"""
     from ap_adapter_amd import ops
@@ -404,15 +454,16 @@ def test_graph_captured_micro_step_equals_eager(dev):
     assert float(tr.micro_step(*args2)) == l2 and torch.equal(tr.grad, g2)
 
 
-@pytest.mark.parametrize("dtype,frames", [(torch.bfloat16, 250), (torch.float32, 64)])
-def test_full_geometry_adapter_gradients_vs_oracle(dev, dtype, frames):
+@pytest.mark.parametrize("dtype,frames,B", [(torch.bfloat16, 250, 1), (torch.float32, 64, 1), (torch.bfloat16, 64, 4)])
+def test_full_geometry_adapter_gradients_vs_oracle(dev, dtype, frames, B):
     """BASELINE config 5 geometry (AudioLDM2-large, 718 M frozen parameters, 64 trainable tensors = 21 626 880 elements),
     one 10 s sample at a random t: every adapter gradient after a backward through the whole UNet vs torch autograd
     through the fp32 oracle.  Bound (bf16): the flat gradient's direction within 1 - cos < 5e-3 and its norm within 3 %;
     per tensor, max-abs error below 0.15 of that tensor's largest entry (the smallest gradients sit deep in the stack).
     fp32 (the reference's default training precision, train.sh): 1 - cos < 1e-7, norm within 1e-4, every tensor within 1e-3 of its max
     (on a 2.56 s sample, ``frames`` = 64: same network, a quarter of the oracle's autograd work; the 10 s fp32 run measured cos 1.000000,
-    worst tensor 2.1e-5)."""
+    worst tensor 2.1e-5).  B = 4: the cfg-5 micro-batch -- four samples at FOUR DIFFERENT timesteps (train_apadapter_v2.py:900-905 draws one
+    per sample), 2.56 s each: the per-sample time projection and the batch-mean loss at full geometry."""
     import ap_adapter_amd as A
     from ap_adapter_amd.synthetic import init_synthetic_, synthetic_inputs
     from oracle import train as OT
@@ -421,14 +472,14 @@ def test_full_geometry_adapter_gradients_vs_oracle(dev, dtype, frames):
     u = u.to(dtype)
     sd = {k: v.detach().float() for k, v in u.state_dict().items()}
     procs = {n: dict(scale=p.scale, num_tokens=p.num_tokens) for n, p in u.attn_processors.items() if hasattr(p, "to_k_ip")}
-    inp = synthetic_inputs(1, 32)
+    inp = synthetic_inputs(B, 32)
     pipe = A.AudioLDM2Pipeline(u)
-    ehs = pipe.assemble_condition(inp["generated_prompt_embeds"], inp["audio_tokens"], inp["uncond_audio_tokens"], dtype)[1:]
-    ehs1 = inp["prompt_embeds"].to(dtype)[1:]
-    m1 = inp["attention_mask"].float()[1:]
+    ehs = pipe.assemble_condition(inp["generated_prompt_embeds"], inp["audio_tokens"], inp["uncond_audio_tokens"], dtype)[B:]
+    ehs1 = inp["prompt_embeds"].to(dtype)[B:]
+    m1 = inp["attention_mask"].float()[B:]
     g = torch.Generator().manual_seed(9)
-    noise = torch.randn(1, 8, 250, 16, generator=g)[:, :, :frames].contiguous()
-    t = torch.tensor([437])
+    noise = torch.randn(B, 8, 250, 16, generator=g)[:, :, :frames].contiguous()
+    t = torch.tensor([437, 12, 880, 651][:B])
     noisy = q(OT.add_noise(inp["latents"].float()[:, :, :frames].contiguous(), noise, t), dtype)
     ref_loss, ref_grads, _ = OT.loss_and_grads(sd, u.config.geometry_dict(), procs, noisy, t, ehs.float(), ehs1.float(), m1, noise)
     u = u.to(dev)

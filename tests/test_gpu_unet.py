@@ -9,10 +9,10 @@ from util import rel_err
 pytestmark = pytest.mark.gpu
 
 
-def _small_unet(dev, dtype, seed=100):
+def _small_unet(dev, dtype, seed=100, cad=(None, 768, 1024, None)):
     import ap_adapter_amd as A
     from ap_adapter_amd.synthetic import init_synthetic_
-    cfg = A.UNetConfig(block_out_channels=(64, 128, 192, 256), attention_head_dim=4, norm_num_groups=16)
+    cfg = A.UNetConfig(block_out_channels=(64, 128, 192, 256), attention_head_dim=4, norm_num_groups=16, cross_attention_dim=cad)
     u = A.AudioLDM2UNet2DConditionModel(cfg)
     A.install_ap_adapter(u, None, scale=0.5)
     init_synthetic_(u, seed, w_std=0.05, bias_std=0.02, norm_jitter=0.1)
@@ -45,6 +45,37 @@ def test_small_unet_forward_vs_oracle(dev, dtype, tol):
             encoder_attention_mask_1=m1.to(dev), return_dict=False)[0]
     assert out.shape == ref.shape
     assert rel_err(out, ref) < tol
+
+
+def test_small_unet_upstream_slot_layout_vs_oracle(dev, monkeypatch):
+    """cross_attention_dim = (None, 768, None, 1024): the transformer-slot layout of the diffusers AudioLDM2 checkpoints (T5 in the LAST
+    slot, an unconditioned double-self-attention slot between the two conditioned ones; routing modeling_audioldm2.py:1140-1149).  Forward
+    vs the oracle, then a 2-step CFG + DDIM loop with the CFG-shared prefix on and off: bit-equal, and vs the oracle loop."""
+    import ap_adapter_amd as A
+    from ap_adapter_amd import unet as U
+    from oracle import unet as OU, ddim
+    dtype = torch.float16
+    u, cfg, sd, procs = _small_unet(dev, dtype, cad=(None, 768, None, 1024))
+    assert len(procs) == len(A.ip_layer_names(u)) == 32  # (one 768-wide slot x 2 blocks per transformer layer, 16 layers)
+    B, H, W = 2, 26, 16
+    x = torch.randn(B, 8, H, W, generator=torch.Generator().manual_seed(1)).to(dtype).float()
+    ehs, ehs1, m1 = _cond(B, 32, dtype)
+    t = torch.tensor(991)
+    ref = OU.unet_forward(sd, cfg.geometry_dict(), x, t, ehs, ehs1, None, m1, procs)
+    out = u(x.to(dev, dtype), t, encoder_hidden_states=ehs.to(dev, dtype), encoder_hidden_states_1=ehs1.to(dev, dtype),
+            encoder_attention_mask_1=m1.to(dev), return_dict=False)[0]
+    assert rel_err(out, ref) < 1e-2
+    lat = torch.randn(B, 8, H, W, generator=torch.Generator().manual_seed(2))
+    ehs, ehs1, m1 = _cond(2 * B, 32, dtype)
+    pipe = A.AudioLDM2Pipeline(u)
+    res = {}
+    for share in (False, True):
+        monkeypatch.setattr(U, "CFG_SHARED_PREFIX", share)
+        res[share] = pipe.denoise(lat.to(dev), ehs.to(dev), ehs1.to(dev), m1.to(dev), 2, 7.5, use_graph=False)
+    assert torch.equal(res[False], res[True])
+    fn = lambda x_, t_: OU.unet_forward(sd, cfg.geometry_dict(), x_, t_, ehs, ehs1, None, m1, procs)
+    ref2, _ = ddim.denoise_loop(fn, lat, 2, 7.5)
+    assert rel_err(res[True], ref2) < 3e-2
 
 
 def test_small_unet_graph_loop_vs_oracle_loop(dev):
@@ -485,3 +516,72 @@ def test_rccl_world1_flat_gradient_allreduce(dev):
         assert D.gather_latents(lat) is lat
     finally:
         dist.destroy_process_group()
+
+
+# ---- ready for the first multi-GPU box: these run only where >= 2 GPUs are visible (the round's box has one) ----
+def _need_gpus(n):
+    if torch.cuda.device_count() < n:
+        pytest.skip(f"needs {n} GPUs (this box has {torch.cuda.device_count()})")
+
+
+def test_two_gpu_bench_and_rccl_gradient_allreduce(dev):
+    """`bench.py --gpus 2` starts its two ranks itself (one process per GPU, RCCL): n_gpus 2, two per-rank timings, about twice the
+    1-GPU throughput (weak scaling, no collective in the loop); then the training step's ONE collective -- the flat 86.5 MB fp32
+    adapter-gradient all-reduce (train_apadapter_v2.py:831-833, :958 under DDP) -- on two ranks over RCCL"""
+    _need_gpus(2)
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    run = lambda n: json.loads(subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "5", "--warmup", "2", "--step-only"],
+                                              capture_output=True, text=True, env=env, timeout=1200, check=True).stdout.strip().splitlines()[-1])
+    one, two = run(1), run(2)
+    assert two["n_gpus"] == 2 and len(two["rank_ms_per_step"]) == 2 and two["scaling"] == "weak"
+    assert 1.7 < two["value"] / one["value"] < 2.2, (one["value"], two["value"])
+    code = ("import os, torch, torch.distributed as dist\n"
+            "import ap_adapter_amd as A\n"
+            "from ap_adapter_amd import distributed as D\n"
+            "rank, world, local = D.init_from_env('nccl')\n"
+            "flat = torch.full((21626880,), float(rank + 1), device=f'cuda:{local}')\n"
+            "den = D.average_flat_gradient_(flat, 4)\n"
+            "torch.cuda.synchronize()\n"
+            "assert den == 8.0 and bool((flat == 3.0 / 8.0).all()), (den, float(flat[0]))\n"
+            "dist.barrier(); print('ok', rank)\n")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", "-c", code], capture_output=True, text=True, env=dict(env, PYTHONPATH=root), timeout=600)
+    if r.returncode != 0 and "-c" in (r.stderr or ""):  # (a torchrun without -c: run the same body from a temp file)
+        import tempfile
+        with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+            f.write(code)
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", "29534", f.name], capture_output=True, text=True, env=dict(env, PYTHONPATH=root), timeout=600)
+    assert r.returncode == 0 and r.stdout.count("ok") == 2, r.stderr[-2000:]
+
+
+def test_cfg4_dry_run_with_the_eval_sets_sample_rate_mix(dev, tmp_path):
+    """tools/run_sharded.py's job on synthetic wavs with the evaluation set's sample-rate mix (44.1 k x 45, 48 k x 5, 16 k x 2): every
+    rate goes through the polyphase resampler + Kaldi fbank + AudioMAE into a condition, clips are denoised in one captured geometry"""
+    import sys
+    import wave
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import run_sharded as RS
+    import ap_adapter_amd as A
+    from ap_adapter_amd import sharded as S
+    from ap_adapter_amd.frontend import load_mel
+    files = RS.write_synthetic_wavs(str(tmp_path), n=8, seconds=1.5, rate_mix=RS.EVAL_RATE_MIX)
+    rates = []
+    for f in files:
+        with wave.open(f) as w:
+            rates.append(w.getframerate())
+    assert set(rates) == {44100, 48000, 16000}
+    cfg = A.get_config("style_transfer")
+    pipe = RS.build_job(dev, torch.bfloat16, cfg, small=True)
+    mels = [load_mel(f, device=dev) for f in files]
+    assert all(m.shape == mels[0].shape and bool(torch.isfinite(m).all()) for m in mels)
+    clips = S.list_clips(files, cfg, 8)
+    enc = lambda path, tp, fp: tuple(t[0] for t in pipe.encode_audio(load_mel(path, device=dev), tp, fp))
+    den = lambda lat, gen, t5, mask, gs: pipe.denoise(lat, gen, t5, mask, 2, gs)
+    out = S.run_sharded(clips, cfg, enc, den, batch=4, latent_shape=(8, 24, 16), device=dev)
+    assert sorted(out) == list(range(8)) and all(torch.isfinite(v).all() for v in out.values())
+    assert pipe.graph_captures == 1

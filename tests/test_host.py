@@ -34,6 +34,20 @@ def test_geometry_matches_the_shipped_adapter_weights(unet):
         assert list(attn.to_v.weight.shape) == INDEX[n + "_v.bin"]
 
 
+def test_upstream_transformer_slot_layout_selects_the_same_sites():
+    """the diffusers AudioLDM2 checkpoints lay the four transformer slots out as (None, 768, None, 1024) (the author's table
+    inference.py:16 implies (None, 768, 1024, None); the routing modeling_audioldm2.py:1140-1149 takes either): the adapter sites are
+    the 768-wide slot in both, so the same 32 names and shapes"""
+    u = A.AudioLDM2UNet2DConditionModel(A.UNetConfig(cross_attention_dim=(None, 768, None, 1024)))
+    assert len(u.attn_processors) == 256
+    names = A.ip_layer_names(u)
+    assert sorted(names) == sorted({re.sub(r"_[kv]\.bin$", "", f) for f in INDEX})
+    t5 = [n for n, m in u.named_modules() if n.endswith("attn2") and m.to_k.in_features == 1024]
+    assert len(t5) == 32 and all(".attentions." in n and int(n.split(".attentions.")[1].split(".")[0]) % 4 == 3 for n in t5)
+    procs = A.install_ap_adapter(u, None, scale=0.5)
+    assert sum(hasattr(p, "to_k_ip") for p in procs.values()) == 32
+
+
 def test_reference_wiring_loop_selects_the_same_sites(unet):
     """inference.py:16-49 verbatim logic: cross[layer_num % 8] over the attn2 processors in attn_processors order"""
     cross = [None, None, 768, 768, 1024, 1024, None, None]

@@ -48,3 +48,35 @@ def test_checkpoint_rotation(tmp_path):
     assert removed == ["checkpoint-100", "checkpoint-200"]
     assert sorted(os.listdir(out), key=lambda d: int(d.split("-")[1])) == ["checkpoint-300", "checkpoint-1000"]
     assert T.rotate_checkpoints(out, 5) == []
+
+
+def test_lr_schedules_match_the_published_lambdas():
+    """ap_adapter_amd.training.get_scheduler restates diffusers.optimization.get_scheduler (0.21.2, absent offline; call site
+    train_apadapter_v2.py:809-815); the installed transformers ships the same schedule functions (diffusers' file is a copy of it) --
+    pinned against their LambdaLR multipliers step by step"""
+    import transformers.optimization as TO
+    opt = lambda: torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+    W, N = 7, 50
+    cases = {
+        "constant": TO.get_constant_schedule(opt()),
+        "constant_with_warmup": TO.get_constant_schedule_with_warmup(opt(), W),
+        "linear": TO.get_linear_schedule_with_warmup(opt(), W, N),
+        "cosine": TO.get_cosine_schedule_with_warmup(opt(), W, N),
+        "cosine_with_restarts": TO.get_cosine_with_hard_restarts_schedule_with_warmup(opt(), W, N, num_cycles=3),
+    }
+    for name, sched in cases.items():
+        f = T.get_scheduler(name, W, N, num_cycles=3)
+        lam = sched.lr_lambdas[0]
+        for step in range(0, N + 5):
+            assert abs(f(step) - lam(step)) < 1e-12, (name, step)
+    p_opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1e-4)
+    lam = TO.get_polynomial_decay_schedule_with_warmup(p_opt, W, N, lr_end=1e-7, power=2.0).lr_lambdas[0]
+    f = T.get_scheduler("polynomial", W, N, power=2.0, lr_init=1e-4)
+    assert all(abs(f(s_) - lam(s_)) < 1e-12 for s_ in range(N + 5))
+    pw = T.get_scheduler("piecewise_constant", step_rules="1:10,0.1:20,0.01")
+    assert [pw(0), pw(9), pw(10), pw(19), pw(20), pw(10 ** 6)] == [1.0, 1.0, 0.1, 0.1, 0.01, 0.01]
+    import pytest
+    with pytest.raises(ValueError):
+        T.get_scheduler("linear", W)
+    with pytest.raises(ValueError):
+        T.get_scheduler("exponential")

@@ -22,11 +22,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 
-def write_synthetic_wavs(out_dir, n=8, seconds=10.0, sr=16000):
-    """seeded two-partial tones with a slow envelope, 16-bit PCM: stand-ins for eval_audio_in_domain/*.wav"""
+EVAL_RATE_MIX = ((44100, 45), (48000, 5), (16000, 2))  # sample rates of the reference's eval_audio_* wavs: 45 + 5 + 2 files
+
+
+def write_synthetic_wavs(out_dir, n=8, seconds=10.0, sr=16000, rate_mix=None):
+    """seeded two-partial tones with a slow envelope, 16-bit PCM: stand-ins for eval_audio_in_domain/*.wav.  rate_mix = ((rate, weight), ...):
+    file i takes the sample rate of its slot in the weighted cycle (EVAL_RATE_MIX: the evaluation set's 44.1 k / 48 k / 16 k proportions),
+    so the front-end's resampler is on the path as it is for the real set"""
     os.makedirs(out_dir, exist_ok=True)
     paths = []
+    cycle = [r for r, w_ in (rate_mix or ((sr, 1),)) for _ in range(w_)]
     for i in range(n):
+        sr = cycle[(i * 7) % len(cycle)] if rate_mix else sr  # (stride 7: every rate shows up within the first few files)
         g = torch.Generator().manual_seed(i)
         f0 = 110.0 * 2 ** (float(torch.rand(1, generator=g)) * 3)
         t = torch.arange(int(seconds * sr)) / sr
