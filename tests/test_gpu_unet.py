@@ -50,9 +50,12 @@ def test_small_unet_forward_vs_oracle(dev, dtype, tol):
 def test_small_unet_upstream_slot_layout_vs_oracle(dev, monkeypatch):
     """cross_attention_dim = (None, 768, None, 1024): the transformer-slot layout of the diffusers AudioLDM2 checkpoints (T5 in the LAST
     slot, an unconditioned double-self-attention slot between the two conditioned ones; routing modeling_audioldm2.py:1140-1149).  Forward
-    vs the oracle, then a 2-step CFG + DDIM loop with the CFG-shared prefix on and off: bit-equal, and vs the oracle loop."""
+    vs the oracle, then a 2-step CFG + DDIM loop with the CFG-shared prefix on and off: both track the oracle loop, and in the fp32 mode the
+    two agree to summation-order rounding (1e-5) -- the un-duplicated prefix and cfg_expand sit where this layout's first conditioned slot
+    is.  (Bit-equality of the two is a property of the full geometry, where a launch's kernel form does not change between B and 2 B rows:
+    test_cfg_shared_prefix_and_two_source_resnets_equal_the_plain_step; on this 13-token toy level it does, in either layout.)"""
     import ap_adapter_amd as A
-    from ap_adapter_amd import unet as U
+    from ap_adapter_amd import ops, unet as U
     from oracle import unet as OU, ddim
     dtype = torch.float16
     u, cfg, sd, procs = _small_unet(dev, dtype, cad=(None, 768, None, 1024))
@@ -68,14 +71,23 @@ def test_small_unet_upstream_slot_layout_vs_oracle(dev, monkeypatch):
     lat = torch.randn(B, 8, H, W, generator=torch.Generator().manual_seed(2))
     ehs, ehs1, m1 = _cond(2 * B, 32, dtype)
     pipe = A.AudioLDM2Pipeline(u)
-    res = {}
-    for share in (False, True):
-        monkeypatch.setattr(U, "CFG_SHARED_PREFIX", share)
-        res[share] = pipe.denoise(lat.to(dev), ehs.to(dev), ehs1.to(dev), m1.to(dev), 2, 7.5, use_graph=False)
-    assert torch.equal(res[False], res[True])
     fn = lambda x_, t_: OU.unet_forward(sd, cfg.geometry_dict(), x_, t_, ehs, ehs1, None, m1, procs)
     ref2, _ = ddim.denoise_loop(fn, lat, 2, 7.5)
-    assert rel_err(res[True], ref2) < 3e-2
+    first, real = [], ops.conv3x3
+    monkeypatch.setattr(ops, "conv3x3", lambda x_, w, b_, Bc, *a, **kw: (first.append(Bc) if not first else None, real(x_, w, b_, Bc, *a, **kw))[1])
+    for share in (False, True):
+        monkeypatch.setattr(U, "CFG_SHARED_PREFIX", share)
+        del first[:]
+        res = pipe.denoise(lat.to(dev), ehs.to(dev), ehs1.to(dev), m1.to(dev), 2, 7.5, use_graph=False)
+        assert first[0] == (B if share else 2 * B)        # conv_in really ran un-duplicated
+        assert rel_err(res, ref2) < 3e-2
+    u32 = u.float()
+    pipe32 = A.AudioLDM2Pipeline(u32)
+    r32 = {}
+    for share in (False, True):
+        monkeypatch.setattr(U, "CFG_SHARED_PREFIX", share)
+        r32[share] = pipe32.denoise(lat.to(dev), ehs.to(dev), ehs1.to(dev), m1.to(dev), 2, 7.5, use_graph=False)
+    assert rel_err(r32[True], r32[False].cpu()) < 1e-5 and rel_err(r32[True], ref2) < 1e-4
 
 
 def test_small_unet_graph_loop_vs_oracle_loop(dev):
@@ -569,7 +581,7 @@ def test_cfg4_dry_run_with_the_eval_sets_sample_rate_mix(dev, tmp_path):
     import ap_adapter_amd as A
     from ap_adapter_amd import sharded as S
     from ap_adapter_amd.frontend import load_mel
-    files = RS.write_synthetic_wavs(str(tmp_path), n=8, seconds=1.5, rate_mix=RS.EVAL_RATE_MIX)
+    files = RS.write_synthetic_wavs(str(tmp_path), n=16, seconds=1.5, rate_mix=RS.EVAL_RATE_MIX)
     rates = []
     for f in files:
         with wave.open(f) as w:
@@ -579,9 +591,9 @@ def test_cfg4_dry_run_with_the_eval_sets_sample_rate_mix(dev, tmp_path):
     pipe = RS.build_job(dev, torch.bfloat16, cfg, small=True)
     mels = [load_mel(f, device=dev) for f in files]
     assert all(m.shape == mels[0].shape and bool(torch.isfinite(m).all()) for m in mels)
-    clips = S.list_clips(files, cfg, 8)
+    clips = S.list_clips(files, cfg, 16)
     enc = lambda path, tp, fp: tuple(t[0] for t in pipe.encode_audio(load_mel(path, device=dev), tp, fp))
     den = lambda lat, gen, t5, mask, gs: pipe.denoise(lat, gen, t5, mask, 2, gs)
     out = S.run_sharded(clips, cfg, enc, den, batch=4, latent_shape=(8, 24, 16), device=dev)
-    assert sorted(out) == list(range(8)) and all(torch.isfinite(v).all() for v in out.values())
+    assert sorted(out) == list(range(16)) and all(torch.isfinite(v).all() for v in out.values())
     assert pipe.graph_captures == 1

@@ -43,4 +43,37 @@ if fa and wa and rd and wr:
     out["write_bytes_per_launch"] = w
     out["traffic_bytes_per_launch"] = f + w
     out["algorithmic_bytes_per_launch"] = 131072000
+
+
+def totals(sub, counter):
+    """(sum over every dispatch, {kernel: (dispatches, sum)}) of one pass"""
+    dbs = glob.glob(os.path.join(root, sub, "**", "*.db"), recursive=True)
+    if not dbs:
+        return None, {}
+    c = sqlite3.connect(dbs[0])
+    rows = c.execute("select kernel_name, count(distinct dispatch_id), sum(value) from counters_collection where counter_name = ? group by kernel_name",
+                     (counter,)).fetchall()
+    return sum(r[2] for r in rows), {r[0]: (r[1], r[2]) for r in rows}
+
+
+# the whole captured step: bench.py --step-only with 1 and with 5 timed steps; (5 - 1) / 4 = one step (set-up, warm-up and capture cancel)
+f1, fk1 = totals("FETCH_SIZE_step1", "FETCH_SIZE")
+f5, fk5 = totals("FETCH_SIZE_step5", "FETCH_SIZE")
+w1, wk1 = totals("WRITE_SIZE_step1", "WRITE_SIZE")
+w5, wk5 = totals("WRITE_SIZE_step5", "WRITE_SIZE")
+if None not in (f1, f5, w1, w5) and rd and wr:
+    rf, wf = out["calibration"]["read_factor"], out["calibration"]["write_factor"]
+    rbytes, wbytes = (f5 - f1) / 4.0 * 1024.0 * rf, (w5 - w1) / 4.0 * 1024.0 * wf
+    out["whole_step"] = {"read_bytes_per_step": rbytes, "write_bytes_per_step": wbytes, "bytes_per_step": rbytes + wbytes,
+                         "how": "bench.py --step-only (batch 32, La 32): (5-step pass - 1-step pass) / 4, each counter in its own pass"}
+    import re
+    per = {}
+    for name in fk5:
+        if name in fk1 and name in wk5 and name in wk1 and fk5[name][0] > fk1[name][0]:
+            n = fk5[name][0] - fk1[name][0]
+            per[name] = (n / 4.0, (fk5[name][1] - fk1[name][1]) / n * 1024.0 * rf, (wk5[name][1] - wk1[name][1]) / n * 1024.0 * wf)
+    top = sorted(per.items(), key=lambda kv: -kv[1][0] * (kv[1][1] + kv[1][2]))[:24]
+    out["per_kernel"] = [{"kernel": re.sub(r"\(anonymous namespace\)::", "", k)[:100], "launches_per_step": round(v[0], 1),
+                          "read_bytes_per_launch": round(v[1]), "write_bytes_per_launch": round(v[2]),
+                          "share_of_step_bytes": round(v[0] * (v[1] + v[2]) / (rbytes + wbytes), 4)} for k, v in top]
 print(json.dumps(out, indent=1))

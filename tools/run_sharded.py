@@ -31,9 +31,10 @@ def write_synthetic_wavs(out_dir, n=8, seconds=10.0, sr=16000, rate_mix=None):
     so the front-end's resampler is on the path as it is for the real set"""
     os.makedirs(out_dir, exist_ok=True)
     paths = []
-    cycle = [r for r, w_ in (rate_mix or ((sr, 1),)) for _ in range(w_)]
+    # (each rate's slots spread evenly over the cycle: 16 files of EVAL_RATE_MIX already hold all three rates)
+    cycle = [r for _, r in sorted(((k + 0.5) / w_, r) for r, w_ in (rate_mix or ((sr, 1),)) for k in range(w_))]
     for i in range(n):
-        sr = cycle[(i * 7) % len(cycle)] if rate_mix else sr  # (stride 7: every rate shows up within the first few files)
+        sr = cycle[i % len(cycle)] if rate_mix else sr
         g = torch.Generator().manual_seed(i)
         f0 = 110.0 * 2 ** (float(torch.rand(1, generator=g)) * 3)
         t = torch.arange(int(seconds * sr)) / sr
