@@ -215,6 +215,96 @@ def profile_in_step_avg_us(substr):
     return None, None
 
 
+def profile_top_line():
+    """the first entry of the newest committed rocprofv3 kernel-trace summary of `bench.py --step-only`, whatever kernel it is: share of the
+    kernel time, launches per step, average duration"""
+    import glob
+    import re
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats*.txt")), reverse=True):
+        steps = None
+        with open(path) as f:
+            for line in f:
+                m = re.search(r"over (\d+) steps", line)
+                if m:
+                    steps = int(m.group(1))
+                if not line.startswith("#") and line.strip():
+                    t = line.split(None, 5)
+                    return {"kernel": t[5].strip()[:100], "pct_of_kernel_time": float(t[0]), "launches_per_step": round(int(t[1]) / steps, 1) if steps else None,
+                            "avg_us": float(t[2]), "source": os.path.relpath(path, ROOT)}
+    return None
+
+
+# algorithmic work of the 64-token level's row-tile kernels per launch at B' sample-forwards (N = 64, C = 640; csrc/hsattn.hip)
+LEVEL64 = {"hs_attn_kernel<0, true": ("self-attention sub-layer part 1: LN + q|k|v + attention (apad_hs_attention)", lambda b: 2.0 * b * 64 * 640 * 1920 + 4.0 * b * 8 * 64 * 64 * 80),
+           "hs_out_kernel": ("to_out + bias + residual (apad_hs_out)", lambda b: 2.0 * b * 64 * 640 * 640),
+           "hs_geglu_kernel": ("LN + GEGLU projection (apad_hs_geglu)", lambda b: 2.0 * b * 64 * 640 * 5120),
+           "hs_ff2_kernel": ("FF2 + bias + residual (apad_hs_ff2)", lambda b: 2.0 * b * 64 * 2560 * 640)}
+
+
+def level64_from_profile(B2, n_streams):
+    """in-step averages of the 64-token level's kernels from the committed profile -> achieved TFLOP/s (each launch covers B' / streams samples)"""
+    out = {}
+    for sub, (what, fl) in LEVEL64.items():
+        us, src = profile_in_step_avg_us(sub)
+        if us:
+            b = B2 // max(n_streams, 1)
+            out[sub.split("<")[0]] = {"what": what, "in_step_avg_us": us, "samples_per_launch": b, "tflops": round(fl(b) / (us * 1e-6) / 1e12, 1),
+                                      "mfma_frac": round(fl(b) / (us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4), "source": src}
+    return out
+
+
+def whole_step_hbm(ms_per_step):
+    """HBM bytes of one captured step from the committed PMC passes (tools/round_pmc_traffic.sh) -> fraction of the 8 TB/s peak at this step time"""
+    import glob
+    for tp in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
+        with open(tp) as f:
+            d = json.load(f)
+        ws = d.get("whole_step")
+        if ws:
+            gbs = ws["bytes_per_step"] / (ms_per_step * 1e-3) / 1e9
+            return {"bytes_per_step": int(ws["bytes_per_step"]), "read_bytes": int(ws["read_bytes_per_step"]), "write_bytes": int(ws["write_bytes_per_step"]),
+                    "achieved_GBs": round(gbs, 1), "hbm_frac_whole_step": round(gbs / HBM_PEAK_GBS, 4), "source": os.path.relpath(tp, ROOT)}
+    return None
+
+
+def fp32_mode_step_ms(A, unet, inp, args, dev, steps=2):
+    """the SAME step in the fp32 precision mode (exact-f32 MFMA, the mode whose noise_pred meets the 1e-3 bar: DESIGN 5), eager, `steps` timed
+    steps after one warm-up.  Converts the model in place: called after every 16-bit measurement."""
+    from ap_adapter_amd import ops
+    unet = unet.float()
+    unet.set_kv_cache(False)
+    unet.set_kv_cache(True)
+    pipe = A.AudioLDM2Pipeline(unet)
+    B = args.batch
+    ge = pipe.assemble_condition(inp["generated_prompt_embeds"].to(dev), inp["audio_tokens"].to(dev), inp["uncond_audio_tokens"].to(dev), torch.float32)
+    pe, am = inp["prompt_embeds"].to(dev, torch.float32), inp["attention_mask"].to(dev)
+    H, W, Cc = 250, 16, 8
+    sched = pipe.scheduler
+    sched.set_timesteps(DDIM_STEPS_PER_CLIP)
+    coef = sched.coef_table().to(dev)
+    step_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
+    lat = inp["latents"].to(dev).float().permute(0, 2, 3, 1).reshape(B, H * W, Cc).contiguous()
+    unet_in = lat.clone()
+    unet.precompute_time_tables(sched.timesteps.to(dev), step_ptr)
+
+    def step():
+        eps2 = unet.forward_nhwc(unet_in, H, W, None, ge, pe, None, am, batch_repeat=2)
+        ops.cfg_ddim_step(eps2, lat, unet_in, coef, step_ptr, args.guidance)
+        ops.step_advance(step_ptr)
+
+    with torch.no_grad():
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"ms_per_step": round(ms, 1), "clips_per_s": round(B / (DDIM_STEPS_PER_CLIP * ms * 1e-3), 4), "steps": steps,
+            "what": "the same batch-32 step with fp32 storage and exact-f32 MFMA (v_mfma_f32_32x32x2_f32, 1/16 of the bf16 rate), eager launches: "
+                    "the mode in which noise_pred is within 1e-3 of the oracle chain (measured 1e-5)", "finite": bool(torch.isfinite(lat).all().item())}
+
+
 def dominant_kernel_roofline(dev, dtype, B2, in_step=None, in_step_how=None):
     """Roofline of the kernel with the largest share of the step in the committed rocprof summary: the self-attention of the
     1000-token level (single segment, d = 32), softmax(Q K^T / sqrt(32)) V over B2 samples x 8 heads x 1000 x 1000.
@@ -333,18 +423,19 @@ def fused_attn2_grid(dev, dtype, B2, ap_scale):
         ln = (torch.ones(C_, device=dev, dtype=dtype), torch.zeros(C_, device=dev, dtype=dtype), 1e-5)
         for La in (8, 32, 128, 512):
             ehs = torch.randn(B2, 8 + La, 768, device=dev).to(dtype)
-            calls = []
-            real, real_rows = ops.fused_cross_attention, ops.cross_attention_rows
+            calls, hs = [], []
+            real, real_rows, real_hs = ops.fused_cross_attention, ops.cross_attention_rows, ops.hs_attention
             ops.fused_cross_attention = lambda *a, **kw: (calls.append(1), real(*a, **kw))[1]
             ops.cross_attention_rows = lambda *a, **kw: (calls.append(1), real_rows(*a, **kw))[1]  # (the 384-wide level's one-launch kernel)
+            ops.hs_attention = lambda *a, **kw: (hs.append(1), real_hs(*a, **kw))[1]               # (the 64-token level: head-sliced, + hs_out)
             try:
                 with torch.no_grad():
                     ms = time_kernel_graphed(lambda: attn(x, encoder_hidden_states=ehs, residual=x, ln=ln))
             finally:
-                ops.fused_cross_attention, ops.cross_attention_rows = real, real_rows
+                ops.fused_cross_attention, ops.cross_attention_rows, ops.hs_attention = real, real_rows, real_hs
             flops = (4.0 * N * C_ * C_ + 4.0 * N * (8 + La) * C_) * B2
             nbytes = 2 * B2 * N * C_ * 2 + 2 * C_ * C_ * 2 + 2 * B2 * (8 + La) * C_ * 2
-            grid[f"C{C_}_N{N}_La{La}"] = {"us": round(ms * 1e3, 2), "route": "one launch" if calls else "three launches",
+            grid[f"C{C_}_N{N}_La{La}"] = {"us": round(ms * 1e3, 2), "route": "one launch" if calls else ("two launches (head-sliced + to_out)" if hs else "three launches"),
                                          "mfma_frac": round(flops / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
                                          "hbm_frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             proc.clear_kv_cache()
@@ -505,6 +596,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="2 = run the two CFG halves on concurrent streams")
     ap.add_argument("--low-res-streams", type=int, default=1, help="n > 0: run the two batch halves of the n lowest-resolution levels on two streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32-precision-mode timing of the same step")
     ap.add_argument("--step-only", action="store_true", help="only the timed step (for rocprofv3 runs: no roofline re-timings, no AudioMAE, no CPU leg)")
     ap.add_argument("--train", action="store_true", help="time BASELINE cfg 5 (the adapter's training step) instead of the denoise step")
     ap.add_argument("--train-batch", type=int, default=4)
@@ -658,6 +750,10 @@ def main():
                     "fused_attn2_ip": ("fused_cross_attention", lambda x, *a, **kw: kw.get("L2", 0) > 0),
                     "fused_attn2_t5": ("fused_cross_attention", lambda x, *a, **kw: not kw.get("L2", 0))})
         line["roofline"] = dominant_kernel_roofline(dev, dtype, 2 * B, ins.get("self_attn_1000"), how)
+        line["roofline_top_line"] = profile_top_line()
+        nst = len(unet.low_res_streams) if getattr(unet, "low_res_streams", None) else 1
+        line["level64_kernels"] = level64_from_profile(2 * B, nst)
+        line["hbm_whole_step"] = whole_step_hbm(ms_per_step)
         line["fused_attn2"] = fused_attn2_roofline(dev, dtype, 2 * B, args.la, args.ap_scale, ins.get("fused_attn2_ip"), how)
         line["fused_attn2"]["t5_sites_in_step"] = ins.get("fused_attn2_t5")
         try:
@@ -682,6 +778,11 @@ def main():
                                                      "loss_last", "finite")}
             except Exception as e:  # noqa: BLE001
                 line["train"] = {"error": repr(e)}
+        if not args.no_fp32_leg and world == 1:
+            try:
+                line["fp32_mode"] = fp32_mode_step_ms(A, unet, inp, args, dev)
+            except Exception as e:  # noqa: BLE001
+                line["fp32_mode"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:  # the host baseline is reported at N = 1 only
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

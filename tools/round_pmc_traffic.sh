@@ -9,16 +9,20 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-r04_v1}
 OUT=$R/gpurun_out/traffic_$TAG
 rm -rf $OUT; mkdir -p $OUT
-[ -x $R/tools/probes/rbw ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $R/tools/probes/rbw $R/tools/probes/rbw.hip
-[ -x $R/tools/probes/wbw ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $R/tools/probes/wbw $R/tools/probes/wbw.hip
+[ -x $R/tools/probes/rbw ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o $R/tools/probes/rbw $R/tools/probes/rbw.hip
+[ -x $R/tools/probes/wbw ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o $R/tools/probes/wbw $R/tools/probes/wbw.hip
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   for n in 1 5; do
-    rocprofv3 --pmc $c -d $OUT/${c}_step$n -o p -- python $R/bench.py --steps $n --warmup 1 --step-only > $OUT/${c}_step$n.log 2>&1
+    for try in 1 2 3; do  # (a counter pass over the graph-replayed step occasionally never returns on this ROCm: bounded, retried)
+      rm -rf $OUT/${c}_step$n
+      APAD_LOW_RES_NSTREAMS=1 timeout 150 rocprofv3 --pmc $c -d $OUT/${c}_step$n -o p -- python $R/bench.py --steps $n --warmup 1 --step-only > $OUT/${c}_step$n.log 2>&1 && break
+      echo "pass ${c}_step$n try $try failed / timed out"
+    done
   done
-  rocprofv3 --pmc $c -d $OUT/${c}_attn -o p -- python $R/tools/one_op.py attn_self 5 > $OUT/${c}_attn.log 2>&1
-  rocprofv3 --pmc $c -d $OUT/${c}_rbw -o p -- $R/tools/probes/rbw > $OUT/${c}_rbw.log 2>&1
-  rocprofv3 --pmc $c -d $OUT/${c}_wbw -o p -- $R/tools/probes/wbw > $OUT/${c}_wbw.log 2>&1
+  timeout 300 rocprofv3 --pmc $c -d $OUT/${c}_attn -o p -- python $R/tools/one_op.py attn_self 5 > $OUT/${c}_attn.log 2>&1
+  timeout 120 rocprofv3 --pmc $c -d $OUT/${c}_rbw -o p -- $R/tools/probes/rbw > $OUT/${c}_rbw.log 2>&1
+  timeout 120 rocprofv3 --pmc $c -d $OUT/${c}_wbw -o p -- $R/tools/probes/wbw > $OUT/${c}_wbw.log 2>&1
 done
 cd $R && python tools/pmc_traffic_summary.py $OUT > gpurun_out/${TAG}_pmc_traffic.json
 cat gpurun_out/${TAG}_pmc_traffic.json | head -80
