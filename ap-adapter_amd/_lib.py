@@ -110,6 +110,7 @@ SYMBOLS = {
     "apad_cross_attention_rows": (C.c_int, [C.POINTER(XrowsDesc), _vp]),
     "apad_sizeof_hs_attn_desc": (C.c_int, []),
     "apad_hs_attention": (C.c_int, [C.POINTER(HsAttnDesc), _vp]),
+    "apad_self_attention_fused": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
     "apad_hs_geglu": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
     "apad_sizeof_hs_out_desc": (C.c_int, []),
     "apad_hs_out": (C.c_int, [C.POINTER(HsOutDesc), _vp]),

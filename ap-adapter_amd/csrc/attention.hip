@@ -785,6 +785,255 @@ __global__ __launch_bounds__(NW * 64) void attn2q_kernel(AttnP p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// apad_self_attention_fused: LayerNorm + to_q | to_k | to_v + softmax attention of a self-attention sub-layer in ONE launch for the two large
+// levels (C = 256 / d = 32 / <= 1024 tokens, C = 384 / d = 48 / <= 256 tokens): the row-panel projection launch (q, k, v^T written to HBM and read
+// back: 196 MB at the 1000-token level) and the attention launch become one workgroup = (sample, head) that
+//   1. projects the head's K, V^T for ALL tokens of the sample into LDS (in tile_compute2's 64-key tile layout: 16 tiles = 148 KB at 1000 tokens)
+//      and its Q for the tokens each wave will attend from -- 32-token panels, wave w owns panels w, w + NW, ...; the head's packed weight
+//      fragments (48 KB) stream from L2 / L1 k-step by k-step into registers (NSET k-steps ahead), the token fragments are read RAW straight from
+//      global memory in the B-operand layout and the LayerNorm is applied by algebra on the accumulators (statistics summed while the fragments
+//      pass: y = rstd (W' x - mean colsum(W')) + W beta, W' = W gamma; apad_gemm's folded LayerNorm) -- nothing of x is staged or kept;
+//   2. one barrier, then every wave runs the two-query-tile key loop (tile_compute2, direct form: q carries log2(e) / sqrt(d)) over the RESIDENT
+//      K / V^T tiles: no staging, no barrier in the loop; its q fragments never left the registers (the score MFMA contracts over d in the
+//      order the projection's C layout produced it: K is stored with the same permutation of d inside every 16-wide k-step).
+// to_out + residual stay a separate launch (all heads).  Replaces norm1 + to_q / to_k / to_v + scaled_dot_product_attention of
+// attention_processor.py:256-276 behind BasicTransformerBlock.norm1 / norm2 (double self-attention).
+struct SfP {
+    const uint8_t* x;
+    const uint8_t* w;     // packed [H][3 NTD row tiles: q.., k.., v..][KC k-steps][64 lanes][8] (gamma and the softmax scale folded in)
+    const float* csbb;    // [H][2][3 NTD * 32] fp32: row sums of the packed weights, then W . beta
+    uint8_t* out;         // O [B][N][C]
+    int32_t B, N, H;
+    float eps;
+};
+typedef const __attribute__((address_space(1))) uint8_t* sf_gptr;
+typedef const __attribute__((address_space(1))) u32x4* sf_gptr16;
+__device__ __forceinline__ sf_gptr sf_sgpr_ptr(const uint8_t* p) {
+    const uint64_t a = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return (sf_gptr)(((uint64_t)hi << 32) | lo);
+}
+#ifndef SF_NSET
+#define SF_NSET 0  // (0: per-geometry default)
+#endif
+#ifndef SF_ABL
+#define SF_ABL 0  // timing ablations (tools/ab_build.sh; results are wrong): 1 = no key loop, 2 = no projection, 4 = projection without the statistics, 8 = x fragments loaded once
+#endif
+
+// acc[n][j] += W_tile_j . x_panel_n^T over the KC k-steps (raw x), with the row statistics of the panels summed on the way (shifted by the row's
+// first element: both halves of a row use the same shift)
+template <int DT, int NT3, int NPP, int KC, int NSET>
+__device__ __forceinline__ void sf_project(sf_gptr wb, uint32_t loff, const uint8_t* const (&xrow)[NPP], f32x16 (&acc)[NPP][NT3], float (&ssum)[NPP],
+                                           float (&sq)[NPP], float (&shift)[NPP]) {
+    using E = ET<DT>;
+    static_assert(KC % NSET == 0, "the register sets rotate over the k-steps");
+    typename E::v8 wf[NSET][NT3], xf[NSET][NPP];
+#define SF_LD(i_, kk_)                                                                                                                \
+    _Pragma("unroll") for (int j = 0; j < NT3; ++j) wf[i_][j] = __builtin_bit_cast(typename E::v8, *(sf_gptr16)(wb + (j * KC + (kk_)) * 1024 + loff)); \
+    _Pragma("unroll") for (int n = 0; n < NPP; ++n) xf[i_][n] = as_v8<DT>(*reinterpret_cast<const uint4*>(xrow[n] + ((SF_ABL & 8) ? 0 : (kk_)) * 32));
+#define SF_MM(i_)                                                                                   \
+    _Pragma("unroll") for (int n = 0; n < NPP; ++n) {                                               \
+        _Pragma("unroll") for (int j = 0; j < NT3; ++j) acc[n][j] = E::mfma32(wf[i_][j], xf[i_][n], acc[n][j]); \
+        if (!(SF_ABL & 4)) _Pragma("unroll") for (int e = 0; e < 8; ++e) {                          \
+            const float d_ = (float)xf[i_][n][e] - shift[n];                                        \
+            ssum[n] += d_;                                                                          \
+            sq[n] = __builtin_fmaf(d_, d_, sq[n]);                                                  \
+        }                                                                                           \
+    }
+#pragma unroll
+    for (int i = 0; i < NSET; ++i) { SF_LD(i, i); }
+#pragma unroll
+    for (int n = 0; n < NPP; ++n) {
+        shift[n] = half_lo((float)xf[0][n][0]);
+        ssum[n] = 0.f;
+        sq[n] = 0.f;
+    }
+#pragma unroll 1
+    for (int kk = 0; kk < KC - NSET; kk += NSET) {
+#pragma unroll
+        for (int i = 0; i < NSET; ++i) {
+            SF_MM(i);
+            SF_LD(i, kk + i + NSET);
+        }
+#pragma unroll
+        for (int i = 0; i < NSET; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, NT3 * NPP, 0);   // the MFMAs of this k-step
+            __builtin_amdgcn_sched_group_barrier(0x002, 24 * NPP, 0);    // its statistics
+            __builtin_amdgcn_sched_group_barrier(0x020, NT3 + NPP, 0);   // the fragments NSET k-steps ahead
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NSET; ++i) { SF_MM(i); }
+#undef SF_LD
+#undef SF_MM
+}
+
+template <int DT, int D, int KC, int NW, int NPP, int NSET>
+__global__ __launch_bounds__(NW * 64) void sattn_fused_kernel(SfP p) {
+    using E = ET<DT>;
+    using Y = Lay<D>;
+    constexpr int C = KC * 16, NTD = (D + 31) / 32, NT3 = 3 * NTD, KCD = D / 16, NPW = 2;  // NPW: query panels a wave attends at once
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int b = (seq / p.H) * 8 + xcd, h = seq % p.H;  // (all heads of a sample on one XCD: they share its rows)
+    if (b >= p.B) return;
+    const int N = p.N;
+    const int npan = (N + 31) >> 5, ntiles = (N + KT - 1) / KT, nfull = N / KT;
+    const int rounds = (npan + NPW * NW - 1) / (NPW * NW);
+    float* const csbb = reinterpret_cast<float*>(smem + ntiles * Y::BUF);  // [2][NT3 * 32]
+    // the head's colsum / bias vectors -> LDS; the last key tile is cleared (its unwritten V^T columns / rows meet zero probabilities)
+    for (int i = tid; i < 2 * NT3 * 32; i += NW * 64) csbb[i] = p.csbb[(int64_t)h * 2 * NT3 * 32 + i];
+    for (int i = tid; i < Y::BUF / 4; i += NW * 64) reinterpret_cast<uint32_t*>(smem + (ntiles - 1) * Y::BUF)[i] = 0u;
+    if (Y::VROWS > D) {  // (d = 48: rows 48 .. 63 of every V^T tile feed discarded output rows, but must be finite)
+        for (int t = 0; t < ntiles - 1; ++t)
+            for (int i = tid; i < (Y::VROWS - D) * Y::VROW / 4; i += NW * 64) reinterpret_cast<uint32_t*>(smem + t * Y::BUF + Y::K_BYTES + D * Y::VROW)[i] = 0u;
+    }
+    __syncthreads();
+    const sf_gptr wb = sf_sgpr_ptr(p.w + (int64_t)h * NT3 * KC * 1024);
+    const uint32_t loff = (uint32_t)lane * 16u;
+    const uint8_t* const xb = p.x + (int64_t)b * N * C * 2;
+    typename E::v8 qkeep[2][NPW][KCD];  // [round][panel of the pair][k-step]: this wave's q fragments, projection -> key loop
+    // ---- 1. projection: K, V^T -> LDS tiles; Q -> registers ----
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        if (r >= rounds) break;
+#pragma unroll
+        for (int g0 = 0; g0 < NPW; g0 += NPP) {
+            int pan[NPP];
+            const uint8_t* xrow[NPP];
+            bool act = false;
+#pragma unroll
+            for (int n = 0; n < NPP; ++n) {
+                pan[n] = (r * NPW + g0 + n) * NW + wave;
+                int tok = pan[n] * 32 + l31;
+                tok = tok < N ? tok : N - 1;
+                xrow[n] = xb + ((int64_t)tok * C + half * 8) * 2;
+                act = act || pan[n] < npan;
+            }
+            if (!act) continue;  // (wave-uniform)
+            f32x16 acc[NPP][NT3];
+#pragma unroll
+            for (int n = 0; n < NPP; ++n)
+#pragma unroll
+                for (int j = 0; j < NT3; ++j)
+#pragma unroll
+                    for (int q_ = 0; q_ < 16; ++q_) acc[n][j][q_] = 0.f;
+            float ssum[NPP], sq[NPP], shift[NPP];
+            if (SF_ABL & 2) {
+#pragma unroll
+                for (int n = 0; n < NPP; ++n) ssum[n] = sq[n] = shift[n] = 1.f;
+            } else
+            sf_project<DT, NT3, NPP, KC, NSET>(wb, loff, xrow, acc, ssum, sq, shift);
+#pragma unroll
+            for (int n = 0; n < NPP; ++n) {
+                const int key = pan[n] * 32 + l31;
+                const bool ok = key < N;
+                const float s1 = half_sum(ssum[n]), s2 = half_sum(sq[n]);
+                const float md = s1 * (1.0f / C), mean = shift[n] + md;
+                const float var = fmaxf(s2 * (1.0f / C) - md * md, 0.f);
+                const float rstd = ok ? rsqrtf(var + p.eps) : 0.f, nmr = -mean * rstd, okf = ok ? 1.f : 0.f;
+                uint8_t* const kt = smem + (key >> 6) * Y::BUF;
+                const int krow = key & 63;
+#pragma unroll
+                for (int j = 0; j < NT3; ++j) {
+                    const int which = j / NTD, jt = j % NTD;  // 0 q, 1 k, 2 v; row tile inside the head
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int fl = 8 * g + 4 * half;  // first of this lane's 4 consecutive features inside the tile
+                        if (jt * 32 + fl >= D) continue;
+                        const float4 cs = *reinterpret_cast<const float4*>(csbb + j * 32 + fl);
+                        const float4 bb = *reinterpret_cast<const float4*>(csbb + NT3 * 32 + j * 32 + fl);
+                        float y[4];
+                        y[0] = __builtin_fmaf(acc[n][j][4 * g + 0], rstd, __builtin_fmaf(cs.x, nmr, bb.x * okf));
+                        y[1] = __builtin_fmaf(acc[n][j][4 * g + 1], rstd, __builtin_fmaf(cs.y, nmr, bb.y * okf));
+                        y[2] = __builtin_fmaf(acc[n][j][4 * g + 2], rstd, __builtin_fmaf(cs.z, nmr, bb.z * okf));
+                        y[3] = __builtin_fmaf(acc[n][j][4 * g + 3], rstd, __builtin_fmaf(cs.w, nmr, bb.w * okf));
+                        if (which == 0) {  // q: registers 8 cc .. 8 cc + 7 of the tile are the B-operand fragment of k-step 2 jt + cc
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) qkeep[r][g0 + n][2 * jt + (g >> 1)][4 * (g & 1) + e] = (typename E::elem)y[e];
+                        } else if (which == 1) {  // k: [key][d] with d permuted inside each 16-wide k-step exactly as q's fragments hold it
+                            typename E::v4 kv;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) kv[e] = (typename E::elem)y[e];
+                            if (pan[n] < npan)
+                                *reinterpret_cast<uint2*>(kt + krow * Y::KROW + (jt * 32 + 16 * (g >> 1) + 8 * half + 4 * (g & 1)) * 2) = __builtin_bit_cast(uint2, kv);
+                        } else {  // v: transposed, V^T[d][key] (natural key order: the P.V product reads it with the C-layout key permutation)
+                            if (pan[n] < npan) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    *reinterpret_cast<typename E::elem*>(kt + Y::K_BYTES + (jt * 32 + fl + e) * Y::VROW + krow * 2) = (typename E::elem)y[e];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 2. attention over the resident tiles: two query panels per wave and round ----
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        if (r >= rounds) break;
+        const int pa = (r * NPW) * NW + wave, pb = pa + NW;
+        if (pa >= npan || (SF_ABL & 1)) continue;  // (wave-uniform; pb >= npan: its lanes carry the clamped last row and are not stored)
+        f32x16 o[2][Y::DT_TILES];
+        f32x2 osum[2];
+        float m[2];
+        f32x16 mi[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            osum[qt] = (f32x2){0.f, 0.f};
+            m[qt] = NEG_BIG;
+#pragma unroll
+            for (int q_ = 0; q_ < 16; ++q_) mi[qt][q_] = -NEG_BIG;  // exp2(s + 1e30) = inf: the first tile takes the classic path
+#pragma unroll
+            for (int dt = 0; dt < Y::DT_TILES; ++dt)
+#pragma unroll
+                for (int q_ = 0; q_ < 16; ++q_) o[qt][dt][q_] = 0.f;
+        }
+        int t = 0;
+#pragma unroll 1
+        for (; t < nfull; ++t) tile_compute2<DT, D, false, true>(smem + t * Y::BUF, t * KT, N, 1.0f, qkeep[r], o, osum, m, mi, l31, half);
+        if (t < ntiles) tile_compute2<DT, D, true, true>(smem + t * Y::BUF, t * KT, N, 1.0f, qkeep[r], o, osum, m, mi, l31, half);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int q = (qt == 0 ? pa : pb) * 32 + l31;
+            const float inv = 1.0f / half_sum(osum[qt][0] + osum[qt][1]);
+            if (q < N) {
+                uint8_t* const ob = p.out + (((int64_t)b * N + q) * C + h * D) * 2;
+#pragma unroll
+                for (int dt = 0; dt < Y::DT_TILES; ++dt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int dcol = dt * 32 + 8 * g + 4 * half;
+                        if (dcol < D) {
+                            typename E::v4 pk;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) pk[e] = (typename E::elem)(o[qt][dt][g * 4 + e] * inv);
+                            *reinterpret_cast<uint2*>(ob + dcol * 2) = __builtin_bit_cast(uint2, pk);
+                        }
+                    }
+            }
+        }
+    }
+}
+
+template <int DT, int D, int KC, int NW, int NPP, int NSET> int sf_go(const SfP& p, hipStream_t s) {
+    using Y = Lay<D>;
+    constexpr int NT3 = 3 * ((D + 31) / 32);
+    const int ntiles = (p.N + KT - 1) / KT;
+    const int lds = ntiles * Y::BUF + 2 * NT3 * 32 * 4;
+    auto kern = sattn_fused_kernel<DT, D, KC, NW, NPP, NSET>;
+    static unsigned devs = 0;
+    constexpr int MAXT = D == 32 ? 16 : 4;  // key tiles of the largest routed sequence (1024 / 256 tokens)
+    if (apad_ensure_dyn_lds(reinterpret_cast<const void*>(kern), MAXT * Y::BUF + 2 * NT3 * 32 * 4, &devs) != 0) return -1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(((p.B + 7) / 8) * 8 * p.H)), dim3(NW * 64), lds, s, p);
+    return apad_check_launch("apad_self_attention_fused");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Short-segment variant: every softmax segment has at most 64 keys (the adapter's decoupled cross-attention at
 // La <= 64 -- 8 text + 32 audio tokens in the style_transfer preset --, the 16-token T5 cross-attention).  Such a launch
 // is bound by reading Q and writing O; the staged kernel above spends it on LDS staging and four workgroup barriers per
@@ -1360,6 +1609,24 @@ extern "C" int apad_attention(const apad_attn_desc* d, void* stream) {
     dim3 grid((unsigned)(((d->N + 127) / 128) * (((d->H * d->B) + 7) / 8 * 8)));
     hipStream_t s = (hipStream_t)stream;
     return d->dtype == APAD_BF16 ? launch_dt<APAD_BF16>(p, d->D, dual, grid, s) : launch_dt<APAD_F16>(p, d->D, dual, grid, s);
+}
+
+extern "C" int apad_self_attention_fused(const void* x, const void* w_packed, const float* colsum_bias, void* out, int32_t B, int32_t N, int32_t C, int32_t heads,
+                                         float ln_eps, int32_t dtype, void* stream) {
+    APAD_CHECK(dtype == APAD_BF16 || dtype == APAD_F16, "apad_self_attention_fused: dtype %d not supported (16-bit only)", dtype);
+    const bool g256 = C == 256 && heads == 8 && N >= 1 && N <= 1024, g384 = C == 384 && heads == 8 && N >= 1 && N <= 256;
+    if (!g256 && !g384) {
+        apad_set_error("apad_self_attention_fused: C=%d heads=%d N=%d outside the kernel envelope (256 / 8 / <= 1024, 384 / 8 / <= 256)", C, heads, N);
+        return -3;
+    }
+    APAD_CHECK(x && w_packed && colsum_bias && out && B > 0, "apad_self_attention_fused: null operand / empty batch");
+    APAD_CHECK(al16(x) && al16(w_packed) && al16(out) && al16(colsum_bias), "apad_self_attention_fused: pointers must be 16-byte aligned");
+    SfP p;
+    p.x = (const uint8_t*)x; p.w = (const uint8_t*)w_packed; p.csbb = colsum_bias; p.out = (uint8_t*)out; p.B = B; p.N = N; p.H = heads; p.eps = ln_eps;
+    hipStream_t s = (hipStream_t)stream;
+    constexpr int NS32 = SF_NSET ? SF_NSET : 4, NS48 = SF_NSET ? SF_NSET : 3;
+    if (g256) return dtype == APAD_BF16 ? sf_go<APAD_BF16, 32, 16, 8, 2, NS32>(p, s) : sf_go<APAD_F16, 32, 16, 8, 2, NS32>(p, s);
+    return dtype == APAD_BF16 ? sf_go<APAD_BF16, 48, 24, 4, 1, NS48>(p, s) : sf_go<APAD_F16, 48, 24, 4, 1, NS48>(p, s);
 }
 
 extern "C" int apad_cross_attention_rows(const apad_xrows_desc* d, void* stream) {

@@ -334,6 +334,60 @@ def cross_attention_rows(x, wq_packed, wo_packed, bo, k1, vt1, heads, ln=None, k
     return out
 
 
+# ---- LayerNorm + q|k|v + self-attention in one launch for the two large levels (csrc/attention.hip, sattn_fused_kernel) ----
+SATTN_FUSED = _os.environ.get("APAD_SATTN_FUSED", "1") == "1"  # A/B switch (read once): 0 = row-panel LN + q|k|v launch, then apad_attention
+SATTN_ENVELOPE = {256: (513, 1024), 384: (129, 256)}  # C -> token counts routed to it (shorter sequences keep the two-launch route)
+
+
+def sattn_ok(x, heads):
+    """[B, N, C] 16-bit contiguous rows inside apad_self_attention_fused's routed envelope"""
+    if not (SATTN_FUSED and x.dim() == 3 and x.dtype in FUSED_DTYPES and x.is_contiguous() and heads == 8):
+        return False
+    lo_hi = SATTN_ENVELOPE.get(x.shape[-1])
+    return lo_hi is not None and lo_hi[0] <= x.shape[1] <= lo_hi[1]
+
+
+def sattn_pack(wq, wk, wv, ln, heads):
+    """to_q / to_k / to_v [C, C] behind LayerNorm ln = (gamma, beta, eps) -> (per-head fragment packing [H][3 T tiles][C/16][64][8] with gamma and the
+    softmax scale log2(e) / sqrt(d) folded in, fp32 [H][2][3 T * 32]: row sums of the ROUNDED packed weights, then W . beta) -- see
+    apad_self_attention_fused in include/apadapter_hip.h"""
+    Cc = wq.shape[0]
+    d = Cc // heads
+    T = (d + 31) // 32
+    qs = LOG2E / math.sqrt(d)
+    gamma, beta = ln[0].detach().float(), ln[1].detach().float()
+    wf = torch.cat([wq.detach().float() * qs, wk.detach().float(), wv.detach().float()], 0)  # [3C, C]
+    bb = wf @ beta
+    wg = (wf * gamma).to(wq.dtype)
+    cs = wg.float().sum(1)
+    pad = torch.zeros(32, Cc, dtype=wg.dtype, device=wg.device)
+    wg = torch.cat([wg, pad], 0)
+    cs, bb = torch.cat([cs, cs.new_zeros(32)]), torch.cat([bb, bb.new_zeros(32)])
+    dev = wg.device
+    hh = torch.arange(heads, device=dev).view(heads, 1, 1, 1)
+    which = torch.arange(3, device=dev).view(1, 3, 1, 1)
+    jt = torch.arange(T, device=dev).view(1, 1, T, 1)
+    rr = torch.arange(32, device=dev).view(1, 1, 1, 32)
+    rows = (which * Cc + hh * d + jt * 32 + rr).reshape(heads, 3 * T, 32)  # rows past a head's d: the following rows (results unused)
+    w = wg[rows.reshape(-1)].reshape(heads, 3 * T, 32, Cc // 16, 2, 8).permute(0, 1, 3, 4, 2, 5).contiguous().reshape(-1)
+    csbb = torch.stack([cs[rows.reshape(-1)].reshape(heads, 3 * T * 32), bb[rows.reshape(-1)].reshape(heads, 3 * T * 32)], 1).contiguous().reshape(-1)
+    return w, csbb
+
+
+def self_attention_fused(x, w_packed, csbb, heads, ln_eps, out=None):
+    """O [B, N, C] = the heads' softmax(q k^T / sqrt(d)) v with q | k | v = Linear(LayerNorm(x)), one launch (apad_self_attention_fused; weights
+    from sattn_pack)"""
+    _req(x, "self_attention_fused.x", w_packed.dtype)
+    B, N, Cc = x.shape
+    if x.dtype not in FUSED_DTYPES or not x.is_contiguous() or csbb.dtype != torch.float32:
+        raise ValueError("self_attention_fused: x must be contiguous 16-bit, colsum / bias fp32")
+    if out is None:
+        out = torch.empty_like(x)
+    L.check(L.lib().apad_self_attention_fused(x.data_ptr(), w_packed.data_ptr(), csbb.data_ptr(), out.data_ptr(), B, N, Cc, heads, float(ln_eps),
+                                              _DT[x.dtype], _stream()), "apad_self_attention_fused")
+    return out
+
+
 # ---- the 64-token level's attention sub-layers (csrc/hsattn.hip): head-sliced LayerNorm + projections + attention, then to_out + residual ----
 HS_C, HS_HEADS, HS_MAXN = 640, 8, 64
 HS_ATTN = _os.environ.get("APAD_HS_ATTN", "1") == "1"  # A/B switch (read once): 0 = the LN-folded q|k|v GEMM -> attention -> to_out chain

@@ -280,6 +280,15 @@ class AttnProcessor2_0(nn.Module):
         hs_route = _hs_route(attn, hidden_states, _residual, _ln)
         if encoder_hidden_states is None and hs_route:
             return _hs_sublayer(attn, hidden_states, _residual, _ln)
+        if (encoder_hidden_states is None and _ln is not None and ops.sattn_ok(hidden_states, heads) and attn.to_q.bias is None
+                and tuple(attn.to_q.weight.shape) == (C_, C_)):
+            # the two large levels: LayerNorm + q | k | v + attention in ONE launch (workgroup = (sample, head), K / V^T in LDS), then to_out
+            key = (_pkey(attn.to_q.weight, attn.to_k.weight, attn.to_v.weight, _ln[0], _ln[1]), float(_ln[2]))
+            if getattr(attn, "_sattn_key", None) != key:
+                attn._sattn_w = ops.sattn_pack(attn.to_q.weight, attn.to_k.weight, attn.to_v.weight, _ln, heads)
+                attn._sattn_key = key
+            o = ops.self_attention_fused(hidden_states, attn._sattn_w[0], attn._sattn_w[1], heads, _ln[2])
+            return ops.fused_linear(o, attn.to_out[0].weight, attn.to_out[0].bias, residual=_residual, rowstat=True)
         if encoder_hidden_states is None:
             Lk = N
             if ops.rp_ok(hidden_states) and attn.to_q.weight.shape[0] == C_:

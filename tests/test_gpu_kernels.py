@@ -858,6 +858,37 @@ def test_fused_cross_attention_outside_envelope(dev):
     assert not ops.xattn_lengths_ok(8, 128, True) and not ops.xattn_lengths_ok(8, 96) and not ops.xattn_lengths_ok(16, 128) and not ops.xattn_lengths_ok(8, 512)
 
 
+# ---- LayerNorm + q|k|v + self-attention in one launch (the two large levels) ----
+@pytest.mark.parametrize("dtype", DTYPES16)
+@pytest.mark.parametrize("B,N,C", [(2, 1000, 256), (9, 1000, 256), (1, 1024, 256), (2, 513, 256), (3, 700, 256), (2, 33, 256), (2, 252, 384), (9, 252, 384),
+                                   (1, 256, 384), (3, 130, 384), (2, 200, 384)])
+def test_self_attention_fused(dev, dtype, B, N, C):
+    """workgroup = (sample, head): K / V^T of the whole sample projected into LDS tiles, Q kept in registers, LayerNorm by algebra on the
+    accumulators; full and ragged last panels / key tiles, odd batches (XCD-padded grid); against fp32 torch on storage-rounded operands and
+    against the two-launch route (row-panel LN + q|k|v, then apad_attention); rows far from zero mean (the algebra subtracts mean * colsum)"""
+    from ap_adapter_amd import ops
+    H = 8
+    x = q(R(B, N, C, seed=461) + 1.5, dtype)
+    g, be = q(1 + 0.1 * R(C, seed=462), dtype), q(0.1 * R(C, seed=463), dtype)
+    wq, wk, wv = (q(R(C, C, seed=464 + i, std=0.06), dtype) for i in range(3))
+    hs = F.layer_norm(x, (C,), g, be, 1e-5)
+    sp = lambda t: t.reshape(B, N, H, C // H).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sp(F.linear(hs, wq)), sp(F.linear(hs, wk)), sp(F.linear(hs, wv))).transpose(1, 2).reshape(B, N, C)
+    D = lambda t: t.to(dev, dtype)
+    xd, ln = D(x), (D(g), D(be), 1e-5)
+    pk, csbb = ops.sattn_pack(D(wq), D(wk), D(wv), ln, H)
+    out = ops.self_attention_fused(xd, pk, csbb, H, 1e-5)
+    assert out.shape == ref.shape and rel_err(out, ref) < 1.5 * TOL[dtype]
+    hn = ops.layer_norm(xd, *ln)
+    qd, kd = ops.linear(hn, D(wq)), ops.linear(hn, D(wk))
+    vt = torch.zeros(B, H, C // H, ops.round_up(N, 32), device=dev, dtype=dtype)
+    ops.linear_vt(hn, D(wv), B, N, H, vt)
+    chain = ops.attention(qd, kd, vt, N, H)
+    assert rel_err(out, chain.float().cpu()) < TOL[dtype]
+    i = B // 2  # a sample's rows do not depend on its batch
+    assert torch.equal(ops.self_attention_fused(xd[i:i + 1].contiguous(), pk, csbb, H, 1e-5)[0], out[i])
+
+
 # ---- the 64-token level's attention sub-layers: apad_hs_attention (head-sliced) + apad_hs_out ----
 def _hs_self_ref(x, g, be, wq, wk, wv, wo, bo, heads, residual=True):
     B, N, C = x.shape

@@ -77,3 +77,19 @@ for B in (64, 32):
     tffh = timeit(lambda: ops.hs_ff2(ops.hs_geglu(x, pg, bg, ln_eps=1e-5, out=hh), w2p, b2, x, rowstat=True, out=out))
     print(f"ff    B={B}: hs_ff2 {tf2h:6.1f} us ({2.0 * B * N * C * 4 * C / tf2h / 1e6:6.0f} TF/s)   hs_geglu + hs_ff2 {tffh:6.1f} us", flush=True)
     print(f"ff    B={B}: hs_geglu {tg:6.1f} us ({2.0 * B * N * C * 8 * C / tg / 1e6:6.0f} TF/s)   chain LN-folded GEGLU GEMM {tgc:6.1f} us   FF2 GEMM {tf2:6.1f} us", flush=True)
+
+# ---- LayerNorm + q|k|v + self-attention in one launch at the two large levels, against the two launches it replaces ----
+for (N2, C2, B) in ((1000, 256, 64), (1000, 256, 32), (252, 384, 64)):
+    x = R(B, N2, C2)
+    ln = (1 + 0.1 * R(C2), 0.1 * R(C2), 1e-5)
+    wq, wk, wv = R(C2, C2, std=0.03), R(C2, C2, std=0.03), R(C2, C2, std=0.03)
+    pk, csbb = ops.sattn_pack(wq, wk, wv, ln, H)
+    o = torch.empty_like(x)
+    tf = timeit(lambda: ops.self_attention_fused(x, pk, csbb, H, 1e-5, out=o))
+    wqkv = torch.cat([(wq.float() * ops.LOG2E / math.sqrt(C2 // H)).to(dt), wk, wv], 0).contiguous()
+    q_, k_ = torch.empty_like(x), torch.empty_like(x)
+    vt = torch.zeros(B, H, C2 // H, ops.round_up(N2, 32), device=dev, dtype=dt)
+    t1 = timeit(lambda: ops.rowpanel(x, wqkv, [(q_, None, C2, "row"), (k_, None, C2, "row"), (vt, None, C2, "vt")], ln=ln, vt_geom=(H, C2 // H, N2, vt.shape[-1])))
+    t2 = timeit(lambda: ops.attention(q_, k_, vt, N2, H, q_prescaled=True, out=o))
+    fl = 2.0 * B * N2 * C2 * 3 * C2 + 4.0 * B * N2 * N2 * C2
+    print(f"sattn N={N2} C={C2} B={B}: fused {tf:6.1f} us ({fl / tf / 1e6:6.0f} TF/s)   row-panel LN+q|k|v {t1:6.1f} us + attention {t2:6.1f} us = {t1 + t2:6.1f} us", flush=True)
