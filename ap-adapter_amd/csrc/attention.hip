@@ -816,6 +816,9 @@ __device__ __forceinline__ sf_gptr sf_sgpr_ptr(const uint8_t* p) {
 #ifndef SF_NSET
 #define SF_NSET 0  // (0: per-geometry default)
 #endif
+#ifndef SF_VPM
+#define SF_VPM 9  // vector instructions scheduled behind each MFMA of the projection loop
+#endif
 #ifndef SF_ABL
 #define SF_ABL 0  // timing ablations (tools/ab_build.sh; results are wrong): 1 = no key loop, 2 = no projection, 4 = projection without the statistics, 8 = x fragments loaded once
 #endif
@@ -829,7 +832,7 @@ __device__ __forceinline__ void sf_project(sf_gptr wb, uint32_t loff, const uint
     static_assert(KC % NSET == 0, "the register sets rotate over the k-steps");
     typename E::v8 wf[NSET][NT3], xf[NSET][NPP];
 #define SF_LD(i_, kk_)                                                                                                                \
-    _Pragma("unroll") for (int j = 0; j < NT3; ++j) wf[i_][j] = __builtin_bit_cast(typename E::v8, *(sf_gptr16)(wb + (j * KC + (kk_)) * 1024 + loff)); \
+    _Pragma("unroll") for (int j = 0; j < NT3; ++j) wf[i_][j] = __builtin_bit_cast(typename E::v8, *(sf_gptr16)(wb + (j * KC + ((SF_ABL & 16) ? 0 : (kk_))) * 1024 + loff)); \
     _Pragma("unroll") for (int n = 0; n < NPP; ++n) xf[i_][n] = as_v8<DT>(*reinterpret_cast<const uint4*>(xrow[n] + ((SF_ABL & 8) ? 0 : (kk_)) * 32));
 #define SF_MM(i_)                                                                                   \
     _Pragma("unroll") for (int n = 0; n < NPP; ++n) {                                               \
@@ -855,11 +858,16 @@ __device__ __forceinline__ void sf_project(sf_gptr wb, uint32_t loff, const uint
             SF_MM(i);
             SF_LD(i, kk + i + NSET);
         }
+        // one MFMA, then its share of the statistics arithmetic, in program order: the matrix pipe runs beside vector work only when both
+        // sit interleaved in ONE wave's stream (tools/probes/overlap.hip: 474 vs 635 cycles clustered); then the fragments NSET k-steps ahead
 #pragma unroll
         for (int i = 0; i < NSET; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, NT3 * NPP, 0);   // the MFMAs of this k-step
-            __builtin_amdgcn_sched_group_barrier(0x002, 24 * NPP, 0);    // its statistics
-            __builtin_amdgcn_sched_group_barrier(0x020, NT3 + NPP, 0);   // the fragments NSET k-steps ahead
+#pragma unroll
+            for (int m_ = 0; m_ < NT3 * NPP; ++m_) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, SF_VPM, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x020, NT3 + NPP, 0);
         }
     }
 #pragma unroll
@@ -937,7 +945,7 @@ __global__ __launch_bounds__(NW * 64) void sattn_fused_kernel(SfP p) {
                 uint8_t* const kt = smem + (key >> 6) * Y::BUF;
                 const int krow = key & 63;
 #pragma unroll
-                for (int j = 0; j < NT3; ++j) {
+                for (int j = 0; j < ((SF_ABL & 32) ? NTD : NT3); ++j) {
                     const int which = j / NTD, jt = j % NTD;  // 0 q, 1 k, 2 v; row tile inside the head
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
