@@ -228,15 +228,31 @@ class Transformer2DModel(nn.Module):
             [BasicTransformerBlock(inner, heads, dim_head, cross_attention_dim) for _ in range(num_layers)])
         self.proj_out = nn.Conv2d(inner, in_channels, 1)
 
+    def _hs_packed(self, which):
+        """fragment-packed proj_in / proj_out weight for apad_hs_out, re-packed when the parameter is re-assigned, moved, cast or updated"""
+        w = (self.proj_in if which == "in" else self.proj_out).weight
+        key = (id(w), w.data_ptr(), w._version, w.dtype, w.device)
+        cache = self.__dict__.setdefault("_hs_pk", {})
+        if cache.get(which, (None,))[0] != key:
+            cache[which] = (key, ops.hs_pack_rows(w.detach().reshape(w.shape[0], -1))[0])
+        return cache[which][1]
+
     def forward(self, x, ehs, emask):
         if AG.on(x):
             h = AG.group_norm(x, self.norm.weight, self.norm.bias, self.groups, self.norm.eps, False)
             h = AG.linear(h, self.proj_in.weight, self.proj_in.bias)
         else:
             h = ops.group_norm(x, self.norm.weight, self.norm.bias, self.groups, self.norm.eps, silu=False)
-            h = ops.fused_linear(h, _w2d(self.proj_in), self.proj_in.bias, rowstat=True)
+            hs_io = ops.HS_ATTN and ops.hs_rows_ok(h) and tuple(self.proj_in.weight.shape[:2]) == (ops.HS_C, ops.HS_C) == tuple(self.proj_out.weight.shape[:2])
+            if hs_io:  # the 64-token level: the 1x1 projections on the row-tile kernel of its attention sub-layers (csrc/hsattn.hip, apad_hs_out)
+                h = ops.hs_out(h, self._hs_packed("in"), self.proj_in.bias, None, rowstat=True)
+            else:
+                h = ops.fused_linear(h, _w2d(self.proj_in), self.proj_in.bias, rowstat=True)
         for blk in self.transformer_blocks:
             h = blk(h, ehs, emask)
+        if not AG.on(h, x) and h.shape[0] == x.shape[0] and ops.HS_ATTN and ops.hs_rows_ok(h) and ops.hs_rows_ok(x) \
+                and tuple(self.proj_in.weight.shape[:2]) == (ops.HS_C, ops.HS_C) == tuple(self.proj_out.weight.shape[:2]):
+            return ops.hs_out(h, self._hs_packed("out"), self.proj_out.bias, x)
         if h.shape[0] != x.shape[0]:  # the CFG batch was expanded inside (cfg_expand): the residual rows are the same for both halves
             if h.dtype in ops.FUSED_DTYPES and not AG.on(h, x):  # read modulo its rows by the GEMM's epilogue: no copy
                 return ops.linear(h, _w2d(self.proj_out), self.proj_out.bias, residual=x.contiguous(),
