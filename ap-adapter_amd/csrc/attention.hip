@@ -800,8 +800,8 @@ __global__ __launch_bounds__(NW * 64) void attn2q_kernel(AttnP p) {
 // attention_processor.py:256-276 behind BasicTransformerBlock.norm1 / norm2 (double self-attention).
 struct SfP {
     const uint8_t* x;
-    const uint8_t* w;     // packed [H][3 NTD row tiles: q.., k.., v..][KC k-steps][64 lanes][8] (gamma and the softmax scale folded in)
-    const float* csbb;    // [H][2][3 NTD * 32] fp32: row sums of the packed weights, then W . beta
+    const uint8_t* w;     // packed [H][T3 = ceil(3 d / 32) row tiles over the head's q | k | v rows][KC k-steps][64 lanes][8] (gamma, softmax scale folded in)
+    const float* csbb;    // [H][2][T3 * 32] fp32: row sums of the packed weights, then W . beta
     uint8_t* out;         // O [B][N][C]
     int32_t B, N, H;
     float eps;
@@ -815,6 +815,9 @@ __device__ __forceinline__ sf_gptr sf_sgpr_ptr(const uint8_t* p) {
 }
 #ifndef SF_NSET
 #define SF_NSET 0  // (0: per-geometry default)
+#endif
+#ifndef SF_NPP48
+#define SF_NPP48 2  // panels projected at once at d = 48 (2: 160 accumulator registers; 47.7 -> 42.4 us at 64 x 252 tokens: every weight fragment feeds two panels)
 #endif
 #ifndef SF_VPM
 #define SF_VPM 9  // vector instructions scheduled behind each MFMA of the projection loop
@@ -880,7 +883,9 @@ template <int DT, int D, int KC, int NW, int NPP, int NSET>
 __global__ __launch_bounds__(NW * 64) void sattn_fused_kernel(SfP p) {
     using E = ET<DT>;
     using Y = Lay<D>;
-    constexpr int C = KC * 16, NTD = (D + 31) / 32, NT3 = 3 * NTD, KCD = D / 16, NPW = 2;  // NPW: query panels a wave attends at once
+    // the head's q | k | v rows are packed DENSELY: 3 d virtual rows in ceil(3 d / 32) row tiles (d = 48: 4.5 -> 5 tiles, not 3 x 2); an 8-row
+    // group never straddles two of the three (d % 8 == 0)
+    constexpr int C = KC * 16, D8 = D / 8, NT3 = (3 * D + 31) / 32, KCD = D / 16, NPW = 2;  // NPW: query panels a wave attends at once
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
@@ -945,12 +950,13 @@ __global__ __launch_bounds__(NW * 64) void sattn_fused_kernel(SfP p) {
                 uint8_t* const kt = smem + (key >> 6) * Y::BUF;
                 const int krow = key & 63;
 #pragma unroll
-                for (int j = 0; j < ((SF_ABL & 32) ? NTD : NT3); ++j) {
-                    const int which = j / NTD, jt = j % NTD;  // 0 q, 1 k, 2 v; row tile inside the head
+                for (int j = 0; j < NT3; ++j) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const int fl = 8 * g + 4 * half;  // first of this lane's 4 consecutive features inside the tile
-                        if (jt * 32 + fl >= D) continue;
+                        const int vr8 = 4 * j + g;                    // 8-row group of the head's virtual rows
+                        if (vr8 >= 3 * D8) continue;                  // (the padding rows of the last tile)
+                        const int which = vr8 / D8, G = vr8 % D8;     // 0 q, 1 k, 2 v; 8-feature group inside the head
+                        const int fl = 8 * g + 4 * half;              // first of this lane's 4 consecutive rows inside the tile
                         const float4 cs = *reinterpret_cast<const float4*>(csbb + j * 32 + fl);
                         const float4 bb = *reinterpret_cast<const float4*>(csbb + NT3 * 32 + j * 32 + fl);
                         float y[4];
@@ -960,18 +966,18 @@ __global__ __launch_bounds__(NW * 64) void sattn_fused_kernel(SfP p) {
                         y[3] = __builtin_fmaf(acc[n][j][4 * g + 3], rstd, __builtin_fmaf(cs.w, nmr, bb.w * okf));
                         if (which == 0) {  // q: registers 8 cc .. 8 cc + 7 of the tile are the B-operand fragment of k-step 2 jt + cc
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) qkeep[r][g0 + n][2 * jt + (g >> 1)][4 * (g & 1) + e] = (typename E::elem)y[e];
+                            for (int e = 0; e < 4; ++e) qkeep[r][g0 + n][G >> 1][4 * (G & 1) + e] = (typename E::elem)y[e];
                         } else if (which == 1) {  // k: [key][d] with d permuted inside each 16-wide k-step exactly as q's fragments hold it
                             typename E::v4 kv;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) kv[e] = (typename E::elem)y[e];
                             if (pan[n] < npan)
-                                *reinterpret_cast<uint2*>(kt + krow * Y::KROW + (jt * 32 + 16 * (g >> 1) + 8 * half + 4 * (g & 1)) * 2) = __builtin_bit_cast(uint2, kv);
+                                *reinterpret_cast<uint2*>(kt + krow * Y::KROW + (16 * (G >> 1) + 8 * half + 4 * (G & 1)) * 2) = __builtin_bit_cast(uint2, kv);
                         } else {  // v: transposed, V^T[d][key] (natural key order: the P.V product reads it with the C-layout key permutation)
                             if (pan[n] < npan) {
 #pragma unroll
                                 for (int e = 0; e < 4; ++e)
-                                    *reinterpret_cast<typename E::elem*>(kt + Y::K_BYTES + (jt * 32 + fl + e) * Y::VROW + krow * 2) = (typename E::elem)y[e];
+                                    *reinterpret_cast<typename E::elem*>(kt + Y::K_BYTES + (8 * G + 4 * half + e) * Y::VROW + krow * 2) = (typename E::elem)y[e];
                             }
                         }
                     }
@@ -1030,7 +1036,7 @@ __global__ __launch_bounds__(NW * 64) void sattn_fused_kernel(SfP p) {
 
 template <int DT, int D, int KC, int NW, int NPP, int NSET> int sf_go(const SfP& p, hipStream_t s) {
     using Y = Lay<D>;
-    constexpr int NT3 = 3 * ((D + 31) / 32);
+    constexpr int NT3 = (3 * D + 31) / 32;
     const int ntiles = (p.N + KT - 1) / KT;
     const int lds = ntiles * Y::BUF + 2 * NT3 * 32 * 4;
     auto kern = sattn_fused_kernel<DT, D, KC, NW, NPP, NSET>;
@@ -1632,9 +1638,9 @@ extern "C" int apad_self_attention_fused(const void* x, const void* w_packed, co
     SfP p;
     p.x = (const uint8_t*)x; p.w = (const uint8_t*)w_packed; p.csbb = colsum_bias; p.out = (uint8_t*)out; p.B = B; p.N = N; p.H = heads; p.eps = ln_eps;
     hipStream_t s = (hipStream_t)stream;
-    constexpr int NS32 = SF_NSET ? SF_NSET : 4, NS48 = SF_NSET ? SF_NSET : 3;
+    constexpr int NS32 = SF_NSET ? SF_NSET : 4, NS48 = SF_NSET ? SF_NSET : 2;
     if (g256) return dtype == APAD_BF16 ? sf_go<APAD_BF16, 32, 16, 8, 2, NS32>(p, s) : sf_go<APAD_F16, 32, 16, 8, 2, NS32>(p, s);
-    return dtype == APAD_BF16 ? sf_go<APAD_BF16, 48, 24, 4, 1, NS48>(p, s) : sf_go<APAD_F16, 48, 24, 4, 1, NS48>(p, s);
+    return dtype == APAD_BF16 ? sf_go<APAD_BF16, 48, 24, 4, SF_NPP48, NS48>(p, s) : sf_go<APAD_F16, 48, 24, 4, SF_NPP48, NS48>(p, s);
 }
 
 extern "C" int apad_cross_attention_rows(const apad_xrows_desc* d, void* stream) {

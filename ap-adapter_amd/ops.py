@@ -348,29 +348,24 @@ def sattn_ok(x, heads):
 
 
 def sattn_pack(wq, wk, wv, ln, heads):
-    """to_q / to_k / to_v [C, C] behind LayerNorm ln = (gamma, beta, eps) -> (per-head fragment packing [H][3 T tiles][C/16][64][8] with gamma and the
-    softmax scale log2(e) / sqrt(d) folded in, fp32 [H][2][3 T * 32]: row sums of the ROUNDED packed weights, then W . beta) -- see
+    """to_q / to_k / to_v [C, C] behind LayerNorm ln = (gamma, beta, eps) -> (per-head fragment packing [H][T3 = ceil(3 d / 32) tiles][C/16][64][8] with
+    gamma and the softmax scale log2(e) / sqrt(d) folded in, fp32 [H][2][T3 * 32]: row sums of the ROUNDED packed weights, then W . beta) -- see
     apad_self_attention_fused in include/apadapter_hip.h"""
     Cc = wq.shape[0]
     d = Cc // heads
-    T = (d + 31) // 32
+    T3 = (3 * d + 31) // 32
     qs = LOG2E / math.sqrt(d)
     gamma, beta = ln[0].detach().float(), ln[1].detach().float()
-    wf = torch.cat([wq.detach().float() * qs, wk.detach().float(), wv.detach().float()], 0)  # [3C, C]
-    bb = wf @ beta
+    wf = torch.stack([wq.detach().float() * qs, wk.detach().float(), wv.detach().float()], 0)  # [3, C, C]
+    bb = wf @ beta                                                                               # [3, C]
     wg = (wf * gamma).to(wq.dtype)
-    cs = wg.float().sum(1)
-    pad = torch.zeros(32, Cc, dtype=wg.dtype, device=wg.device)
-    wg = torch.cat([wg, pad], 0)
-    cs, bb = torch.cat([cs, cs.new_zeros(32)]), torch.cat([bb, bb.new_zeros(32)])
-    dev = wg.device
-    hh = torch.arange(heads, device=dev).view(heads, 1, 1, 1)
-    which = torch.arange(3, device=dev).view(1, 3, 1, 1)
-    jt = torch.arange(T, device=dev).view(1, 1, T, 1)
-    rr = torch.arange(32, device=dev).view(1, 1, 1, 32)
-    rows = (which * Cc + hh * d + jt * 32 + rr).reshape(heads, 3 * T, 32)  # rows past a head's d: the following rows (results unused)
-    w = wg[rows.reshape(-1)].reshape(heads, 3 * T, 32, Cc // 16, 2, 8).permute(0, 1, 3, 4, 2, 5).contiguous().reshape(-1)
-    csbb = torch.stack([cs[rows.reshape(-1)].reshape(heads, 3 * T * 32), bb[rows.reshape(-1)].reshape(heads, 3 * T * 32)], 1).contiguous().reshape(-1)
+    cs = wg.float().sum(-1)
+    # per head: its 3 d rows [q | k | v] packed densely, zero-padded to T3 row tiles
+    per_head = lambda t: t.reshape(3, heads, d, *t.shape[2:]).transpose(0, 1).reshape(heads, 3 * d, *t.shape[2:])
+    pad = T3 * 32 - 3 * d
+    wh = torch.nn.functional.pad(per_head(wg), (0, 0, 0, pad))                                   # [H, T3 * 32, C]
+    w = wh.reshape(heads, T3, 32, Cc // 16, 2, 8).permute(0, 1, 3, 4, 2, 5).contiguous().reshape(-1)
+    csbb = torch.stack([torch.nn.functional.pad(per_head(cs), (0, pad)), torch.nn.functional.pad(per_head(bb), (0, pad))], 1).contiguous().reshape(-1)
     return w, csbb
 
 

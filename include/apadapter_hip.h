@@ -313,10 +313,10 @@ int apad_hs_ff2(const apad_hs_out_desc* d, void* stream);
 /* LayerNorm + to_q | to_k | to_v + softmax self-attention in ONE launch, workgroup = (sample, head): K / V^T of the whole sample projected into LDS,
  * Q kept in registers, the key loop over the resident tiles (attention.hip, sattn_fused_kernel; ABI 7).  Envelope: C = 256 / 8 heads / N <= 1024 and
  * C = 384 / 8 heads / N <= 256, 16-bit (else -3).  The LayerNorm is applied by algebra (gamma folded into the weights by the caller):
- *   w_packed[((h * T3 + j) * (C / 16) + ks) * 512 + lane * 8 + e] = W'[(j / T) * C + h * d + (j % T) * 32 + (lane & 31)][ks * 16 + (lane >> 5) * 8 + e]
- *       W' = [to_q * log2(e) / sqrt(d) ; to_k ; to_v] * gamma (rows past a head's d: the next rows of the matrix, results unused), T = ceil(d / 32), T3 = 3 T
- *   colsum_bias[(h * 2 + 0) * T3 * 32 + j * 32 + r] = sum_k W'[row(j, r)][k]   (fp32, of the ROUNDED packed weights)
- *   colsum_bias[(h * 2 + 1) * T3 * 32 + j * 32 + r] = (W . beta)[row(j, r)]     (to_q part scaled like the weights)
+ *   the head's 3 d rows [to_q rows h d .. | to_k rows | to_v rows] of W' = [to_q * log2(e) / sqrt(d) ; to_k ; to_v] * gamma, zero-padded to T3 = ceil(3 d / 32)
+ *   row tiles: virtual row v = j * 32 + (lane & 31)  ->  W'[(v / d) * C + h * d + v % d]
+ *   w_packed[((h * T3 + j) * (C / 16) + ks) * 512 + lane * 8 + e] = that row's [ks * 16 + (lane >> 5) * 8 + e]
+ *   colsum_bias[(h * 2 + 0) * T3 * 32 + v] = sum_k of the ROUNDED packed row (fp32);   colsum_bias[(h * 2 + 1) * T3 * 32 + v] = (W . beta) of that row
  * x [B*N][C] un-normalised -> out O [B*N][C] (all heads; to_out + residual: apad_rowpanel_gemm as before).
  * Replaces norm1 + to_q / to_k / to_v + scaled_dot_product_attention of attention_processor.py:256-276. */
 int apad_self_attention_fused(const void* x, const void* w_packed, const float* colsum_bias, void* out, int32_t B, int32_t N, int32_t C, int32_t heads,
