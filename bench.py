@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 DDIM_STEPS_PER_CLIP = 200
-SELF_ATTN_KERNEL_SUBSTR = "attn2q_kernel<0, 32"  # name of the 1000-token self-attention kernel in the rocprofv3 summaries
+SELF_ATTN_KERNEL_SUBSTR = "sattn_fused_kernel<0, 32"  # name of the 1000-token self-attention kernel in the rocprofv3 summaries
 DTYPE_NAME = {torch.bfloat16: "bf16", torch.float16: "f16", torch.float32: "f32"}
 MFMA_PEAK_TFLOPS = 2500.0   # bf16 dense, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
@@ -306,51 +306,53 @@ def fp32_mode_step_ms(A, unet, inp, args, dev, steps=2):
 
 
 def dominant_kernel_roofline(dev, dtype, B2, in_step=None, in_step_how=None):
-    """Roofline of the kernel with the largest share of the step in the committed rocprof summary: the self-attention of the
-    1000-token level (single segment, d = 32), softmax(Q K^T / sqrt(32)) V over B2 samples x 8 heads x 1000 x 1000.
-    Algorithmic FLOPs = 4 * N^2 * C * B2 (QK^T + PV); bound = MFMA (AI = 512 F/B > ridge 310).
+    """Roofline of the kernel with the largest share of the step in the committed rocprof summary: the self-attention sub-layer of the
+    1000-token level up to to_out -- LayerNorm + to_q | to_k | to_v + softmax(Q K^T / sqrt(32)) V in ONE launch since round 4
+    (apad_self_attention_fused, sattn_fused_kernel<bf16, 32>; until round 3 two launches, of which the attention core alone was this
+    object).  Algorithmic FLOPs per launch = attention core 4 N^2 C B' + projections 6 N C^2 B'; algorithmic bytes = x read + O written +
+    the weights (q, k, v never reach HBM); bound = MFMA (AI = 1370 F/B > ridge 310).
     ONE source for `achieved` / `frac` / `avg_launch_ms`: the kernel's average duration INSIDE the step, measured live by
-    in_step_launch_times (HIP events on the launching stream).  Beside it: `frac_isolated` (20 back-to-back launches inside one
-    hipGraph on operands produced the way the model produces them) and `rocprof_in_step_avg_us`, the same kernel's average in the
-    committed `rocprofv3 --kernel-trace --stats` summary of `bench.py --step-only`, which must agree with `avg_launch_ms`."""
+    in_step_launch_times (HIP events on the launching stream).  Beside it: `frac_isolated` (20 back-to-back launches inside one hipGraph)
+    and `rocprof_in_step_avg_us`, the same kernel's average in the committed `rocprofv3 --kernel-trace --stats` summary of
+    `bench.py --step-only`, which must agree with `avg_launch_ms`."""
     from ap_adapter_amd import ops
     N, C, heads = 1000, 256, 8
     x = torch.randn(B2, N, C, device=dev).to(dtype)
-    g_, b_ = torch.ones(C, device=dev, dtype=dtype), torch.zeros(C, device=dev, dtype=dtype)
-    w = (torch.randn(3 * C, C, device=dev) * 0.02).to(dtype)
-    q = torch.empty(B2, N, C, device=dev, dtype=dtype)
-    k = torch.empty_like(q)
-    vt = torch.zeros(B2, heads, C // heads, ops.round_up(N, 32), device=dev, dtype=dtype)
-    ops.rowpanel(x.reshape(-1, C), w, [(q, None, C, "row"), (k, None, C, "row"), (vt, None, C, "vt")], ln=(g_, b_, 1e-5),
-                 vt_geom=(heads, C // heads, N, vt.shape[-1]))
-    out = torch.empty_like(q)
-    ms = time_kernel_graphed(lambda: ops.attention(q, k, vt, N, heads, out=out))
-    flops = 4.0 * N * N * C * B2
+    ln = (torch.ones(C, device=dev, dtype=dtype), torch.zeros(C, device=dev, dtype=dtype), 1e-5)
+    wq, wk, wv = ((torch.randn(C, C, device=dev) * 0.02).to(dtype) for _ in range(3))
+    pk, csbb = ops.sattn_pack(wq, wk, wv, ln, heads)
+    out = torch.empty_like(x)
+    ms = time_kernel_graphed(lambda: ops.self_attention_fused(x, pk, csbb, heads, 1e-5, out=out))
+    flops_core, flops_proj = 4.0 * N * N * C * B2, 6.0 * N * C * C * B2
+    flops = flops_core + flops_proj
+    nbytes = 2 * B2 * N * C * 2 + 3 * C * C * 2
     ach = flops / (ms * 1e-3) / 1e12
-    # HBM bytes per launch from the PMC passes (tools/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3
-    # runs, read counter x2 on gfx950 as calibrated by a known-size probe in the same run); the counters cannot be
-    # collected from inside this process, so the committed measurement is reported when it is for this exact launch
+    # HBM bytes per launch from the PMC passes (tools/round_pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 runs over the
+    # step, counter units calibrated by a known-size probe in the same run); the counters cannot be collected from inside this process,
+    # so the committed measurement is reported when it is for this exact launch
     traffic = tsrc = None
     import glob
-    for tp in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+    for tp in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
         if dtype == torch.bfloat16 and B2 == 64:
             with open(tp) as f:
-                traffic = json.load(f).get("traffic_bytes_per_launch")
-            traffic, tsrc = (None if traffic is None else int(traffic)), os.path.relpath(tp, ROOT)
-            break
+                for k in json.load(f).get("per_kernel", []):
+                    if SELF_ATTN_KERNEL_SUBSTR in k["kernel"]:
+                        traffic, tsrc = int(k["read_bytes_per_launch"] + k["write_bytes_per_launch"]), os.path.relpath(tp, ROOT)
+            if traffic:
+                break
     prof_us, psrc = profile_in_step_avg_us(SELF_ATTN_KERNEL_SUBSTR)
     if in_step is not None and in_step["launches"] > 0:
         ms_src, how, n_l = in_step["avg_us"] * 1e-3, in_step_how, in_step["launches"]
     else:  # (--no-in-step: only the isolated timing exists)
         ms_src, how, n_l = ms, "isolated re-timing (20 launches in one hipGraph, HIP events)", 20
     ach_src = flops / (ms_src * 1e-3) / 1e12
-    return {"kernel": "self-attention of the 1000-token level (apad_attention, single segment, d=32) B'=%d heads=8 N=L=1000" % B2,
+    return {"kernel": "LayerNorm + q|k|v + self-attention of the 1000-token level in one launch (apad_self_attention_fused, d=32) B'=%d heads=8 N=L=1000" % B2,
             "bound": "mfma", "achieved": round(ach_src, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach_src / MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(ms_src, 4), "avg_launch_is": how, "launches_timed": n_l,
             "frac_isolated": round(ach / MFMA_PEAK_TFLOPS, 4), "isolated_avg_launch_ms": round(ms, 4),
             "rocprof_in_step_avg_us": prof_us, "rocprof_source": psrc,
-            "flops_per_launch": flops, "algorithmic_bytes": 4 * B2 * N * C * 2, "traffic": traffic,
-            "traffic_source": (tsrc + " (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes)") if traffic else None}
+            "flops_per_launch": flops, "flops_attention_core": flops_core, "flops_projections": flops_proj, "algorithmic_bytes": nbytes, "traffic": traffic,
+            "traffic_source": (tsrc + " (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes over the step)") if traffic else None}
 
 
 def fused_attn2_roofline(dev, dtype, B2, La, ap_scale, in_step=None, in_step_how=None):
@@ -746,7 +748,7 @@ def main():
         if not args.no_in_step:
             with torch.no_grad():
                 ins, how = in_step_launch_times(step, ops, {
-                    "self_attn_1000": ("attention", lambda q, k, vt, Lk, heads, **kw: q.shape[1] == 1000 and Lk == 1000 and not kw.get("L2")),
+                    "self_attn_1000": ("self_attention_fused", lambda x, *a, **kw: x.shape[1] == 1000),
                     "fused_attn2_ip": ("fused_cross_attention", lambda x, *a, **kw: kw.get("L2", 0) > 0),
                     "fused_attn2_t5": ("fused_cross_attention", lambda x, *a, **kw: not kw.get("L2", 0))})
         line["roofline"] = dominant_kernel_roofline(dev, dtype, 2 * B, ins.get("self_attn_1000"), how)

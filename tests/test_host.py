@@ -265,16 +265,16 @@ def test_flop_model_is_consistent_with_the_survey():
 
 
 def test_processors_reject_what_is_not_on_the_path_before_any_kernel():
-    """reference :365-367 folds a 4-D hidden state to tokens (not taken on the AudioLDM2 path) and :359-363 applies a
-    spatial norm; the drop-in processors refuse both loudly instead of computing something else -- on the host, before any
-    launch (so this runs without a GPU)."""
+    """reference :359-363 applies a spatial norm (never configured on the AudioLDM2 path): the drop-in processors refuse it loudly instead of
+    computing something else, and so a hidden state that is neither [B, N, C] nor the 4-D [B, C, H, W] of :365-367 (accepted since round 4,
+    tests/test_gpu_processors.py: *4d* goldens) -- on the host, before any launch (so this runs without a GPU)."""
     from ap_adapter_amd.unet import Attention
     for proc, cross in ((A.AttnProcessor2_0(), None), (A.IPAttnProcessor2_0(256, "t", cross_attention_dim=768, num_tokens=8), 768)):
         attn = Attention(256, cross, 8, 32)
         attn.set_processor(proc)
         ehs = None if cross is None else torch.zeros(1, 40, 768)
         with pytest.raises(ValueError):
-            proc(attn, torch.zeros(1, 256, 4, 4), encoder_hidden_states=ehs)
+            proc(attn, torch.zeros(1, 256, 4, 4, 2), encoder_hidden_states=ehs)
         attn.spatial_norm = torch.nn.Identity()
         with pytest.raises(NotImplementedError):
             proc(attn, torch.zeros(1, 16, 256), encoder_hidden_states=ehs)
