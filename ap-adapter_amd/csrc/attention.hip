@@ -868,7 +868,7 @@ __device__ __forceinline__ void sf_project(sf_gptr wb, uint32_t loff, const uint
 #pragma unroll
             for (int m_ = 0; m_ < NT3 * NPP; ++m_) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, SF_VPM, 0);
+                if (!(SF_ABL & 4)) __builtin_amdgcn_sched_group_barrier(0x002, SF_VPM, 0);
             }
             __builtin_amdgcn_sched_group_barrier(0x020, NT3 + NPP, 0);
         }
