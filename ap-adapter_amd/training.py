@@ -157,17 +157,25 @@ class AdapterTrainer:
         self.alphas_cumprod = DDIMScheduler().alphas_cumprod  # same beta schedule as the DDPM training scheduler
 
     # ---- one micro-batch: forward + loss + backward, gradients accumulated in the flat fp32 buffer ----
-    def micro_step(self, noisy_latents, timesteps, generated_prompt_embeds, prompt_embeds, attention_mask, target):
+    def micro_step(self, noisy_latents, timesteps, generated_prompt_embeds, prompt_embeds, attention_mask, target, micro_batches=1):
         """Arguments as the reference passes them to the UNet (:941-948); target = the noise (epsilon prediction, :949-950).
-        Returns the fp32 loss (0-dim tensor, on device)."""
+        Returns the fp32 loss (0-dim tensor, on device).
+        micro_batches = k > 1: the batch is k micro-batches of the accumulation window CONCATENATED (accumulation as batch).  The
+        reference runs them one after another and averages their gradients (accelerate divides each loss by k, :549 / :951); the mean
+        loss over the concatenation is that same average, so one pass at k x the batch gives the same optimizer step at a fraction
+        of the launches (a batch-4 pass is launch-bound on this chip).  The pass enters the accumulator with weight k and counts k
+        micro-batches; the loss returned is the mean over all of them.  Needs equal shapes (one pooling rate across the window)."""
         dtype = self.work.dtype
+        k = int(micro_batches)
+        if k < 1 or noisy_latents.shape[0] % k:
+            raise ValueError(f"micro_batches={micro_batches} does not divide the batch of {noisy_latents.shape[0]}")
         # the step's ~2600 small GEMM launches run on one stream: the LDS-DMA ring form of the 64 x 64 tile (gemm.hip; bit-equal)
         ring0 = ops.set_gemm_ring(TRAIN_GEMM_RING) if TRAIN_GEMM_RING >= 0 else None
         try:
             pred = self.unet(noisy_latents.to(dtype), timesteps, encoder_hidden_states=generated_prompt_embeds.to(dtype),
                              encoder_hidden_states_1=prompt_embeds.to(dtype), encoder_attention_mask_1=attention_mask,
                              return_dict=False)[0]
-            loss = AG.mse_loss(pred, target, self.loss_scale)
+            loss = AG.mse_loss(pred, target, self.loss_scale * k)  # (d mean / d pred is k x smaller per sample than in one micro-batch)
             loss.backward()  # adapter weight gradients land in self.grad (fp32, unscaled) through the parameters' grad sinks
         finally:
             if ring0 is not None:
@@ -176,11 +184,11 @@ class AdapterTrainer:
             if p.grad is not None:  # (a gradient that reached the parameter another way, e.g. a foreign layer)
                 self.grad[off:off + p.numel()].add_(p.grad.reshape(-1).float(), alpha=1.0 / self.loss_scale)
                 p.grad = None
-        self._micro += 1
+        self._micro += k
         return loss.detach()
 
     # ---- the same micro-batch as ONE hipGraph: the un-fused training chain is ~7k launches, host-bound when eager ----
-    def capture_micro_step(self, batch, height, width, n_gen_tokens, n_t5_tokens):
+    def capture_micro_step(self, batch, height, width, n_gen_tokens, n_t5_tokens, micro_batches=1):
         """Capture forward + loss + backward + gradient accumulation for a fixed batch geometry and return
         ``replay(noisy_latents, timesteps, generated_prompt_embeds, prompt_embeds, attention_mask, target) -> loss``.
         The autograd tape is recorded once at capture; replays re-run its kernels on new data copied into static buffers.
@@ -193,7 +201,7 @@ class AdapterTrainer:
               "pe": torch.zeros(batch, n_t5_tokens, 1024, dtype=dtype, device=dev),
               "mask": torch.ones(batch, n_t5_tokens, device=dev),
               "target": torch.zeros(batch, C_in, height, width, device=dev)}
-        run = lambda: self.micro_step(st["noisy"], st["t"], st["gen"], st["pe"], st["mask"], st["target"])
+        run = lambda: self.micro_step(st["noisy"], st["t"], st["gen"], st["pe"], st["mask"], st["target"], micro_batches)
         grad0, micro0 = self.grad.clone(), self._micro
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -229,7 +237,7 @@ class AdapterTrainer:
             st["mask"].copy_(attention_mask)
             st["target"].copy_(target)
             graph.replay()
-            self._micro += 1
+            self._micro += int(micro_batches)
             return loss
 
         replay.graph = graph
@@ -294,10 +302,11 @@ class AdapterTrainer:
         ``dynamic_loss_scale`` the scale halves behind an overflowed step like accelerate's GradScaler (one step late, no sync)."""
         return self.global_step - int(self.step_t.item())
 
-    def train_step(self, latents, noise, timesteps, generated_prompt_embeds, prompt_embeds, attention_mask):
-        """noise the latents, run one micro-batch, and step the optimizer on the accumulation boundary (:892-979)."""
+    def train_step(self, latents, noise, timesteps, generated_prompt_embeds, prompt_embeds, attention_mask, micro_batches=1):
+        """noise the latents, run one micro-batch (or ``micro_batches`` concatenated ones, see micro_step), and step the optimizer on
+        the accumulation boundary (:892-979)."""
         noisy = add_noise(latents, noise, timesteps, self.alphas_cumprod)
-        loss = self.micro_step(noisy, timesteps, generated_prompt_embeds, prompt_embeds, attention_mask, noise.float())
+        loss = self.micro_step(noisy, timesteps, generated_prompt_embeds, prompt_embeds, attention_mask, noise.float(), micro_batches)
         if self._micro >= self.accum:
             self.optimizer_step()
         return loss

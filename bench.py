@@ -546,7 +546,29 @@ def train_measure(args, A, rank, world, dev, steps, warmup):
         one()
     dt, every = A.distributed.timed_steps(lambda n: [one() for _ in range(n)], steps, world, torch.cuda.synchronize, dev)
     ms = dt / steps * 1e3
+    accum = None
+    k = int(getattr(args, "train_accum", 0) or 0)
+    if k > 1:
+        # train.sh's gradient_accumulation_steps=4 two ways (same optimizer step, tests/test_gpu_train.py): the reference's k micro-batches
+        # of B one after another, and ONE pass over their concatenation (AdapterTrainer.micro_step(micro_batches=k))
+        def window(rp, nb, reps):
+            noise = torch.randn(nb, 8, 250, 16, generator=g).to(dev)
+            t = torch.randint(0, 1000, (nb,), generator=g).to(dev)
+            r = lambda x: x.repeat(nb // B, *([1] * (x.dim() - 1)))
+            for _ in range(reps):
+                rp(A.add_noise(r(lat), noise, t, tr.alphas_cumprod), t, r(ehs), r(ehs1), r(m1), noise)
+            tr.optimizer_step()
+        replay_k = tr.capture_micro_step(B * k, 250, 16, 8 + La, 16, micro_batches=k)
+        res = {}
+        for name, rp, nb, reps in (("sequential", replay, B, k), ("as_batch", replay_k, B * k, 1)):
+            window(rp, nb, reps)
+            dtk, _ = A.distributed.timed_steps(lambda n: [window(rp, nb, reps) for _ in range(n)], max(steps // 2, 2), world, torch.cuda.synchronize, dev)
+            msk = dtk / max(steps // 2, 2) * 1e3
+            res[name] = {"ms_per_optimizer_step": round(msk, 3), "samples_per_s": round(B * k * world / (msk * 1e-3), 3)}
+        accum = {"gradient_accumulation_steps": k, "per_gpu_micro_batch": B, **res,
+                 "note": "train.sh runs accumulation 4; one pass over the 4 concatenated micro-batches is the same optimizer step"}
     return {"metric": "adapter training samples/sec, AudioLDM2-large+AP (BASELINE cfg 5)", "value": round(B * world / (ms * 1e-3), 3),
+            "accumulation": accum,
             "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 3),
             "rank_ms_per_step": [round(t / steps * 1e3, 3) for t in every],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.train_dtype, "data": "synthetic",
@@ -603,6 +625,7 @@ def main():
     ap.add_argument("--train", action="store_true", help="time BASELINE cfg 5 (the adapter's training step) instead of the denoise step")
     ap.add_argument("--train-batch", type=int, default=4)
     ap.add_argument("--train-dtype", choices=["bf16", "f16", "f32"], default="bf16", help="compute type of the training step (fp32 master weights in every mode)")
+    ap.add_argument("--train-accum", type=int, default=4, help="also time an accumulation window of this many micro-batches, sequential and as one batch (0 = skip)")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the `train` sub-object (cfg 5: 5 optimizer steps at batch 4) of the default line")
     ap.add_argument("--no-in-step", action="store_true", help="skip the live in-step kernel timing (roofline falls back to the isolated timing)")
     ap.add_argument("--stub-step-ms", type=float, default=None, help=argparse.SUPPRESS)
@@ -777,7 +800,7 @@ def main():
                 targs = argparse.Namespace(**{**vars(args), "la": 32})
                 t_ = train_measure(targs, A, rank, world, dev, steps=5, warmup=2)
                 line["train"] = {k: t_[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "loss_first",
-                                                     "loss_last", "finite")}
+                                                     "loss_last", "finite", "accumulation")}
             except Exception as e:  # noqa: BLE001
                 line["train"] = {"error": repr(e)}
         if not args.no_fp32_leg and world == 1:

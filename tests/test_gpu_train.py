@@ -396,6 +396,38 @@ def test_trainer_steps_track_the_oracle(dev, dtype):
     assert torch.equal(tr.work.float().cpu(), tr.master.cpu().to(dtype).float())
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 6e-2)])
+def test_accumulation_as_batch_equals_sequential_micro_batches(dev, dtype, tol):
+    """gradient_accumulation_steps = 2 run the reference's way (two micro-batches of 2, :892 `with accelerator.accumulate`) against ONE
+    pass over their concatenation with micro_batches=2: same accumulated gradient (fp32: to rounding of the summation order; bf16: to
+    the storage rounding of two different kernel forms), same mean loss, same optimizer step, same counters."""
+    import ap_adapter_amd as A
+    u1, _, _, _ = _small_unet(dev, dtype)
+    u2, _, _, _ = _small_unet(dev, dtype)
+    lat, noise, t, ehs, ehs1, m1 = (x.to(dev) for x in _batch(4, 8, dtype))
+    tr1 = A.AdapterTrainer(u1, lr=1e-2, gradient_accumulation_steps=2)
+    tr2 = A.AdapterTrainer(u2, lr=1e-2, gradient_accumulation_steps=2)
+    noisy = A.add_noise(lat, noise, t, tr1.alphas_cumprod)
+    l1 = [tr1.micro_step(noisy[i:i + 2], t[i:i + 2], ehs[i:i + 2], ehs1[i:i + 2], m1[i:i + 2], noise[i:i + 2]) for i in (0, 2)]
+    l2 = tr2.micro_step(noisy, t, ehs, ehs1, m1, noise, micro_batches=2)
+    assert tr1._micro == tr2._micro == 2
+    assert abs(float(l2) - 0.5 * float(l1[0] + l1[1])) < (1e-6 if dtype == torch.float32 else 1e-2) * float(l2)
+    assert float(tr1.grad.abs().max()) > 0
+    assert rel_err(tr2.grad, tr1.grad) < tol
+    assert 1 - float(F.cosine_similarity(tr1.grad.double(), tr2.grad.double(), dim=0)) < (1e-9 if dtype == torch.float32 else 2e-3)
+    tr1.optimizer_step()
+    tr2.optimizer_step()
+    assert tr1.global_step == tr2.global_step == 1 and tr1._micro == tr2._micro == 0
+    if dtype == torch.float32:
+        assert float((tr1.master - tr2.master).abs().mean()) < 1e-3 * 1e-2  # (the first AdamW step moves every weight by ~lr: compare on that scale)
+    with pytest.raises(ValueError):
+        tr2.micro_step(noisy[:3], t[:3], ehs[:3], ehs1[:3], m1[:3], noise[:3], micro_batches=2)
+    # the captured form counts the same way
+    replay = tr2.capture_micro_step(4, 26, 16, 16, 16, micro_batches=2)
+    replay(noisy, t, ehs, ehs1, m1, noise)
+    assert tr2._micro == 2
+
+
 def test_collate_and_checkpoint(dev, tmp_path):
     """f-3: per-batch pooling choice + condition dropout in front of AudioMAE (text tokens first, :471), and a checkpoint
     that carries the fp32 master weights under the reference key scheme plus the optimizer state"""
