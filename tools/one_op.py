@@ -12,6 +12,11 @@ if op == "attn_self":
     # q as the model hands it over: already multiplied by log2(e) / sqrt(d) (the direct-form kernel of the 1000-token level)
     q = R(B2, N, C, std=1.4427 / 32 ** 0.5); k = R(B2, N, C); v = R(B2, 8, C // 8, ops.round_up(N, 32)); out = torch.empty_like(q)
     fn = lambda: ops.attention(q, k, v, N, 8, out=out, q_prescaled=True)
+elif op == "sattn_fused":
+    N, C = 1000, 256
+    x = R(B2, N, C); g = R(C); be = R(C); wq, wk, wv = R(C, C, std=0.05), R(C, C, std=0.05), R(C, C, std=0.05); out = torch.empty_like(x)
+    wp, cs = ops.sattn_pack(wq, wk, wv, (g, be, 1e-5), 8)
+    fn = lambda: ops.self_attention_fused(x, wp, cs, 8, 1e-5, out=out)
 elif op == "attn_ip":
     N, C, La = 1000, 256, 32
     q = R(B2, N, C); kt = R(B2, 8, C); vt_ = R(B2, 8, C // 8, 32); ka = R(B2, La, C); va = R(B2, 8, C // 8, ops.round_up(La, 32)); out = torch.empty_like(q)

@@ -30,19 +30,19 @@ if wr:
     out["calibration"]["write_probe_bytes"] = 131072000
     out["calibration"]["write_probe_WRITE_SIZE_KB"] = w
     out["calibration"]["write_factor"] = 131072000 / (w * 1024.0)
-KERNEL = "attn2q_kernel"  # the self-attention kernel of the 1000-token level (two query tiles per wave since round 2)
+KERNEL = "sattn_fused_kernel"  # LN + q|k|v + self-attention of the 1000-token level in one launch (round 4; tools/one_op.py sattn_fused)
 fa = per_dispatch("FETCH_SIZE_attn", "FETCH_SIZE", KERNEL)
 wa = per_dispatch("WRITE_SIZE_attn", "WRITE_SIZE", KERNEL)
 if fa and wa and rd and wr:
     f = sorted(fa)[len(fa) // 2] * 1024.0 * out["calibration"]["read_factor"]
     w = sorted(wa)[len(wa) // 2] * 1024.0 * out["calibration"]["write_factor"]
-    out["kernel"] = KERNEL + "<bf16,D=32> self-attention B'=64 heads=8 N=L=1000"
+    out["kernel"] = KERNEL + "<bf16,D=32> LN + q|k|v + self-attention B'=64 heads=8 N=L=1000 (isolated probe)"
     out["raw_FETCH_SIZE_KB"] = sorted(fa)[len(fa) // 2]
     out["raw_WRITE_SIZE_KB"] = sorted(wa)[len(wa) // 2]
     out["read_bytes_per_launch"] = f
     out["write_bytes_per_launch"] = w
     out["traffic_bytes_per_launch"] = f + w
-    out["algorithmic_bytes_per_launch"] = 131072000
+    out["algorithmic_bytes_per_launch"] = 2 * 64 * 1000 * 256 * 2 + 3 * 256 * 256 * 2  # x in, O out, the packed weights once
 
 
 def totals(sub, counter):

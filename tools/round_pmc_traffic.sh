@@ -20,7 +20,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
       echo "pass ${c}_step$n try $try failed / timed out"
     done
   done
-  timeout 300 rocprofv3 --pmc $c -d $OUT/${c}_attn -o p -- python $R/tools/one_op.py attn_self 5 > $OUT/${c}_attn.log 2>&1
+  timeout 150 rocprofv3 --pmc $c -d $OUT/${c}_attn -o p -- python $R/tools/one_op.py sattn_fused 5 > $OUT/${c}_attn.log 2>&1
   timeout 120 rocprofv3 --pmc $c -d $OUT/${c}_rbw -o p -- $R/tools/probes/rbw > $OUT/${c}_rbw.log 2>&1
   timeout 120 rocprofv3 --pmc $c -d $OUT/${c}_wbw -o p -- $R/tools/probes/wbw > $OUT/${c}_wbw.log 2>&1
 done
