@@ -826,6 +826,20 @@ __device__ __forceinline__ sf_gptr sf_sgpr_ptr(const uint8_t* p) {
 #define SF_ABL 0  // timing ablations (tools/ab_build.sh; results are wrong): 1 = no key loop, 2 = no projection, 4 = projection without the statistics, 8 = x fragments loaded once
 #endif
 
+// probe build (tools/ab_build.sh <tag> attention.hip -DSF_TRACE=<wave>; tools/sf_trace.py): s_memtime at the phase boundaries of one wave of every
+// workgroup.  Never part of the product library.
+#ifdef SF_TRACE
+__device__ unsigned long long sf_trace_buf[1024][16];
+#define SF_STAMP(i_)                                                                                      \
+    if (lane == 0 && wave == (SF_TRACE) && blockIdx.x < 1024) {                                           \
+        sf_trace_buf[blockIdx.x][i_] = __builtin_amdgcn_s_memtime();                                      \
+        if ((i_) == 0) sf_trace_buf[blockIdx.x][14] = wall_clock64();                                     \
+        if ((i_) == 9) sf_trace_buf[blockIdx.x][15] = wall_clock64();                                     \
+    }
+#else
+#define SF_STAMP(i_)
+#endif
+
 // acc[n][j] += W_tile_j . x_panel_n^T over the KC k-steps (raw x), with the row statistics of the panels summed on the way (shifted by the row's
 // first element: both halves of a row use the same shift)
 template <int DT, int NT3, int NPP, int KC, int NSET>
@@ -892,6 +906,7 @@ __global__ __launch_bounds__(NW * 64) void sattn_fused_kernel(SfP p) {
     const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
     const int b = (seq / p.H) * 8 + xcd, h = seq % p.H;  // (all heads of a sample on one XCD: they share its rows)
     if (b >= p.B) return;
+    SF_STAMP(0);
     const int N = p.N;
     const int npan = (N + 31) >> 5, ntiles = (N + KT - 1) / KT, nfull = N / KT;
     const int rounds = (npan + NPW * NW - 1) / (NPW * NW);
@@ -904,6 +919,7 @@ __global__ __launch_bounds__(NW * 64) void sattn_fused_kernel(SfP p) {
             for (int i = tid; i < (Y::VROWS - D) * Y::VROW / 4; i += NW * 64) reinterpret_cast<uint32_t*>(smem + t * Y::BUF + Y::K_BYTES + D * Y::VROW)[i] = 0u;
     }
     __syncthreads();
+    SF_STAMP(1);
     const sf_gptr wb = sf_sgpr_ptr(p.w + (int64_t)h * NT3 * KC * 1024);
     const uint32_t loff = (uint32_t)lane * 16u;
     const uint8_t* const xb = p.x + (int64_t)b * N * C * 2;
@@ -939,6 +955,7 @@ __global__ __launch_bounds__(NW * 64) void sattn_fused_kernel(SfP p) {
                 for (int n = 0; n < NPP; ++n) ssum[n] = sq[n] = shift[n] = 1.f;
             } else
             sf_project<DT, NT3, NPP, KC, NSET>(wb, loff, xrow, acc, ssum, sq, shift);
+            SF_STAMP(2 + 2 * r);
 #pragma unroll
             for (int n = 0; n < NPP; ++n) {
                 const int key = pan[n] * 32 + l31;
@@ -983,9 +1000,11 @@ __global__ __launch_bounds__(NW * 64) void sattn_fused_kernel(SfP p) {
                     }
                 }
             }
+            SF_STAMP(3 + 2 * r);
         }
     }
     __syncthreads();
+    SF_STAMP(6);
     // ---- 2. attention over the resident tiles: two query panels per wave and round ----
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -1031,8 +1050,15 @@ __global__ __launch_bounds__(NW * 64) void sattn_fused_kernel(SfP p) {
                     }
             }
         }
+        SF_STAMP(7 + r);
     }
+    SF_STAMP(9);
 }
+#ifdef SF_TRACE
+extern "C" int apad_sf_trace_read(void* dst, int bytes) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(sf_trace_buf), (size_t)bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
 
 template <int DT, int D, int KC, int NW, int NPP, int NSET> int sf_go(const SfP& p, hipStream_t s) {
     using Y = Lay<D>;
