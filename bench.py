@@ -617,7 +617,6 @@ def main():
     ap.add_argument("--la", type=int, default=32, help="audio tokens (32 = style_transfer preset, pooling 4x4)")
     ap.add_argument("--guidance", type=float, default=9.5)
     ap.add_argument("--ap-scale", type=float, default=0.55)
-    ap.add_argument("--streams", type=int, default=1, help="2 = run the two CFG halves on concurrent streams")
     ap.add_argument("--low-res-streams", type=int, default=1, help="n > 0: run the two batch halves of the n lowest-resolution levels on two streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32-precision-mode timing of the same step")
@@ -684,25 +683,10 @@ def main():
     if args.low_res_streams:
         unet.low_res_streams = tuple(torch.cuda.Stream() for _ in range(int(os.environ.get("APAD_LOW_RES_NSTREAMS", "2"))))
         unet.low_res_levels = args.low_res_streams
-    side = [torch.cuda.Stream() for _ in range(2)] if args.streams == 2 else None
-    eps_buf = torch.empty(2 * B, H * W, Cc, dtype=dtype, device=dev)
-    ge_h, pe_h, am_h = ge.chunk(2), pe.chunk(2), am.chunk(2)
 
     def step():
-        if side is None:
-            eps2 = unet.forward_nhwc(unet_in, H, W, None, ge, pe, None, am, batch_repeat=2)
-        else:
-            # the unconditional and the conditional half of the CFG batch are independent until the combine: run them
-            # as two concurrent streams (forked / joined inside the captured graph) so that one half's latency-bound
-            # phases overlap the other half's compute
-            cur = torch.cuda.current_stream()
-            for i, s in enumerate(side):
-                s.wait_stream(cur)
-                with torch.cuda.stream(s):
-                    eps_buf[i * B:(i + 1) * B].copy_(unet.forward_nhwc(unet_in, H, W, None, ge_h[i], pe_h[i], None, am_h[i]))
-            for s in side:
-                cur.wait_stream(s)
-            eps2 = eps_buf
+        # (round 2 also ran the two CFG halves as two concurrent batch-32 forwards on forked streams: +1.5 % step time, removed)
+        eps2 = unet.forward_nhwc(unet_in, H, W, None, ge, pe, None, am, batch_repeat=2)
         ops.cfg_ddim_step(eps2, lat, unet_in, coef, step_ptr, args.guidance)
         ops.step_advance(step_ptr)
 
