@@ -823,7 +823,7 @@ __device__ __forceinline__ sf_gptr sf_sgpr_ptr(const uint8_t* p) {
 #define SF_VPM 9  // vector instructions scheduled behind each MFMA of the projection loop
 #endif
 #ifndef SF_ABL
-#define SF_ABL 0  // timing ablations (tools/ab_build.sh; results are wrong): 1 = no key loop, 2 = no projection, 4 = projection without the statistics, 8 = x fragments loaded once
+#define SF_ABL 0  // timing ablations (tools/ab_build.sh; results are wrong): 1 = no key loop, 2 = no projection, 4 = projection without the statistics, 8 = x fragments loaded once, 16 = weight fragments loaded once, 64 = x loaded as whole rows (same bytes, 8 instead of 32 rows per instruction)
 #endif
 
 // probe build (tools/ab_build.sh <tag> attention.hip -DSF_TRACE=<wave>; tools/sf_trace.py): s_memtime at the phase boundaries of one wave of every
@@ -850,7 +850,7 @@ __device__ __forceinline__ void sf_project(sf_gptr wb, uint32_t loff, const uint
     typename E::v8 wf[NSET][NT3], xf[NSET][NPP];
 #define SF_LD(i_, kk_)                                                                                                                \
     _Pragma("unroll") for (int j = 0; j < NT3; ++j) wf[i_][j] = __builtin_bit_cast(typename E::v8, *(sf_gptr16)(wb + (j * KC + ((SF_ABL & 16) ? 0 : (kk_))) * 1024 + loff)); \
-    _Pragma("unroll") for (int n = 0; n < NPP; ++n) xf[i_][n] = as_v8<DT>(*reinterpret_cast<const uint4*>(xrow[n] + ((SF_ABL & 8) ? 0 : (kk_)) * 32));
+    _Pragma("unroll") for (int n = 0; n < NPP; ++n) xf[i_][n] = as_v8<DT>(*reinterpret_cast<const uint4*>(xrow[n] + ((SF_ABL & 8) ? 0 : (kk_)) * ((SF_ABL & 64) ? 1024 : 32)));
 #define SF_MM(i_)                                                                                   \
     _Pragma("unroll") for (int n = 0; n < NPP; ++n) {                                               \
         _Pragma("unroll") for (int j = 0; j < NT3; ++j) acc[n][j] = E::mfma32(wf[i_][j], xf[i_][n], acc[n][j]); \
@@ -939,6 +939,7 @@ __global__ __launch_bounds__(NW * 64) void sattn_fused_kernel(SfP p) {
                 int tok = pan[n] * 32 + l31;
                 tok = tok < N ? tok : N - 1;
                 xrow[n] = xb + ((int64_t)tok * C + half * 8) * 2;
+                if (SF_ABL & 64) xrow[n] = xb + ((int64_t)min(pan[n] * 32 + half, N - 32) * C + l31 * 8) * 2;  // (timing only: two whole rows per load instruction)
                 act = act || pan[n] < npan;
             }
             if (!act) continue;  // (wave-uniform)
