@@ -13,6 +13,15 @@
 
 namespace {
 
+// probe build (tools/ab_build.sh wstr wsgemm.hip -DWS_TRACE=<wave>; tools/ws_trace.py): wall-clock stamps (100 MHz) of one wave of every workgroup.  Never
+// part of the product library.
+#ifdef WS_TRACE
+__device__ unsigned long long ws_trace_buf[1024][16];
+#define WS_STAMP(i_) if (lane == 0 && wave == (WS_TRACE) && blockIdx.x < 1024) ws_trace_buf[blockIdx.x][i_] = wall_clock64();
+#else
+#define WS_STAMP(i_)
+#endif
+
 template <int KC> struct WsCfg {
     static constexpr int NS = (KC <= 16) ? 256 : 128;  // weight rows resident in LDS per workgroup
     static constexpr int NTILES = NS / 32;             // MFMA tiles per slice
@@ -23,7 +32,11 @@ template <int KC> struct WsCfg {
     static constexpr bool PREFETCH = (KC <= 16);       // second x panel in registers only fits at K=256
 };
 
-template <int DT, int KC, bool LN, bool GEGLU>
+// RES: the launch adds a residual (to_out / proj_out: one segment, row-major).  These are the launches with about ONE panel per wave (64 x 1000 tokens =
+// 2000 panels over 2048 waves): the residual rows of all the wave's tiles are requested with its x panel, behind the weight requests and in front of the
+// barrier, instead of one HBM round trip in every tile's epilogue; the registers of the second x panel hold them (the next panel, if any, is loaded at the
+// end of the loop).
+template <int DT, int KC, bool LN, bool GEGLU, bool RES>
 __global__ __launch_bounds__(512) void wsgemm_kernel(RpP p) {
     using E = ET<DT>;
     using W = WsCfg<KC>;
@@ -34,6 +47,25 @@ __global__ __launch_bounds__(512) void wsgemm_kernel(RpP p) {
     const int nslices = p.nsplit;
     const int slice = blockIdx.x % nslices, rgrp = blockIdx.x / nslices, ngrp = gridDim.x / nslices;
     const int t0 = slice * W::NTILES;  // first MFMA tile (global tile index) of this slice
+    WS_STAMP(0);
+    constexpr bool PREFETCH = W::PREFETCH && !RES;
+    const int64_t npanels = (p.M + 31) >> 5;
+    const int64_t pstride = (int64_t)ngrp * W::WAVES;
+    int64_t pi = (int64_t)rgrp * W::WAVES + wave;
+    typename E::v8 xf[KC];
+    typename E::v8 xn[PREFETCH ? KC : 1];
+    uint4 rall[RES ? W::NTILES : 1][2];  // residual rows of the panel's tiles in scratch_flush_res's lane order (lane, lane + 64 -> (row, 16-byte chunk))
+    auto res_load = [&](int64_t mw0_) {
+#pragma unroll
+        for (int ti_ = 0; ti_ < (RES ? W::NTILES : 0); ++ti_)
+#pragma unroll
+            for (int k_ = 0; k_ < 2; ++k_) {
+                const int idx = lane + 64 * k_, row = idx >> 2, ch = idx & 3;
+                int64_t m = mw0_ + row;
+                m = m < p.M ? m : p.M - 1;
+                rall[ti_][k_] = *reinterpret_cast<const uint4*>(p.res + (m * p.ldr + (t0 + ti_) * 32 - p.seg[0].n_begin + ch * 8) * 2);
+            }
+    };
 
     // ---- weight slice + bias -> LDS, once.  Batches of 8 loads are issued back to back before their LDS stores: a plain
     //      load/store loop exposed one full memory latency per 16 bytes per thread (measured: ~20 us of fixed cost). ----
@@ -70,6 +102,12 @@ __global__ __launch_bounds__(512) void wsgemm_kernel(RpP p) {
             }
         }
     }
+    if (RES && pi < npanels) {  // behind the weight requests (they are on the critical path), in front of the barrier
+        __builtin_amdgcn_sched_barrier(0);
+        load_panel<DT, KC>(xf, p.x, p.lda, p.M, pi * 32, l31, half);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    WS_STAMP(1);
     uint8_t* const scr = smem + W::W_BYTES + wave * SCR_BYTES;
     float* const lbias = reinterpret_cast<float*>(smem + W::W_BYTES + W::WAVES * SCR_BYTES);
     const int bias_cols = W::NTILES * COLS_PER_TILE;
@@ -92,18 +130,18 @@ __global__ __launch_bounds__(512) void wsgemm_kernel(RpP p) {
         }
     }
     __syncthreads();  // the only workgroup barrier
+    WS_STAMP(2);
+    if (RES && pi < npanels) {  // (behind the barrier: in front of it the 32 requests per lane slowed the weight staging of the whole chip down, 1.4 -> 4.9 us)
+        res_load(pi * 32);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 
-    const int64_t npanels = (p.M + 31) >> 5;
-    const int64_t pstride = (int64_t)ngrp * W::WAVES;
-    int64_t pi = (int64_t)rgrp * W::WAVES + wave;
-    typename E::v8 xf[KC];
-    typename E::v8 xn[W::PREFETCH ? KC : 1];
-    if (pi < npanels) load_panel<DT, KC>(xf, p.x, p.lda, p.M, pi * 32, l31, half);
+    if (!RES && pi < npanels) load_panel<DT, KC>(xf, p.x, p.lda, p.M, pi * 32, l31, half);
 
     for (; pi < npanels; pi += pstride) {
         const int64_t mw0 = pi * 32;
         if (LN) layernorm_panel<DT, KC>(xf, p.gamma, p.beta, p.eps, l31, half);
-        if constexpr (W::PREFETCH) {
+        if constexpr (PREFETCH) {
             if (pi + pstride < npanels) load_panel<DT, KC>(xn, p.x, p.lda, p.M, (pi + pstride) * 32, l31, half);
         }
         int64_t vt_b0 = 0;
@@ -114,7 +152,73 @@ __global__ __launch_bounds__(512) void wsgemm_kernel(RpP p) {
         }
         int cursor = 0, win_col0 = 0;
 
+        if constexpr (RES) {
+            // the lean tile loop of the residual launches: one row-major segment, no activation -- none of the general loop's per-tile segment selection,
+            // 64-bit row arithmetic and activation branches (the general loop issues ~400 instructions per tile and wave: 1.4-2.0 us per tile, tools/ws_trace.py)
+            uint8_t* op[2];
+            bool ok[2];
+#pragma unroll
+            for (int k_ = 0; k_ < 2; ++k_) {
+                const int idx = lane + 64 * k_, row = idx >> 2, ch = idx & 3;
+                const int64_t m = mw0 + row;
+                ok[k_] = m < p.M;
+                op[k_] = p.seg[0].out + ((ok[k_] ? m : p.M - 1) * p.seg[0].ldo + (t0 * 32 - p.seg[0].n_begin) + ch * 8) * 2;
+            }
+            const uint8_t* const sr0 = scr + (lane >> 2) * SCR_ROWB + (lane & 3) * 16;
+            static_assert(W::NTILES % 2 == 0, "tiles run in pairs");
+#pragma unroll
+            for (int tp = 0; tp < W::NTILES; tp += 2) {
+                if (tp < 9) { WS_STAMP(3 + tp); }
+                // two tiles at a time: 2 independent accumulator chains (a single tile's 16-24 MFMAs are one dependent chain: ~1000 cycles of latency per
+                // tile with nothing else to issue); the fragments of a group of 4 k-steps are read together, the next group's reads run under these MFMAs
+                f32x16 acc[2];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
+                const uint8_t* const w0p = smem + (tp * 32 + l31) * W::ROWB + half * 16;
+#pragma unroll
+                for (int g = 0; g < KC / 4; ++g) {
+                    typename E::v8 f0[4], f1[4];
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        f0[cc] = as_v8<DT>(*reinterpret_cast<const uint4*>(w0p + (4 * g + cc) * 32));
+                        f1[cc] = as_v8<DT>(*reinterpret_cast<const uint4*>(w0p + 32 * W::ROWB + (4 * g + cc) * 32));
+                    }
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) asm volatile("" : "+v"(f0[cc]), "+v"(f1[cc]) : : "memory");
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        acc[0] = E::mfma32(f0[cc], xf[4 * g + cc], acc[0]);
+                        acc[1] = E::mfma32(f1[cc], xf[4 * g + cc], acc[1]);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int ti = tp + q;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(lbias + ti * 32 + 8 * g + 4 * half);
+                        typename E::v4 y;
+                        y[0] = (typename E::elem)(acc[q][4 * g + 0] + b4.x);
+                        y[1] = (typename E::elem)(acc[q][4 * g + 1] + b4.y);
+                        y[2] = (typename E::elem)(acc[q][4 * g + 2] + b4.z);
+                        y[3] = (typename E::elem)(acc[q][4 * g + 3] + b4.w);
+                        *reinterpret_cast<uint2*>(scr + l31 * SCR_ROWB + (8 * g + 4 * half) * 2) = __builtin_bit_cast(uint2, y);
+                    }
+#pragma unroll
+                    for (int k_ = 0; k_ < 2; ++k_) {
+                        const uint2 lo = *reinterpret_cast<const uint2*>(sr0 + k_ * 16 * SCR_ROWB), hi = *reinterpret_cast<const uint2*>(sr0 + k_ * 16 * SCR_ROWB + 8);
+                        float f[8], rr[8];
+                        unpack8<DT>(make_uint4(lo.x, lo.y, hi.x, hi.y), f);
+                        unpack8<DT>(rall[ti][k_], rr);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] += rr[e];
+                        if (ok[k_]) *reinterpret_cast<uint4*>(op[k_] + ti * 64) = pack8<DT>(f);
+                    }
+                }
+            }
+        } else
         for (int ti = 0; ti < W::NTILES; ++ti) {
+            if (ti < 9) { WS_STAMP(3 + ti); }
             const int n0 = (t0 + ti) * COLS_PER_TILE;
             const bool s1 = p.nseg > 1 && n0 >= p.seg[1].n_begin, s2 = p.nseg > 2 && n0 >= p.seg[2].n_begin;
             uint8_t* sg_out = s2 ? p.seg[2].out : (s1 ? p.seg[1].out : p.seg[0].out);
@@ -190,17 +294,24 @@ __global__ __launch_bounds__(512) void wsgemm_kernel(RpP p) {
             }
         }
         if (GEGLU && cursor > 0) scratch_flush<DT>(scr, cursor, p.seg[0].out, p.seg[0].ldo, win_col0, nullptr, 0, mw0, p.M, lane);
+        WS_STAMP(12);
 
-        if constexpr (W::PREFETCH) {
+        if constexpr (PREFETCH) {
 #pragma unroll
             for (int c = 0; c < KC; ++c) xf[c] = xn[c];
         } else {
-            if (pi + pstride < npanels) load_panel<DT, KC>(xf, p.x, p.lda, p.M, (pi + pstride) * 32, l31, half);
+            if (pi + pstride < npanels) {
+                load_panel<DT, KC>(xf, p.x, p.lda, p.M, (pi + pstride) * 32, l31, half);
+                if (RES) res_load((pi + pstride) * 32);
+            }
         }
     }
 }
 
-template <int DT, int KC, bool LN, bool GEGLU> int ws_launch(RpP& p, hipStream_t s) {
+template <int DT, int KC, bool LN, bool GEGLU, bool RES = false> int ws_launch(RpP& p, hipStream_t s) {
+    if constexpr (!RES && !GEGLU) {
+        if (p.res != nullptr && p.nseg == 1 && p.seg[0].mode == APAD_OUT_ROWMAJOR && p.epi == APAD_EPI_NONE) return ws_launch<DT, KC, LN, GEGLU, true>(p, s);
+    }
     using W = WsCfg<KC>;
     constexpr int COLS_PER_TILE = GEGLU ? 16 : 32;
     const int cols_per_slice = W::NTILES * COLS_PER_TILE;
@@ -214,7 +325,7 @@ template <int DT, int KC, bool LN, bool GEGLU> int ws_launch(RpP& p, hipStream_t
     const int64_t max_grp = (npanels + W::WAVES - 1) / W::WAVES;
     if (ngrp > max_grp) ngrp = (int)max_grp;
     const size_t lds = W::W_BYTES + W::WAVES * SCR_BYTES + (size_t)cols_per_slice * (GEGLU ? 2 : 1) * sizeof(float);
-    auto kern = wsgemm_kernel<DT, KC, LN, GEGLU>;
+    auto kern = wsgemm_kernel<DT, KC, LN, GEGLU, RES>;
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -230,6 +341,12 @@ template <int DT, int KC> int ws_dispatch2(RpP& p, bool ln, bool geglu, hipStrea
 }
 
 }  // namespace
+
+#ifdef WS_TRACE
+extern "C" int apad_ws_trace_read(void* dst, int bytes) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(ws_trace_buf), (size_t)bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // returns -3 when the shape does not fit the weight-stationary schedule (caller falls back to the streamed kernel)
 int apad_ws_dispatch(void* rp_params, int K, int dtype, bool ln, bool geglu, void* stream) {

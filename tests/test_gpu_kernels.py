@@ -591,6 +591,25 @@ def test_rowpanel_plain_bias_act_residual(dev, dtype, M, K, ln):
     assert rel_err(out, ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,K", [(63990, 256), (100003, 256), (16128, 384), (70001, 384), (17, 256)])
+def test_to_out_residual_launch_lean_tile_loop(dev, dtype, M, K):
+    """to_out / proj_out of the two large levels: Linear + bias + residual through the weight-stationary kernel's residual form (x panel and the
+    residual rows of all the wave's tiles requested up front, two tiles per step, no segment / activation logic in the loop).  Ragged last panel, more than
+    one panel per wave (100003 rows > 2048 waves x 32; 70001 rows at K = 384: 3 column slices x 85 row groups), and IN PLACE on the residual buffer as the
+    transformer blocks call it."""
+    from ap_adapter_amd import ops
+    x = q(R(M, K, seed=150), dtype)
+    w, b, r = q(R(K, K, seed=151, std=0.05), dtype), q(R(K, seed=152, std=0.3), dtype), q(R(M, K, seed=153), dtype)
+    ref = F.linear(x, w, b) + r
+    xd, wd, bd = x.to(dev, dtype), w.to(dev, dtype), b.to(dev, dtype)
+    out = ops.fused_linear(xd, wd, bd, residual=r.to(dev, dtype))
+    assert rel_err(out, ref) < TOL[dtype]
+    buf = r.to(dev, dtype).clone()
+    out2 = ops.fused_linear(xd, wd, bd, residual=buf, out=buf)
+    assert out2.data_ptr() == buf.data_ptr() and torch.equal(out2, out)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,K", [(1000, 256), (300, 384), (33000, 256), (32900, 384)])
 @pytest.mark.parametrize("ln", [False, True])
