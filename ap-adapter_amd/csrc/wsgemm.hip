@@ -32,7 +32,7 @@ template <int KC> struct WsCfg {
     static constexpr bool PREFETCH = (KC <= 16);       // second x panel in registers only fits at K=256
 };
 
-// RES: the launch adds a residual (to_out / proj_out: one segment, row-major).  These are the launches with about ONE panel per wave (64 x 1000 tokens =
+// RES: a launch with ONE row-major segment and no activation, with or without a residual (to_out / proj_out / proj_in).  These are the launches with about ONE panel per wave (64 x 1000 tokens =
 // 2000 panels over 2048 waves): the residual rows of all the wave's tiles are requested with its x panel, behind the weight requests and in front of the
 // barrier, instead of one HBM round trip in every tile's epilogue; the registers of the second x panel hold them (the next panel, if any, is loaded at the
 // end of the loop).
@@ -54,6 +54,7 @@ __global__ __launch_bounds__(512) void wsgemm_kernel(RpP p) {
     int64_t pi = (int64_t)rgrp * W::WAVES + wave;
     typename E::v8 xf[KC];
     typename E::v8 xn[PREFETCH ? KC : 1];
+    const bool has_res = RES && p.res != nullptr;  // (the lean form also serves one-segment launches WITHOUT a residual: proj_in)
     uint4 rall[RES ? W::NTILES : 1][2];  // residual rows of the panel's tiles in scratch_flush_res's lane order (lane, lane + 64 -> (row, 16-byte chunk))
     auto res_load = [&](int64_t mw0_) {
 #pragma unroll
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(512) void wsgemm_kernel(RpP p) {
     }
     __syncthreads();  // the only workgroup barrier
     WS_STAMP(2);
-    if (RES && pi < npanels) {  // (behind the barrier: in front of it the 32 requests per lane slowed the weight staging of the whole chip down, 1.4 -> 4.9 us)
+    if (has_res && pi < npanels) {  // (behind the barrier: in front of it the 32 requests per lane slowed the weight staging of the whole chip down, 1.4 -> 4.9 us)
         res_load(pi * 32);
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -207,12 +208,16 @@ __global__ __launch_bounds__(512) void wsgemm_kernel(RpP p) {
 #pragma unroll
                     for (int k_ = 0; k_ < 2; ++k_) {
                         const uint2 lo = *reinterpret_cast<const uint2*>(sr0 + k_ * 16 * SCR_ROWB), hi = *reinterpret_cast<const uint2*>(sr0 + k_ * 16 * SCR_ROWB + 8);
-                        float f[8], rr[8];
-                        unpack8<DT>(make_uint4(lo.x, lo.y, hi.x, hi.y), f);
-                        unpack8<DT>(rall[ti][k_], rr);
+                        uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                        if (has_res) {  // (wave-uniform)
+                            float f[8], rr[8];
+                            unpack8<DT>(v, f);
+                            unpack8<DT>(rall[ti][k_], rr);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) f[e] += rr[e];
-                        if (ok[k_]) *reinterpret_cast<uint4*>(op[k_] + ti * 64) = pack8<DT>(f);
+                            for (int e = 0; e < 8; ++e) f[e] += rr[e];
+                            v = pack8<DT>(f);
+                        }
+                        if (ok[k_]) *reinterpret_cast<uint4*>(op[k_] + ti * 64) = v;
                     }
                 }
             }
@@ -302,15 +307,15 @@ __global__ __launch_bounds__(512) void wsgemm_kernel(RpP p) {
         } else {
             if (pi + pstride < npanels) {
                 load_panel<DT, KC>(xf, p.x, p.lda, p.M, (pi + pstride) * 32, l31, half);
-                if (RES) res_load((pi + pstride) * 32);
+                if (has_res) res_load((pi + pstride) * 32);
             }
         }
     }
 }
 
 template <int DT, int KC, bool LN, bool GEGLU, bool RES = false> int ws_launch(RpP& p, hipStream_t s) {
-    if constexpr (!RES && !GEGLU) {
-        if (p.res != nullptr && p.nseg == 1 && p.seg[0].mode == APAD_OUT_ROWMAJOR && p.epi == APAD_EPI_NONE) return ws_launch<DT, KC, LN, GEGLU, true>(p, s);
+    if constexpr (!RES && !GEGLU && !LN) {  // (with the LayerNorm in front the unrolled form does not fit its registers)
+        if (p.nseg == 1 && p.seg[0].mode == APAD_OUT_ROWMAJOR && p.epi == APAD_EPI_NONE) return ws_launch<DT, KC, LN, GEGLU, true>(p, s);
     }
     using W = WsCfg<KC>;
     constexpr int COLS_PER_TILE = GEGLU ? 16 : 32;
