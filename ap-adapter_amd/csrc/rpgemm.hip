@@ -305,11 +305,9 @@ template <int DT, int KC, bool LN, bool GEGLU, int NW = 4> int launch(RpP& p, hi
     p.nsplit = (p.n_tiles + p.tiles_per_block - 1) / p.tiles_per_block;
     const size_t lds = 2 * C::TILE_BYTES + NW * SCR_BYTES + (size_t)p.tiles_per_block * COLS_PER_TILE * (GEGLU ? 2 : 1) * sizeof(float);
     auto kern = rpgemm_kernel<DT, KC, LN, GEGLU, NW>;
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_lds = lds;
-    }
+    // (the attribute is the per-device ceiling of this instantiation, not the launch's size: set once per device to the CU's whole LDS)
+    static unsigned devs = 0;
+    if (apad_ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, &devs) != 0) return -1;
     hipLaunchKernelGGL(kern, dim3((unsigned)(m_tiles * p.nsplit)), dim3(NW * 64), lds, s, p);
     return apad_check_launch("apad_rowpanel_gemm");
 }

@@ -331,11 +331,9 @@ template <int DT, int KC, bool LN, bool GEGLU, bool RES = false> int ws_launch(R
     if (ngrp > max_grp) ngrp = (int)max_grp;
     const size_t lds = W::W_BYTES + W::WAVES * SCR_BYTES + (size_t)cols_per_slice * (GEGLU ? 2 : 1) * sizeof(float);
     auto kern = wsgemm_kernel<DT, KC, LN, GEGLU, RES>;
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_lds = lds;
-    }
+    // (the attribute is the per-device ceiling of this instantiation, not the launch's size: set once per device to the CU's whole LDS)
+    static unsigned devs = 0;
+    if (apad_ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, &devs) != 0) return -1;
     hipLaunchKernelGGL(kern, dim3((unsigned)(ngrp * p.nsplit)), dim3(512), lds, s, p);
     return apad_check_launch("apad_rowpanel_gemm(ws)");
 }

@@ -278,9 +278,11 @@ class AttnProcessor2_0(nn.Module):
         if attn.residual_connection or attn.rescale_output_factor != 1.0:
             raise NotImplementedError("residual_connection / rescale_output_factor are not on the AudioLDM2 path")
         hs_route = _hs_route(attn, hidden_states, _residual, _ln)
-        if encoder_hidden_states is None and hs_route:
+        # (a masked self-attention -- the reference applies attention_mask to attn1 too, attention_processor.py:245-249 -- takes the generic
+        #  q|k|v + apad_attention(key_bias) route below: the two fused self-attention kernels carry no key bias)
+        if encoder_hidden_states is None and attention_mask is None and hs_route:
             return _hs_sublayer(attn, hidden_states, _residual, _ln)
-        if (encoder_hidden_states is None and _ln is not None and ops.sattn_ok(hidden_states, heads) and attn.to_q.bias is None
+        if (encoder_hidden_states is None and attention_mask is None and _ln is not None and ops.sattn_ok(hidden_states, heads) and attn.to_q.bias is None
                 and tuple(attn.to_q.weight.shape) == (C_, C_)):
             # the two large levels: LayerNorm + q | k | v + attention in ONE launch (workgroup = (sample, head), K / V^T in LDS), then to_out
             key = (_pkey(attn.to_q.weight, attn.to_k.weight, attn.to_v.weight, _ln[0], _ln[1]), float(_ln[2]))

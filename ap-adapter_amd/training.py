@@ -52,8 +52,11 @@ def get_scheduler(name, num_warmup_steps=0, num_training_steps=None, num_cycles=
     if name == "constant_with_warmup":
         return lambda step: float(step) / float(max(1.0, W)) if step < W else 1.0
     if name == "piecewise_constant":
-        rules = (step_rules or "").split(",")
-        table = [(int(r.split(":")[1]), float(r.split(":")[0])) for r in rules[:-1]]
+        if not step_rules:
+            raise ValueError('piecewise_constant requires `step_rules`, e.g. "1:10,0.1:20,0.01" (multiplier:until-step, ..., last multiplier)')
+        rules = step_rules.split(",")
+        # (diffusers walks the rule dict in sorted step order)
+        table = sorted((int(r.split(":")[1]), float(r.split(":")[0])) for r in rules[:-1])
         last = float(rules[-1])
 
         def piecewise(step):
@@ -103,13 +106,17 @@ TRAIN_GEMM_RING = int(os.environ.get("APAD_TRAIN_GEMM_RING", "2"))
 class AdapterTrainer:
     def __init__(self, unet, lr=1e-4, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8, max_grad_norm=1.0,
                  gradient_accumulation_steps=1, loss_scale=None, lr_scheduler="constant", lr_warmup_steps=0, max_train_steps=None,
-                 lr_num_cycles=1, lr_power=1.0, scheduler_steps_per_update=1, dynamic_loss_scale=None, scale_growth_interval=2000):
+                 lr_num_cycles=1, lr_power=1.0, scheduler_steps_per_update=1, dynamic_loss_scale=None, scale_growth_interval=2000,
+                 lr_step_rules=None):
         """lr_scheduler / lr_warmup_steps / max_train_steps / lr_num_cycles: the reference's arguments (train_apadapter_v2.py:125-140); like
         it, warm-up, length and cycles are multiplied by gradient_accumulation_steps before they reach the schedule (:812-814), and the
         schedule advances ``scheduler_steps_per_update`` per optimizer step -- 1 here; accelerate's prepared scheduler advances once per
         PROCESS (pass the world size to reproduce a multi-GPU reference run's curve).  dynamic_loss_scale (default: on for f16 with the
         default scale): the GradScaler behind accelerate's fp16 mode -- halve on an overflowed step, double after
-        ``scale_growth_interval`` clean ones."""
+        ``scale_growth_interval`` clean ones.  lr_step_rules: the rule string of ``piecewise_constant``.
+        Like accelerate's prepared scheduler (which returns early while ``optimizer.step_was_skipped``), the schedule does not advance on an
+        optimizer step the device skipped for a non-finite gradient norm: the skip count is read back one step late (no host sync), so the
+        position is corrected on the following boundary."""
         self.unet = unet
         unet.requires_grad_(False)  # :604 (processors are submodules of the UNet: re-enabled below)
         self.params = adapter_parameters(unet)
@@ -144,7 +151,7 @@ class AdapterTrainer:
         self.base_lr, self.betas, self.weight_decay, self.eps = lr, betas, weight_decay, eps
         acc = gradient_accumulation_steps
         self._lr_mult = get_scheduler(lr_scheduler, lr_warmup_steps * acc, None if max_train_steps is None else max_train_steps * acc,
-                                      lr_num_cycles * acc, lr_power, lr_init=lr)
+                                      lr_num_cycles * acc, lr_power, step_rules=lr_step_rules, lr_init=lr)
         self._sched_step, self._sched_per_update = 0, int(scheduler_steps_per_update)
         self.dynamic_loss_scale = (dtype == torch.float16 and loss_scale is None) if dynamic_loss_scale is None else bool(dynamic_loss_scale)
         self.scale_growth_interval, self._good_steps, self._scale_epoch = int(scale_growth_interval), 0, 0
@@ -217,7 +224,8 @@ class AdapterTrainer:
         self._micro = micro0
         cap = {"graph": graph, "loss": loss, "epoch": self._scale_epoch}
 
-        def recapture():  # the loss scale changed (dynamic_loss_scale): it is a kernel argument of the captured launches
+        def recapture():  # the loss scale changed (dynamic_loss_scale): it is a kernel argument of the captured launches (a multi-second stall,
+            # paid on the first replay after the change wherever in the accumulation window that falls)
             g0, m0 = self.grad.clone(), self._micro
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
@@ -240,7 +248,7 @@ class AdapterTrainer:
             self._micro += int(micro_batches)
             return loss
 
-        replay.graph = graph
+        replay.graph = lambda: cap["graph"]  # (the CURRENT capture: a loss-scale change re-captures, and the old graph bakes the old scale in)
         return replay
 
     @property
@@ -262,6 +270,7 @@ class AdapterTrainer:
             skipped = (self._applied_expect - applied) - self._applied_seen
             if skipped > 0:
                 self._applied_seen += skipped
+                self._sched_step = max(0, self._sched_step - skipped * self._sched_per_update)  # (a skipped update does not step the schedule)
                 self._good_steps = 0
                 self._set_loss_scale(max(self.loss_scale * 0.5, 1.0))
             else:

@@ -22,7 +22,7 @@ sys.path.insert(0, HERE)
 sys.dont_write_bytecode = True
 sys.path.insert(0, "/root/reference")
 
-from cases import CASES, BLOCK_CASES, R4_BLOCK_CASES, R4_CASES, LN_EPS, make_inputs  # noqa: E402
+from cases import CASES, BLOCK_CASES, R4_BLOCK_CASES, R4_CASES, R5_BLOCK_CASES, R5_CASES, LN_EPS, make_inputs  # noqa: E402
 from APadapter.ap_adapter.attention_processor import AttnProcessor2_0, IPAttnProcessor2_0  # noqa: E402
 from safetensors.torch import save_file  # noqa: E402
 
@@ -87,19 +87,20 @@ def run_case(case, dtype):
     return out
 
 
-def main_r4():
-    """round 4's additions only (attn_r4.safetensors); attn_processors / attn_blocks stay byte-identical"""
+def main_r4(cases=None, fname="attn_r4.safetensors", flag="--r4"):
+    """one round's additions only (attn_r4 / attn_r5.safetensors); attn_processors / attn_blocks stay byte-identical"""
+    cases = R4_BLOCK_CASES + R4_CASES if cases is None else cases
     tensors = {}
-    for case in R4_BLOCK_CASES + R4_CASES:
+    for case in cases:
         tensors[case["name"] + ".fp32"] = run_case(case, torch.float32).contiguous()
         if case.get("bf16"):
             tensors[case["name"] + ".bf16"] = run_case(case, torch.bfloat16).contiguous()
         print(case["name"], tuple(tensors[case["name"] + ".fp32"].shape))
-    meta = {"generator": "tests/golden/make_golden.py --r4", "torch": torch.__version__,
+    meta = {"generator": "tests/golden/make_golden.py " + flag, "torch": torch.__version__,
             "reference": "fundwotsai2001/AP-adapter @ 2024-10-22, APadapter/ap_adapter/attention_processor.py",
-            "cases": json.dumps([c["name"] for c in R4_BLOCK_CASES + R4_CASES])}
-    save_file(tensors, os.path.join(HERE, "attn_r4.safetensors"), metadata=meta)
-    print("wrote attn_r4.safetensors", os.path.getsize(os.path.join(HERE, "attn_r4.safetensors")), "bytes")
+            "cases": json.dumps([c["name"] for c in cases])}
+    save_file(tensors, os.path.join(HERE, fname), metadata=meta)
+    print("wrote", fname, os.path.getsize(os.path.join(HERE, fname)), "bytes")
 
 
 def main():
@@ -129,6 +130,9 @@ def main():
 if __name__ == "__main__":
     if "--r4" in sys.argv:
         main_r4()
+        sys.exit(0)
+    if "--r5" in sys.argv:
+        main_r4(R5_BLOCK_CASES + R5_CASES, "attn_r5.safetensors", "--r5")
         sys.exit(0)
     main()
 

@@ -6,13 +6,18 @@ import pytest
 import torch
 from safetensors.torch import load_file
 
-from cases import BLOCK_CASES, CASES, LN_EPS, R4_BLOCK_CASES, R4_CASES, make_inputs
+from cases import BLOCK_CASES, CASES, LN_EPS, R4_BLOCK_CASES, R4_CASES, R5_BLOCK_CASES, R5_CASES, make_inputs
 from oracle.attention import attn_processor_2_0, ip_attn_processor_2_0
 
 GOLD = load_file(os.path.join(os.path.dirname(__file__), "golden", "attn_processors.safetensors"))
 GOLD_BLK = load_file(os.path.join(os.path.dirname(__file__), "golden", "attn_blocks.safetensors"))
 GOLD.update({k: v for k, v in load_file(os.path.join(os.path.dirname(__file__), "golden", "attn_r4.safetensors")).items() if not k.startswith("blk_")})
 GOLD_BLK.update({k: v for k, v in load_file(os.path.join(os.path.dirname(__file__), "golden", "attn_r4.safetensors")).items() if k.startswith("blk_")})
+_R5 = load_file(os.path.join(os.path.dirname(__file__), "golden", "attn_r5.safetensors"))  # round 5's additions (make_golden.py --r5)
+GOLD.update({k: v for k, v in _R5.items() if not k.startswith("blk_")})
+GOLD_BLK.update({k: v for k, v in _R5.items() if k.startswith("blk_")})
+R4_CASES = R4_CASES + R5_CASES
+R4_BLOCK_CASES = R4_BLOCK_CASES + R5_BLOCK_CASES
 
 
 def run_oracle(c, t, **over):

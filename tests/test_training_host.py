@@ -80,3 +80,8 @@ def test_lr_schedules_match_the_published_lambdas():
         T.get_scheduler("linear", W)
     with pytest.raises(ValueError):
         T.get_scheduler("exponential")
+    # rules given out of order are walked in sorted step order (diffusers sorts the rule dict); a missing rule string is a clear error
+    pw2 = T.get_scheduler("piecewise_constant", step_rules="0.1:20,1:10,0.01")
+    assert [pw2(0), pw2(9), pw2(10), pw2(19), pw2(20)] == [1.0, 1.0, 0.1, 0.1, 0.01]
+    with pytest.raises(ValueError, match="step_rules"):
+        T.get_scheduler("piecewise_constant")
