@@ -103,6 +103,10 @@ SYMBOLS = {
     "apad_sizeof_mlp_desc": (C.c_int, []),
     "apad_echo_mlp_desc": (C.c_int, [C.POINTER(MlpDesc), C.POINTER(C.c_double), C.c_int]),
     "apad_geglu_mlp": (C.c_int, [C.POINTER(MlpDesc), _vp]),
+    "apad_mlp_packed_bytes": (_i64, [_i32]),
+    "apad_mlp_packed_bias_floats": (_i64, [_i32]),
+    "apad_mlp_pack": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "apad_geglu_mlp_packed": (C.c_int, [C.POINTER(MlpDesc), _vp, _vp, _vp]),
     "apad_sizeof_xattn_desc": (C.c_int, []),
     "apad_echo_xattn_desc": (C.c_int, [C.POINTER(XattnDesc), C.POINTER(C.c_double), C.c_int]),
     "apad_fused_cross_attention": (C.c_int, [C.POINTER(XattnDesc), _vp]),
@@ -190,7 +194,7 @@ def lib():
                 fn = getattr(h, name)  # AttributeError if the ABI lost a symbol
                 fn.restype = res
                 fn.argtypes = args
-            if h.apad_abi_version() != 7:
+            if h.apad_abi_version() != 8:
                 raise RuntimeError("libapadapter_hip.so ABI version mismatch")
             if h.apad_sizeof_gemm_desc() != C.sizeof(GemmDesc) or h.apad_sizeof_attn_desc() != C.sizeof(AttnDesc) \
                     or h.apad_sizeof_rp_desc() != C.sizeof(RpDesc) \

@@ -567,6 +567,42 @@ def hs_out(o, wo_packed, bias, residual, rowstat=False, out=None):
 
 
 MLP_C = (256,)  # envelope of apad_geglu_mlp
+# the 64-token register-block form from packed weights (csrc/mlp3.hip): routed from MLP_PACKED_MIN_M rows -- 256-token workgroups, one per CU, so a
+# launch needs most of a chip's worth of them (the CFG-shared prefix's 32 000-row launches keep the 128-token kernel)
+MLP_PACKED = _os.environ.get("APAD_MLP_PACKED", "1") == "1"  # A/B switch (read once)
+MLP_PACKED_MIN_M = 48000
+
+
+def mlp_pack(w1, b1, w2):
+    """GEGLU.proj [8C, C] (+ bias [8C]) and net[2] [C, 4C] -> (the packed stream, the fp32 bias table) of apad_geglu_mlp_packed"""
+    _req(w1, "mlp_pack.w1")
+    _req(w2, "mlp_pack.w2", w1.dtype)
+    Cc = w2.shape[0]
+    if Cc not in MLP_C or tuple(w1.shape) != (8 * Cc, Cc) or tuple(w2.shape) != (Cc, 4 * Cc) or w1.dtype not in FUSED_DTYPES or not (w1.is_contiguous() and w2.is_contiguous()):
+        raise ValueError(f"mlp_pack: w1 {tuple(w1.shape)}, w2 {tuple(w2.shape)} {w1.dtype} outside the kernel envelope")
+    if b1 is not None and (b1.dtype != w1.dtype or not b1.is_contiguous()):
+        raise ValueError("mlp_pack.b1: must be contiguous and of the weights' dtype")
+    wp = torch.empty(L.lib().apad_mlp_packed_bytes(Cc) // w1.element_size(), dtype=w1.dtype, device=w1.device)
+    bp = torch.empty(L.lib().apad_mlp_packed_bias_floats(Cc), dtype=torch.float32, device=w1.device)
+    L.check(L.lib().apad_mlp_pack(w1.data_ptr(), _ptr(b1), w2.data_ptr(), wp.data_ptr(), bp.data_ptr(), Cc, _DT[w1.dtype], _stream()), "apad_mlp_pack")
+    return wp, bp
+
+
+def geglu_mlp_packed(x, w_packed, b1_packed, b2, ln=None, out=None):
+    """geglu_mlp from mlp_pack's weights: the same operator on the 64-token register-block kernel"""
+    _req(x, "geglu_mlp_packed.x", w_packed.dtype)
+    Cc = x.shape[-1]
+    if Cc not in MLP_C or x.dtype not in FUSED_DTYPES or not x.is_contiguous() or b1_packed.dtype != torch.float32:
+        raise ValueError(f"geglu_mlp_packed: x {tuple(x.shape)} {x.dtype} outside the kernel envelope")
+    if out is None:
+        out = torch.empty_like(x)
+    d = L.MlpDesc()
+    d.x, d.b2, d.out = x.data_ptr(), _ptr(b2), out.data_ptr()
+    if ln is not None:
+        d.ln_gamma, d.ln_beta, d.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), float(ln[2])
+    d.M, d.C, d.dtype = x.numel() // Cc, Cc, _DT[x.dtype]
+    L.check(L.lib().apad_geglu_mlp_packed(C.byref(d), w_packed.data_ptr(), b1_packed.data_ptr(), _stream()), "apad_geglu_mlp_packed")
+    return out
 
 
 def geglu_mlp(x, w1, b1, w2, b2, ln=None, out=None):

@@ -156,6 +156,15 @@ class FeedForward(nn.Module):
             self._hs_key = key
         return self._hs_w
 
+    def _packed_weights(self):
+        """the weight stream of apad_geglu_mlp_packed (ops.mlp_pack), re-packed when a parameter is re-assigned, moved, cast or updated"""
+        ps = (self.net[0].proj.weight, self.net[0].proj.bias, self.net[2].weight)
+        key = tuple((id(p), p.data_ptr(), p._version, p.dtype, p.device) for p in ps)
+        if getattr(self, "_mlp3_key", None) != key:
+            self._mlp3_w = ops.mlp_pack(ps[0].detach(), ps[1].detach(), ps[2].detach())
+            self._mlp3_key = key
+        return self._mlp3_w
+
     def forward(self, x, ln):
         """x un-normalised; ln = norm3.  C in ops.MLP_C: the whole feed-forward + residual in one launch (the 4C-wide
         activation never reaches HBM); otherwise LayerNorm + GEGLU projection in one launch, then the 4C->C GEMM +
@@ -172,6 +181,9 @@ class FeedForward(nn.Module):
                 return ops.hs_ff2(h, w2p, self.net[2].bias, x, rowstat=True)
             return ops.linear(h, self.net[2].weight, self.net[2].bias, residual=x, rowstat=True)
         if x.shape[-1] in ops.MLP_C and x.dtype in ops.FUSED_DTYPES and os.environ.get("APAD_FUSED_MLP", "1") != "0":
+            if ops.MLP_PACKED and x.numel() // x.shape[-1] >= ops.MLP_PACKED_MIN_M and x.is_contiguous():
+                wp, bp = self._packed_weights()
+                return ops.geglu_mlp_packed(x, wp, bp, self.net[2].bias, ln=ln)
             return ops.geglu_mlp(x, self.net[0].proj.weight, self.net[0].proj.bias, self.net[2].weight, self.net[2].bias, ln=ln)
         h = ops.fused_linear(x, self.net[0].proj.weight, self.net[0].proj.bias, ln=ln, act="geglu")
         return ops.linear(h, self.net[2].weight, self.net[2].bias, residual=x, rowstat=True)  # (the next block's norm1 folds into its q|k|v)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define APAD_ABI_VERSION 7
+#define APAD_ABI_VERSION 8
 
 /* element types of activations / weights */
 enum { APAD_BF16 = 0, APAD_F16 = 1, APAD_F32 = 2 };
@@ -327,6 +327,18 @@ int apad_self_attention_fused(const void* x, const void* w_packed, const float* 
  *   w_bias[((q * 20 + t) * 2 + j) * 32 + r] (fp32) = (W . beta + b)[j * 2560 + q * 640 + t * 32 + r]          x [B*N][640] -> out H [B*N][2560]      (ABI 7) */
 int apad_hs_geglu(const void* x, const void* w_packed, const float* w_bias, void* out, int32_t B, int32_t N, int32_t C, int32_t normalize, float ln_eps,
                   int32_t dtype, void* stream);
+/* The same feed-forward from PACKED weights (ABI 8; csrc/mlp3.hip): a wave owns 64 tokens and all C output columns, so every weight fragment read from LDS
+ * feeds two MFMAs; the weights travel L2 -> LDS by DMA in exactly the order the loop consumes them.  apad_mlp_pack builds that stream once per
+ * FeedForward (re-pack when a parameter changes):
+ *   w_packed: 66 stages of 24 KB; stage i = 16 fragments of GEGLU.proj rows (value units 16 i .. 16 i + 15, then their gate rows) x k-steps of 16, then
+ *             8 fragments of net[2] columns of units 16 (i - 2) .. in the order (j & 3) + 8 (j >> 2) + 4 half (the MFMA C layout of the first GEMM
+ *             read as the B operand of the second); one fragment = 64 lanes x 8 elements = 1 KB; stages past either end are zero
+ *   b1_packed: fp32 [66][2][16], b1 in the C-layout register order of the lane half
+ * d->w1 / d->b1 / d->w2 are ignored; d->b2, the LayerNorm and the residual (= x) as in apad_geglu_mlp.  C = 256 (else -3). */
+int64_t apad_mlp_packed_bytes(int32_t C);
+int64_t apad_mlp_packed_bias_floats(int32_t C);
+int apad_mlp_pack(const void* w1, const void* b1, const void* w2, void* w_packed, float* b1_packed, int32_t C, int32_t dtype, void* stream);
+int apad_geglu_mlp_packed(const apad_mlp_desc* d, const void* w_packed, const float* b1_packed, void* stream);
 /* w [256][ldw] (nn.Linear layout) -> packed [8 row slices][16 k-steps][64 lanes][8], 128 KB */
 int apad_xattn_pack_weight(const void* w, void* packed, int64_t ldw, int32_t dtype, void* stream);
 /* bytes of the packed form of one segment's K / V^T: B * 8 heads * ceil(L/32) * 4 KB */

@@ -652,6 +652,65 @@ def test_geglu_mlp(dev, dtype, M, C, ln):
     assert torch.equal(out2, out)
 
 
+@pytest.mark.parametrize("dtype", DTYPES16)
+@pytest.mark.parametrize("M", [1000, 37, 256, 257, 8000])
+@pytest.mark.parametrize("ln,bias", [(True, True), (False, True), (True, False)])
+def test_geglu_mlp_packed(dev, dtype, M, ln, bias):
+    """the same operator on the 64-token register-block kernel from packed weights (apad_mlp_pack + apad_geglu_mlp_packed): against fp32 torch on
+    the storage-rounded operands, and against the 128-token kernel -- the same k-order per 16-unit chunk, the same GELU arithmetic and rounding
+    points: at most an odd last bit apart (b1 enters as the first MFMA's C operand here, as a separate add there); ragged / partial workgroups"""
+    from ap_adapter_amd import ops
+    C = 256
+    x = q(R(M, C, seed=256), dtype)
+    w1, b1 = q(R(8 * C, C, seed=257, std=0.08), dtype), (q(R(8 * C, seed=258, std=0.5), dtype) if bias else None)
+    w2, b2 = q(R(C, 4 * C, seed=259, std=0.04), dtype), (q(R(C, seed=260, std=0.5), dtype) if bias else None)
+    g, be = q(1 + 0.1 * R(C, seed=261), dtype), q(0.1 * R(C, seed=262), dtype)
+    xin = q(F.layer_norm(x, (C,), g, be, 1e-5), dtype) if ln else x
+    a, gate = F.linear(xin, w1, b1).chunk(2, dim=-1)
+    ref = x + F.linear(a * F.gelu(gate), w2, b2)
+    lnp = (g.to(dev, dtype), be.to(dev, dtype), 1e-5) if ln else None
+    dv = lambda t: None if t is None else t.to(dev, dtype)
+    xd = dv(x)
+    wp, bp = ops.mlp_pack(dv(w1), dv(b1), dv(w2))
+    out = ops.geglu_mlp_packed(xd, wp, bp, dv(b2), ln=lnp)
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < TOL[dtype]
+    old = ops.geglu_mlp(xd, dv(w1), dv(b1), dv(w2), dv(b2), ln=lnp)
+    assert rel_err(out, old.float().cpu()) < (8e-3 if dtype == torch.bfloat16 else 1e-3)
+    assert float((out != old).float().mean()) < 0.05  # (most elements are bit-equal)
+    # in place (out aliases x) gives the same bits
+    assert torch.equal(ops.geglu_mlp_packed(xd, wp, bp, dv(b2), ln=lnp, out=xd), out)
+
+
+def test_geglu_mlp_packed_route_and_repack(dev, monkeypatch):
+    """FeedForward takes the packed kernel from ops.MLP_PACKED_MIN_M rows, packs once, and re-packs when a parameter is updated in place"""
+    from ap_adapter_amd import ops
+    from ap_adapter_amd.unet import FeedForward
+    from ap_adapter_amd.synthetic import init_synthetic_
+    dtype = torch.bfloat16
+    ff = FeedForward(256)
+    init_synthetic_(ff, 5, w_std=0.05, bias_std=0.05)
+    ff = ff.to(dev, dtype).requires_grad_(False)
+    ln = (torch.ones(256, device=dev, dtype=dtype), torch.zeros(256, device=dev, dtype=dtype), 1e-5)
+    x = torch.randn(600, 256, device=dev).to(dtype)
+    calls = []
+    real = ops.geglu_mlp_packed
+    monkeypatch.setattr(ops, "geglu_mlp_packed", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    a = ff(x, ln)
+    assert not calls  # below the row threshold: the 128-token kernel
+    monkeypatch.setattr(ops, "MLP_PACKED_MIN_M", 512)
+    b = ff(x, ln)
+    assert len(calls) == 1 and rel_err(b, a.float().cpu()) < 8e-3
+    wp0 = ff._mlp3_w[0]
+    assert ff(x, ln) is not None and ff._mlp3_w[0] is wp0  # packed once
+    with torch.no_grad():
+        ff.net[2].weight.mul_(0.5)
+    c = ff(x, ln)
+    assert ff._mlp3_w[0] is not wp0 and not torch.equal(b, c)
+    monkeypatch.setattr(ops, "MLP_PACKED", False)
+    assert rel_err(c, ff(x, ln).float().cpu()) < 8e-3
+
+
 def test_geglu_mlp_outside_envelope_is_an_error(dev):
     from ap_adapter_amd import ops
     x = torch.zeros(64, 640, device=dev, dtype=torch.bfloat16)

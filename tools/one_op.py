@@ -40,6 +40,12 @@ elif op == "mlp":
     x = R(M, C); g = R(C); be = R(C); w1 = R(8 * C, C, std=0.02); b1 = R(8 * C, std=0.02)
     w2 = R(C, 4 * C, std=0.02); b2 = R(C, std=0.02); out = torch.empty(M, C, device=dev, dtype=dt)
     fn = lambda: ops.geglu_mlp(x, w1, b1, w2, b2, ln=(g, be, 1e-5), out=out)
+elif op == "mlp3":
+    M, C = B2 * 1000, 256
+    x = R(M, C); g = R(C); be = R(C); w1 = R(8 * C, C, std=0.02); b1 = R(8 * C, std=0.02)
+    w2 = R(C, 4 * C, std=0.02); b2 = R(C, std=0.02); out = torch.empty(M, C, device=dev, dtype=dt)
+    wp, bp = ops.mlp_pack(w1, b1, w2)
+    fn = lambda: ops.geglu_mlp_packed(x, wp, bp, b2, ln=(g, be, 1e-5), out=out)
 elif op == "xattn":
     N, C, H, Lt, La = 1000, 256, 8, 8, int(os.environ.get("LA", "32"))
     x, g, be, wq, wo, bo = R(B2, N, C), R(C), R(C), R(C, C, std=0.02), R(C, C, std=0.02), R(C, std=0.02)
