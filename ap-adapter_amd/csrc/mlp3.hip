@@ -18,6 +18,15 @@
 #include <stdlib.h>
 #include "rp_shared.h"
 
+#ifndef M3_DMA_IMM
+#define M3_DMA_IMM 1  // 1: a wave's pieces of a stage share one LDS base / scalar offset, the piece picked by the instruction's immediate offset
+#endif
+#ifndef M3_DMA_BARE
+#define M3_DMA_BARE 1  // 1: the DMA instructions sit between the MFMAs of the gemm1 steps that carry no GEGLU arithmetic
+#endif
+#ifndef M3_NOZ
+#define M3_NOZ 0       // 1: erf argument scale folded into the constants (one multiply less per value; not bit-equal to gelu_erf_2 any more)
+#endif
 #ifndef M3_ABL
 #define M3_ABL 0  // timing ablations (results are wrong): 1 no GELU arithmetic, 2 no gemm1 MFMAs, 4 no gemm2 MFMAs, 8 no DMA in the loop, 16 no barrier
 #endif
@@ -68,15 +77,21 @@ struct M3Geglu {
     float g0, g1, t0, t1, q0, q1, e0, e1, p0, p1, r0, r1;
     __device__ __forceinline__ void ph1(float ga, float gb) {
         g0 = ga; g1 = gb;
+#if M3_NOZ
+        t0 = __builtin_amdgcn_rcpf(fmaf(fabsf(g0), 0.3275911f * 0.70710678118654752440f, 1.0f));
+        t1 = __builtin_amdgcn_rcpf(fmaf(fabsf(g1), 0.3275911f * 0.70710678118654752440f, 1.0f));
+        q0 = g0 * g0; q1 = g1 * g1;
+#else
         const float z0 = g0 * 0.70710678118654752440f, z1 = g1 * 0.70710678118654752440f;
         t0 = __builtin_amdgcn_rcpf(fmaf(fabsf(z0), 0.3275911f, 1.0f));
         t1 = __builtin_amdgcn_rcpf(fmaf(fabsf(z1), 0.3275911f, 1.0f));
         q0 = z0 * z0; q1 = z1 * z1;
+#endif
         asm volatile("" : "+v"(t0), "+v"(t1), "+v"(q0), "+v"(q1));  // (anchors: the phase is computed HERE, between the MFMAs around it)
     }
     __device__ __forceinline__ void ph2() {
-        e0 = __builtin_amdgcn_exp2f(q0 * -1.4426950408889634f);
-        e1 = __builtin_amdgcn_exp2f(q1 * -1.4426950408889634f);
+        e0 = __builtin_amdgcn_exp2f(q0 * (M3_NOZ ? -0.5f * 1.4426950408889634f : -1.4426950408889634f));
+        e1 = __builtin_amdgcn_exp2f(q1 * (M3_NOZ ? -0.5f * 1.4426950408889634f : -1.4426950408889634f));
         p0 = fmaf(fmaf(t0, 1.061405429f, -1.453152027f), t0, 1.421413741f);
         p1 = fmaf(fmaf(t1, 1.061405429f, -1.453152027f), t1, 1.421413741f);
         asm volatile("" : "+v"(e0), "+v"(e1), "+v"(p0), "+v"(p1));
@@ -89,9 +104,20 @@ struct M3Geglu {
         asm volatile("" : "+v"(r0), "+v"(r1));
     }
     template <typename V8, typename EL> __device__ __forceinline__ void ph4(float v0, float v1, V8& hn, int r) {
-        const float h0 = g0 * 0.5f, h1 = g1 * 0.5f;
-        hn[r] = (EL)(v0 * fmaf(fabsf(h0), r0, h0));
-        hn[r + 1] = (EL)(v1 * fmaf(fabsf(h1), r1, h1));
+        // (one value after the other: the SLP vectoriser pairs them into v_pk_* otherwise, each followed by a hazard s_nop)
+        float h0 = g0 * 0.5f;
+        asm volatile("" : "+v"(h0));
+        float h1 = g1 * 0.5f;
+        asm volatile("" : "+v"(h1));
+        float u0 = fmaf(fabsf(h0), r0, h0);
+        asm volatile("" : "+v"(u0));
+        float u1 = fmaf(fabsf(h1), r1, h1);
+        asm volatile("" : "+v"(u1));
+        u0 *= v0;
+        asm volatile("" : "+v"(u0));
+        u1 *= v1;
+        hn[r] = (EL)u0;
+        hn[r + 1] = (EL)u1;
     }
 };
 
@@ -134,8 +160,22 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(Mlp3P p) {
     const uint32_t dvoff = (uint32_t)(lane * 16);
     auto dma = [&](int stage, int slot, int q) __attribute__((always_inline)) {
         if (M3_ABL & 8) return;
+#if M3_DMA_IMM
+        // the instruction's immediate offset moves the memory address AND the LDS address: pieces 0..3 of the wave share one M0 / scalar offset,
+        // pieces 4, 5 the next (the packed stream and the ring slot have the same piece order)
+        const int grp = q >> 2;
+        const m3_lds_ptr lp = (m3_lds_ptr)(smem + slot * M3_STAGE + wave * 6144 + grp * 4096);
+        const int so = stage * M3_STAGE + wave * 6144 + grp * 4096;
+        switch (q & 3) {
+            case 0: __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, lp, 16, dvoff, so, 0, 0); break;
+            case 1: __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, lp, 16, dvoff, so, 1024, 0); break;
+            case 2: __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, lp, 16, dvoff, so, 2048, 0); break;
+            default: __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, lp, 16, dvoff, so, 3072, 0); break;
+        }
+#else
         const int piece = wave * 6 + q;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (m3_lds_ptr)(smem + slot * M3_STAGE + piece * 1024), 16, dvoff, stage * M3_STAGE + piece * 1024, 0, 0);
+#endif
     };
 
     // ---- x panels -> registers (requested first: HBM latency), biases -> LDS (fp32; ahead of the first DMA: an LDS store the compiler can see is
@@ -196,7 +236,7 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(Mlp3P p) {
         // one step of gemm2 (chunk i - 2): output-column tiles ct, ct + 1 x two panels, the GEGLU of hidden units r, r + 1 of panel 0 between the MFMAs
         auto step2 = [&](const u32x4 (&f)[2], int ct, int r, int q) __attribute__((always_inline)) {
             const V8 w0 = __builtin_bit_cast(V8, f[0]), w1 = __builtin_bit_cast(V8, f[1]);
-            dma(nstage, nslot, q);
+            if (!M3_DMA_BARE) dma(nstage, nslot, q);
             if (!(M3_ABL & 4)) y0[ct] = E::mfma32(w0, hp0, y0[ct]);
             M3_PIN();
             if (!(M3_ABL & 1)) gg.ph1(acur0[8 + r], acur0[9 + r]);
@@ -215,11 +255,12 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(Mlp3P p) {
             M3_PIN();
         };
         // one step of gemm1 (chunk i): k-steps ks, ks + 1 x two panels; r >= 0: the GEGLU of hidden units r, r + 1 of panel 1 between the MFMAs
-        auto step1 = [&](const u32x4 (&f)[2], int ks, int r, int q) __attribute__((always_inline)) {
+        auto step1 = [&](const u32x4 (&f)[2], int ks, int r, int q, int q2) __attribute__((always_inline)) {
             const V8 w0 = __builtin_bit_cast(V8, f[0]), w1 = __builtin_bit_cast(V8, f[1]);
-            if (q >= 0) dma(nstage, nslot, q);
+            if (!M3_DMA_BARE && q >= 0) dma(nstage, nslot, q);
             if (!(M3_ABL & 2)) M3Asm<DT>::acc(anxt0, w0, xf0[ks]);
             M3_PIN();
+            if (M3_DMA_BARE && q >= 0) dma(nstage, nslot, q);
             if (r >= 0 && !(M3_ABL & 1)) gg.ph1(acur1[8 + r], acur1[9 + r]);
             M3_PIN();
             if (!(M3_ABL & 2)) M3Asm<DT>::acc(anxt1, w0, xf1[ks]);
@@ -228,6 +269,7 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(Mlp3P p) {
             M3_PIN();
             if (!(M3_ABL & 2)) M3Asm<DT>::acc(anxt0, w1, xf0[ks + 1]);
             M3_PIN();
+            if (M3_DMA_BARE && q2 >= 0) dma(nstage, nslot, q2);
             if (r >= 0 && !(M3_ABL & 1)) gg.ph3();
             M3_PIN();
             if (!(M3_ABL & 2)) M3Asm<DT>::acc(anxt1, w1, xf1[ks + 1]);
@@ -263,7 +305,7 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(Mlp3P p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) bias[qd * 4 + e] = __uint_as_float(bq[qd][e]);
             const V8 w0 = __builtin_bit_cast(V8, fA[0]), w1 = __builtin_bit_cast(V8, fA[1]);
-            dma(nstage, nslot, 4);
+            if (!M3_DMA_BARE) dma(nstage, nslot, 4);
             if (!(M3_ABL & 2)) {
                 M3Asm<DT>::first(anxt0, w0, xf0[0], bias);
                 M3Asm<DT>::first(anxt1, w0, xf1[0], bias);
@@ -289,24 +331,24 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(Mlp3P p) {
         }
         m3_read2<4>(fA, fa);
         m3_wait_lgkm<2>();
-        step1(fB, 2, -1, 5);
+        step1(fB, 2, -1, M3_DMA_BARE ? 0 : 5, M3_DMA_BARE ? 1 : -1);
         m3_read2<6>(fB, fa);
         m3_wait_lgkm<2>();
-        step1(fA, 4, 2, -1);
+        step1(fA, 4, 2, -1, -1);
         m3_read2<8>(fA, fa);
         m3_wait_lgkm<2>();
-        step1(fB, 6, -1, -1);
+        step1(fB, 6, -1, M3_DMA_BARE ? 2 : -1, M3_DMA_BARE ? 3 : -1);
         m3_read2<10>(fB, fa);
         m3_wait_lgkm<2>();
-        step1(fA, 8, 4, -1);
+        step1(fA, 8, 4, -1, -1);
         m3_read2<12>(fA, fa);
         m3_wait_lgkm<2>();
-        step1(fB, 10, -1, -1);
+        step1(fB, 10, -1, M3_DMA_BARE ? 4 : -1, M3_DMA_BARE ? 5 : -1);
         m3_read2<14>(fB, fa);
         m3_wait_lgkm<2>();
-        step1(fA, 12, 6, -1);
+        step1(fA, 12, 6, -1, -1);
         m3_wait_lgkm<0>();
-        step1(fB, 14, -1, -1);
+        step1(fB, 14, -1, -1, -1);
     };
 
     int slot = 0;
