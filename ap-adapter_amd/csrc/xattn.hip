@@ -33,7 +33,8 @@ constexpr int XTM = 128;                  // tokens per workgroup
 constexpr int TROWB = XC * 2 + 16;        // tile row stride (bytes): 33 sixteen-byte slots (odd -> conflict-free fragment reads)
 constexpr int TILE_BYTES = XTM * TROWB;   // 67 584
 constexpr int XA_LDS = 2 * TILE_BYTES + XC * 4;
-constexpr int XMAXSUB = 4;                // <= 128 keys per segment (segment 1: <= 64)
+constexpr int XMAXSUB = 4;                // <= 128 keys per segment with resident fragments (segment 1: <= 64)
+constexpr int XMAXSUB2 = 16;              // <= 512 keys in segment 2 on the chunked form (64-key chunks, running max / sum)
 #ifndef XA_SPLIT_Q
 #define XA_SPLIT_Q 0
 #endif
@@ -224,6 +225,55 @@ __device__ __forceinline__ void xa_segment(const XaFrags<DT, NS>& f, int L, cons
     }
 }
 
+// One 64-key chunk of a LONG second segment (more than 128 audio tokens: pooling 1 / the mixed poolings of the cfg-3 sweep, AudioMAE.py:148-182):
+// scores of the chunk, running maximum m (raw score domain) and per-lane partial sums l0 / l1 of the query's row, the accumulator rescaled when the
+// maximum moves, O2^T += V^T . P^T with the UN-normalised probabilities rounded to the storage type (the flash form apad_attention uses for such
+// lengths); the caller divides by the sum and applies ap_scale at the end.
+template <int DT>
+__device__ __forceinline__ void xa_chunk64(const typename ET<DT>::v8 (&kf)[2][2], const typename ET<DT>::v8 (&vf)[4], float c,
+                                           const typename ET<DT>::v8 (&qb)[2], f32x16& o2, float& m, float& l0, float& l1) {
+    using E = ET<DT>;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 s[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        s[u] = E::mfma32(kf[u][0], qb[0], zero16);
+        s[u] = E::mfma32(kf[u][1], qb[1], s[u]);
+    }
+    float tmax = s[0][0];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[u][r]);
+    const float mnew = fmaxf(m, half_max(tmax));
+    const float alpha = __builtin_amdgcn_exp2f((m - mnew) * c);  // c > 0; the first chunk: exp2(-huge) = 0 against a zero accumulator
+    const float nm = -mnew * c;
+    float sum0 = 0.f, sum1 = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const float v0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r], c, nm));
+            const float v1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r + 1], c, nm));
+            s[u][r] = v0;
+            s[u][r + 1] = v1;
+            sum0 += v0;
+            sum1 += v1;
+        }
+    l0 = __builtin_fmaf(l0, alpha, sum0);
+    l1 = __builtin_fmaf(l1, alpha, sum1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o2[r] *= alpha;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        typename E::v8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (typename E::elem)s[st >> 1][(st & 1) * 8 + j];
+        o2 = E::mfma32(vf[st], pf, o2);
+    }
+    m = mnew;
+}
+
 #ifdef XATTN_TRACE  // probe build (tools/xattn_trace.py): s_memtime stamps of wave 0 / wave 7 at the phase boundaries
 __device__ unsigned long long g_xa_trace[1024 * 32];
 #define XA_STAMP(i) \
@@ -234,7 +284,9 @@ __device__ unsigned long long g_xa_trace[1024 * 32];
 
 // NS1 / NS2 = 32-key sub-tiles per segment (NS2 = 0: single segment).  G1 > 0 selects the exact form: L1 = 8 G1 and L2 = 8 G2
 // keys precisely, BIAS1 = segment 1 carries a key bias; G1 = 0: lengths and bias are run-time (any L <= 32 NS).
-template <int DT, int NS1, int NS2, int G1 = 0, int G2 = 0, bool BIAS1 = false>
+// CHUNK: segment 2 is LONG (L2 = 64 * n <= 512 keys): its fragments are fetched 64 keys at a time (NS2 = 2 is the chunk's shape) and folded in with a
+// running max / sum (xa_chunk64); segment 1 is the exact 8-key text segment.
+template <int DT, int NS1, int NS2, int G1 = 0, int G2 = 0, bool BIAS1 = false, bool CHUNK = false>
 __global__ __launch_bounds__(512) void xattn_kernel(XaP p) {
     constexpr bool DUAL = NS2 > 0;
     constexpr bool EXACT = G1 > 0;
@@ -242,7 +294,7 @@ __global__ __launch_bounds__(512) void xattn_kernel(XaP p) {
     // fragments + four score tiles do not fit beside the stationary Wq rows, so the q-projection of all four panels runs first (q parked
     // in LDS, Wq registers dead afterwards), the fragments are fetched behind it, and panels are attended one at a time
     constexpr bool BIG2 = NS2 > 2;
-    constexpr bool SPLIT = XA_SPLIT || BIG2;
+    constexpr bool SPLIT = XA_SPLIT || BIG2 || CHUNK;
     using E = ET<DT>;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* const xt = smem;                 // x^ tile, later the output tile
@@ -385,7 +437,7 @@ __global__ __launch_bounds__(512) void xattn_kernel(XaP p) {
             if (DUAL) xa_fetch<DT, DUAL ? NS2 : 1>(f2, p.kv2 + ((int64_t)b * XH + h) * xa_kv_block(p.L2), p.L2, lane);
         };
         const int bfirst = (tile * 4) / p.ppn;
-        if constexpr (EXACT && !BIG2) fetch_kv(bfirst < p.B ? bfirst : p.B - 1);  // (general form: after the q-projection -- registers)
+        if constexpr (EXACT && !BIG2 && !CHUNK) fetch_kv(bfirst < p.B ? bfirst : p.B - 1);  // (general form: after the q-projection -- registers)
         if constexpr (SPLIT) {
             f32x16 qa[4];
             const uint8_t* bt = xt + l31 * TROWB + half * 16;
@@ -416,7 +468,7 @@ __global__ __launch_bounds__(512) void xattn_kernel(XaP p) {
                 *reinterpret_cast<uint4*>(qd + 16) = as_u4<DT>(qb[1]);
             }
         }
-        if constexpr (!EXACT || BIG2) fetch_kv(bfirst < p.B ? bfirst : p.B - 1);
+        if constexpr ((!EXACT || BIG2) && !CHUNK) fetch_kv(bfirst < p.B ? bfirst : p.B - 1);
         XA_STAMP(3);
         // attention of `n` panels (pp, pp + 1) of ONE sample, interleaved: the panels share the K / V fragments
         auto attend = [&](int pp, auto n_tag, int b) {
@@ -482,8 +534,78 @@ __global__ __launch_bounds__(512) void xattn_kernel(XaP p) {
                 }
             }
         };
+        // CHUNK form: the panels pp .. pp + CNT - 1 of ONE sample; chunks outer (each chunk's 8 KB of fragments fetched once for all of them), panels inner
+        auto chunk_group = [&](int pp, auto cnt_tag, int b) {
+            constexpr int CNT = decltype(cnt_tag)::value;
+            xa_fetch<DT, NS1>(f1, p.kv1 + ((int64_t)b * XH + h) * xa_kv_block(p.L1), p.L1, lane);
+            const int nsub2 = p.L2 >> 5;
+            const xa_gptr kb = sgpr_ptr(p.kv2 + ((int64_t)b * XH + h) * xa_kv_block(p.L2));
+            const xa_gptr vb = kb + nsub2 * 2048;
+            f32x16 o2[CNT];
+            float mx[CNT], l0[CNT], l1[CNT];
+#pragma unroll
+            for (int u = 0; u < CNT; ++u) {
+                o2[u] = zero16;
+                mx[u] = XA_NEG_BIG;
+                l0[u] = l1[u] = 0.f;
+            }
+            auto load_q = [&](int u, typename E::v8 (&qb)[2]) {
+                const uint8_t* qd = ot + ((pp + u) * 32 + l31) * TROWB + h * 64 + half * 32;
+                qb[0] = as_v8<DT>(*reinterpret_cast<const uint4*>(qd));
+                qb[1] = as_v8<DT>(*reinterpret_cast<const uint4*>(qd + 16));
+            };
+#pragma unroll 1
+            for (int c = 0; c < (nsub2 >> 1); ++c) {
+                typename E::v8 kf[2][2], vf[4];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+                        kf[u][kk] = __builtin_bit_cast(typename E::v8, xa_ld16(kb + (c * 4 + u * 2 + kk) * 1024, (uint32_t)(lane * 16)));
+#pragma unroll
+                for (int st = 0; st < 4; ++st) vf[st] = __builtin_bit_cast(typename E::v8, xa_ld16(vb + (c * 4 + st) * 1024, (uint32_t)(lane * 16)));
+#pragma unroll
+                for (int u = 0; u < CNT; ++u) {
+                    typename E::v8 qb[2];
+                    load_q(u, qb);
+                    xa_chunk64<DT>(kf, vf, p.scale_log2, qb, o2[u], mx[u], l0[u], l1[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < CNT; ++u) {
+                typename E::v8 qb[2];
+                load_q(u, qb);
+                const float w2 = p.scale2 * __builtin_amdgcn_rcpf(half_sum(l0[u] + l1[u]));  // ap_scale / row sum (attention_processor.py:454)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o2[u][r] *= w2;
+                // the text segment on top (its probabilities normalised before they are rounded, as in the resident-fragment forms)
+                xa_segment_exact<DT, (G1 > 0 ? G1 : 1), false>(f1, nullptr, p.scale_log2, 1.0f, qb, o2[u], false, half);
+                uint8_t* od = ot + ((pp + u) * 32 + l31) * TROWB + (h * XD + 4 * half) * 2;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    typename E::v4 y;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) y[j] = (typename E::elem)o2[u][4 * g + j];
+                    *reinterpret_cast<uint2*>(od + g * 16) = __builtin_bit_cast(uint2, y);
+                }
+            }
+        };
         using One = std::integral_constant<int, 1>;
         using Two = std::integral_constant<int, (EXACT && !BIG2) ? 2 : 1>;  // (the general form's / a big segment's fragment sets leave no room for two chains)
+        if constexpr (CHUNK) {
+            const int blast = (tile * 4 + 3) / p.ppn;
+            if (blast == bfirst) {  // wave-uniform; every tile when the sample's panel count is a multiple of 4 (1000 tokens: 32 panels)
+                chunk_group(0, std::integral_constant<int, 4>{}, bfirst < p.B ? bfirst : p.B - 1);
+            } else {
+#pragma unroll 1
+                for (int pp = 0; pp < 4; ++pp) {
+                    const int bp = (tile * 4 + pp) / p.ppn;
+                    chunk_group(pp, One{}, bp < p.B ? bp : p.B - 1);
+                }
+            }
+            XA_STAMP(4);
+            XA_STAMP(5);
+        } else {
         int bnext = bfirst, rem = tile * 4 - bfirst * p.ppn;  // sample / panel-in-sample walk over the tile's panels
         int bcur = bfirst < p.B ? bfirst : p.B - 1;           // sample whose fragments are loaded
 #pragma unroll 1
@@ -510,6 +632,7 @@ __global__ __launch_bounds__(512) void xattn_kernel(XaP p) {
                 }
             }
             XA_STAMP(4 + (pp >> 1));
+        }
         }
     }
     // ---- weights of this wave for phase 3: rows (output channels) wave*32.. of Wo ----
@@ -655,8 +778,8 @@ template <int DT> __global__ void xa_pack_kv_kernel(const uint8_t* k, const uint
     }
 }
 
-template <int DT, int NS1, int NS2, int G1 = 0, int G2 = 0, bool BIAS1 = false> int xa_launch(const XaP& p, hipStream_t s) {
-    auto kern = xattn_kernel<DT, NS1, NS2, G1, G2, BIAS1>;
+template <int DT, int NS1, int NS2, int G1 = 0, int G2 = 0, bool BIAS1 = false, bool CHUNK = false> int xa_launch(const XaP& p, hipStream_t s) {
+    auto kern = xattn_kernel<DT, NS1, NS2, G1, G2, BIAS1, CHUNK>;
     static unsigned devs = 0;
     if (apad_ensure_dyn_lds(reinterpret_cast<const void*>(kern), XA_LDS, &devs) != 0) return -1;
     // persistent: one workgroup per CU (a multiple of 8 so that virtual id % 8 stays the XCD), fewer when there are fewer tiles
@@ -697,8 +820,8 @@ extern "C" int apad_xattn_pack_kv(const void* k, const void* vt, void* packed, i
                                   int64_t k_stride_l, int64_t vt_stride_b, int32_t dtype, void* stream) {
     APAD_CHECK(k && vt && packed && al16(packed), "apad_xattn_pack_kv: bad operand");
     APAD_CHECK(dtype == APAD_BF16 || dtype == APAD_F16, "apad_xattn_pack_kv: dtype %d not supported", dtype);
-    APAD_CHECK(B > 0 && L > 0 && L <= 32 * XMAXSUB && Lpad >= L && Lpad % 16 == 0 && Lpad >= ((L + 15) / 16) * 16,
-               "apad_xattn_pack_kv: need 0 < L <= %d and Lpad >= L (B=%d L=%d Lpad=%d)", 32 * XMAXSUB, B, L, Lpad);
+    APAD_CHECK(B > 0 && L > 0 && L <= 32 * XMAXSUB2 && Lpad >= L && Lpad % 16 == 0 && Lpad >= ((L + 15) / 16) * 16,
+               "apad_xattn_pack_kv: need 0 < L <= %d and Lpad >= L (B=%d L=%d Lpad=%d)", 32 * XMAXSUB2, B, L, Lpad);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == APAD_BF16)
         hipLaunchKernelGGL((xa_pack_kv_kernel<APAD_BF16>), dim3((unsigned)(B * XH)), dim3(256), 0, s, (const uint8_t*)k, (const uint8_t*)vt,
@@ -712,9 +835,10 @@ extern "C" int apad_xattn_pack_kv(const void* k, const void* vt, void* packed, i
 extern "C" int apad_fused_cross_attention(const apad_xattn_desc* d, void* stream) {
     APAD_CHECK(d != nullptr, "apad_fused_cross_attention: null descriptor");
     APAD_CHECK(d->dtype == APAD_BF16 || d->dtype == APAD_F16, "apad_fused_cross_attention: dtype %d not supported", d->dtype);
-    if (d->C != XC || d->heads != XH || d->L1 > 64 || d->L2 > 32 * XMAXSUB) {
-        apad_set_error("apad_fused_cross_attention: C=%d heads=%d L1=%d L2=%d outside the kernel envelope (C 256, 8 heads, <= 64 + %d keys)",
-                       d->C, d->heads, d->L1, d->L2, 32 * XMAXSUB);
+    const bool long2 = d->L2 > 32 * XMAXSUB;  // the chunked form: 8 text keys + 64 n <= 512 audio keys, no key bias
+    if (d->C != XC || d->heads != XH || d->L1 > 64 || d->L2 > 32 * XMAXSUB2 || (long2 && (d->L1 != 8 || d->L2 % 64 != 0 || d->key_bias != nullptr))) {
+        apad_set_error("apad_fused_cross_attention: C=%d heads=%d L1=%d L2=%d outside the kernel envelope (C 256, 8 heads, <= 64 + %d keys, or 8 + 64 n <= %d "
+                       "unmasked)", d->C, d->heads, d->L1, d->L2, 32 * XMAXSUB, 32 * XMAXSUB2);
         return -3;
     }
     APAD_CHECK(d->x && d->wq_packed && d->wo_packed && d->kv1_packed && d->out, "apad_fused_cross_attention: null operand");
@@ -736,6 +860,7 @@ extern "C" int apad_fused_cross_attention(const apad_xattn_desc* d, void* stream
     p.eps = d->ln_eps; p.scale_log2 = d->softmax_scale * XA_LOG2E; p.scale2 = d->scale2;
     hipStream_t s = (hipStream_t)stream;
     const int ns1 = (d->L1 + 31) / 32, ns2 = (d->L2 + 31) / 32;
+    if (long2) return d->dtype == APAD_BF16 ? xa_launch<APAD_BF16, 1, 2, 1, 8, false, true>(p, s) : xa_launch<APAD_F16, 1, 2, 1, 8, false, true>(p, s);
     // exact forms: the adapter's presets (8 text tokens + 8 / 32 / 64 audio tokens, no mask) and the masked 16-token T5 stream
 #define XA_EXACT(g1, g2, hasb)                                                                                          \
     if (d->L1 == 8 * g1 && d->L2 == 8 * g2 && (d->key_bias != nullptr) == hasb)                                        \

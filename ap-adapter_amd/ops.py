@@ -228,11 +228,12 @@ def fused_linear(x, w, bias=None, ln=None, residual=None, act=None, out=None, ro
 
 XATTN_C, XATTN_HEADS, XATTN_MAXL = 256, 8, 64  # envelope of apad_fused_cross_attention
 XATTN_MAXL2 = 128  # ... plus the adapter's 8 text + 128 audio keys (pooling 2: the timbre / accompaniment presets), unmasked
+XATTN_LONG2 = 512  # ... plus 8 text + 64 n <= 512 audio keys on the chunked form (pooling 1 and the mixed poolings of the sweep), unmasked
 
 
 def xattn_lengths_ok(L1, L2=0, masked=False):
-    """key counts apad_fused_cross_attention has a kernel for: <= 64 per segment, or exactly 8 + 128 without a key bias"""
-    return L1 <= XATTN_MAXL and (L2 <= XATTN_MAXL or (L2 == XATTN_MAXL2 and L1 == 8 and not masked))
+    """key counts apad_fused_cross_attention has a kernel for: <= 64 per segment, or exactly 8 + 128, or 8 + 64 n <= 512 (both without a key bias)"""
+    return L1 <= XATTN_MAXL and (L2 <= XATTN_MAXL or (L1 == 8 and not masked and (L2 == XATTN_MAXL2 or (XATTN_MAXL2 < L2 <= XATTN_LONG2 and L2 % 64 == 0))))
 
 
 def xattn_pack_weight(w):
@@ -250,7 +251,7 @@ def xattn_pack_kv(k, vt, Lk):
     _req(k, "xattn_pack_kv.k")
     _req(vt, "xattn_pack_kv.vt", k.dtype)
     B = k.shape[0]
-    if k.shape[-1] != XATTN_C or Lk > XATTN_MAXL2 or tuple(vt.shape[:3]) != (B, XATTN_HEADS, XATTN_C // XATTN_HEADS) or not vt.is_contiguous():
+    if k.shape[-1] != XATTN_C or Lk > XATTN_LONG2 or tuple(vt.shape[:3]) != (B, XATTN_HEADS, XATTN_C // XATTN_HEADS) or not vt.is_contiguous():
         raise ValueError(f"xattn_pack_kv: k {tuple(k.shape)}, vt {tuple(vt.shape)}, Lk={Lk} outside the kernel envelope")
     nbytes = L.lib().apad_xattn_packed_kv_bytes(B, Lk)
     out = torch.empty(nbytes // k.element_size(), dtype=k.dtype, device=k.device)

@@ -423,7 +423,7 @@ def fused_attn2_grid(dev, dtype, B2, ap_scale):
         proc.kv_cache_enabled = True
         x = torch.randn(B2, N, C_, device=dev).to(dtype)
         ln = (torch.ones(C_, device=dev, dtype=dtype), torch.zeros(C_, device=dev, dtype=dtype), 1e-5)
-        for La in (8, 32, 128, 512):
+        for La in (8, 32, 128, 256, 512):
             ehs = torch.randn(B2, 8 + La, 768, device=dev).to(dtype)
             calls, hs = [], []
             real, real_rows, real_hs = ops.fused_cross_attention, ops.cross_attention_rows, ops.hs_attention

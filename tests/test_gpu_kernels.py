@@ -805,11 +805,13 @@ def _xattn_ref(x, g, be, wq, wo, bo, ehs_t, wk, wv, heads, bias=None, ehs_a=None
 @pytest.mark.parametrize("dtype", DTYPES16)
 @pytest.mark.parametrize("B,N,Lt,La,masked", [(2, 1000, 8, 32, False), (3, 100, 8, 8, False), (2, 250, 16, 0, True), (1, 33, 8, 64, False),
                                                (5, 64, 40, 0, False), (2, 130, 8, 33, False), (9, 1000, 8, 32, False), (2, 31, 40, 50, True),
-                                               (2, 1000, 8, 128, False), (3, 77, 8, 128, False), (9, 250, 8, 128, False)])
+                                               (2, 1000, 8, 128, False), (3, 77, 8, 128, False), (9, 250, 8, 128, False),
+                                               (2, 1000, 8, 512, False), (3, 300, 8, 256, False), (2, 77, 8, 192, False), (9, 250, 8, 512, False)])
 def test_fused_cross_attention(dev, dtype, B, N, Lt, La, masked):
     """LayerNorm + to_q + (decoupled) attention + to_out + residual in one launch, incl. panels that end inside a sample,
-    a tail workgroup with idle waves, the masked T5 form, a 2-sub-tile segment and the 8 + 128-key form of the timbre /
-    accompaniment presets (q of all four panels projected first, one panel attended at a time)"""
+    a tail workgroup with idle waves, the masked T5 form, a 2-sub-tile segment, the 8 + 128-key form of the timbre /
+    accompaniment presets (q of all four panels projected first, one panel attended at a time) and the chunked form of longer audio segments
+    (192 / 256 / 512 keys: 64-key chunks with a running max / sum; tiles inside one sample and tiles that cross a sample boundary)"""
     from ap_adapter_amd import ops
     C, H = 256, 8
     x = q(R(B, N, C, seed=201), dtype)
@@ -933,7 +935,8 @@ def test_fused_cross_attention_outside_envelope(dev):
     with pytest.raises(ValueError):
         ops.fused_cross_attention(x, w, w, None, w, 8, 8)
     assert ops.xattn_lengths_ok(8, 128) and ops.xattn_lengths_ok(64, 64, True) and ops.xattn_lengths_ok(16, 0, True)
-    assert not ops.xattn_lengths_ok(8, 128, True) and not ops.xattn_lengths_ok(8, 96) and not ops.xattn_lengths_ok(16, 128) and not ops.xattn_lengths_ok(8, 512)
+    assert not ops.xattn_lengths_ok(8, 128, True) and not ops.xattn_lengths_ok(8, 96) and not ops.xattn_lengths_ok(16, 128) and not ops.xattn_lengths_ok(8, 576)
+    assert ops.xattn_lengths_ok(8, 512) and ops.xattn_lengths_ok(8, 256) and not ops.xattn_lengths_ok(8, 512, True) and not ops.xattn_lengths_ok(8, 200)
 
 
 # ---- LayerNorm + q|k|v + self-attention in one launch (the two large levels) ----
