@@ -230,16 +230,18 @@ __device__ __forceinline__ void xa_segment(const XaFrags<DT, NS>& f, int L, cons
 // maximum moves, O2^T += V^T . P^T with the UN-normalised probabilities rounded to the storage type (the flash form apad_attention uses for such
 // lengths); the caller divides by the sum and applies ap_scale at the end.
 template <int DT>
-__device__ __forceinline__ void xa_chunk64(const typename ET<DT>::v8 (&kf)[2][2], const typename ET<DT>::v8 (&vf)[4], float c,
-                                           const typename ET<DT>::v8 (&qb)[2], f32x16& o2, float& m, float& l0, float& l1) {
+__device__ __forceinline__ void xa_chunk64_scores(f32x16 (&s)[2], const typename ET<DT>::v8 (&kf)[2][2], const typename ET<DT>::v8 (&qb)[2]) {
     using E = ET<DT>;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    f32x16 s[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         s[u] = E::mfma32(kf[u][0], qb[0], zero16);
         s[u] = E::mfma32(kf[u][1], qb[1], s[u]);
     }
+}
+template <int DT>
+__device__ __forceinline__ void xa_chunk64_fold(f32x16 (&s)[2], const typename ET<DT>::v8 (&vf)[4], float c, f32x16& o2, float& m, float& l0, float& l1) {
+    using E = ET<DT>;
     float tmax = s[0][0];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -260,6 +262,8 @@ __device__ __forceinline__ void xa_chunk64(const typename ET<DT>::v8 (&kf)[2][2]
             sum0 += v0;
             sum1 += v1;
         }
+    // (a wave-uniform "rescale only when some maximum jumped" branch was measured: 93 -> 109 us at 512 keys -- the branch costs the straight-line
+    //  schedule more than the 18 multiplies it skips)
     l0 = __builtin_fmaf(l0, alpha, sum0);
     l1 = __builtin_fmaf(l1, alpha, sum1);
 #pragma unroll
@@ -554,21 +558,36 @@ __global__ __launch_bounds__(512) void xattn_kernel(XaP p) {
                 qb[0] = as_v8<DT>(*reinterpret_cast<const uint4*>(qd));
                 qb[1] = as_v8<DT>(*reinterpret_cast<const uint4*>(qd + 16));
             };
-#pragma unroll 1
-            for (int c = 0; c < (nsub2 >> 1); ++c) {
-                typename E::v8 kf[2][2], vf[4];
+            // ONE fragment set, refilled in place: the next chunk's K fragments are requested as soon as the last panel's score MFMAs have read the
+            // current ones (their latency under that panel's softmax + P.V), its V^T fragments behind the last P.V (under the next chunk's first scores)
+            typename E::v8 kf[2][2], vf[4];
+            const int nch = nsub2 >> 1;
+            auto load_k = [&](int c) {
+                c = c < nch ? c : nch - 1;  // (past the end: a harmless re-load keeps the loads unconditional)
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
                     for (int kk = 0; kk < 2; ++kk)
                         kf[u][kk] = __builtin_bit_cast(typename E::v8, xa_ld16(kb + (c * 4 + u * 2 + kk) * 1024, (uint32_t)(lane * 16)));
+            };
+            auto load_v = [&](int c) {
+                c = c < nch ? c : nch - 1;
 #pragma unroll
                 for (int st = 0; st < 4; ++st) vf[st] = __builtin_bit_cast(typename E::v8, xa_ld16(vb + (c * 4 + st) * 1024, (uint32_t)(lane * 16)));
+            };
+            load_k(0);
+            load_v(0);
+#pragma unroll 1
+            for (int c = 0; c < nch; ++c) {
 #pragma unroll
                 for (int u = 0; u < CNT; ++u) {
                     typename E::v8 qb[2];
                     load_q(u, qb);
-                    xa_chunk64<DT>(kf, vf, p.scale_log2, qb, o2[u], mx[u], l0[u], l1[u]);
+                    f32x16 sc[2];
+                    xa_chunk64_scores<DT>(sc, kf, qb);
+                    if (u == CNT - 1) load_k(c + 1);
+                    xa_chunk64_fold<DT>(sc, vf, p.scale_log2, o2[u], mx[u], l0[u], l1[u]);
+                    if (u == CNT - 1) load_v(c + 1);
                 }
             }
 #pragma unroll
