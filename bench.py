@@ -74,6 +74,72 @@ def unet_flops_per_sample(La, t5_len=16):
     return fl
 
 
+def unet_min_bytes_per_step(B2, La, t5_len=16):
+    """Algorithmic HBM bytes of one UNet step under the CURRENT launch structure: the sum over launches of their minimal operand bytes -- every
+    launch reads each activation operand once and writes its result once (2 bytes per element, B' sample-forwards), weights once per launch;
+    intermediates that stay inside a fused launch (q / k / v, the 4C-wide feed-forward activation at C = 256, scores) do not count.  The
+    denominator of hbm_whole_step: measured bytes / this = re-reads, partial-line writes and passes a further fusion would remove."""
+    hw = [250 * 16, 125 * 8, 63 * 4, 32 * 2]
+    act = [0.0]
+    wgt = [0.0]
+
+    def op(n, cin, cout, k=1, res=False, extra_out=0.0):
+        act[0] += n * cin + n * cout * (2 if res else 1) + extra_out
+        wgt[0] += cin * cout * k
+
+    def norm(n, c):
+        act[0] += 2.0 * n * c
+
+    def resnet(n, cin, cout):
+        norm(n, cin); op(n, cin, cout, 9); norm(n, cout)
+        if cin != cout:
+            op(n, cin, cout, 1)
+        op(n, cout, cout, 9, res=True)
+
+    def tblock(n, c, kind):
+        def self_attn():
+            op(n, c, c, 3)            # LayerNorm + q|k|v + attention in one launch (x in, O out)
+            op(n, c, c, 1, res=True)  # to_out + residual
+        self_attn()
+        if kind == "self":
+            self_attn()
+        else:                         # one-launch cross-attention sub-layer (x in, out; to_q + to_out weights; hoisted K / V)
+            keys = (8 + La) if kind == "ip" else t5_len
+            op(n, c, c, 2)
+            act[0] += 2.0 * keys * c
+            if c == 640:              # the 64-token level: attention part + to_out part
+                act[0] += 2.0 * n * c
+        if c == 256:
+            op(n, c, c, 12)           # the whole feed-forward in one launch
+        else:
+            op(n, c, 4 * c, 2)        # LN + GEGLU projection -> 4C-wide activation
+            op(n, 4 * c, c, 1, res=True)
+
+    def layer(n, c):
+        for kind in ("self", "ip", "t5", "self"):
+            norm(n, c); op(n, c, c); tblock(n, c, kind); tblock(n, c, kind); op(n, c, c, res=True)
+
+    op(hw[0], 8, 128, 9)
+    resnet(hw[0], 128, 128); resnet(hw[0], 128, 128); op(hw[1], 128, 128, 9)
+    resnet(hw[1], 128, 256); layer(hw[1], 256); resnet(hw[1], 256, 256); layer(hw[1], 256); op(hw[2], 256, 256, 9)
+    resnet(hw[2], 256, 384); layer(hw[2], 384); resnet(hw[2], 384, 384); layer(hw[2], 384); op(hw[3], 384, 384, 9)
+    resnet(hw[3], 384, 640); layer(hw[3], 640); resnet(hw[3], 640, 640); layer(hw[3], 640)
+    resnet(hw[3], 640, 640); layer(hw[3], 640); resnet(hw[3], 640, 640)
+    for cin in (1280, 1280, 1024):
+        resnet(hw[3], cin, 640); layer(hw[3], 640)
+    op(hw[2], 640, 640, 9)
+    for cin in (1024, 768, 640):
+        resnet(hw[2], cin, 384); layer(hw[2], 384)
+    op(hw[1], 384, 384, 9)
+    for cin in (640, 512, 384):
+        resnet(hw[1], cin, 256); layer(hw[1], 256)
+    op(hw[0], 256, 256, 9)
+    for cin in (384, 256, 256):
+        resnet(hw[0], cin, 128)
+    norm(hw[0], 128); op(hw[0], 128, 8, 9)
+    return 2.0 * (act[0] * B2 + wgt[0])
+
+
 def cfg_shared_prefix_flops():
     """FLOPs of the part of a sample-forward that reads no condition (conv_in, the first down block, the first resnet + the
     double-self-attention transformer + proj_in / attn1 of the first conditioned one at the 1000-pixel level): identical rows in both
@@ -230,7 +296,7 @@ def profile_top_line():
                 if not line.startswith("#") and line.strip():
                     t = line.split(None, 5)
                     return {"kernel": t[5].strip()[:100], "pct_of_kernel_time": float(t[0]), "launches_per_step": round(int(t[1]) / steps, 1) if steps else None,
-                            "avg_us": float(t[2]), "source": os.path.relpath(path, ROOT)}
+                            "avg_us": float(t[2]), "live": False, "source": os.path.relpath(path, ROOT)}
     return None
 
 
@@ -249,11 +315,11 @@ def level64_from_profile(B2, n_streams):
         if us:
             b = B2 // max(n_streams, 1)
             out[sub.split("<")[0]] = {"what": what, "in_step_avg_us": us, "samples_per_launch": b, "tflops": round(fl(b) / (us * 1e-6) / 1e12, 1),
-                                      "mfma_frac": round(fl(b) / (us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4), "source": src}
+                                      "mfma_frac": round(fl(b) / (us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4), "live": False, "source": src}
     return out
 
 
-def whole_step_hbm(ms_per_step):
+def whole_step_hbm(ms_per_step, B2=64, La=32):
     """HBM bytes of one captured step from the committed PMC passes (tools/round_pmc_traffic.sh) -> fraction of the 8 TB/s peak at this step time"""
     import glob
     for tp in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
@@ -262,29 +328,36 @@ def whole_step_hbm(ms_per_step):
         ws = d.get("whole_step")
         if ws:
             gbs = ws["bytes_per_step"] / (ms_per_step * 1e-3) / 1e9
+            alg = unet_min_bytes_per_step(B2, La)
             return {"bytes_per_step": int(ws["bytes_per_step"]), "read_bytes": int(ws["read_bytes_per_step"]), "write_bytes": int(ws["write_bytes_per_step"]),
-                    "achieved_GBs": round(gbs, 1), "hbm_frac_whole_step": round(gbs / HBM_PEAK_GBS, 4), "source": os.path.relpath(tp, ROOT)}
+                    "achieved_GBs": round(gbs, 1), "hbm_frac_whole_step": round(gbs / HBM_PEAK_GBS, 4),
+                    "algorithmic_bytes": int(alg), "measured_over_algorithmic": round(ws["bytes_per_step"] / alg, 3),
+                    "algorithmic_bytes_is": "sum over the step's launches of their minimal operand bytes (bench.py::unet_min_bytes_per_step; the CFG-shared "
+                                            "prefix counted at the full batch)",
+                    "live": False, "source": os.path.relpath(tp, ROOT)}
     return None
 
 
-def fp32_mode_step_ms(A, unet, inp, args, dev, steps=2):
-    """the SAME step in the fp32 precision mode (exact-f32 MFMA, the mode whose noise_pred meets the 1e-3 bar: DESIGN 5), eager, `steps` timed
-    steps after one warm-up.  Converts the model in place: called after every 16-bit measurement."""
+def precision_leg(A, unet, inp, args, dev, dtype, steps, graph):
+    """the SAME batch-32 step with the model converted (in place) to ``dtype``: ms per step (hipGraph replay when ``graph``, else eager) and the
+    guided noise_pred of the FIRST step (fp32 copy) -- the north-star tensor, compared across modes by the caller.  The weights are the
+    bf16-rounded synthetic weights in every mode (bf16 -> f16 / f32 is exact for them), so the differences are arithmetic precision only."""
     from ap_adapter_amd import ops
-    unet = unet.float()
+    unet = unet.to(dtype)
     unet.set_kv_cache(False)
     unet.set_kv_cache(True)
     pipe = A.AudioLDM2Pipeline(unet)
     B = args.batch
-    ge = pipe.assemble_condition(inp["generated_prompt_embeds"].to(dev), inp["audio_tokens"].to(dev), inp["uncond_audio_tokens"].to(dev), torch.float32)
-    pe, am = inp["prompt_embeds"].to(dev, torch.float32), inp["attention_mask"].to(dev)
+    ge = pipe.assemble_condition(inp["generated_prompt_embeds"].to(dev), inp["audio_tokens"].to(dev), inp["uncond_audio_tokens"].to(dev), dtype)
+    pe, am = inp["prompt_embeds"].to(dev, dtype), inp["attention_mask"].to(dev)
     H, W, Cc = 250, 16, 8
     sched = pipe.scheduler
     sched.set_timesteps(DDIM_STEPS_PER_CLIP)
     coef = sched.coef_table().to(dev)
     step_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
     lat = inp["latents"].to(dev).float().permute(0, 2, 3, 1).reshape(B, H * W, Cc).contiguous()
-    unet_in = lat.clone()
+    lat0 = lat.clone()
+    unet_in = lat.to(dtype)
     unet.precompute_time_tables(sched.timesteps.to(dev), step_ptr)
 
     def step():
@@ -293,16 +366,32 @@ def fp32_mode_step_ms(A, unet, inp, args, dev, steps=2):
         ops.step_advance(step_ptr)
 
     with torch.no_grad():
-        step()
+        e2 = unet.forward_nhwc(unet_in, H, W, None, ge, pe, None, am, batch_repeat=2).float()
+        noise_pred = e2[:B] + args.guidance * (e2[B:] - e2[:B])  # pipeline_audioldm2.py:1021-1022
+        if graph:
+            s_ = torch.cuda.Stream()
+            s_.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s_):
+                step()
+            torch.cuda.current_stream().wait_stream(s_)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                step()
+            run1 = g.replay
+        else:
+            step()
+            run1 = step
+        lat.copy_(lat0); unet_in.copy_(lat0.to(dtype)); step_ptr.zero_()
+        run1()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            step()
+            run1()
         torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
-    return {"ms_per_step": round(ms, 1), "clips_per_s": round(B / (DDIM_STEPS_PER_CLIP * ms * 1e-3), 4), "steps": steps,
-            "what": "the same batch-32 step with fp32 storage and exact-f32 MFMA (v_mfma_f32_32x32x2_f32, 1/16 of the bf16 rate), eager launches: "
-                    "the mode in which noise_pred is within 1e-3 of the oracle chain (measured 1e-5)", "finite": bool(torch.isfinite(lat).all().item())}
+    return {"ms_per_step": round(ms, 2 if graph else 1), "clips_per_s": round(B / (DDIM_STEPS_PER_CLIP * ms * 1e-3), 4), "steps": steps,
+            "launch": "hipGraph replay" if graph else "eager", "finite": bool(torch.isfinite(lat).all().item())}, noise_pred
 
 
 def dominant_kernel_roofline(dev, dtype, B2, in_step=None, in_step_how=None):
@@ -351,6 +440,7 @@ def dominant_kernel_roofline(dev, dtype, B2, in_step=None, in_step_how=None):
             "frac": round(ach_src / MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(ms_src, 4), "avg_launch_is": how, "launches_timed": n_l,
             "frac_isolated": round(ach / MFMA_PEAK_TFLOPS, 4), "isolated_avg_launch_ms": round(ms, 4),
             "rocprof_in_step_avg_us": prof_us, "rocprof_source": psrc,
+            "live": {"avg_launch_ms": True, "frac": True, "isolated_avg_launch_ms": True, "rocprof_in_step_avg_us": False, "traffic": False},
             "flops_per_launch": flops, "flops_attention_core": flops_core, "flops_projections": flops_proj, "algorithmic_bytes": nbytes, "traffic": traffic,
             "traffic_source": (tsrc + " (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes over the step)") if traffic else None}
 
@@ -755,14 +845,16 @@ def main():
         if not args.no_in_step:
             with torch.no_grad():
                 ins, how = in_step_launch_times(step, ops, {
-                    "self_attn_1000": ("self_attention_fused", lambda x, *a, **kw: x.shape[1] == 1000),
+                    # (only the launches at the full CFG batch: the shared prefix's transformer runs its self-attention at half the batch, and the FLOPs per
+                    #  launch below are those of 2B sample-forwards)
+                    "self_attn_1000": ("self_attention_fused", lambda x, *a, **kw: x.shape[1] == 1000 and x.shape[0] == 2 * B),
                     "fused_attn2_ip": ("fused_cross_attention", lambda x, *a, **kw: kw.get("L2", 0) > 0),
                     "fused_attn2_t5": ("fused_cross_attention", lambda x, *a, **kw: not kw.get("L2", 0))})
         line["roofline"] = dominant_kernel_roofline(dev, dtype, 2 * B, ins.get("self_attn_1000"), how)
         line["roofline_top_line"] = profile_top_line()
         nst = len(unet.low_res_streams) if getattr(unet, "low_res_streams", None) else 1
         line["level64_kernels"] = level64_from_profile(2 * B, nst)
-        line["hbm_whole_step"] = whole_step_hbm(ms_per_step)
+        line["hbm_whole_step"] = whole_step_hbm(ms_per_step, 2 * B, args.la)
         line["fused_attn2"] = fused_attn2_roofline(dev, dtype, 2 * B, args.la, args.ap_scale, ins.get("fused_attn2_ip"), how)
         line["fused_attn2"]["t5_sites_in_step"] = ins.get("fused_attn2_t5")
         try:
@@ -788,8 +880,25 @@ def main():
             except Exception as e:  # noqa: BLE001
                 line["train"] = {"error": repr(e)}
         if not args.no_fp32_leg and world == 1:
+            # the other two precision modes of the SAME step, beside the headline (all live): f16 -- what the reference ships (inference.py:13,
+            # torch_dtype=float16) --, graph-replayed like the bf16 line, and fp32 (exact-f32 MFMA, eager).  noise_pred (the guided epsilon of
+            # the first step, batch 32) of the 16-bit modes is compared with the fp32 mode's, which tests/test_gpu_unet.py holds within 1e-3
+            # (measured 1e-5) of the oracle chain at the same geometry
             try:
-                line["fp32_mode"] = fp32_mode_step_ms(A, unet, inp, args, dev)
+                with torch.no_grad():
+                    step_ptr.zero_()  # (the time tables are indexed by the device step counter: the first step, like the other modes below)
+                    e2 = unet.forward_nhwc(lat0.to(dtype), H, W, None, ge, pe, None, am, batch_repeat=2).float()
+                    np_bf16 = e2[:B] + args.guidance * (e2[B:] - e2[:B])
+                f16, np_f16 = precision_leg(A, unet, inp, args, dev, torch.float16, steps=10, graph=True)
+                f32, np_f32 = precision_leg(A, unet, inp, args, dev, torch.float32, steps=2, graph=False)
+                mx = float(np_f32.abs().max())
+                f16["noise_pred_max_abs_vs_fp32_mode"] = round(float((np_f16 - np_f32).abs().max()), 6)
+                f16["what"] = "the same batch-32 step in f16 storage (the reference's inference dtype, inference.py:13), hipGraph replay"
+                f32["what"] = ("the same batch-32 step with fp32 storage and exact-f32 MFMA (v_mfma_f32_32x32x2_f32, 1/16 of the bf16 rate), eager launches: "
+                               "the mode in which noise_pred is within 1e-3 of the oracle chain (measured 1e-5)")
+                line["f16_mode"], line["fp32_mode"] = f16, f32
+                line["noise_pred_vs_fp32_mode"] = {"bf16_max_abs": round(float((np_bf16 - np_f32).abs().max()), 6), "f16_max_abs": f16["noise_pred_max_abs_vs_fp32_mode"],
+                                                   "max_abs_noise_pred": round(mx, 4), "tensor": f"guided noise_pred of the first DDIM step, batch {B}, CFG {args.guidance}"}
             except Exception as e:  # noqa: BLE001
                 line["fp32_mode"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:  # the host baseline is reported at N = 1 only
