@@ -107,7 +107,7 @@ def linear(x, w, b=None, residual=None):
     return _Linear.apply(x, w, b, residual)
 
 
-_BWD_PACKED = _os.environ.get("APAD_TRAIN_BWD_PACKED", "1") == "1"  # A/B switch (read once)
+_BWD_PACKED = True
 
 
 def _packed_grads(dq, dk, dv):
@@ -164,7 +164,7 @@ class _QKVT(_QKV):
         return _QKV.backward(ctx, dq, dk, dv) + (None,)
 
 
-_QKV_FUSED = _os.environ.get("APAD_TRAIN_QKV_FUSED", "1") == "1"  # A/B switch (read once)
+_QKV_FUSED = True
 
 
 def qkv(x, wq, wk, wv, heads=None):
@@ -217,7 +217,7 @@ class _LayerNormRes(torch.autograd.Function):
         return ops.layer_norm_bwd(x, g, _c(dy), ctx.eps, dres=None if dres is None else _c(dres)), None, None, None
 
 
-_LN_RES = _os.environ.get("APAD_TRAIN_LN_RES", "1") == "1"  # A/B switch (read once)
+_LN_RES = True
 
 
 def layer_norm_res(x, g, b, eps):

@@ -1238,7 +1238,7 @@ __global__ __launch_bounds__(256) void attn_short_kernel(AttnP p) {
 }
 
 template <int DT, int D> int launch_d(const AttnP& p, bool dual, dim3 grid, hipStream_t s) {
-    static const bool no_short = getenv("APAD_ATTN_NO_SHORT") != nullptr;
+    constexpr bool no_short = false;
     if (!no_short && p.L <= 64 && (!dual || p.L2 <= 64) && p.lse == nullptr) {
         dim3 g2((unsigned)((p.N + 127) / 128), (unsigned)(p.B * p.H));
         if (dual)
@@ -1249,13 +1249,13 @@ template <int DT, int D> int launch_d(const AttnP& p, bool dual, dim3 grid, hipS
     }
     if constexpr (D == 32 || D == 48 || D == 64) {
         // long single-segment launches without a key bias (the UNet's self-attention): two query tiles per wave
-        static const int two_q = [] { const char* e = getenv("APAD_ATTN_2Q"); return e ? atoi(e) : 1; }();
+        constexpr int two_q = 1;
         // (A/B knob; round 3: 512 -> 200, i.e. the 252-token level's d = 48 self-attention too: step 44.87 -> 44.74 ms; in round 2,
         //  before the batched fragment reads, it measured slower there; the gain is 0.1 ms)
-        static const int two_q_min = [] { const char* e = getenv("APAD_ATTN_2Q_MIN_N"); return e ? atoi(e) : 200; }();
+        constexpr int two_q_min = 200;
         if (two_q && !dual && p.key_bias == nullptr && p.N >= two_q_min && p.L >= (two_q_min < 256 ? two_q_min : 256) && (D == 32 || D == 48 || two_q > 1)) {
             if constexpr (D == 32) {
-                static const int nw8 = [] { const char* e = getenv("APAD_ATTN_NW8"); return e ? atoi(e) : 0; }();  // off: step 49.68 -> 50.12 ms (the 8-wave barrier costs more than the halved staging saves)
+                constexpr int nw8 = 0;  // off: step 49.68 -> 50.12 ms (the 8-wave barrier costs more than the halved staging saves)
                 if (nw8) {
                     dim3 g8((unsigned)(((p.N + 511) / 512) * 8 * ((p.B + 7) / 8) * p.H));
                     hipLaunchKernelGGL((attn2q_kernel<DT, D, 8>), g8, dim3(512), 0, s, p);
@@ -1267,7 +1267,7 @@ template <int DT, int D> int launch_d(const AttnP& p, bool dual, dim3 grid, hipS
                 // pre-scaled q: the softmax without per-score max / scale instructions (APAD_ATTN_DIRECT=0: A/B switch).  d = 48 (the
                 // 252-token level) keeps the classic two-tile form: its direct form needs 256 VGPRs and measured slower in-step
                 // (44.82 vs 44.69 ms)
-                static const int direct = [] { const char* e = getenv("APAD_ATTN_DIRECT"); return e ? atoi(e) : 1; }();
+                constexpr int direct = 1;
                 if (direct && p.prescaled) {
                     hipLaunchKernelGGL((attn2q_kernel<DT, D, 4, true>), g2, dim3(256), 0, s, p);
                     return apad_check_launch("apad_attention");

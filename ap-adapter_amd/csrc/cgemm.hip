@@ -596,12 +596,12 @@ template <int DT, int MODE, int BN> int cg_launch(const CgP& p, hipStream_t s) {
 // 0 after a launch, < 0 on a launch error.
 int apad_cgemm_try(const apad_gemm_desc* d, hipStream_t s) {
     static const int mode = [] { const char* e = getenv("APAD_CGEMM"); return e ? atoi(e) : 1; }();  // A/B knob: 0 = off
-    static const long min_rows = [] { const char* e = getenv("APAD_CGEMM_MIN_M"); return e ? atol(e) : 16000L; }();  // (step-level A/B: 32768 -> 16000 = -1.0 ms, 4000 / 2000: no further gain)
+    constexpr long min_rows = 16000L;  // (step-level A/B: 32768 -> 16000 = -1.0 ms, 4000 / 2000: no further gain)
     if (!mode) return 1;
     if (d->dtype != APAD_BF16 && d->dtype != APAD_F16) return 1;
     if (d->epilogue != APAD_EPI_NONE || d->out_mode != APAD_OUT_ROWMAJOR || d->rowstat_out || d->rowstat_in) return 1;
-    static const int bn_mode = [] { const char* e = getenv("APAD_CGEMM_BN"); return e ? atoi(e) : 0; }();  // A/B knob: 128 = never the square tile
-    static const int small_mode = [] { const char* e = getenv("APAD_CGEMM_SMALL"); return e ? atoi(e) : 1; }();  // A/B knob: 0 = off
+    constexpr int bn_mode = 0;  // A/B knob: 128 = never the square tile
+    constexpr int small_mode = 1;  // A/B knob: 0 = off
     // below the row threshold: the small-tile form for 3x3 convolutions with long reductions (the 64-token level)
     const bool small = d->M < min_rows && small_mode && d->a_mode == APAD_A_CONV3X3 && d->K >= 2304 && d->N % SBN == 0;
     if ((d->N % 128 != 0 && !small) || d->K % CBK != 0 || (d->M < min_rows && !small) || d->M >= (1LL << 30)) return 1;
@@ -611,7 +611,7 @@ int apad_cgemm_try(const apad_gemm_desc* d, hipStream_t s) {
     bool general = false;
     int64_t a_bytes;
     if (conv) {
-        static const int gen_mode = [] { const char* e = getenv("APAD_CGEMM_GENCONV"); return e ? atoi(e) : 1; }();  // A/B knob: 0 = stride-1 only
+        constexpr int gen_mode = 1;  // A/B knob: 0 = stride-1 only
         general = d->stride != 1 || d->Hup != 0;
         if ((d->stride != 1 && d->stride != 2) || d->src_batch_mod != 0 || d->conv_asym_pad || d->Cin % CBK != 0 || (general && !gen_mode)) return 1;
         if (!general && (d->Hout != d->Hin || d->Wout != d->Win)) return 1;

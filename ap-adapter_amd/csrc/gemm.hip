@@ -866,16 +866,16 @@ int launch(const GemmP& p, hipStream_t s) {
     const int64_t blocks128 = ((p.N + BN_OUT - 1) / BN_OUT) * ((p.M + 127) / 128);
     // long reductions amortise the under-fill: with K >= 1024 the 128-tile wins from ~1.25 workgroups per CU (measured:
     // conv 63x4 384->384 76.5 -> 71.5 us, FF2 M=16128 K=1536 38.5 -> 37.1 us), short-K launches prefer the 64-tile
-    static const int t128_min = [] { const char* e = getenv("APAD_GEMM_T128_MIN"); return e ? atoi(e) : 512; }();  // (A/B knob)
+    constexpr int t128_min = 512;  // (A/B knob)
     const bool t128 = blocks128 >= t128_min || (blocks128 >= 320 && t128_min <= 512 && p.K >= 1024);
     if constexpr (AMODE == APAD_A_CONV3X3_FAST && EPI == APAD_EPI_NONE && OUTMODE == APAD_OUT_ROWMAJOR) {
         // under-filled 3x3 convolutions (the 640- / 384-wide resnets: 90..180 k-tiles on a few hundred 64x64 tiles): K groups
-        static const int conv_kg = [] { const char* e = getenv("APAD_CONV_KG"); return e ? atoi(e) : 0; }();  // (A/B knob)
+        constexpr int conv_kg = 0;  // (A/B knob)
         if (!t128 && conv_kg >= 4) return launch_tm<DT, AMODE, EPI, OUTMODE, 64, 1, 4>(p, s);
         if (!t128 && conv_kg >= 2) return launch_tm<DT, AMODE, EPI, OUTMODE, 64, 1, 2>(p, s);
     }
     if constexpr (AMODE == APAD_A_CONV3X3_FAST || AMODE == APAD_A_CONV3X3 || AMODE == APAD_A_CONV1D) {
-        static const bool one_stage = getenv("APAD_GEMM_ONE_STAGE") != nullptr;
+        constexpr bool one_stage = false;
         // long reductions on launches of <= ~4 workgroups per CU: two LDS stages, one barrier per k-tile (larger grids
         // lose more from the halved residency than they gain: 250x16 128->128 118.9 -> 132.6 us)
         if (p.K >= 2048 && blocks128 <= 1024 && !one_stage)
@@ -886,14 +886,14 @@ int launch(const GemmP& p, hipStream_t s) {
         // latency-bound launches: the LDS-DMA ring form (apad_set_gemm_ring / APAD_GEMM_RING: 0 off, 1 = grids the 128-tile rule calls
         // under-filled, 2 = every launch; below APAD_GEMM_RING_MAX_M = 16000 rows).  Bit-equal to the tiled kernels (same k-summation order, K groups included).
         static const int ring_env = [] { const char* e = getenv("APAD_GEMM_RING"); return e ? atoi(e) : 0; }();
-        static const int kg_mode_r = [] { const char* e = getenv("APAD_GEMM_KG"); return e ? atoi(e) : 2; }();
-        static const int ring_max_m = [] { const char* e = getenv("APAD_GEMM_RING_MAX_M"); return e ? atoi(e) : 16000; }();
+        constexpr int kg_mode_r = 2;
+        constexpr int ring_max_m = 16000;
         const int ring_mode = g_ring_mode >= 0 ? g_ring_mode : ring_env;
-        static const int ring_max_wg = [] { const char* e = getenv("APAD_GEMM_RING_MAX_WG"); return e ? atoi(e) : (1 << 30); }();
-        static const int ring_min_wg = [] { const char* e = getenv("APAD_GEMM_RING_MIN_WG"); return e ? atoi(e) : 0; }();
+        constexpr int ring_max_wg = (1 << 30);
+        constexpr int ring_min_wg = 0;
         const int64_t ring_wgs = ((p.M + 63) / 64) * (p.N / (EPI == APAD_EPI_GEGLU ? 32 : 64));
         if (ring_mode && p.K >= 128 && p.M < ring_max_m && (!t128 || ring_mode >= 2) && ring_wgs <= ring_max_wg && ring_wgs >= ring_min_wg) {
-            static const int ring_kg = [] { const char* e = getenv("APAD_GEMM_RING_KG"); return e ? atoi(e) : 1; }();
+            constexpr int ring_kg = 1;
             const bool kgroups = EPI == APAD_EPI_NONE && kg_mode_r >= 2 && p.K >= 384 && p.N >= 640;
             if (!kgroups || ring_kg) {
                 const int rc = launch_ring<DT, EPI, OUTMODE>(p, kgroups, s);
@@ -905,7 +905,7 @@ int launch(const GemmP& p, hipStream_t s) {
         // K groups inside the workgroup for the skinny launches of the 640- / 384-wide levels.  The choice depends on (N, K) ONLY,
         // never on M, and both tile sizes implement it: a row's k-summation order must not change with the batch size -- a clip's
         // result is bit-identical whatever batch it rides in (tests/test_gpu_unet.py::test_full_size_clips_are_independent_of_their_batch)
-        static const int kg_mode = [] { const char* e = getenv("APAD_GEMM_KG"); return e ? atoi(e) : 2; }();  // (A/B knob: 1 = off)
+        constexpr int kg_mode = 2;  // (A/B knob: 1 = off)
         // (N >= 640: the 640-wide level's to_q / to_out / FF2 / q|k|v.  At N = 384 the FF2 of the 384-wide level, M = 16128 on 128-tiles,
         //  measured 39 -> 58 us with K groups: the rule stops short of it)
         if (kg_mode >= 2 && p.K >= 384 && p.N >= 640)
@@ -945,7 +945,7 @@ template <int DT> int dispatch_amode(const GemmP& p, const apad_gemm_desc* d, hi
         case APAD_A_CONV3X3:
             APAD_CHECK(d->epilogue == APAD_EPI_NONE && d->out_mode == APAD_OUT_ROWMAJOR,
                        "apad_gemm: conv3x3 supports epilogue NONE / row-major output only");
-            if (d->Cin % 64 == 0 && d->Hup == 0 && getenv("APAD_CONV_SLOW") == nullptr)
+            if (d->Cin % 64 == 0 && d->Hup == 0)
                 return launch<DT, APAD_A_CONV3X3_FAST, APAD_EPI_NONE, APAD_OUT_ROWMAJOR>(p, s);
             return launch<DT, APAD_A_CONV3X3, APAD_EPI_NONE, APAD_OUT_ROWMAJOR>(p, s);
         case APAD_A_PATCH16:

@@ -891,11 +891,6 @@ template <int DT> int hs_ff2_launch(const HfP& p, hipStream_t s) {
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-inline int hs_env_xm(const char* name, int dflt) {
-    const char* e = getenv(name);
-    const int v = e ? atoi(e) : dflt;
-    return (v == 2 || v == 4 || v == 8) ? v : dflt;
-}
 
 }  // namespace
 
@@ -938,7 +933,7 @@ extern "C" int apad_hs_attention(const apad_hs_attn_desc* d, void* stream) {
     p.out = (uint8_t*)d->out;
     p.B = d->B; p.N = d->N; p.L1 = d->L1; p.Lpad1 = d->Lpad1; p.L2 = d->L2; p.Lpad2 = d->Lpad2;
     p.eps = d->ln_eps; p.scale_log2 = d->q_prescaled ? 1.0f : d->softmax_scale * LOG2E; p.scale2 = d->scale2;
-    static const int xm_self = hs_env_xm("APAD_HS_XM_SELF", 8), xm_cross = hs_env_xm("APAD_HS_XM_CROSS", 8);  // (A/B knobs, read once)
+    static const int xm_self = 8, xm_cross = 8;  // (A/B knobs, read once)
     p.xm = self ? xm_self : xm_cross;
     hipStream_t s = (hipStream_t)stream;
     return d->dtype == APAD_BF16 ? hs_attn_launch<APAD_BF16>(p, self, s) : hs_attn_launch<APAD_F16>(p, self, s);
@@ -956,7 +951,7 @@ extern "C" int apad_hs_geglu(const void* x, const void* w_packed, const float* w
     HgP p;
     p.x = (const uint8_t*)x; p.w = (const uint8_t*)w_packed; p.wbias = w_bias; p.out = (uint8_t*)out;
     p.B = B; p.N = N; p.normalize = normalize ? 1 : 0; p.eps = ln_eps;
-    static const int xm = hs_env_xm("APAD_HS_XM_GEGLU", 2);
+    static const int xm = 2;
     p.xm = xm;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == APAD_BF16) return p.normalize ? hs_geglu_go<APAD_BF16, true>(p, s) : hs_geglu_go<APAD_BF16, false>(p, s);
@@ -976,7 +971,7 @@ extern "C" int apad_hs_ff2(const apad_hs_out_desc* d, void* stream) {
     HfP p;
     p.h = (const uint8_t*)d->o; p.w = (const uint8_t*)d->w_packed; p.bo = (const uint8_t*)d->bias; p.res = (const uint8_t*)d->residual;
     p.out = (uint8_t*)d->out; p.rs_out = d->rowstat_out; p.B = d->B; p.N = d->N;
-    static const int xm = hs_env_xm("APAD_HS_XM_FF2", 8);
+    static const int xm = 8;
     p.xm = xm;
     hipStream_t s = (hipStream_t)stream;
     return d->dtype == APAD_BF16 ? hs_ff2_launch<APAD_BF16>(p, s) : hs_ff2_launch<APAD_F16>(p, s);
@@ -996,7 +991,7 @@ extern "C" int apad_hs_out(const apad_hs_out_desc* d, void* stream) {
     HoP p;
     p.o = (const uint8_t*)d->o; p.w = (const uint8_t*)d->w_packed; p.bo = (const uint8_t*)d->bias; p.res = (const uint8_t*)d->residual;
     p.out = (uint8_t*)d->out; p.rs_out = d->rowstat_out; p.B = d->B; p.N = d->N;
-    static const int xm_out = hs_env_xm("APAD_HS_XM_OUT", 8);
+    static const int xm_out = 8;
     p.xm = xm_out;
     hipStream_t s = (hipStream_t)stream;
     return d->dtype == APAD_BF16 ? hs_out_launch<APAD_BF16>(p, s) : hs_out_launch<APAD_F16>(p, s);

@@ -645,10 +645,10 @@ template <int DT, int KC, int NWV, bool LN> int mlp_launch(const MlpP& p, hipStr
 template <int DT, int KC> int mlp_dispatch(const MlpP& p, bool ln, hipStream_t s) {
     // 4 waves (128 tokens) per workgroup when that still fills the chip, else 2 waves
     const bool big = (p.M + 127) / 128 >= 256;
-    static const int v2 = [] { const char* e = getenv("APAD_MLP_V2"); return e ? atoi(e) : 1; }();
+    constexpr int v2 = 1;
     // (mlp2 from half a chip's worth of 128-token workgroups: the CFG-shared prefix runs this level at 32 x 1000 = 32000 rows = 250 workgroups;
     //  the one-wave-per-SIMD kernel below stays for the small launches, where its 64-token workgroups fill more CUs)
-    static const int v2_min = [] { const char* e = getenv("APAD_MLP_V2_MIN_WG"); return e ? atoi(e) : 128; }();
+    constexpr int v2_min = 128;
     if (v2 && (p.M + 127) / 128 >= v2_min) return ln ? mlp2_launch<DT, KC, true>(p, s) : mlp2_launch<DT, KC, false>(p, s);
     if (big) return ln ? mlp_launch<DT, KC, 4, true>(p, s) : mlp_launch<DT, KC, 4, false>(p, s);
     return ln ? mlp_launch<DT, KC, 2, true>(p, s) : mlp_launch<DT, KC, 2, false>(p, s);

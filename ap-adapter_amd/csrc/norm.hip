@@ -308,7 +308,7 @@ __global__ __launch_bounds__(NTH) void gn_onepass_kernel(GnSrc x, const uint8_t*
 template <int DT, bool SILU>
 bool gn_onepass_launch(const GnSrc& x, const void* gamma, const void* beta, void* out, int B, int HW, int C, int G, float eps,
                        hipStream_t s) {
-    static const int max_hw = [] { const char* e = getenv("APAD_GN_ONEPASS_MAXHW"); return e ? atoi(e) : 1024; }();
+    constexpr int max_hw = 1024;
     const int cg = C / G;
     if (HW > max_hw || G % GN1_GPB != 0 || cg % 4 != 0 || cg > 40) return false;
     const int vps = GN1_GPB * cg / 8;

@@ -277,7 +277,7 @@ template <int DT, int KC, bool LN, bool GEGLU, int NW = 4> int launch(RpP& p, hi
     using C = Cfg<KC>;
     constexpr int COLS_PER_TILE = GEGLU ? C::NT * 16 : C::BNT;
     if constexpr (NW == 4) {
-        static const int nw8 = [] { const char* e = getenv("APAD_RP_NW8"); return e ? atoi(e) : 1; }();  // step 49.12 -> 48.95 ms
+        constexpr int nw8 = 1;  // step 49.12 -> 48.95 ms
         if (nw8 && p.M >= 256 * 128) return launch<DT, KC, LN, GEGLU, 8>(p, s);
     }
     p.n_tiles = p.n_total / COLS_PER_TILE;
@@ -380,8 +380,7 @@ extern "C" int apad_rowpanel_gemm(const apad_rp_desc* d, void* stream) {
                    "apad_rowpanel_gemm: residual needs a single row-major segment and 8-byte aligned rows");
     hipStream_t s = (hipStream_t)stream;
     // weight-stationary schedule first; APAD_RP_IMPL=stream forces the x-stationary kernel (A/B tests)
-    static const bool force_stream = [] { const char* e = getenv("APAD_RP_IMPL"); return e && e[0] == 's'; }();
-    static const bool force_ws = [] { const char* e = getenv("APAD_RP_IMPL"); return e && e[0] == 'w'; }();
+    constexpr bool force_stream = false, force_ws = false;
     // measured on MI355X (tools/microbench.py): the weight-stationary schedule wins when all weight rows fit one or a
     // few resident slices (q / to_out / proj_in / proj_out, N = C); fused q|k|v and the 8C-wide GEGLU re-read x once
     // per slice and are faster on the streamed-tile kernel.

@@ -278,6 +278,34 @@ __device__ __forceinline__ void xa_chunk64_fold(f32x16 (&s)[2], const typename E
     m = mnew;
 }
 
+// A C-layout accumulator tile (lane = token, registers 4 g + j = channels 8 g + 4 half + j of a 32-channel slice) -> LDS row pieces of 16 bytes:
+// the two half-waves exchange 8-byte pieces (v_permlane32_swap) so that the lower half owns channels 0..15 of the token's slice and the upper
+// half channels 16..31, each as two whole 16-byte stores (the 8-byte stores this replaces were 2-way bank conflicts on the 33-slot rows and
+// twice the store instructions).  `add` = per-register addend (bias) or nullptr; dst = the token's row + the slice's byte offset.
+template <int DT> __device__ __forceinline__ void xa_store_slice(uint8_t* dst, const f32x16& o, const float* add, int half) {
+    using E = ET<DT>;
+    uint32_t d[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        typename E::v4 y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = (typename E::elem)(add ? o[4 * g + j] + add[4 * g + j] : o[4 * g + j]);
+        const uint2 u = __builtin_bit_cast(uint2, y);
+        d[g][0] = u.x;
+        d[g][1] = u.y;
+    }
+    uint4 pc[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const auto a = __builtin_amdgcn_permlane32_swap(d[g][0], d[g + 2][0], false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(d[g][1], d[g + 2][1], false, false);
+        pc[g] = make_uint4(a[0], b[0], a[1], b[1]);
+    }
+    uint8_t* q = dst + half * 32;
+    *reinterpret_cast<uint4*>(q) = pc[0];
+    *reinterpret_cast<uint4*>(q + 16) = pc[1];
+}
+
 #ifdef XATTN_TRACE  // probe build (tools/xattn_trace.py): s_memtime stamps of wave 0 / wave 7 at the phase boundaries
 __device__ unsigned long long g_xa_trace[1024 * 32];
 #define XA_STAMP(i) \
@@ -528,14 +556,7 @@ __global__ __launch_bounds__(512) void xattn_kernel(XaP p) {
             // O_h^T (lane = token, registers = head dims 8g + 4 half + j) -> O tile [token][h*32 + dim] (over the parked q)
 #pragma unroll
             for (int u = 0; u < NP; ++u) {
-                uint8_t* od = ot + ((pp + u) * 32 + l31) * TROWB + (h * XD + 4 * half) * 2;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    typename E::v4 y;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) y[j] = (typename E::elem)o[u][4 * g + j];
-                    *reinterpret_cast<uint2*>(od + g * 16) = __builtin_bit_cast(uint2, y);
-                }
+                xa_store_slice<DT>(ot + ((pp + u) * 32 + l31) * TROWB + h * XD * 2, o[u], nullptr, half);
             }
         };
         // CHUNK form: the panels pp .. pp + CNT - 1 of ONE sample; chunks outer (each chunk's 8 KB of fragments fetched once for all of them), panels inner
@@ -599,14 +620,7 @@ __global__ __launch_bounds__(512) void xattn_kernel(XaP p) {
                 for (int r = 0; r < 16; ++r) o2[u][r] *= w2;
                 // the text segment on top (its probabilities normalised before they are rounded, as in the resident-fragment forms)
                 xa_segment_exact<DT, (G1 > 0 ? G1 : 1), false>(f1, nullptr, p.scale_log2, 1.0f, qb, o2[u], false, half);
-                uint8_t* od = ot + ((pp + u) * 32 + l31) * TROWB + (h * XD + 4 * half) * 2;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    typename E::v4 y;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) y[j] = (typename E::elem)o2[u][4 * g + j];
-                    *reinterpret_cast<uint2*>(od + g * 16) = __builtin_bit_cast(uint2, y);
-                }
+                xa_store_slice<DT>(ot + ((pp + u) * 32 + l31) * TROWB + h * XD * 2, o2[u], nullptr, half);
             }
         };
         using One = std::integral_constant<int, 1>;
@@ -700,20 +714,15 @@ __global__ __launch_bounds__(512) void xattn_kernel(XaP p) {
                     yb = E::mfma32(wf[g * 2 + cc], ga[cur][cc], yb);
                 }
             }
-            uint8_t* d0 = xt + (pn * 32 + l31) * TROWB + (wave * 32 + 4 * half) * 2;
+            uint8_t* d0 = xt + (pn * 32 + l31) * TROWB + wave * 32 * 2;
+            float bo[16];  // (short-lived: registers are tight here)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float4 b4 = *reinterpret_cast<const float4*>(lbo + wave * 32 + 8 * g + 4 * half);  // (short-lived: registers are tight here)
-                const float bo[4] = {b4.x, b4.y, b4.z, b4.w};
-                typename E::v4 y0, y1;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    y0[j] = (typename E::elem)(ya[4 * g + j] + bo[j]);
-                    y1[j] = (typename E::elem)(yb[4 * g + j] + bo[j]);
-                }
-                *reinterpret_cast<uint2*>(d0 + g * 16) = __builtin_bit_cast(uint2, y0);
-                *reinterpret_cast<uint2*>(d0 + 32 * TROWB + g * 16) = __builtin_bit_cast(uint2, y1);
+                const float4 b4 = *reinterpret_cast<const float4*>(lbo + wave * 32 + 8 * g + 4 * half);
+                bo[4 * g] = b4.x; bo[4 * g + 1] = b4.y; bo[4 * g + 2] = b4.z; bo[4 * g + 3] = b4.w;
             }
+            xa_store_slice<DT>(d0, ya, bo, half);
+            xa_store_slice<DT>(d0 + 32 * TROWB, yb, bo, half);
         }
     }
     XA_STAMP(9);

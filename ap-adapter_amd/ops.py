@@ -78,7 +78,7 @@ import weakref as _weakref
 
 # LayerNorm folded into the Linear behind it where no fused row-panel kernel covers the width (the 640-wide level): the producing
 # GEMM emits row statistics, the consuming GEMM applies (x - mean) * rstd * gamma + beta by algebra.  APAD_LN_FOLD=0: A/B switch
-LN_FOLD = _os.environ.get("APAD_LN_FOLD", "1") == "1"
+LN_FOLD = True  # (module attribute only: no environment switch since round 5)
 _fold_cache = {}
 
 
@@ -168,8 +168,8 @@ def ln_foldable(x, w):
 
 
 RP_K = (256, 384)  # reduction dims the row-panel kernel covers
-CGEMM_LINEAR = _os.environ.get("APAD_CGEMM_LINEAR", "0") == "1"  # A/B switch (read once)
-CGEMM_MIN_M = int(_os.environ.get("APAD_CGEMM_MIN_M", "16000"))  # the row threshold of csrc/cgemm.hip
+CGEMM_LINEAR = False  # (measured in round 3: no gain on the HBM-bound to_out / proj launches; module attribute only)
+CGEMM_MIN_M = 16000  # the row threshold of csrc/cgemm.hip
 FUSED_DTYPES = (torch.bfloat16, torch.float16)  # the fused kernels (row-panel, feed-forward, cross-attention) are 16-bit only;
 # the fp32 precision mode (exact-f32 MFMA, csrc/f32_ops.hip) runs the un-fused apad_layernorm / apad_gemm / apad_attention chain
 
@@ -395,8 +395,8 @@ def hs_ok(x, heads, n_q_rows):
             and x.dtype in FUSED_DTYPES and x.is_contiguous())
 
 
-HS_FF2 = _os.environ.get("APAD_HS_FF2", "1") == "1"  # A/B switch: its second Linear through apad_hs_ff2 (0: the tiled GEMM)
-HS_FF = _os.environ.get("APAD_HS_FF", "1") == "1"  # A/B switch: the feed-forward of that level through apad_hs_geglu (+ apad_hs_ff2)
+HS_FF2 = True  # its second Linear through apad_hs_ff2 (False: the tiled GEMM); module attribute only
+HS_FF = True  # the feed-forward of that level through apad_hs_geglu (+ apad_hs_ff2); follows HS_ATTN (unet.FeedForward); module attribute only
 
 
 def hs_rows_ok(x):

@@ -27,8 +27,8 @@ _vt_pool = {}
 import os as _os
 USE_FUSED_XATTN = _os.environ.get("APAD_FUSED_XATTN", "1") == "1"
 # Self-attention behind the row-panel projection: scale the to_q rows by log2(e) / sqrt(d) once (cached with the stacked weight) so
-# that apad_attention takes q as the base-2 exponent operand (q_prescaled; APAD_PRESCALE_Q=0: A/B switch)
-PRESCALE_Q = _os.environ.get("APAD_PRESCALE_Q", "1") == "1"
+# that apad_attention takes q as the base-2 exponent operand (q_prescaled)
+PRESCALE_Q = True
 
 
 def _fused_xattn_ok(attn, hidden_states, residual, ln, L1, L2=0, masked=False):
@@ -38,7 +38,7 @@ def _fused_xattn_ok(attn, hidden_states, residual, ln, L1, L2=0, masked=False):
             and hidden_states.is_contiguous() and hidden_states.dtype in ops.FUSED_DTYPES)
 
 
-USE_XATTN_ROWS = _os.environ.get("APAD_XATTN_ROWS", "1") == "1"  # the 384-wide level's single-launch route (A/B switch; tests)
+USE_XATTN_ROWS = True  # the 384-wide level's single-launch route (follows USE_FUSED_XATTN; module attribute only)
 
 
 def _xrows_ok(attn, hidden_states, residual, ln, L1, L2=0):

@@ -100,7 +100,7 @@ def get_scheduler(name, num_warmup_steps=0, num_training_steps=None, num_cycles=
 
 # kernel form of the training step's latency-bound GEMMs (ops.set_gemm_ring; measured 60.0 -> 50.4 ms per cfg-5 step): -1 = leave the
 # process setting alone
-TRAIN_GEMM_RING = int(os.environ.get("APAD_TRAIN_GEMM_RING", "2"))
+TRAIN_GEMM_RING = 2
 
 
 class AdapterTrainer:

@@ -180,7 +180,7 @@ class FeedForward(nn.Module):
             if ops.HS_FF2:
                 return ops.hs_ff2(h, w2p, self.net[2].bias, x, rowstat=True)
             return ops.linear(h, self.net[2].weight, self.net[2].bias, residual=x, rowstat=True)
-        if x.shape[-1] in ops.MLP_C and x.dtype in ops.FUSED_DTYPES and os.environ.get("APAD_FUSED_MLP", "1") != "0":
+        if x.shape[-1] in ops.MLP_C and x.dtype in ops.FUSED_DTYPES:
             if ops.MLP_PACKED and x.numel() // x.shape[-1] >= ops.MLP_PACKED_MIN_M and x.is_contiguous():
                 wp, bp = self._packed_weights()
                 return ops.geglu_mlp_packed(x, wp, bp, self.net[2].bias, ln=ln)

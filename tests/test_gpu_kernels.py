@@ -1225,3 +1225,35 @@ def test_layernorm_fold_needs_the_producers_statistics(dev):
     assert rel_err(out, ref) < TOL[dtype]
     y = ops.linear(x, w, None, rowstat=True)
     assert ops.rowstat_of(y) is not None and ops.rowstat_of(y[:128]) is None and ops.rowstat_of(y.clone()) is None
+
+
+def test_kernel_form_environment_switches_are_bit_equal(dev, tmp_path):
+    """the two C-ABI-level environment switches (read once per process, so flipped in a child process): APAD_CGEMM=0 (the tiled kernel
+    instead of the big-tile LDS-DMA kernel) and APAD_GEMM_RING=2 (the LDS-DMA ring form of the 64 x 64 tile) select other kernel FORMS of
+    apad_gemm with the same accumulation order -- the results are the same bits"""
+    import subprocess
+    import sys
+    script = r'''
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from ap_adapter_amd import ops
+torch.manual_seed(0)
+dev = torch.device("cuda:0"); dt = torch.bfloat16
+x = torch.randn(8, 1000, 256, device=dev).to(dt); w = (torch.randn(256, 9 * 256, device=dev) * 0.02).to(dt); b = torch.randn(256, device=dev).to(dt)
+y, _, _ = ops.conv3x3(x.repeat(3, 1, 1), w, b, 24, 125, 8)          # 24 000 output pixels: the big-tile kernel's envelope
+a = torch.randn(1000, 640, device=dev).to(dt); w2 = (torch.randn(640, 640, device=dev) * 0.03).to(dt)
+z = ops.linear(a, w2, b.repeat(3)[:640])                            # a latency-bound 64 x 64-tile launch: the ring form's envelope
+torch.save({"y": y.cpu(), "z": z.cpu()}, sys.argv[2])
+'''
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for i, extra in enumerate(({}, {"APAD_CGEMM": "0", "APAD_GEMM_RING": "2"})):
+        env = dict(os.environ, **extra)
+        for k in ("APAD_CGEMM", "APAD_GEMM_RING"):
+            if k not in extra:
+                env.pop(k, None)
+        path = str(tmp_path / f"o{i}.pt")
+        subprocess.run([sys.executable, "-c", script, root, path], check=True, env=env, timeout=600)
+        outs.append(torch.load(path))
+    assert torch.equal(outs[0]["y"], outs[1]["y"]) and torch.equal(outs[0]["z"], outs[1]["z"])

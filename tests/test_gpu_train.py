@@ -256,7 +256,9 @@ def test_trainer_lr_schedule_and_backing_off_loss_scale(dev):
     tr.grad.zero_()
     tr._micro = 0
     sd_ = tr.state_dict()
-    assert sd_["loss_scale"] == 32768.0 and sd_["scheduler_step"] == 4
+    # (the schedule does not advance on the skipped update -- accelerate's prepared scheduler returns early while
+    #  optimizer.step_was_skipped --: 4 boundaries, 1 of them skipped)
+    assert sd_["loss_scale"] == 32768.0 and sd_["scheduler_step"] == 3
     # growth: scale_growth_interval clean boundaries double it
     u2, *_ = _small_unet(dev, torch.float16)
     tr2 = A.AdapterTrainer(u2, lr=1e-4, scale_growth_interval=2)
