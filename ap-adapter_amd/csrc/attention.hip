@@ -552,7 +552,7 @@ __device__ __forceinline__ void tile_compute2(const uint8_t* buf, int key0, int 
         tmax = half_max(tmax);
         const float mnew = fmaxf(m[qt], tmax);
         // rescale only when some lane's running max moved (wave-uniform; rare after the first tiles).  MFMA and VALU time add up
-        // on this part whatever the interleave, so the branch costs nothing and the skipped multiplies are a net gain
+        // on this part whatever the interleave (NOTES §4b), so the branch costs nothing and the skipped multiplies are a net gain
         if (__any(mnew > m[qt])) {
             const float alpha = __builtin_amdgcn_exp2f(m[qt] - mnew);
             osum[qt] *= alpha;

@@ -143,10 +143,18 @@ __global__ __launch_bounds__(NWV * 64, 1) void mlp_kernel(MlpP p) {
     __syncthreads();
 
     // first GEMM of chunk 0 (not overlapped with anything)
+    // b1 enters every first-GEMM accumulator as its INITIAL value (register r: value unit, r + 8: its gate), like the C operand of
+    // mlp3_kernel's first MFMA: the three feed-forward kernels run the same MFMA chain on the same operands and give the same bits
+    auto bias_init = [&](int jc, f32x16& a) {
+        const int u0 = jc * 16 + 4 * half;
+        const float4 v0 = *reinterpret_cast<const float4*>(lb1 + u0), v1 = *reinterpret_cast<const float4*>(lb1 + u0 + 8);
+        const float4 g0 = *reinterpret_cast<const float4*>(lb1 + G::HID + u0), g1 = *reinterpret_cast<const float4*>(lb1 + G::HID + u0 + 8);
+        a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w; a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
+        a[8] = g0.x; a[9] = g0.y; a[10] = g0.z; a[11] = g0.w; a[12] = g1.x; a[13] = g1.y; a[14] = g1.z; a[15] = g1.w;
+    };
     f32x16 acur;
     {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acur[r] = 0.f;
+        bias_init(0, acur);
         const uint8_t* wt = w1s + l31 * G::ROWB1 + half * 16;
         typename E::v8 wf[4][1];
 #pragma unroll
@@ -172,16 +180,6 @@ __global__ __launch_bounds__(NWV * 64, 1) void mlp_kernel(MlpP p) {
     u32x2 w2lo_p[G::CT], w2hi_p[G::CT];
 #pragma unroll
     for (int ct = 0; ct < G::CT; ++ct) w2lo_p[ct] = w2hi_p[ct] = (u32x2){0u, 0u};
-    // biases of the chunk whose GEGLU runs this iteration: fetched from LDS one iteration ahead
-    auto load_bias = [&](int jc, float4 (&b)[4]) {
-        const int u0 = jc * 16 + 4 * half;
-        b[0] = *reinterpret_cast<const float4*>(lb1 + u0);
-        b[1] = *reinterpret_cast<const float4*>(lb1 + u0 + 8);
-        b[2] = *reinterpret_cast<const float4*>(lb1 + G::HID + u0);
-        b[3] = *reinterpret_cast<const float4*>(lb1 + G::HID + u0 + 8);
-    };
-    float4 bcur[4];
-    load_bias(0, bcur);
     for (int jc = 0; jc < G::NCHUNK; ++jc) {
         if (!(MLP_ABL & 8)) {
             load_w1(jc + 2 < G::NCHUNK ? jc + 2 : G::NCHUNK - 1);
@@ -202,22 +200,20 @@ __global__ __launch_bounds__(NWV * 64, 1) void mlp_kernel(MlpP p) {
                 w2hi[ct] = *reinterpret_cast<const u32x2*>(w2t + ct * 32 * G::ROWB2 + 16);
             }
         }
-        float4 bnxt[4];
-        load_bias(jc + 1 < G::NCHUNK ? jc + 1 : jc, bnxt);
-        const float bv[8] = {bcur[0].x, bcur[0].y, bcur[0].z, bcur[0].w, bcur[1].x, bcur[1].y, bcur[1].z, bcur[1].w};
-        const float bg[8] = {bcur[2].x, bcur[2].y, bcur[2].z, bcur[2].w, bcur[3].x, bcur[3].y, bcur[3].z, bcur[3].w};
-
         f32x16 anxt;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) anxt[r] = 0.f;
+        bias_init(jc + 1 < G::NCHUNK ? jc + 1 : jc, anxt);
         typename E::v8 hb;
         auto geglu_step = [&](int r) {
-            const float v0 = acur[r] + bv[r];
-            const float v1 = acur[r + 1] + bv[r + 1];
-            const apad_f32x2 gt = {acur[8 + r] + bg[r], acur[9 + r] + bg[r + 1]};
+            const float v0 = acur[r];
+            const float v1 = acur[r + 1];
+            const apad_f32x2 gt = {acur[8 + r], acur[9 + r]};
             const apad_f32x2 ge = (MLP_ABL & 1) ? gt : gelu_erf_2(gt);
-            hb[r] = (typename E::elem)(v0 * ge[0]);
-            hb[r + 1] = (typename E::elem)(v1 * ge[1]);
+            // (the product is formed in fp32 and THEN rounded: left to the compiler, (f16)(a * b) may become one v_fma_mix with a single
+            //  rounding for some elements and not for others -- the three feed-forward kernels must agree bit for bit)
+            float pr0 = v0 * ge[0], pr1 = v1 * ge[1];
+            asm volatile("" : "+v"(pr0), "+v"(pr1));
+            hb[r] = (typename E::elem)pr0;
+            hb[r + 1] = (typename E::elem)pr1;
         };
 #ifndef MLP_ORDER
 #define MLP_ORDER 0
@@ -284,8 +280,6 @@ __global__ __launch_bounds__(NWV * 64, 1) void mlp_kernel(MlpP p) {
             w2lo_p[ct] = w2lo[ct];
             w2hi_p[ct] = w2hi[ct];
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) bcur[i] = bnxt[i];
     }
     // drain: second GEMM of the last chunk
 #pragma unroll
@@ -293,86 +287,6 @@ __global__ __launch_bounds__(NWV * 64, 1) void mlp_kernel(MlpP p) {
         typename E::v8 w2f = as_v8<DT>(make_uint4(w2lo_p[ct][0], w2lo_p[ct][1], w2hi_p[ct][0], w2hi_p[ct][1]));
         yacc[ct] = E::mfma32(w2f, hb_prev, yacc[ct]);
     }
-#else
-    // Software pipeline: iteration jc runs the first GEMM of chunk jc+1 (matrix pipe) underneath the GEGLU arithmetic
-    // of chunk jc (VALU) -- independent instruction streams of the same wave -- then the second GEMM of chunk jc.
-    // On entry: W1[jc+1] in w1 stage (jc+1)&1, W2[jc] in w2 stage jc&1, acur = first-GEMM accumulators of chunk jc.
-    for (int jc = 0; jc < G::NCHUNK; ++jc) {
-        // tail iterations re-load a valid chunk and run a dead first GEMM: no divergent code paths
-        load_w1(jc + 2 < G::NCHUNK ? jc + 2 : G::NCHUNK - 1);
-        load_w2(jc + 1 < G::NCHUNK ? jc + 1 : G::NCHUNK - 1);
-
-        u32x2 w2lo[G::CT], w2hi[G::CT];
-        {
-            const uint8_t* w2t = w2s + (jc & 1) * G::W2_BYTES + l31 * G::ROWB2 + half * 8;
-#pragma unroll
-            for (int ct = 0; ct < G::CT; ++ct) {
-                w2lo[ct] = *reinterpret_cast<const u32x2*>(w2t + ct * 32 * G::ROWB2);
-                w2hi[ct] = *reinterpret_cast<const u32x2*>(w2t + ct * 32 * G::ROWB2 + 16);
-            }
-        }
-        const int u0 = jc * 16 + 4 * half;
-        const float4 bv0 = *reinterpret_cast<const float4*>(lb1 + u0), bv1 = *reinterpret_cast<const float4*>(lb1 + u0 + 8);
-        const float4 bg0 = *reinterpret_cast<const float4*>(lb1 + G::HID + u0), bg1 = *reinterpret_cast<const float4*>(lb1 + G::HID + u0 + 8);
-        const float bv[8] = {bv0.x, bv0.y, bv0.z, bv0.w, bv1.x, bv1.y, bv1.z, bv1.w};
-        const float bg[8] = {bg0.x, bg0.y, bg0.z, bg0.w, bg1.x, bg1.y, bg1.z, bg1.w};
-
-        f32x16 anxt;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) anxt[r] = 0.f;
-        typename E::v8 hb;
-        const uint8_t* wt = w1s + ((jc + 1) & 1) * G::W1_BYTES + l31 * G::ROWB1 + half * 16;
-        typename E::v8 wfa[4][1], wfb[4][1];
-        rp_load_group<DT, KC>(wfa, wt, 0);
-        // register r (0..7) of acur = value, r+8 = gate of hidden unit jc*16 + (r&3) + 8(r>>2) + 4half
-        auto geglu_step = [&](int r) {
-            // value and gate stay fp32 here (the un-fused path rounds the 8C projection to the storage type first; skipping
-            // that rounding is closer to the fp32 reference and saves ~50 VALU instructions per chunk)
-            const float v0 = acur[r] + bv[r];
-            const float v1 = acur[r + 1] + bv[r + 1];
-            const apad_f32x2 gt = {acur[8 + r] + bg[r], acur[9 + r] + bg[r + 1]};
-#ifdef MLP_NOGELU
-            const apad_f32x2 ge = gt;
-#else
-            const apad_f32x2 ge = gelu_erf_2(gt);
-#endif
-            hb[r] = (typename E::elem)(v0 * ge[0]);
-            hb[r + 1] = (typename E::elem)(v1 * ge[1]);
-        };
-#pragma unroll
-        for (int g = 0; g < NG; g += 2) {
-            rp_load_group<DT, KC>(wfb, wt, (g + 1) * 4);
-            rp_pin<DT, KC>(wfa);
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) anxt = E::mfma32(wfa[cc][0], xf[g * 4 + cc], anxt);
-            geglu_step(2 * g);
-            if (g + 2 < NG) rp_load_group<DT, KC>(wfa, wt, (g + 2) * 4);
-            rp_pin<DT, KC>(wfb);
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) anxt = E::mfma32(wfb[cc][0], xf[(g + 1) * 4 + cc], anxt);
-            geglu_step(2 * g + 2);
-        }
-#if MLP_VALU_PER_MFMA > 0
-#pragma unroll
-        for (int i = 0; i < 4 * NG; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, MLP_VALU_PER_MFMA, 0);
-        }
-#endif
-        // ---- second GEMM: y^T[c][token] += W2[c][hidden chunk] . h^T  (A = W2 rows read with the C-layout permutation) ----
-#pragma unroll
-        for (int ct = 0; ct < G::CT; ++ct) asm volatile("" : "+v"(w2lo[ct]), "+v"(w2hi[ct])::"memory");
-#pragma unroll
-        for (int ct = 0; ct < G::CT; ++ct) {
-            typename E::v8 wf = as_v8<DT>(make_uint4(w2lo[ct][0], w2lo[ct][1], w2hi[ct][0], w2hi[ct][1]));
-            yacc[ct] = E::mfma32(wf, hb, yacc[ct]);
-        }
-        store_w1(w1s + (jc & 1) * G::W1_BYTES);
-        store_w2(w2s + ((jc + 1) & 1) * G::W2_BYTES);
-        __syncthreads();
-        acur = anxt;
-    }
-
 #endif
 
     // ---- epilogue: y + b2 + residual(x) through the per-wave transpose scratch ----
@@ -486,10 +400,17 @@ __global__ __launch_bounds__(512, 1) void mlp2_kernel(MlpP p) {
     __syncthreads();
 
     const int wrow = (32 * hh + l31) * G::ROWB1 + half * 16;  // this wave's rows of a W1 stage
+    // (b1 as the accumulators' initial value: see mlp_kernel)
+    auto bias_init = [&](int jc, f32x16& a) {
+        const int u0 = jc * 32 + 16 * hh + 4 * half;
+        const float4 v0 = *reinterpret_cast<const float4*>(lb1 + u0), v1 = *reinterpret_cast<const float4*>(lb1 + u0 + 8);
+        const float4 g0 = *reinterpret_cast<const float4*>(lb1 + G::HID + u0), g1 = *reinterpret_cast<const float4*>(lb1 + G::HID + u0 + 8);
+        a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w; a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
+        a[8] = g0.x; a[9] = g0.y; a[10] = g0.z; a[11] = g0.w; a[12] = g1.x; a[13] = g1.y; a[14] = g1.z; a[15] = g1.w;
+    };
     f32x16 acur;
     {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acur[r] = 0.f;
+        bias_init(0, acur);
         typename E::v8 wf[4][1];
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -500,13 +421,6 @@ __global__ __launch_bounds__(512, 1) void mlp2_kernel(MlpP p) {
     }
     __syncthreads();
 
-    auto load_bias = [&](int jc, float4 (&b)[4]) {
-        const int u0 = jc * 32 + 16 * hh + 4 * half;
-        b[0] = *reinterpret_cast<const float4*>(lb1 + u0);
-        b[1] = *reinterpret_cast<const float4*>(lb1 + u0 + 8);
-        b[2] = *reinterpret_cast<const float4*>(lb1 + G::HID + u0);
-        b[3] = *reinterpret_cast<const float4*>(lb1 + G::HID + u0 + 8);
-    };
     const int w2row = (128 * hh + l31) * G::ROWB2 + half * 8;
     const int hxoff = pair * 2048 + lane * 16;
     auto gemm2 = [&](int slot, int parity) {  // y (this wave's 128 columns) += W2[:, chunk] . h(chunk), both halves of the chunk
@@ -532,10 +446,6 @@ __global__ __launch_bounds__(512, 1) void mlp2_kernel(MlpP p) {
             load_w1(jc + 2 < G::NCHUNK ? jc + 2 : G::NCHUNK - 1);
             load_w2(jc + 1 < G::NCHUNK ? jc + 1 : G::NCHUNK - 1);
         }
-        float4 bcur[4];
-        load_bias(jc, bcur);
-        const float bv[8] = {bcur[0].x, bcur[0].y, bcur[0].z, bcur[0].w, bcur[1].x, bcur[1].y, bcur[1].z, bcur[1].w};
-        const float bg[8] = {bcur[2].x, bcur[2].y, bcur[2].z, bcur[2].w, bcur[3].x, bcur[3].y, bcur[3].z, bcur[3].w};
         // operands of the second GEMM of chunk jc-1 (weights in slot (jc+2)%3, activations of both halves handed over at the last
         // barrier) and the first fragment group of the first GEMM of chunk jc+1: one batch of LDS reads
         typename E::v8 w2f[G::CT][2], hp[2];
@@ -554,16 +464,17 @@ __global__ __launch_bounds__(512, 1) void mlp2_kernel(MlpP p) {
                 }
         }
         f32x16 anxt;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) anxt[r] = 0.f;
+        bias_init(jc + 1 < G::NCHUNK ? jc + 1 : jc, anxt);
         typename E::v8 hb;
         auto geglu_step = [&](int r) {
-            const float v0 = acur[r] + bv[r];
-            const float v1 = acur[r + 1] + bv[r + 1];
-            const apad_f32x2 gt = {acur[8 + r] + bg[r], acur[9 + r] + bg[r + 1]};
+            const float v0 = acur[r];
+            const float v1 = acur[r + 1];
+            const apad_f32x2 gt = {acur[8 + r], acur[9 + r]};
             const apad_f32x2 ge = (MLP2_ABL & 8) ? gt : gelu_erf_2(gt);
-            hb[r] = (typename E::elem)(v0 * ge[0]);
-            hb[r + 1] = (typename E::elem)(v1 * ge[1]);
+            float pr0 = v0 * ge[0], pr1 = v1 * ge[1];  // (fp32 product, then one rounding: see mlp_kernel)
+            asm volatile("" : "+v"(pr0), "+v"(pr1));
+            hb[r] = (typename E::elem)pr0;
+            hb[r + 1] = (typename E::elem)pr1;
         };
         const uint8_t* wt = w1s + ((jc + 1) & 1) * G::W1_BYTES + wrow;
         typename E::v8 wfa[4][1], wfb[4][1];

@@ -11,7 +11,7 @@
 //     L2 -> LDS by `buffer_load ... lds` into a ring of six 24 KB slots, requested five chunks ahead, waited for with a counted vmcnt, one raw s_barrier
 //     per chunk: no staging registers, no ds_write, no __syncthreads, every fragment read one conflict-free ds_read_b128;
 //   * per chunk a wave issues 48 MFMAs (gemm2 of chunk i-2, then gemm1 of chunk i) with the GEGLU arithmetic of chunk i-1 dealt between them -- MFMA and
-//     VALU overlap only inside ONE wave's instruction stream on this part, which is exactly what a one-wave-per-SIMD kernel offers;
+//     VALU overlap only inside ONE wave's instruction stream on this part (NOTES §4b), which is exactly what a one-wave-per-SIMD kernel offers;
 //   * b1 enters as the C operand of the first gemm1 MFMA (no per-element add).
 // Workgroup = 4 waves = 256 tokens (250 workgroups at the 1000-token level's 64 000 rows: one per CU, one round).  Numerics: the same MFMA k-order per
 // 16-unit chunk, the same GELU (gelu_erf_2's operation order) and the same rounding points as mlp_kernel / mlp2_kernel.
@@ -116,6 +116,7 @@ struct M3Geglu {
         u0 *= v0;
         asm volatile("" : "+v"(u0));
         u1 *= v1;
+        asm volatile("" : "+v"(u1));  // (fp32 product, then one rounding -- never a fused v_fma_mix: bit-equal to mlp_kernel / mlp2_kernel)
         hn[r] = (EL)u0;
         hn[r + 1] = (EL)u1;
     }

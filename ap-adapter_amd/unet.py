@@ -629,7 +629,10 @@ class AudioLDM2UNet2DConditionModel(nn.Module):
 
         cond = (ehs, emask, ehs1, emask1)
         nsp = len(self.low_res_streams) if self.low_res_streams is not None else 0
-        split = nsp > 1 and timestep is None and B % nsp == 0 and not AG.on(x) and nb >= 2
+        # (only while a hipGraph is being captured -- that is what the fork / join is for, and the captured allocations come from the graph's
+        #  private pool; an EAGER forward on side streams was measured wrong in the fp32 mode at batch 32, round 5: it stays on one stream)
+        split = (nsp > 1 and timestep is None and B % nsp == 0 and not AG.on(x) and nb >= 2 and x.is_cuda
+                 and torch.cuda.is_current_stream_capturing())
         k0 = max(1, nb - self.low_res_levels) if split else nb  # first down block of the two-stream section
         for i in range(k0):
             x, H, W = down(i, x, H, W, skips, *cond)

@@ -29,7 +29,7 @@ HBM_PEAK_GBS = 8000.0
 
 
 def unet_flops_per_sample(La, t5_len=16):
-    """Algorithmic FLOPs (2*MACs) of one UNet sample-forward, AudioLDM2-large geometry at 10 s (DESIGN.md 'FLOP model')."""
+    """Algorithmic FLOPs (2*MACs) of one UNet sample-forward, AudioLDM2-large geometry at 10 s (NOTES.md 'FLOP model')."""
     boc = (128, 256, 384, 640)
     hw = [250 * 16, 125 * 8, 63 * 4, 32 * 2]
     fl = 0.0
@@ -771,7 +771,9 @@ def main():
     unet.precompute_time_tables(sched.timesteps.to(dev), step_ptr)
 
     if args.low_res_streams:
-        unet.low_res_streams = tuple(torch.cuda.Stream() for _ in range(int(os.environ.get("APAD_LOW_RES_NSTREAMS", "2"))))
+        # (round 5 default: ONE stream -- the 64-token level's launches are 4 x 64 = 256 workgroups at the full CFG batch and fill the chip by
+        #  themselves; same-box A/B 37.49 / 37.54 ms with two half-batch streams vs 37.35 / 37.36 with one, and half the launches at that level)
+        unet.low_res_streams = tuple(torch.cuda.Stream() for _ in range(int(os.environ.get("APAD_LOW_RES_NSTREAMS", "1"))))
         unet.low_res_levels = args.low_res_streams
 
     def step():

@@ -14,6 +14,9 @@ with torch.device(dev):
 init_synthetic_(unet, 100, on_device=True)
 unet = unet.to(dev, torch.bfloat16)
 inp = synthetic_inputs(B, 32, seed=0)
+if os.environ.get("NP_STREAMS"):
+    unet.low_res_streams = tuple(torch.cuda.Stream() for _ in range(int(os.environ["NP_STREAMS"])))
+    unet.low_res_levels = 1
 out = {}
 for name, dt, graph in (("bf16", torch.bfloat16, True), ("f16", torch.float16, True), ("f32", torch.float32, False)):
     r, npred = bench.precision_leg(A, unet, inp, args, dev, dt, steps=2, graph=graph)
