@@ -61,7 +61,7 @@ class MlpDesc(C.Structure):
 
 
 class XattnDesc(C.Structure):
-    _fields_ = [(n, _vp) for n in ("x", "ln_gamma", "ln_beta", "wq_packed", "wo_packed", "bo", "kv1_packed", "key_bias", "kv2_packed", "out")] + \
+    _fields_ = [(n, _vp) for n in ("x", "ln_gamma", "ln_beta", "wq_packed", "wo_packed", "bo", "kv1_packed", "key_bias", "kv2_packed", "out", "q_fold")] + \
                [(n, _i32) for n in ("B", "N", "C", "heads", "L1", "L2", "dtype", "reserved")] + \
                [(n, _f32) for n in ("ln_eps", "softmax_scale", "scale2", "reserved_f")]
 

@@ -114,7 +114,7 @@ extern "C" int apad_sizeof_xrows_desc(void) { return (int)sizeof(apad_xrows_desc
 extern "C" int apad_echo_xattn_desc(const apad_xattn_desc* d, double* out, int cap) {
     int n = 0;
     PUTP(d->x); PUTP(d->ln_gamma); PUTP(d->ln_beta); PUTP(d->wq_packed); PUTP(d->wo_packed); PUTP(d->bo); PUTP(d->kv1_packed);
-    PUTP(d->key_bias); PUTP(d->kv2_packed); PUTP(d->out);
+    PUTP(d->key_bias); PUTP(d->kv2_packed); PUTP(d->out); PUTP(d->q_fold);
     PUT(d->B); PUT(d->N); PUT(d->C); PUT(d->heads); PUT(d->L1); PUT(d->L2);
     PUT(d->dtype); PUT(d->reserved); PUT(d->ln_eps); PUT(d->softmax_scale); PUT(d->scale2); PUT(d->reserved_f);
     return n;

@@ -13,11 +13,13 @@
 //     that head, then the 32 rows of Wo of OUTPUT-CHANNEL slice h for the output projection: weights never pass through
 //     LDS, and they are read from a fragment-major packing (apad_xattn_pack_weight) so that every wave-load is one
 //     contiguous KB
-//   * tokens are what moves through LDS: phase 1 LayerNorm -> x^ tile [128][256]; phase 2 (wave = head)
-//     q_h^T = Wq_h . x^^T -> S^T = K_h . q_h -> softmax (per segment) -> O_h^T = V_h^T . P^T, the three products chained in
-//     registers (each MFMA's C layout is the next one's B operand, the other operand being stored in the matching
-//     permuted k order by apad_xattn_pack_kv) -> O tile [128][256]; phase 3 (wave = channel slice)
-//     out^T = Wo_slice . O^T + bias -> back into the x^ tile; phase 4 adds the residual and streams whole rows out
+//   * tokens are what moves through LDS: phase 1 copies the tile's RAW rows into the x tile [128][256] and leaves their LayerNorm statistics
+//     beside it; phase 2 (wave = head) q_h^T = Wq'_h . x^T, the LayerNorm applied by algebra on the accumulators (Wq' = Wq * gamma, its row
+//     sums and Wq . beta come packed: apad_xattn_desc::q_fold) -> S^T = K_h . q_h -> softmax (per segment) -> O_h^T = V_h^T . P^T, the three
+//     products chained in registers (each MFMA's C layout is the next one's B operand, the other operand being stored in the matching permuted k
+//     order by apad_xattn_pack_kv) -> O tile [128][256]; phase 3 (wave = channel slice) out^T = Wo_slice . O^T + bias, rounded, ADDED IN PLACE to
+//     the raw rows the x tile still holds (round 5: x is read from HBM once -- the round-4 kernel re-fetched the residual rows, 1.31 x its
+//     algorithmic bytes); phase 4 streams whole rows out
 //   * K / V of a (sample, head) are a few KB, fragment-packed at hoist time: coalesced 1 KB loads, L2-resident
 #include <type_traits>
 #include "rp_shared.h"
@@ -32,7 +34,7 @@ constexpr int XC = 256, XKC = 16, XH = 8, XD = 32;
 constexpr int XTM = 128;                  // tokens per workgroup
 constexpr int TROWB = XC * 2 + 16;        // tile row stride (bytes): 33 sixteen-byte slots (odd -> conflict-free fragment reads)
 constexpr int TILE_BYTES = XTM * TROWB;   // 67 584
-constexpr int XA_LDS = 2 * TILE_BYTES + XC * 4;
+constexpr int XA_LDS = 2 * TILE_BYTES + XC * 4 + XTM * 2 * 4 + 2 * XC * 4;  // + bo, per-row (rstd, -mean rstd), the q-projection's fold vectors
 constexpr int XMAXSUB = 4;                // <= 128 keys per segment with resident fragments (segment 1: <= 64)
 constexpr int XMAXSUB2 = 16;              // <= 512 keys in segment 2 on the chunked form (64-key chunks, running max / sum)
 #ifndef XA_SPLIT_Q
@@ -42,8 +44,7 @@ constexpr bool XA_SPLIT = XA_SPLIT_Q != 0;  // A/B: q-projection of all four pan
 
 struct XaP {
     const uint8_t* x;
-    const uint8_t* gamma;
-    const uint8_t* beta;
+    const float* qfold;  // [2][C] or nullptr: LayerNorm folded into the q-projection (apad_xattn_desc::q_fold)
     const uint8_t* wq;   // packed
     const uint8_t* wo;   // packed
     const uint8_t* bo;
@@ -282,7 +283,7 @@ __device__ __forceinline__ void xa_chunk64_fold(f32x16 (&s)[2], const typename E
 // the two half-waves exchange 8-byte pieces (v_permlane32_swap) so that the lower half owns channels 0..15 of the token's slice and the upper
 // half channels 16..31, each as two whole 16-byte stores (the 8-byte stores this replaces were 2-way bank conflicts on the 33-slot rows and
 // twice the store instructions).  `add` = per-register addend (bias) or nullptr; dst = the token's row + the slice's byte offset.
-template <int DT> __device__ __forceinline__ void xa_store_slice(uint8_t* dst, const f32x16& o, const float* add, int half) {
+template <int DT, bool RES = false> __device__ __forceinline__ void xa_store_slice(uint8_t* dst, const f32x16& o, const float* add, int half) {
     using E = ET<DT>;
     uint32_t d[4][2];
 #pragma unroll
@@ -302,6 +303,17 @@ template <int DT> __device__ __forceinline__ void xa_store_slice(uint8_t* dst, c
         pc[g] = make_uint4(a[0], b[0], a[1], b[1]);
     }
     uint8_t* q = dst + half * 32;
+    if constexpr (RES) {  // += what the destination holds (the residual), after the rounding above -- the order of the un-fused chain
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            float f[8], r[8];
+            unpack8<DT>(pc[g], f);
+            unpack8<DT>(*reinterpret_cast<const uint4*>(q + g * 16), r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += r[e];
+            pc[g] = pack8<DT>(f);
+        }
+    }
     *reinterpret_cast<uint4*>(q) = pc[0];
     *reinterpret_cast<uint4*>(q + 16) = pc[1];
 }
@@ -332,6 +344,8 @@ __global__ __launch_bounds__(512) void xattn_kernel(XaP p) {
     uint8_t* const xt = smem;                 // x^ tile, later the output tile
     uint8_t* const ot = smem + TILE_BYTES;    // O tile
     float* const lbo = reinterpret_cast<float*>(smem + 2 * TILE_BYTES);
+    float* const lst = lbo + XC;           // [128][2]: rstd, -mean * rstd of the tile's rows
+    float* const lfold = lst + XTM * 2;    // [2][256]: row sums of the folded Wq, Wq . beta
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: per-wave bases stay in SGPRs (registers are tight)
     const int half = lane >> 5, l31 = lane & 31;
@@ -376,6 +390,7 @@ __global__ __launch_bounds__(512) void xattn_kernel(XaP p) {
     if (tile_of(v) >= p.ntiles) v = next_valid(v);
     if (v < 0) return;
     for (int i = tid; i < XC; i += 512) lbo[i] = p.bo ? ld_elem<DT>(p.bo, i) : 0.f;
+    if (p.qfold != nullptr) lfold[tid] = p.qfold[tid];  // 512 threads = 2 x 256 floats
     uint32_t xoff[2];
     uint4 raw[2][4];  // the tile's un-normalised rows: requested one tile ahead (under phase 3 of the previous tile)
     rows_of(tile_of(v), xoff);
@@ -393,17 +408,14 @@ __global__ __launch_bounds__(512) void xattn_kernel(XaP p) {
 #ifdef XATTN_TRACE
     if (lane == 0 && wave == 0) g_xa_trace[tile * 32 + 12] = wall_clock64();
 #endif
-    // ---- phase 1: LayerNorm of the tile's rows -> x^ tile ----
+    // ---- phase 1: the tile's RAW rows -> x tile (they stay there: B operand of the q-projection, then the residual, added in place in phase
+    //      3); with a LayerNorm: the rows' statistics -> lst (the normalisation itself is algebra on the q accumulators) ----
     {
-        if (p.gamma != nullptr) {
-            float g[32], bt[32];  // this lane's 32 channels of gamma / beta, shared by its two rows
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                unpack8<DT>(*reinterpret_cast<const uint4*>(p.gamma + (i * 64 + oct * 8) * 2), g + 8 * i);
-                unpack8<DT>(*reinterpret_cast<const uint4*>(p.beta + (i * 64 + oct * 8) * 2), bt + 8 * i);
-            }
+        for (int j = 0; j < 2; ++j) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(xt + trow[j] * TROWB + oct * 16 + i * 128) = raw[j][i];
+            if (p.qfold != nullptr) {
                 float f[32];  // unpacked once; two-pass statistics from registers
 #pragma unroll
                 for (int i = 0; i < 4; ++i) unpack8<DT>(raw[j][i], f + 8 * i);
@@ -417,26 +429,13 @@ __global__ __launch_bounds__(512) void xattn_kernel(XaP p) {
                 float q0 = 0.f, q1 = 0.f;
 #pragma unroll
                 for (int e = 0; e < 32; e += 2) {
-                    f[e] -= mean;
-                    f[e + 1] -= mean;
-                    q0 = __builtin_fmaf(f[e], f[e], q0);
-                    q1 = __builtin_fmaf(f[e + 1], f[e + 1], q1);
+                    const float d0 = f[e] - mean, d1 = f[e + 1] - mean;
+                    q0 = __builtin_fmaf(d0, d0, q0);
+                    q1 = __builtin_fmaf(d1, d1, q1);
                 }
                 const float rstd = rsqrtf(oct_sum(q0 + q1) * (1.0f / XC) + p.eps);
-                uint8_t* dst = xt + trow[j] * TROWB + oct * 16;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float y[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) y[e] = __builtin_fmaf(f[8 * i + e] * rstd, g[8 * i + e], bt[8 * i + e]);
-                    *reinterpret_cast<uint4*>(dst + i * 128) = pack8<DT>(y);
-                }
+                if (oct == 0) *reinterpret_cast<float2*>(lst + trow[j] * 2) = make_float2(rstd, -mean * rstd);
             }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(xt + trow[j] * TROWB + oct * 16 + i * 128) = raw[j][i];
         }
     }
     // ---- weights of this wave: head `wave` of Wq (A operand of the q-projection); requested here, behind the LayerNorm's
@@ -460,6 +459,22 @@ __global__ __launch_bounds__(512) void xattn_kernel(XaP p) {
     {
         const int h = wave;
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // LayerNorm by algebra on a q accumulator tile (lane = token l31 of panel pn, register r = head dim (r & 3) + 8 (r >> 2) + 4 half):
+        // q = rstd * (W' x - mean * rowsum(W')) + W . beta  =  acc * rstd + ((-mean rstd) * cs[dim] + bb[dim]); the fold vectors come from LDS
+        // right here (short-lived: the registers of this phase are spoken for)
+        auto fold_q = [&](f32x16& acc, int pn) {
+            if (p.qfold == nullptr) return;  // (wave-uniform)
+            const float2 st = *reinterpret_cast<const float2*>(lst + (pn * 32 + l31) * 2);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 cs = *reinterpret_cast<const float4*>(lfold + h * XD + 8 * g + 4 * half);
+                const float4 bb = *reinterpret_cast<const float4*>(lfold + XC + h * XD + 8 * g + 4 * half);
+                acc[4 * g + 0] = __builtin_fmaf(acc[4 * g + 0], st.x, __builtin_fmaf(st.y, cs.x, bb.x));
+                acc[4 * g + 1] = __builtin_fmaf(acc[4 * g + 1], st.x, __builtin_fmaf(st.y, cs.y, bb.y));
+                acc[4 * g + 2] = __builtin_fmaf(acc[4 * g + 2], st.x, __builtin_fmaf(st.y, cs.z, bb.z));
+                acc[4 * g + 3] = __builtin_fmaf(acc[4 * g + 3], st.x, __builtin_fmaf(st.y, cs.w, bb.w));
+            }
+        };
         // K / V fragments of this head for the tile's first sample: requested here, so that their L2 latency hides under the
         // q-projection; the panels of a tile share them unless the tile crosses a sample boundary
         XaFrags<DT, NS1> f1;
@@ -493,6 +508,7 @@ __global__ __launch_bounds__(512) void xattn_kernel(XaP p) {
 #pragma unroll
             for (int pn = 0; pn < 4; ++pn) {
                 typename E::v8 qb[2];
+                fold_q(qa[pn], pn);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) qb[r >> 3][r & 7] = (typename E::elem)qa[pn][r];
                 uint8_t* qd = ot + (pn * 32 + l31) * TROWB + h * 64 + half * 32;
@@ -534,9 +550,11 @@ __global__ __launch_bounds__(512) void xattn_kernel(XaP p) {
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < NP; ++u)
+                for (int u = 0; u < NP; ++u) {
+                    fold_q(qa[u], pp + u);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) qb[u][r >> 3][r & 7] = (typename E::elem)qa[u][r];
+                }
             }
             const float* bias1 = p.bias1 ? p.bias1 + (int64_t)b * p.L1 : nullptr;
             f32x16 o[NP];
@@ -678,13 +696,12 @@ __global__ __launch_bounds__(512) void xattn_kernel(XaP p) {
     __syncthreads();  // O tile complete; the x^ tile is free
     XA_STAMP(8);
 
-    // the residual rows of phase 4 and the NEXT tile's rows are requested now: their latency (HBM for the latter) hides
-    // under the output projection instead of standing at the head of the next tile
-    uint4 rx[2][4];
-    load_rows(rx, xoff);
+    // the NEXT tile's rows are requested now: their HBM latency hides under the output projection instead of standing at the head of the
+    // next tile (the residual of THIS tile is in the x tile: nothing is read twice)
     load_rows(raw, xoff_next);
 
-    // ---- phase 3: wave = output-channel slice.  out^T [32 channels x 32 tokens] = Wo_slice . O^T + bias -> x^ tile ----
+    // ---- phase 3: wave = output-channel slice.  out^T [32 channels x 32 tokens] = Wo_slice . O^T + bias, rounded, + the raw x rows the x tile
+    //      still holds (the (token, channel slice) block a lane pair reads is the block it writes: in place) ----
     {
 #pragma unroll  // (a rolled loop makes the wait-count pass emit vmcnt(0) at its header: see the prefetch above)
         for (int pn = 0; pn < 4; pn += 2) {
@@ -721,28 +738,21 @@ __global__ __launch_bounds__(512) void xattn_kernel(XaP p) {
                 const float4 b4 = *reinterpret_cast<const float4*>(lbo + wave * 32 + 8 * g + 4 * half);
                 bo[4 * g] = b4.x; bo[4 * g + 1] = b4.y; bo[4 * g + 2] = b4.z; bo[4 * g + 3] = b4.w;
             }
-            xa_store_slice<DT>(d0, ya, bo, half);
-            xa_store_slice<DT>(d0 + 32 * TROWB, yb, bo, half);
+            xa_store_slice<DT, true>(d0, ya, bo, half);
+            xa_store_slice<DT, true>(d0 + 32 * TROWB, yb, bo, half);
         }
     }
     XA_STAMP(9);
     __syncthreads();
     XA_STAMP(10);
 
-    // ---- phase 4: out = y + x (residual), whole cache lines per store instruction ----
+    // ---- phase 4: the finished rows stream out, whole cache lines per store instruction ----
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         if (xoff[j] == NOROW) continue;
         const uint8_t* src = xt + trow[j] * TROWB + oct * 16;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float f[8], r[8];
-            unpack8<DT>(*reinterpret_cast<const uint4*>(src + i * 128), f);
-            unpack8<DT>(rx[j][i], r);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] += r[e];
-            *reinterpret_cast<uint4*>(p.out + (xoff[j] + i * 128)) = pack8<DT>(f);
-        }
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(p.out + (xoff[j] + i * 128)) = *reinterpret_cast<const uint4*>(src + i * 128);
     }
     XA_STAMP(11);
 #ifdef XATTN_TRACE
@@ -874,11 +884,13 @@ extern "C" int apad_fused_cross_attention(const apad_xattn_desc* d, void* stream
     const bool dual = d->L2 > 0;
     if (dual) APAD_CHECK(d->kv2_packed != nullptr, "apad_fused_cross_attention: segment 2 needs kv2_packed");
     APAD_CHECK((d->ln_gamma == nullptr) == (d->ln_beta == nullptr), "apad_fused_cross_attention: LayerNorm needs gamma and beta");
+    APAD_CHECK((d->ln_gamma == nullptr) == (d->q_fold == nullptr),
+               "apad_fused_cross_attention: a LayerNorm is applied by algebra (ABI 8): pass wq_packed of round(W * gamma) and q_fold (see the header)");
     APAD_CHECK(al16(d->x) && al16(d->wq_packed) && al16(d->wo_packed) && al16(d->kv1_packed) && al16(d->out) && al16(d->kv2_packed) &&
-                   al16(d->ln_gamma) && al16(d->ln_beta),
+                   al16(d->q_fold),
                "apad_fused_cross_attention: pointers must be 16-byte aligned");
     XaP p;
-    p.x = (const uint8_t*)d->x; p.gamma = (const uint8_t*)d->ln_gamma; p.beta = (const uint8_t*)d->ln_beta;
+    p.x = (const uint8_t*)d->x; p.qfold = d->q_fold;
     p.wq = (const uint8_t*)d->wq_packed; p.wo = (const uint8_t*)d->wo_packed; p.bo = (const uint8_t*)d->bo;
     p.kv1 = (const uint8_t*)d->kv1_packed; p.bias1 = d->key_bias; p.kv2 = (const uint8_t*)d->kv2_packed; p.out = (uint8_t*)d->out;
     p.B = d->B; p.N = d->N; p.L1 = d->L1; p.L2 = d->L2;

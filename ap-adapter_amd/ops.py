@@ -236,9 +236,16 @@ def xattn_lengths_ok(L1, L2=0, masked=False):
     return L1 <= XATTN_MAXL and (L2 <= XATTN_MAXL or (L1 == 8 and not masked and (L2 == XATTN_MAXL2 or (XATTN_MAXL2 < L2 <= XATTN_LONG2 and L2 % 64 == 0))))
 
 
-def xattn_pack_weight(w):
-    """[256, 256] nn.Linear weight -> the fragment-major packing apad_fused_cross_attention keeps in registers (128 KB)"""
+def xattn_pack_weight(w, ln=None):
+    """[256, 256] nn.Linear weight -> the fragment-major packing apad_fused_cross_attention keeps in registers (128 KB).
+    ln = (gamma, beta, eps) -- to_q behind a LayerNorm: returns (packing of W' = round(W * gamma), q_fold fp32 [2, 256] = row sums of W', W . beta):
+    the kernel applies the LayerNorm by algebra on the q accumulators (apad_xattn_desc::q_fold)"""
     _req(w, "xattn_pack_weight.w")
+    if ln is not None:
+        wf = w.detach().float()
+        wg = (wf * ln[0].detach().float()).to(w.dtype).contiguous()
+        q_fold = torch.stack([wg.float().sum(1), wf @ ln[1].detach().float()], 0).contiguous()
+        return xattn_pack_weight(wg), q_fold
     if tuple(w.shape) != (XATTN_C, XATTN_C) or w.dtype not in FUSED_DTYPES:
         raise ValueError(f"xattn_pack_weight: weight {tuple(w.shape)} {w.dtype} outside the kernel envelope")
     out = torch.empty(XATTN_C * XATTN_C, dtype=w.dtype, device=w.device)
@@ -261,9 +268,10 @@ def xattn_pack_kv(k, vt, Lk):
 
 
 def fused_cross_attention(x, wq_packed, wo_packed, bo, kv1_packed, L1, heads, ln=None, key_bias=None, kv2_packed=None, L2=0,
-                          scale2=0.0, out=None):
+                          scale2=0.0, out=None, q_fold=None):
     """out = x + to_out(A(q, k1, v1, bias) [+ scale2 * A(q, k2, v2)]) + bo with q = to_q(LayerNorm(x)): the whole
-    cross-attention sub-layer in one launch.  x [B, N, C]; weights from xattn_pack_weight, K/V from xattn_pack_kv."""
+    cross-attention sub-layer in one launch.  x [B, N, C]; weights from xattn_pack_weight, K/V from xattn_pack_kv.  With ln: wq_packed and
+    q_fold = xattn_pack_weight(to_q.weight, ln) (the LayerNorm is folded into the projection)."""
     _req(x, "fused_cross_attention.x", wq_packed.dtype)
     B, N, Cc = x.shape
     if Cc != XATTN_C or heads != XATTN_HEADS or not xattn_lengths_ok(L1, L2, key_bias is not None) or x.dtype not in FUSED_DTYPES:
@@ -276,7 +284,9 @@ def fused_cross_attention(x, wq_packed, wo_packed, bo, kv1_packed, L1, heads, ln
     d.x, d.wq_packed, d.wo_packed, d.bo, d.kv1_packed, d.out = (x.data_ptr(), wq_packed.data_ptr(), wo_packed.data_ptr(), _ptr(bo),
                                                                  kv1_packed.data_ptr(), out.data_ptr())
     if ln is not None:
-        d.ln_gamma, d.ln_beta, d.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), float(ln[2])
+        if q_fold is None or q_fold.dtype != torch.float32 or tuple(q_fold.shape) != (2, Cc) or not q_fold.is_contiguous():
+            raise ValueError("fused_cross_attention(ln=...): needs q_fold = the second result of xattn_pack_weight(to_q.weight, ln)")
+        d.ln_gamma, d.ln_beta, d.ln_eps, d.q_fold = ln[0].data_ptr(), ln[1].data_ptr(), float(ln[2]), q_fold.data_ptr()
     d.key_bias = _ptr(key_bias)
     d.B, d.N, d.C, d.heads, d.L1 = B, N, Cc, heads, L1
     if L2 > 0:

@@ -57,12 +57,13 @@ def _xrows_weights(attn):
     return attn._xrows_w
 
 
-def _xattn_weights(attn):
-    """fragment-packed to_q / to_out[0] weights of the fused kernel, cached on the Attention module and re-packed when a
-    parameter is re-assigned, moved, cast or updated in place"""
-    key = _pkey(attn.to_q.weight, attn.to_out[0].weight)
+def _xattn_weights(attn, ln):
+    """(fragment-packed to_q with the block's LayerNorm folded in, its fold vectors, fragment-packed to_out[0]) of the fused kernel, cached on
+    the Attention module and re-packed when a parameter (the LayerNorm's included) is re-assigned, moved, cast or updated in place"""
+    key = (_pkey(attn.to_q.weight, attn.to_out[0].weight, ln[0], ln[1]), float(ln[2]))
     if getattr(attn, "_xattn_key", None) != key:
-        attn._xattn_w = (ops.xattn_pack_weight(attn.to_q.weight.detach()), ops.xattn_pack_weight(attn.to_out[0].weight.detach()))
+        wq_p, q_fold = ops.xattn_pack_weight(attn.to_q.weight.detach(), ln)
+        attn._xattn_w = (wq_p, q_fold, ops.xattn_pack_weight(attn.to_out[0].weight.detach()))
         attn._xattn_key = key
     return attn._xattn_w
 
@@ -340,8 +341,8 @@ class AttnProcessor2_0(nn.Module):
         else:
             bias = None
         if encoder_hidden_states is not None and fused and pk is not None:
-            wq_p, wo_p = _xattn_weights(attn)
-            return ops.fused_cross_attention(hidden_states, wq_p, wo_p, attn.to_out[0].bias, pk, Lk, heads, ln=_ln, key_bias=bias)
+            wq_p, q_fold, wo_p = _xattn_weights(attn, _ln)
+            return ops.fused_cross_attention(hidden_states, wq_p, wo_p, attn.to_out[0].bias, pk, Lk, heads, ln=_ln, key_bias=bias, q_fold=q_fold)
         if encoder_hidden_states is not None and _xrows_ok(attn, hidden_states, _residual, _ln, Lk) and k.shape[0] == B:
             wq_p, wo_p = _xrows_weights(attn)
             return ops.cross_attention_rows(hidden_states, wq_p, wo_p, attn.to_out[0].bias, k, vt, heads, ln=_ln, key_bias=bias)
@@ -480,9 +481,9 @@ class IPAttnProcessor2_0(nn.Module):
             m = attention_mask.reshape(B, -1)[:, :1].float()
             bias = m.expand(B, Lt).contiguous()
         if pk_t is not None and _fused_xattn_ok(attn, hidden_states, _residual, _ln, Lt, La, bias is not None):
-            wq_p, wo_p = _xattn_weights(attn)
+            wq_p, q_fold, wo_p = _xattn_weights(attn, _ln)
             return ops.fused_cross_attention(hidden_states, wq_p, wo_p, attn.to_out[0].bias, pk_t, Lt, attn.heads, ln=_ln,
-                                             key_bias=bias, kv2_packed=pk_a, L2=La, scale2=self.scale)
+                                             key_bias=bias, kv2_packed=pk_a, L2=La, scale2=self.scale, q_fold=q_fold)
         if _xrows_ok(attn, hidden_states, _residual, _ln, Lt, La) and k_t.shape[0] == B:
             wq_p, wo_p = _xrows_weights(attn)
             return ops.cross_attention_rows(hidden_states, wq_p, wo_p, attn.to_out[0].bias, k_t, vt_t, attn.heads, ln=_ln, key_bias=bias,

@@ -466,10 +466,10 @@ def fused_attn2_roofline(dev, dtype, B2, La, ap_scale, in_step=None, in_step_how
     flops = (4.0 * N * C * C + 4.0 * N * (Lt + La) * C) * B2
     nbytes = 2 * B2 * N * C * 2 + 2 * C * C * 2 + 2 * B2 * (Lt + La) * C * 2
     if ops.xattn_lengths_ok(Lt, La):
-        wq_p, wo_p = ops.xattn_pack_weight(wq), ops.xattn_pack_weight(wo)
+        (wq_p, q_fold), wo_p = ops.xattn_pack_weight(wq, (g_, b_, 1e-5)), ops.xattn_pack_weight(wo)
         pk1, pk2 = ops.xattn_pack_kv(k1, v1t, Lt), ops.xattn_pack_kv(k2, v2t, La)
         fn = lambda: ops.fused_cross_attention(x, wq_p, wo_p, bo, pk1, Lt, heads, ln=(g_, b_, 1e-5), kv2_packed=pk2, L2=La,
-                                               scale2=ap_scale, out=out)
+                                               scale2=ap_scale, out=out, q_fold=q_fold)
         name = "xattn_kernel<bf16> (apad_fused_cross_attention): LN + to_q + decoupled attention + to_out + residual"
     else:  # outside the one-launch kernel's key counts (La = 512): the three-kernel chain (LN + to_q ; decoupled attention ; to_out + residual)
         def fn():

@@ -216,15 +216,20 @@ typedef struct apad_mlp_desc {
  *   apad_xattn_pack_kv      once per hoisted K / V^T set (i.e. per pipeline call, with the K/V projection itself) */
 typedef struct apad_xattn_desc {
     const void* x;          /* [B*N][C] un-normalised hidden states (also the residual)                     */
-    const void* ln_gamma;   /* [C] or NULL                                                                  */
+    const void* ln_gamma;   /* [C] or NULL: LayerNorm(x) in front of to_q -- applied BY ALGEBRA (ABI 8): see q_fold */
     const void* ln_beta;
-    const void* wq_packed;  /* apad_xattn_pack_weight(attn.to_q.weight)                                     */
+    const void* wq_packed;  /* apad_xattn_pack_weight(attn.to_q.weight); with a LayerNorm: of W' = round(W * gamma)   */
     const void* wo_packed;  /* apad_xattn_pack_weight(attn.to_out[0].weight)                                */
     const void* bo;         /* [C] attn.to_out[0].bias or NULL                                              */
     const void* kv1_packed; /* apad_xattn_pack_kv(to_k(tokens), to_v(tokens)^T) of segment 1 (text / T5)     */
     const float* key_bias;  /* [B][L1] fp32 additive bias on segment 1, or NULL                             */
     const void* kv2_packed; /* segment 2 (to_k_ip / to_v_ip of the audio tokens) or NULL                     */
     void* out;              /* [B*N][C]                                                                     */
+    /* ABI 8: the tile keeps the RAW rows of x in LDS from the first phase to the last (the residual is added in place, x is read from HBM
+     * once), so the LayerNorm is folded into the q-projection: q = rstd * (W' x - mean * q_fold[0]) + q_fold[1] with W' = round(W * gamma)
+     * passed as wq_packed, q_fold[0][c] = sum_k W'[c][k] (fp32 sums of the ROUNDED weights), q_fold[1][c] = sum_k W[c][k] * beta[k].
+     * Required when ln_gamma != NULL (fp32 [2][C]); NULL when there is no LayerNorm. */
+    const float* q_fold;
     int32_t B, N, C, heads;
     int32_t L1, L2;         /* L2 = 0: single segment                                                       */
     int32_t dtype, reserved;

@@ -841,11 +841,11 @@ def test_fused_cross_attention(dev, dtype, B, N, Lt, La, masked):
         k2 = ops.linear(D(ea), D(wki))
         v2t = torch.zeros(B, H, C // H, ops.round_up(La, 32), device=dev, dtype=dtype)
         ops.linear_vt(D(ea), D(wvi), B, La, H, v2t)
-    wq_p, wo_p = ops.xattn_pack_weight(D(wq)), ops.xattn_pack_weight(D(wo))
+    (wq_p, q_fold), wo_p = ops.xattn_pack_weight(D(wq), (D(g), D(be), 1e-5)), ops.xattn_pack_weight(D(wo))
     pk1 = ops.xattn_pack_kv(k1, v1t, Lt)
     pk2 = ops.xattn_pack_kv(k2, v2t, La) if La else None
     out = ops.fused_cross_attention(D(x), wq_p, wo_p, D(bo), pk1, Lt, H, ln=(D(g), D(be), 1e-5),
-                                    key_bias=None if bias is None else bias.to(dev), kv2_packed=pk2, L2=La, scale2=0.55)
+                                    key_bias=None if bias is None else bias.to(dev), kv2_packed=pk2, L2=La, scale2=0.55, q_fold=q_fold)
     assert out.shape == ref.shape
     assert rel_err(out, ref) < 1.5 * TOL[dtype]
     # and against the three-kernel chain it replaces

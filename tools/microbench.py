@@ -126,9 +126,9 @@ if "xattn" in flt or not flt:
     out = torch.empty_like(x)
     fl = 2.0 * 2 * B2 * N * C * C + 4.0 * B2 * N * (Lt + La) * C
     by = 2.0 * (2 * B2 * N * C + 2 * C * C + 2 * B2 * (Lt + La) * C)
-    wq_p, wo_p = ops.xattn_pack_weight(wq), ops.xattn_pack_weight(wo)
+    (wq_p, q_fold), wo_p = ops.xattn_pack_weight(wq, (g, be, 1e-5)), ops.xattn_pack_weight(wo)
     pk1, pk2 = ops.xattn_pack_kv(k1, v1t, Lt), ops.xattn_pack_kv(k2, v2t, La)
-    ms = timeit(lambda: ops.fused_cross_attention(x, wq_p, wo_p, bo, pk1, Lt, H, ln=(g, be, 1e-5), kv2_packed=pk2, L2=La, scale2=0.55, out=out))
+    ms = timeit(lambda: ops.fused_cross_attention(x, wq_p, wo_p, bo, pk1, Lt, H, ln=(g, be, 1e-5), kv2_packed=pk2, L2=La, scale2=0.55, out=out, q_fold=q_fold))
     report(f"fused cross-attention sub-layer N={N} C={C} Lt=8 La=32", ms, fl, by)
 
     def three():

@@ -15,11 +15,11 @@ x, g, be, wq, wo, bo = R(B2, N, Cc), R(Cc), R(Cc), R(Cc, Cc, std=0.02), R(Cc, Cc
 k1, k2 = R(B2, Lt, Cc, std=0.3), R(B2, La, Cc, std=0.3)
 v1t = torch.zeros(B2, H, 32, 32, device=dev, dtype=dt); v1t[..., :Lt].normal_(0, 0.3)
 v2t = torch.zeros(B2, H, 32, ops.round_up(La, 32), device=dev, dtype=dt); v2t[..., :La].normal_(0, 0.3)
-wq_p, wo_p = ops.xattn_pack_weight(wq), ops.xattn_pack_weight(wo)
+(wq_p, q_fold), wo_p = ops.xattn_pack_weight(wq, (g, be, 1e-5)), ops.xattn_pack_weight(wo)
 pk1, pk2 = ops.xattn_pack_kv(k1, v1t, Lt), ops.xattn_pack_kv(k2, v2t, La)
 out = torch.empty_like(x)
 for _ in range(3):
-    ops.fused_cross_attention(x, wq_p, wo_p, bo, pk1, Lt, H, ln=(g, be, 1e-5), kv2_packed=pk2, L2=La, scale2=0.55, out=out)
+    ops.fused_cross_attention(x, wq_p, wo_p, bo, pk1, Lt, H, ln=(g, be, 1e-5), kv2_packed=pk2, L2=La, scale2=0.55, out=out, q_fold=q_fold)
 torch.cuda.synchronize()
 ntiles = (B2 * ((N + 31) // 32) + 3) // 4
 buf = (C.c_ulonglong * (ntiles * 32))()
