@@ -1,45 +1,19 @@
 // apad_geglu_mlp: the whole feed-forward of a BasicTransformerBlock in ONE kernel:
 //     out = x + W2 . ( value * gelu(gate) ) + b2,   [value | gate] = W1 . LayerNorm(x) + b1        (diffusers FeedForward/GEGLU)
-// The 8C-wide projection and the 4C-wide activation never exist in memory: per 16 hidden units the kernel runs the
-// first GEMM (K = C, x fragments resident in registers, LayerNorm applied in registers), forms value*gelu(gate) in
-// registers, and immediately feeds it -- still in registers -- to the second GEMM as its B operand: the C-layout of the
-// first MFMA (lane = token, registers = hidden units (r&3)+8(r>>2)+4*half) IS a valid B-operand layout of the second
-// MFMA as long as the W2 fragment is read with the same hidden-unit permutation (two 8-byte pieces per lane) -- the same
-// trick apad_attention uses for P.V.  Accumulators of the output (C/32 MFMA tiles) stay in registers for the whole pass.
-//
-// Per workgroup: NWV waves x 32 tokens.  W1 (16 value + 16 gate rows) and W2 (C rows x 16 hidden) tiles of the current
-// chunk are staged through double-buffered LDS by all threads, one chunk ahead.  The kernel needs ~330 VGPRs (x panel
-// 64-96 + output accumulators 128-192 + pipeline), so it runs one wave per SIMD by design; what it removes is the
-// 2 x 131 MB (C=256, 64 samples) round trip of the activation through HBM, one launch, and two LayerNorm/GEMM passes.
+// The 8C-wide projection and the 4C-wide activation never exist in memory: per 16 hidden units the kernel runs the first GEMM (K = C, x fragments
+// resident in registers, LayerNorm applied in registers), forms value * gelu(gate) in registers, and feeds it -- through a 1 KB LDS hand-over between
+// the two waves of a pair -- to the second GEMM as its B operand: the C layout of the first MFMA (lane = token, registers = hidden units
+// (r & 3) + 8 (r >> 2) + 4 half) IS a valid B-operand layout of the second MFMA as long as the W2 fragment is read with the same hidden-unit
+// permutation -- the trick apad_attention uses for P.V.
+// This file holds the 128-token-workgroup form from UNPACKED weights (mlp2_kernel): launches below 48 000 rows (the CFG-shared prefix, small
+// batches, the training step).  Full-size launches: the 64-token register-block kernel from packed weights (mlp3.hip), bit-equal to this one.
+// (Rounds 1-4 also kept a one-wave-per-SIMD form, mlp_kernel: slower at every size, removed in round 5 -- NOTES 4b / 10.)
 #include <stdlib.h>
 #include "rp_shared.h"
-
-// Optional scheduler hint (VALU instructions requested after each first-GEMM MFMA); 0 = leave it to the scheduler,
-// which measured fastest (183 us vs 192 / 196 us at 6 / 10, M = 64000).
-#ifndef MLP_VALU_PER_MFMA
-#define MLP_VALU_PER_MFMA 0
-#endif
-#ifndef MLP_PIPE2
-#define MLP_PIPE2 1
-#endif
-// timing ablations of the pipelined loop (results are wrong): 1 = no GELU arithmetic, 2 = no first-GEMM MFMAs,
-// 4 = no second-GEMM MFMAs, 8 = no weight staging (global loads / LDS stores), 16 = no per-chunk barrier
-#ifndef MLP_ABL
-#define MLP_ABL 0
-#endif
 
 namespace {
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-
-template <int KC> struct MlpCfg {
-    static constexpr int C = KC * 16, CT = C / 32, HID = 4 * C, NCHUNK = HID / 16;
-    static constexpr int ROWB1 = Cfg<KC>::ROWB;        // W1 tile row stride (K*2 + 16 bytes)
-    static constexpr int W1_BYTES = 32 * ROWB1;
-    static constexpr int ROWB2 = 40;                   // W2 tile row: 16 hidden units (32 B) + 8 B pad (conflict-free b64 reads)
-    static constexpr int W2_BYTES = C * ROWB2;
-    static constexpr int STAGE = W1_BYTES + W2_BYTES;
-};
 
 struct MlpP {
     const uint8_t* x;
@@ -53,258 +27,6 @@ struct MlpP {
     int64_t M;
     float eps;
 };
-
-template <int DT, int KC, int NWV, bool LN>
-__global__ __launch_bounds__(NWV * 64, 1) void mlp_kernel(MlpP p) {
-    using E = ET<DT>;
-    using G = MlpCfg<KC>;
-    constexpr int NTH = NWV * 64;
-    constexpr int N1 = 32 * KC * 2 / NTH;  // 16-byte chunks per thread, W1 tile
-    constexpr int N2 = G::C * 2 / NTH;     // W2 tile
-    constexpr int NG = KC / 4;             // fragment groups of the first GEMM
-    static_assert(32 * KC * 2 % NTH == 0 && G::C * 2 % NTH == 0, "tiles must split evenly over the workgroup");
-    static_assert(NG == 4, "the GEGLU steps are interleaved one per fragment group: 4 groups <-> 4 x 2 hidden units");
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int half = lane >> 5, l31 = lane & 31;
-    const int64_t mw0 = ((int64_t)blockIdx.x * NWV + wave) * 32;
-
-    uint8_t* const w1s = smem;                    // ring of 2 W1 tiles
-    uint8_t* const w2s = smem + 2 * G::W1_BYTES;  // ring of 2 W2 tiles
-    uint8_t* const scr = smem + 2 * G::STAGE + wave * SCR_BYTES;
-    float* const lb1 = reinterpret_cast<float*>(smem + 2 * G::STAGE + NWV * SCR_BYTES);  // [2*HID]: value | gate biases
-    float* const lb2 = lb1 + 2 * G::HID;                                                 // [C]
-
-    // ---- staging helpers (global -> registers -> LDS) ----
-    u32x4 s1[N1], s2[N2];
-    // per-thread byte offsets inside chunk 0's tiles, computed once: a chunk then adds a wave-uniform stride
-    uint32_t o1[N1], o2[N2];
-#pragma unroll
-    for (int i = 0; i < N1; ++i) {
-        const int idx = tid + NTH * i;
-        const int j = idx / (2 * KC), ch = idx - j * (2 * KC);
-        const int64_t row = j < 16 ? j : (int64_t)G::HID + (j - 16);
-        o1[i] = (uint32_t)((row * G::C + ch * 8) * 2);
-    }
-#pragma unroll
-    for (int i = 0; i < N2; ++i) {
-        const int idx = tid + NTH * i;
-        o2[i] = (uint32_t)((((int64_t)(idx >> 1)) * G::HID + (idx & 1) * 8) * 2);
-    }
-    auto load_w1 = [&](int jc) {
-        const uint8_t* base = p.w1 + (int64_t)jc * 16 * G::C * 2;  // value rows jc*16.., gate rows HID + jc*16..
-#pragma unroll
-        for (int i = 0; i < N1; ++i) s1[i] = *reinterpret_cast<const u32x4*>(base + o1[i]);
-    };
-    auto load_w2 = [&](int jc) {
-        const uint8_t* base = p.w2 + (int64_t)jc * 16 * 2;  // hidden columns jc*16..
-#pragma unroll
-        for (int i = 0; i < N2; ++i) s2[i] = *reinterpret_cast<const u32x4*>(base + o2[i]);
-    };
-    auto store_w1 = [&](uint8_t* st) {
-#pragma unroll
-        for (int i = 0; i < N1; ++i) {
-            const int idx = tid + NTH * i;
-            const int j = idx / (2 * KC), ch = idx - j * (2 * KC);
-            *reinterpret_cast<u32x4*>(st + j * G::ROWB1 + ch * 16) = s1[i];
-        }
-    };
-    auto store_w2 = [&](uint8_t* st) {
-#pragma unroll
-        for (int i = 0; i < N2; ++i) {
-            const int idx = tid + NTH * i;
-            const int c = idx >> 1, piece = idx & 1;
-            uint8_t* dst = st + c * G::ROWB2 + piece * 16;  // 8-byte aligned rows: two 8-byte stores
-            const u32x2 lo = {s2[i][0], s2[i][1]}, hi = {s2[i][2], s2[i][3]};
-            *reinterpret_cast<u32x2*>(dst) = lo;
-            *reinterpret_cast<u32x2*>(dst + 8) = hi;
-        }
-    };
-    load_w1(0);
-    load_w2(0);
-
-    // ---- biases -> LDS (fp32), x panel -> registers, LayerNorm ----
-    for (int i = tid; i < 2 * G::HID; i += NTH) lb1[i] = p.b1 ? ld_elem<DT>(p.b1, i) : 0.f;
-    for (int i = tid; i < G::C; i += NTH) lb2[i] = p.b2 ? ld_elem<DT>(p.b2, i) : 0.f;
-    typename E::v8 xf[KC];
-    load_panel<DT, KC>(xf, p.x, G::C, p.M, mw0, l31, half);
-    if (LN) layernorm_panel<DT, KC>(xf, p.gamma, p.beta, p.eps, l31, half);
-
-    f32x16 yacc[G::CT];
-#pragma unroll
-    for (int ct = 0; ct < G::CT; ++ct)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) yacc[ct][r] = 0.f;
-
-    store_w1(w1s);
-    store_w2(w2s);
-    load_w1(1);
-    store_w1(w1s + G::W1_BYTES);
-    __syncthreads();
-
-    // first GEMM of chunk 0 (not overlapped with anything)
-    // b1 enters every first-GEMM accumulator as its INITIAL value (register r: value unit, r + 8: its gate), like the C operand of
-    // mlp3_kernel's first MFMA: the three feed-forward kernels run the same MFMA chain on the same operands and give the same bits
-    auto bias_init = [&](int jc, f32x16& a) {
-        const int u0 = jc * 16 + 4 * half;
-        const float4 v0 = *reinterpret_cast<const float4*>(lb1 + u0), v1 = *reinterpret_cast<const float4*>(lb1 + u0 + 8);
-        const float4 g0 = *reinterpret_cast<const float4*>(lb1 + G::HID + u0), g1 = *reinterpret_cast<const float4*>(lb1 + G::HID + u0 + 8);
-        a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w; a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
-        a[8] = g0.x; a[9] = g0.y; a[10] = g0.z; a[11] = g0.w; a[12] = g1.x; a[13] = g1.y; a[14] = g1.z; a[15] = g1.w;
-    };
-    f32x16 acur;
-    {
-        bias_init(0, acur);
-        const uint8_t* wt = w1s + l31 * G::ROWB1 + half * 16;
-        typename E::v8 wf[4][1];
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            rp_load_group<DT, KC>(wf, wt, g * 4);
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) acur = E::mfma32(wf[cc][0], xf[g * 4 + cc], acur);
-        }
-    }
-    __syncthreads();  // W1 stage 0 is overwritten at the end of iteration 0
-
-#if MLP_PIPE2
-    // Three-stage software pipeline, one iteration = one 16-unit hidden chunk jc:
-    //   matrix pipe: second GEMM of chunk jc-1 (8 MFMAs, operands fetched one iteration ago) + first GEMM of chunk jc+1 (16 MFMAs)
-    //   VALU:        GEGLU arithmetic of chunk jc
-    // The 24 MFMAs depend on nothing the iteration's VALU work produces, so the ~160 VALU instructions can be dealt between
-    // them (a wave's own VALU issues underneath its MFMAs; another wave's does not -- tools/probes/pair.hip); the
-    // sched_group_barrier sequence below asks for exactly that deal.  The former schedule ran the second GEMM of chunk jc in
-    // the same iteration as its GEGLU: half of the VALU stream had no MFMA to hide under and 13 MFMAs ran bare.
-    typename E::v8 hb_prev;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) hb_prev[r] = (typename E::elem)0.f;
-    u32x2 w2lo_p[G::CT], w2hi_p[G::CT];
-#pragma unroll
-    for (int ct = 0; ct < G::CT; ++ct) w2lo_p[ct] = w2hi_p[ct] = (u32x2){0u, 0u};
-    for (int jc = 0; jc < G::NCHUNK; ++jc) {
-        if (!(MLP_ABL & 8)) {
-            load_w1(jc + 2 < G::NCHUNK ? jc + 2 : G::NCHUNK - 1);
-            load_w2(jc + 1 < G::NCHUNK ? jc + 1 : G::NCHUNK - 1);
-        }
-        // every LDS read of the iteration is issued here; the second GEMM of chunk jc-1 (register operands) and the first
-        // GEGLU steps run while they are in flight -- one wave per SIMD: nothing else covers that latency
-        const uint8_t* wt = w1s + ((jc + 1) & 1) * G::W1_BYTES + l31 * G::ROWB1 + half * 16;
-        typename E::v8 wf[NG][4][1];
-#pragma unroll
-        for (int g = 0; g < NG; ++g) rp_load_group<DT, KC>(wf[g], wt, g * 4);
-        u32x2 w2lo[G::CT], w2hi[G::CT];  // W2 fragments of chunk jc: consumed next iteration
-        {
-            const uint8_t* w2t = w2s + (jc & 1) * G::W2_BYTES + l31 * G::ROWB2 + half * 8;
-#pragma unroll
-            for (int ct = 0; ct < G::CT; ++ct) {
-                w2lo[ct] = *reinterpret_cast<const u32x2*>(w2t + ct * 32 * G::ROWB2);
-                w2hi[ct] = *reinterpret_cast<const u32x2*>(w2t + ct * 32 * G::ROWB2 + 16);
-            }
-        }
-        f32x16 anxt;
-        bias_init(jc + 1 < G::NCHUNK ? jc + 1 : jc, anxt);
-        typename E::v8 hb;
-        auto geglu_step = [&](int r) {
-            const float v0 = acur[r];
-            const float v1 = acur[r + 1];
-            const apad_f32x2 gt = {acur[8 + r], acur[9 + r]};
-            const apad_f32x2 ge = (MLP_ABL & 1) ? gt : gelu_erf_2(gt);
-            // (the product is formed in fp32 and THEN rounded: left to the compiler, (f16)(a * b) may become one v_fma_mix with a single
-            //  rounding for some elements and not for others -- the three feed-forward kernels must agree bit for bit)
-            float pr0 = v0 * ge[0], pr1 = v1 * ge[1];
-            asm volatile("" : "+v"(pr0), "+v"(pr1));
-            hb[r] = (typename E::elem)pr0;
-            hb[r + 1] = (typename E::elem)pr1;
-        };
-#ifndef MLP_ORDER
-#define MLP_ORDER 0
-#endif
-#if MLP_ORDER == 1  // second GEMM first, then the first GEMM
-#pragma unroll
-        for (int ct = 0; ct < G::CT; ++ct) {
-            typename E::v8 w2f = as_v8<DT>(make_uint4(w2lo_p[ct][0], w2lo_p[ct][1], w2hi_p[ct][0], w2hi_p[ct][1]));
-            if (MLP_ABL & 4) yacc[ct][ct & 7] += (float)w2f[0] * (float)hb_prev[ct & 7];
-            else yacc[ct] = E::mfma32(w2f, hb_prev, yacc[ct]);
-            if (ct == G::CT / 2 - 1) geglu_step(0);
-        }
-        geglu_step(2);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                if (MLP_ABL & 2) anxt[cc] += (float)wf[g][cc][0][0] * (float)xf[g * 4 + cc][0];
-                else anxt = E::mfma32(wf[g][cc][0], xf[g * 4 + cc], anxt);
-            }
-            if (g == 1) geglu_step(4);
-        }
-        geglu_step(6);
-#else  // per fragment group: 2 second-GEMM MFMAs, 4 first-GEMM MFMAs, one GEGLU step
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-#pragma unroll
-            for (int c2 = 0; c2 < G::CT / NG; ++c2) {
-                const int ct = g * (G::CT / NG) + c2;
-                typename E::v8 w2f = as_v8<DT>(make_uint4(w2lo_p[ct][0], w2lo_p[ct][1], w2hi_p[ct][0], w2hi_p[ct][1]));
-                if (MLP_ABL & 4) yacc[ct][c2] += (float)w2f[0] * (float)hb_prev[c2];
-                else yacc[ct] = E::mfma32(w2f, hb_prev, yacc[ct]);
-            }
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                if (MLP_ABL & 2) anxt[cc] += (float)wf[g][cc][0][0] * (float)xf[g * 4 + cc][0];
-                else anxt = E::mfma32(wf[g][cc][0], xf[g * 4 + cc], anxt);
-            }
-            geglu_step(2 * g);
-        }
-#endif
-#ifndef MLP_PIPE2_VALU
-#define MLP_PIPE2_VALU 7
-#endif
-#if MLP_PIPE2_VALU > 0
-#ifdef MLP_DSFIRST
-        __builtin_amdgcn_sched_group_barrier(0x100, 4 * NG + 2 * G::CT + 4, 0);  // the DS reads first
-#endif
-#pragma unroll
-        for (int i = 0; i < 4 * NG + G::CT; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, MLP_PIPE2_VALU, 0);
-        }
-#endif
-        if (!(MLP_ABL & 8)) {
-            store_w1(w1s + (jc & 1) * G::W1_BYTES);
-            store_w2(w2s + ((jc + 1) & 1) * G::W2_BYTES);
-        }
-        if (!(MLP_ABL & 16)) __syncthreads();
-        acur = anxt;
-        hb_prev = hb;
-#pragma unroll
-        for (int ct = 0; ct < G::CT; ++ct) {
-            w2lo_p[ct] = w2lo[ct];
-            w2hi_p[ct] = w2hi[ct];
-        }
-    }
-    // drain: second GEMM of the last chunk
-#pragma unroll
-    for (int ct = 0; ct < G::CT; ++ct) {
-        typename E::v8 w2f = as_v8<DT>(make_uint4(w2lo_p[ct][0], w2lo_p[ct][1], w2hi_p[ct][0], w2hi_p[ct][1]));
-        yacc[ct] = E::mfma32(w2f, hb_prev, yacc[ct]);
-    }
-#endif
-
-    // ---- epilogue: y + b2 + residual(x) through the per-wave transpose scratch ----
-#pragma unroll
-    for (int ct = 0; ct < G::CT; ++ct) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 b4 = *reinterpret_cast<const float4*>(lb2 + ct * 32 + 8 * g + 4 * half);
-            typename E::v4 y;
-            y[0] = (typename E::elem)(yacc[ct][4 * g + 0] + b4.x);
-            y[1] = (typename E::elem)(yacc[ct][4 * g + 1] + b4.y);
-            y[2] = (typename E::elem)(yacc[ct][4 * g + 2] + b4.z);
-            y[3] = (typename E::elem)(yacc[ct][4 * g + 3] + b4.w);
-            *reinterpret_cast<uint2*>(scr + l31 * SCR_ROWB + (8 * g + 4 * half) * 2) = __builtin_bit_cast(uint2, y);
-        }
-        scratch_flush<DT>(scr, 32, p.out, G::C, ct * 32, p.x, G::C, mw0, p.M, lane);
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Two waves per SIMD (round 2).  mlp_kernel keeps a whole 32-token panel's output (128 accumulator registers) in one wave
@@ -542,27 +264,10 @@ template <int DT, int KC, bool LN> int mlp2_launch(const MlpP& p, hipStream_t s)
     return apad_check_launch("apad_geglu_mlp");
 }
 
-template <int DT, int KC, int NWV, bool LN> int mlp_launch(const MlpP& p, hipStream_t s) {
-    using G = MlpCfg<KC>;
-    const size_t lds = 2 * G::STAGE + NWV * SCR_BYTES + (2 * G::HID + G::C) * sizeof(float);
-    auto kern = mlp_kernel<DT, KC, NWV, LN>;
-    static unsigned devs = 0;
-    if (apad_ensure_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds, &devs) != 0) return -1;
-    const int64_t rows_per_wg = NWV * 32;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((p.M + rows_per_wg - 1) / rows_per_wg)), dim3(NWV * 64), lds, s, p);
-    return apad_check_launch("apad_geglu_mlp");
-}
-
 template <int DT, int KC> int mlp_dispatch(const MlpP& p, bool ln, hipStream_t s) {
-    // 4 waves (128 tokens) per workgroup when that still fills the chip, else 2 waves
-    const bool big = (p.M + 127) / 128 >= 256;
-    constexpr int v2 = 1;
-    // (mlp2 from half a chip's worth of 128-token workgroups: the CFG-shared prefix runs this level at 32 x 1000 = 32000 rows = 250 workgroups;
-    //  the one-wave-per-SIMD kernel below stays for the small launches, where its 64-token workgroups fill more CUs)
-    constexpr int v2_min = 128;
-    if (v2 && (p.M + 127) / 128 >= v2_min) return ln ? mlp2_launch<DT, KC, true>(p, s) : mlp2_launch<DT, KC, false>(p, s);
-    if (big) return ln ? mlp_launch<DT, KC, 4, true>(p, s) : mlp_launch<DT, KC, 4, false>(p, s);
-    return ln ? mlp_launch<DT, KC, 2, true>(p, s) : mlp_launch<DT, KC, 2, false>(p, s);
+    // one form for every launch this entry point serves (round 5): the one-wave-per-SIMD 64- / 128-token kernel of rounds 1-4 measured slower at
+    // every size (4 000 rows: 80.6 vs 65.7 us; 16 000: 86.4 vs 67.1) and was removed; launches of >= 48 000 rows take apad_geglu_mlp_packed (mlp3.hip)
+    return ln ? mlp2_launch<DT, KC, true>(p, s) : mlp2_launch<DT, KC, false>(p, s);
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

@@ -73,6 +73,8 @@ template <int N> __device__ __forceinline__ void m3_wait_lgkm() {
 // GEGLU of two hidden units (value v*, gate g*) in four phases of ~8 vector instructions, so that the phases can be placed between the MFMAs of a
 // step by hand (one wave per SIMD: an MFMA covers the few vector instructions issued right behind it, nothing else does).  gelu_erf_2's arithmetic
 // (A&S 7.1.26) in the same operation order -> the same bits as mlp_kernel / mlp2_kernel.
+// (a packed-math form of these phases -- v_pk_mul / v_pk_fma, 22 instead of 31 instructions per pair -- measured SLOWER, 113.0 -> 122.5 us: the
+//  dependent packed operations need hazard s_nops and cost more issue time beside the MFMAs than the scalar ones they replace)
 struct M3Geglu {
     float g0, g1, t0, t1, q0, q1, e0, e1, p0, p1, r0, r1;
     __device__ __forceinline__ void ph1(float ga, float gb) {

@@ -403,7 +403,9 @@ __global__ __launch_bounds__(512) void xattn_kernel(XaP p) {
     // wait for the NEXT tile's rows before this tile's output projection)
     const int vnext = next_valid(v);
     uint32_t xoff_next[2];
-    rows_of(tile_of(vnext >= 0 ? vnext : v), xoff_next);  // the last tile re-requests its own rows: the loads stay unconditional
+    rows_of(tile_of(vnext >= 0 ? vnext : v), xoff_next);
+    if (vnext < 0) xoff_next[0] = xoff_next[1] = NOROW;  // the last tile: the loads stay unconditional but all hit row 0 (round 4 re-requested the
+                                                        // tile's own rows here: half of all tiles fetched twice, 12 MB of the launch's extra reads)
     XA_STAMP(0);
 #ifdef XATTN_TRACE
     if (lane == 0 && wave == 0) g_xa_trace[tile * 32 + 12] = wall_clock64();

@@ -632,8 +632,7 @@ def test_rowpanel_geglu(dev, dtype, M, K, ln):
 @pytest.mark.parametrize("M,C", [(1000, 256), (300, 256), (33000, 256), (37, 256), (16500, 256), (32000, 256)])
 @pytest.mark.parametrize("ln", [False, True])
 def test_geglu_mlp(dev, dtype, M, C, ln):
-    """norm3 + GEGLU + FeedForward.net[2] + residual in one launch (the three workgroup forms -- 64- / 128-token one wave per SIMD, the
-    two-waves-per-SIMD kernel from 128 workgroups -- and a ragged last panel)"""
+    """norm3 + GEGLU + FeedForward.net[2] + residual in one launch (the 128-token-workgroup kernel from unpacked weights; ragged last panels)"""
     from ap_adapter_amd import ops
     x = q(R(M, C, seed=156), dtype)
     w1, b1 = q(R(8 * C, C, seed=157, std=0.08), dtype), q(R(8 * C, seed=158, std=0.5), dtype)
