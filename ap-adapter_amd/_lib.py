@@ -107,6 +107,10 @@ SYMBOLS = {
     "apad_mlp_packed_bias_floats": (_i64, [_i32]),
     "apad_mlp_pack": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "apad_geglu_mlp_packed": (C.c_int, [C.POINTER(MlpDesc), _vp, _vp, _vp]),
+    "apad_geglu_packed_bytes": (_i64, [_i32]),
+    "apad_geglu_packed_bias_floats": (_i64, [_i32]),
+    "apad_geglu_pack": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "apad_layernorm_geglu_packed": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _i32, _vp]),
     "apad_sizeof_xattn_desc": (C.c_int, []),
     "apad_echo_xattn_desc": (C.c_int, [C.POINTER(XattnDesc), C.POINTER(C.c_double), C.c_int]),
     "apad_fused_cross_attention": (C.c_int, [C.POINTER(XattnDesc), _vp]),

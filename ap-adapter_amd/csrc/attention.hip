@@ -964,7 +964,7 @@ __global__ __launch_bounds__(NW * 64) void sattn_fused_kernel(SfP p) {
                 const float s1 = half_sum(ssum[n]), s2 = half_sum(sq[n]);
                 const float md = s1 * (1.0f / C), mean = shift[n] + md;
                 const float var = fmaxf(s2 * (1.0f / C) - md * md, 0.f);
-                const float rstd = ok ? rsqrtf(var + p.eps) : 0.f, nmr = -mean * rstd, okf = ok ? 1.f : 0.f;
+                const float rstd = (SF_ABL & 4) ? (ok ? 1.f : 0.f) : (ok ? rsqrtf(var + p.eps) : 0.f), nmr = (SF_ABL & 4) ? 0.f : -mean * rstd, okf = ok ? 1.f : 0.f;
                 uint8_t* const kt = smem + (key >> 6) * Y::BUF;
                 const int krow = key & 63;
 #pragma unroll

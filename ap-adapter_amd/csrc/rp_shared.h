@@ -196,7 +196,8 @@ __device__ __forceinline__ void load_panel(typename ET<DT>::v8 (&xf)[KC], const 
     for (int c = 0; c < KC; ++c) xf[c] = as_v8<DT>(*reinterpret_cast<const uint4*>(xp + c * 32));
 }
 
-template <int DT, int KC>
+// RECONVERT: the second pass converts the stored values again instead of keeping the first pass's KC * 8 fp32 values alive (a 128-register budget)
+template <int DT, int KC, bool RECONVERT = false>
 __device__ __forceinline__ void layernorm_panel(typename ET<DT>::v8 (&xf)[KC], const uint8_t* gamma, const uint8_t* beta, float eps,
                                                 int l31, int half) {
     using E = ET<DT>;
@@ -220,6 +221,10 @@ __device__ __forceinline__ void layernorm_panel(typename ET<DT>::v8 (&xf)[KC], c
     const float var = fmaxf(q * (1.0f / (KC * 16)) - md * md, 0.f);
     const float rstd = rsqrtf(var + eps);
     const float nmr = -mean * rstd;
+    if (RECONVERT) {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) asm volatile("" : "+v"(xf[c]));
+    }
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
         typename E::v8 g = as_v8<DT>(*reinterpret_cast<const uint4*>(gamma + (c * 16 + half * 8) * 2));

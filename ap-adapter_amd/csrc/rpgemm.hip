@@ -186,6 +186,21 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void rpgemm_kernel(RpP p)
         for (int s = 0; s < C::NT; ++s)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+        if (GEGLU) {
+            // b1 is the accumulators' INITIAL value (register 4 g + j: value column, 8 + 4 g + j: its gate), as in the feed-forward kernels
+            // (mlp.hip, mlp3.hip) and in geglu3.hip, the form the full-size launches of the 384-wide level take: the same MFMA chain on the same
+            // operands -> the same bits, whichever kernel a batch size selects
+#pragma unroll
+            for (int s = 0; s < C::NT; ++s)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const int o = n0 + s * 16 + 8 * g + 4 * half;
+                    const float4 bv4 = *reinterpret_cast<const float4*>(lbias + (o - bias_c0));
+                    const float4 bg4 = *reinterpret_cast<const float4*>(lbias + bias_cols + (o - bias_c0));
+                    acc[s][4 * g + 0] = bv4.x; acc[s][4 * g + 1] = bv4.y; acc[s][4 * g + 2] = bv4.z; acc[s][4 * g + 3] = bv4.w;
+                    acc[s][8 + 4 * g + 0] = bg4.x; acc[s][8 + 4 * g + 1] = bg4.y; acc[s][8 + 4 * g + 2] = bg4.z; acc[s][8 + 4 * g + 3] = bg4.w;
+                }
+        }
 
         if (!vt)
             rp_mainloop<DT, KC, false>(acc, wt, xf);
@@ -202,17 +217,15 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void rpgemm_kernel(RpP p)
                 if (cursor == 0) win_col0 = n0 + s * 16;
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
-                    const int o = n0 + s * 16 + 8 * g + 4 * half;
-                    const float4 bv4 = *reinterpret_cast<const float4*>(lbias + (o - bias_c0));
-                    const float4 bg4 = *reinterpret_cast<const float4*>(lbias + bias_cols + (o - bias_c0));
-                    const float bv[4] = {bv4.x, bv4.y, bv4.z, bv4.w}, bg[4] = {bg4.x, bg4.y, bg4.z, bg4.w};
                     typename E::v4 y;
 #pragma unroll
                     for (int j = 0; j < 4; j += 2) {
-                        const apad_f32x2 gt = {acc[s][8 + 4 * g + j] + bg[j], acc[s][8 + 4 * g + j + 1] + bg[j + 1]};
+                        const apad_f32x2 gt = {acc[s][8 + 4 * g + j], acc[s][8 + 4 * g + j + 1]};
                         const apad_f32x2 ge = (RP_EXPERIMENT & 2) ? gt : gelu_erf_2(gt);
-                        y[j] = (typename E::elem)((acc[s][4 * g + j] + bv[j]) * ge[0]);
-                        y[j + 1] = (typename E::elem)((acc[s][4 * g + j + 1] + bv[j + 1]) * ge[1]);
+                        float pr0 = acc[s][4 * g + j] * ge[0], pr1 = acc[s][4 * g + j + 1] * ge[1];  // fp32 product, then ONE rounding (never a v_fma_mix)
+                        asm volatile("" : "+v"(pr0), "+v"(pr1));
+                        y[j] = (typename E::elem)pr0;
+                        y[j + 1] = (typename E::elem)pr1;
                     }
                     *reinterpret_cast<uint2*>(scr + l31 * SCR_ROWB + (cursor + 8 * g + 4 * half) * 2) = __builtin_bit_cast(uint2, y);
                 }

@@ -636,6 +636,40 @@ def geglu_mlp(x, w1, b1, w2, b2, ln=None, out=None):
     return out
 
 
+# LayerNorm + GEGLU projection of the 384-wide level's feed-forward on the 64-token register-block kernel (csrc/geglu3.hip): routed from
+# GEGLU_PACKED_MIN_M rows (256-token tiles x 4 hidden quarters: 16 128 rows = 252 workgroups); follows MLP_PACKED; bit-equal to the row-panel launch
+GEGLU_PACKED_C = (384,)
+GEGLU_PACKED_MIN_M = 12000
+
+
+def geglu_pack(w1, b1):
+    """GEGLU.proj [8C, C] (+ bias [8C]) -> (the packed stream, the fp32 bias table) of apad_layernorm_geglu_packed"""
+    _req(w1, "geglu_pack.w1")
+    Cc = w1.shape[1]
+    if Cc not in GEGLU_PACKED_C or w1.shape[0] != 8 * Cc or w1.dtype not in FUSED_DTYPES or not w1.is_contiguous():
+        raise ValueError(f"geglu_pack: w1 {tuple(w1.shape)} {w1.dtype} outside the kernel envelope")
+    if b1 is not None and (b1.dtype != w1.dtype or not b1.is_contiguous()):
+        raise ValueError("geglu_pack.b1: must be contiguous and of the weights' dtype")
+    wp = torch.empty(L.lib().apad_geglu_packed_bytes(Cc) // w1.element_size(), dtype=w1.dtype, device=w1.device)
+    bp = torch.empty(L.lib().apad_geglu_packed_bias_floats(Cc), dtype=torch.float32, device=w1.device)
+    L.check(L.lib().apad_geglu_pack(w1.data_ptr(), _ptr(b1), wp.data_ptr(), bp.data_ptr(), Cc, _DT[w1.dtype], _stream()), "apad_geglu_pack")
+    return wp, bp
+
+
+def layernorm_geglu_packed(x, w_packed, b1_packed, ln=None, out=None):
+    """H [..., 4C] = value * gelu(gate), [value | gate] = Linear(LayerNorm(x)) from geglu_pack's weights (one launch)"""
+    _req(x, "layernorm_geglu_packed.x", w_packed.dtype)
+    Cc = x.shape[-1]
+    if Cc not in GEGLU_PACKED_C or x.dtype not in FUSED_DTYPES or not x.is_contiguous() or b1_packed.dtype != torch.float32:
+        raise ValueError(f"layernorm_geglu_packed: x {tuple(x.shape)} {x.dtype} outside the kernel envelope")
+    if out is None:
+        out = torch.empty(*x.shape[:-1], 4 * Cc, dtype=x.dtype, device=x.device)
+    g, b, eps = (ln[0].data_ptr(), ln[1].data_ptr(), float(ln[2])) if ln is not None else (None, None, 0.0)
+    L.check(L.lib().apad_layernorm_geglu_packed(x.data_ptr(), g, b, w_packed.data_ptr(), b1_packed.data_ptr(), out.data_ptr(), x.numel() // Cc, Cc, eps,
+                                                _DT[x.dtype], _stream()), "apad_layernorm_geglu_packed")
+    return out
+
+
 def linear_vt(x, w, B, Lk, heads, out_vt, bias=None):
     """Values projection stored per-head transposed: x [B*Lk, K] @ w[C,K]^T -> out_vt [B, heads, d, Lpad]
     (zero padded by the caller; only l < Lk is written)."""

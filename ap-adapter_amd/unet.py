@@ -185,7 +185,17 @@ class FeedForward(nn.Module):
                 wp, bp = self._packed_weights()
                 return ops.geglu_mlp_packed(x, wp, bp, self.net[2].bias, ln=ln)
             return ops.geglu_mlp(x, self.net[0].proj.weight, self.net[0].proj.bias, self.net[2].weight, self.net[2].bias, ln=ln)
-        h = ops.fused_linear(x, self.net[0].proj.weight, self.net[0].proj.bias, ln=ln, act="geglu")
+        if (ops.MLP_PACKED and x.shape[-1] in ops.GEGLU_PACKED_C and x.dtype in ops.FUSED_DTYPES and x.is_contiguous()
+                and x.numel() // x.shape[-1] >= ops.GEGLU_PACKED_MIN_M):
+            # the 384-wide level at full size: LayerNorm + GEGLU projection on the 64-token register-block kernel from packed weights
+            ps = (self.net[0].proj.weight, self.net[0].proj.bias)
+            key = tuple((id(p), p.data_ptr(), p._version, p.dtype, p.device) for p in ps)
+            if getattr(self, "_geglu3_key", None) != key:
+                self._geglu3_w = ops.geglu_pack(ps[0].detach(), ps[1].detach())
+                self._geglu3_key = key
+            h = ops.layernorm_geglu_packed(x, self._geglu3_w[0], self._geglu3_w[1], ln=ln)
+        else:
+            h = ops.fused_linear(x, self.net[0].proj.weight, self.net[0].proj.bias, ln=ln, act="geglu")
         return ops.linear(h, self.net[2].weight, self.net[2].bias, residual=x, rowstat=True)  # (the next block's norm1 folds into its q|k|v)
 
 

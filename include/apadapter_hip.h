@@ -344,6 +344,17 @@ int64_t apad_mlp_packed_bytes(int32_t C);
 int64_t apad_mlp_packed_bias_floats(int32_t C);
 int apad_mlp_pack(const void* w1, const void* b1, const void* w2, void* w_packed, float* b1_packed, int32_t C, int32_t dtype, void* stream);
 int apad_geglu_mlp_packed(const apad_mlp_desc* d, const void* w_packed, const float* b1_packed, void* stream);
+/* LayerNorm + the GEGLU projection of a feed-forward at C = 384 from PACKED weights (ABI 8; csrc/geglu3.hip): H [M][4C] = value * gelu(gate),
+ * [value | gate] = W1 . LayerNorm(x) + b1 (diffusers GEGLU behind norm3; ln_gamma / ln_beta NULL: no LayerNorm) on the 64-token register-block loop
+ * of apad_geglu_mlp_packed without its second GEMM (4C -> C stays an apad_gemm).  apad_geglu_pack builds the stream once per FeedForward:
+ *   w_packed: [4 hidden quarters][24 chunks of 16 units][24 k-steps][64 lanes][8]: fragment rows 0..15 the chunk's value units, 16..31 their gate rows
+ *   b1_packed: fp32 [4][24][2][16], b1 in the C-layout register order of the lane half
+ * Bit-equal to apad_rowpanel_gemm's GEGLU epilogue (the form smaller launches take).  C = 384 (else -3). */
+int64_t apad_geglu_packed_bytes(int32_t C);
+int64_t apad_geglu_packed_bias_floats(int32_t C);
+int apad_geglu_pack(const void* w1, const void* b1, void* w_packed, float* b1_packed, int32_t C, int32_t dtype, void* stream);
+int apad_layernorm_geglu_packed(const void* x, const void* ln_gamma, const void* ln_beta, const void* w_packed, const float* b1_packed, void* out, int64_t M,
+                                int32_t C, float ln_eps, int32_t dtype, void* stream);
 /* w [256][ldw] (nn.Linear layout) -> packed [8 row slices][16 k-steps][64 lanes][8], 128 KB */
 int apad_xattn_pack_weight(const void* w, void* packed, int64_t ldw, int32_t dtype, void* stream);
 /* bytes of the packed form of one segment's K / V^T: B * 8 heads * ceil(L/32) * 4 KB */

@@ -1255,3 +1255,56 @@ torch.save({"y": y.cpu(), "z": z.cpu()}, sys.argv[2])
         subprocess.run([sys.executable, "-c", script, root, path], check=True, env=env, timeout=600)
         outs.append(torch.load(path))
     assert torch.equal(outs[0]["y"], outs[1]["y"]) and torch.equal(outs[0]["z"], outs[1]["z"])
+
+
+@pytest.mark.parametrize("dtype", DTYPES16)
+@pytest.mark.parametrize("M", [252, 37, 256, 257, 2100, 16128])
+@pytest.mark.parametrize("ln,bias", [(True, True), (False, True), (True, False)])
+def test_layernorm_geglu_packed(dev, dtype, M, ln, bias):
+    """LayerNorm + GEGLU projection at C = 384 on the 64-token register-block kernel from packed weights (apad_geglu_pack +
+    apad_layernorm_geglu_packed): against fp32 torch on the storage-rounded operands, and BIT-EQUAL to the row-panel launch smaller batches take
+    (b1 as the accumulators' initial value in both, the same MFMA chain, the same GELU arithmetic and rounding); ragged / partial tiles, the
+    XCD-padded grid (tiles beyond the last are skipped)"""
+    from ap_adapter_amd import ops
+    C = 384
+    x = q(R(M, C, seed=356), dtype)
+    w1, b1 = q(R(8 * C, C, seed=357, std=0.06), dtype), (q(R(8 * C, seed=358, std=0.5), dtype) if bias else None)
+    g, be = q(1 + 0.1 * R(C, seed=361), dtype), q(0.1 * R(C, seed=362), dtype)
+    xin = q(F.layer_norm(x, (C,), g, be, 1e-5), dtype) if ln else x
+    a, gate = F.linear(xin, w1, b1).chunk(2, dim=-1)
+    ref = a * F.gelu(gate)
+    lnp = (g.to(dev, dtype), be.to(dev, dtype), 1e-5) if ln else None
+    dv = lambda t: None if t is None else t.to(dev, dtype)
+    wp, bp = ops.geglu_pack(dv(w1), dv(b1))
+    out = ops.layernorm_geglu_packed(dv(x), wp, bp, ln=lnp)
+    assert out.shape == ref.shape and rel_err(out, ref) < TOL[dtype]
+    assert torch.equal(out, ops.fused_linear(dv(x), dv(w1), dv(b1), ln=lnp, act="geglu"))
+
+
+def test_layernorm_geglu_packed_route_and_repack(dev, monkeypatch):
+    """FeedForward at C = 384 takes the packed GEGLU kernel from ops.GEGLU_PACKED_MIN_M rows, packs once, re-packs on an in-place update"""
+    from ap_adapter_amd import ops
+    from ap_adapter_amd.unet import FeedForward
+    from ap_adapter_amd.synthetic import init_synthetic_
+    dtype = torch.bfloat16
+    ff = FeedForward(384)
+    init_synthetic_(ff, 5, w_std=0.05, bias_std=0.05)
+    ff = ff.to(dev, dtype).requires_grad_(False)
+    ln = (torch.ones(384, device=dev, dtype=dtype), torch.zeros(384, device=dev, dtype=dtype), 1e-5)
+    x = torch.randn(600, 384, device=dev).to(dtype)
+    calls = []
+    real = ops.layernorm_geglu_packed
+    monkeypatch.setattr(ops, "layernorm_geglu_packed", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    a = ff(x, ln)
+    assert not calls
+    monkeypatch.setattr(ops, "GEGLU_PACKED_MIN_M", 512)
+    b = ff(x, ln)
+    assert len(calls) == 1 and torch.equal(b, a)
+    wp0 = ff._geglu3_w[0]
+    assert ff(x, ln) is not None and ff._geglu3_w[0] is wp0
+    with torch.no_grad():
+        ff.net[0].proj.weight.mul_(0.5)
+    c = ff(x, ln)
+    assert ff._geglu3_w[0] is not wp0 and not torch.equal(b, c)
+    monkeypatch.setattr(ops, "MLP_PACKED", False)
+    assert torch.equal(c, ff(x, ln))

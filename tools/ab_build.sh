@@ -5,7 +5,7 @@ set -e
 R=$(cd "$(dirname "$0")/.." && pwd); C=$R/ap-adapter_amd/csrc; tag=$1; f=$2; shift 2
 mkdir -p $R/exp
 extra=""
-vg="-mllvm -amdgpu-mfma-vgpr-form"; [ "$f" = mlp.hip ] && vg="-mllvm -amdgpu-use-amdgpu-trackers=1"; [ "$f" = mlp3.hip ] && vg=""
+vg="-mllvm -amdgpu-mfma-vgpr-form"; [ "$f" = mlp.hip ] && vg="-mllvm -amdgpu-use-amdgpu-trackers=1"; { [ "$f" = mlp3.hip ] || [ "$f" = geglu3.hip ]; } && vg=""
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $vg $extra "$@" -c $C/$f -o $R/exp/ab_$tag.o
 objs=$(ls $C/*.o | grep -v "/${f%.hip}.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/exp/lib_$tag.so $objs $R/exp/ab_$tag.o

@@ -3,7 +3,7 @@ instruction mix of the first match.   python tools/kstat.py xattn.hip xattn_kern
 import collections, os, re, subprocess, sys
 src, pat = sys.argv[1], sys.argv[2]
 csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ap-adapter_amd", "csrc")
-flags = ["--offload-arch=gfx950", "-O3", "-std=c++17"] + (["-mllvm", "-amdgpu-use-amdgpu-trackers=1"] if src == "mlp.hip" else [] if src == "mlp3.hip" else ["-mllvm", "-amdgpu-mfma-vgpr-form"]) + sys.argv[3:]
+flags = ["--offload-arch=gfx950", "-O3", "-std=c++17"] + (["-mllvm", "-amdgpu-use-amdgpu-trackers=1"] if src == "mlp.hip" else [] if src in ("mlp3.hip", "geglu3.hip") else ["-mllvm", "-amdgpu-mfma-vgpr-form"]) + sys.argv[3:]
 r = subprocess.run(["/opt/rocm/bin/hipcc", *flags, "-S", "--cuda-device-only", src, "-o", "/tmp/kstat.s", "-Rpass-analysis=kernel-resource-usage"],
                    cwd=csrc, capture_output=True, text=True)
 if r.returncode:

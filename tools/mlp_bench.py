@@ -32,12 +32,13 @@ R = lambda *s, std=1.0: (torch.randn(*s, device=dev) * std).to(dt)
 w1, b1, w2, b2 = R(8 * C, C, std=0.06), R(8 * C, std=0.3), R(C, 4 * C, std=0.04), R(C, std=0.3)
 ln = (1 + 0.1 * R(C), 0.1 * R(C), 1e-5)
 wp, bp = ops.mlp_pack(w1, b1, w2)
-for M in [int(a) for a in sys.argv[1:]] or [64000, 32000]:
-    x = R(M, C)
-    o1, o2 = torch.empty_like(x), torch.empty_like(x)
-    t_old = timeit(lambda: ops.geglu_mlp(x, w1, b1, w2, b2, ln=ln, out=o1))
-    t_new = timeit(lambda: ops.geglu_mlp_packed(x, wp, bp, b2, ln=ln, out=o2))
-    gf = 2.0 * M * C * 12 * C / 1e9
-    diff = float((o1.float() - o2.float()).abs().max() / o1.float().abs().max())
-    print(f"M={M}: geglu_mlp {t_old:7.1f} us ({gf / t_old * 1e3:6.0f} TF/s)   packed {t_new:7.1f} us ({gf / t_new * 1e3:6.0f} TF/s)   rel diff {diff:.2e}"
-          f"   lib={os.environ.get('APAD_LIB_PATH', 'product')}", flush=True)
+if __name__ == "__main__":
+  for M in [int(a) for a in sys.argv[1:]] or [64000, 32000]:
+      x = R(M, C)
+      o1, o2 = torch.empty_like(x), torch.empty_like(x)
+      t_old = timeit(lambda: ops.geglu_mlp(x, w1, b1, w2, b2, ln=ln, out=o1))
+      t_new = timeit(lambda: ops.geglu_mlp_packed(x, wp, bp, b2, ln=ln, out=o2))
+      gf = 2.0 * M * C * 12 * C / 1e9
+      diff = float((o1.float() - o2.float()).abs().max() / o1.float().abs().max())
+      print(f"M={M}: geglu_mlp {t_old:7.1f} us ({gf / t_old * 1e3:6.0f} TF/s)   packed {t_new:7.1f} us ({gf / t_new * 1e3:6.0f} TF/s)   rel diff {diff:.2e}"
+            f"   lib={os.environ.get('APAD_LIB_PATH', 'product')}", flush=True)

@@ -66,6 +66,14 @@ elif op in ("mlp384", "mlp384_chain"):
         def fn():
             h = ops.fused_linear(x, w1, b1, ln=(g, be, 1e-5), act="geglu")
             return ops.linear(h, w2, b2, residual=x, out=out)
+elif op in ("geglu3", "rp_geglu384"):
+    M, C = B2 * 252, 384
+    x = R(M, C); g = R(C); be = R(C); w1 = R(8 * C, C, std=0.02); b1 = R(8 * C, std=0.02); og = torch.empty(M, 4 * C, device=dev, dtype=dt)
+    if op == "geglu3":
+        wp, bp = ops.geglu_pack(w1, b1)
+        fn = lambda: ops.layernorm_geglu_packed(x, wp, bp, ln=(g, be, 1e-5), out=og)
+    else:
+        fn = lambda: ops.fused_linear(x, w1, b1, ln=(g, be, 1e-5), act="geglu", out=og)
 elif op in ("xrows", "xrows_chain"):
     C = int(os.environ.get("XC", "384"))
     N, H, Lt, La = (252 if C == 384 else 64), 8, 8, int(os.environ.get("LA", "32"))

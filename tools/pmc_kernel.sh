@@ -13,7 +13,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_WAVES GRBM_GUI_ACTIVE" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  rocprofv3 --pmc $set -d $OUT/p$i -o p -- python $R/tools/one_op.py $OP 5 > $OUT/p$i.log 2>&1
+  timeout 240 rocprofv3 --pmc $set -d $OUT/p$i -o p -- python $R/tools/one_op.py $OP 5 > $OUT/p$i.log 2>&1
   db=$(find $OUT/p$i -name "*.db" | head -1)
   [ -n "$db" ] && python $R/tools/pmc_summary.py $db "$SUB"
 done 2>&1 | tee $OUT/summary.txt

@@ -1,0 +1,103 @@
+// Issue-model microbenchmark for one gfx950 SIMD: cycles per group of (1 MFMA 32x32x16 bf16 + NV independent VALU instructions), as a function of NV, the
+// VALU kind, where the accumulators / operands live (VGPR or AGPR) and the number of waves per SIMD.  s_memtime around the loop of wave 0 of every workgroup.
+//   build: hipcc --offload-arch=gfx950 -O3 -o exp/issue tools/ubench/issue.hip        run: exp/issue
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+typedef float V16 __attribute__((ext_vector_type(16)));
+typedef short B8 __attribute__((ext_vector_type(8)));
+
+enum { K_FMA = 0, K_EXP = 1, K_PKFMA = 2, K_CVT = 3, K_DSREAD = 4, K_MUL = 5 };
+
+template <int NV, int KIND, bool ACC_A, bool OPB_A, bool MF>
+__global__ __launch_bounds__(512) void k(uint64_t* out, int iters) {
+    __shared__ __attribute__((aligned(16))) char sm[65536];
+    V16 acc0 = {0}, acc1 = {0};
+    B8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (short)(threadIdx.x + i); b[i] = (short)(threadIdx.x * 3 + i); }
+    float x[8];
+    for (int i = 0; i < 8; ++i) x[i] = threadIdx.x * 0.001f + i;
+    typedef float F2 __attribute__((ext_vector_type(2)));
+    F2 y[8];
+    for (int i = 0; i < 8; ++i) y[i] = F2{x[i], x[i] + 1};
+    float c1 = 1.0001f, c2 = 0.5f;
+    uint32_t laddr = (uint32_t)(uintptr_t)sm + threadIdx.x * 16;
+    typedef uint32_t U4 __attribute__((ext_vector_type(4)));
+    U4 d[8];
+    for (int i = 0; i < 8; ++i) d[i] = U4{0, 0, 0, 0};
+    if (OPB_A) asm volatile("" : "+a"(b));
+    uint64_t t0, t1;
+    asm volatile("s_waitcnt lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (MF) {
+                if (ACC_A) {
+                    if (OPB_A) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(h ? acc1 : acc0) : "v"(a), "a"(b));
+                    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(h ? acc1 : acc0) : "v"(a), "v"(b));
+                } else {
+                    if (OPB_A) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(h ? acc1 : acc0) : "v"(a), "a"(b));
+                    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(h ? acc1 : acc0) : "v"(a), "v"(b));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                if (KIND == K_FMA) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[j & 7]) : "v"(c1), "v"(c2));
+                if (KIND == K_MUL) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x[j & 7]) : "v"(c1));
+                if (KIND == K_EXP) asm volatile("v_exp_f32 %0, %0" : "+v"(x[j & 7]));
+                if (KIND == K_PKFMA) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(y[j & 7]) : "v"(y[(j + 1) & 7]));
+                if (KIND == K_CVT) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(x[j & 7]) : "v"(c1));
+                if (KIND == K_DSREAD) asm volatile("ds_read_b128 %0, %1" : "=v"(d[j & 7]) : "v"(laddr));
+            }
+            if (KIND == K_DSREAD) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+    asm volatile("s_nop 7\n s_nop 7\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+    float s = 0;
+    if (ACC_A) { asm volatile("" : "+a"(acc0), "+a"(acc1)); }
+    for (int i = 0; i < 16; ++i) s += acc0[i] + acc1[i];
+    for (int i = 0; i < 8; ++i) s += x[i] + y[i][0] + y[i][1] + __uint_as_float(d[i][0]);
+    if (s == 1234.5678f) out[1000000] = 1;
+    if ((threadIdx.x & 63) == 0 && threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
+}
+
+template <int NV, int KIND, bool ACC_A, bool OPB_A, bool MF>
+double run(int threads, uint64_t* dout, int iters = 2000) {
+    const int nb = 256;
+    k<NV, KIND, ACC_A, OPB_A, MF><<<nb, threads>>>(dout, iters);
+    k<NV, KIND, ACC_A, OPB_A, MF><<<nb, threads>>>(dout, iters);
+    hipDeviceSynchronize();
+    std::vector<uint64_t> h(nb);
+    hipMemcpy(h.data(), dout, nb * 8, hipMemcpyDeviceToHost);
+    double s = 0;
+    for (auto v : h) s += (double)v;
+    return s / nb / iters / 2;  // cycles per group
+}
+
+template <int KIND, bool ACC_A, bool OPB_A>
+void sweep(const char* name, uint64_t* dout) {
+    for (int threads : {256, 512}) {
+        printf("%-8s acc=%s b=%s waves/SIMD=%d | NV: cycles/group with MFMA (VALU only)\n", name, ACC_A ? "AGPR" : "VGPR", OPB_A ? "AGPR" : "VGPR", threads / 256);
+#define ONE(NV) printf("   NV=%2d: %6.1f (%6.1f)\n", NV, run<NV, KIND, ACC_A, OPB_A, true>(threads, dout), run<NV, KIND, ACC_A, OPB_A, false>(threads, dout));
+        ONE(0) ONE(2) ONE(4) ONE(6) ONE(8) ONE(12) ONE(16)
+#undef ONE
+    }
+}
+
+int main() {
+    uint64_t* dout;
+    hipMalloc(&dout, 8 * 1000016);
+    sweep<K_FMA, false, false>("fma", dout);
+    sweep<K_FMA, true, false>("fma", dout);
+    sweep<K_FMA, false, true>("fma", dout);
+    sweep<K_FMA, true, true>("fma", dout);
+    sweep<K_MUL, false, false>("mul", dout);
+    sweep<K_EXP, false, false>("exp", dout);
+    sweep<K_PKFMA, false, false>("pk_fma", dout);
+    sweep<K_PKFMA, true, false>("pk_fma", dout);
+    sweep<K_CVT, false, false>("cvt_pk", dout);
+    sweep<K_DSREAD, false, false>("ds_read", dout);
+    return 0;
+}
