@@ -94,20 +94,25 @@ __device__ __forceinline__ float erf_as(float x) {
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
 
 // Two GELUs at once on packed fp32 math (v_pk_mul/fma_f32 process two lanes-worth per instruction; only rcp / exp2 stay
-// scalar).  Same A&S 7.1.26 erf as erf_as.
+// scalar).  A&S 7.1.26 with the argument scaled ONCE: z' = x sqrt(log2(e) / 2), so that exp(-x^2 / 2) = exp2(-z'^2) (the negation is a source
+// modifier) and the rational argument is |z'| p' with p' = p / sqrt(log2 e) -- two multiplies per value fewer than scaling x / sqrt 2 and
+// z^2 log2(e) separately.  Every GEGLU kernel of the library evaluates THIS operation order (the phased form: M3Geglu, mlp3_shared.h), which
+// is what makes a row's result independent of the kernel its batch size selects.
 typedef float apad_f32x2 __attribute__((ext_vector_type(2)));
+constexpr float APAD_GELU_K1 = 0.84932180028801904272f;  // sqrt(log2(e) / 2)
+constexpr float APAD_GELU_P1 = 0.2727374808792225f;       // 0.3275911 / sqrt(log2(e))
 __device__ __forceinline__ apad_f32x2 gelu_erf_2(apad_f32x2 x) {
-    const apad_f32x2 z = x * 0.70710678118654752440f;
+    const apad_f32x2 z = x * APAD_GELU_K1;
     const apad_f32x2 az = {fabsf(z[0]), fabsf(z[1])};
-    const apad_f32x2 d = __builtin_elementwise_fma(az, (apad_f32x2){0.3275911f, 0.3275911f}, (apad_f32x2){1.0f, 1.0f});
+    const apad_f32x2 d = __builtin_elementwise_fma(az, (apad_f32x2){APAD_GELU_P1, APAD_GELU_P1}, (apad_f32x2){1.0f, 1.0f});
     const apad_f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
     apad_f32x2 p = __builtin_elementwise_fma(t, (apad_f32x2){1.061405429f, 1.061405429f}, (apad_f32x2){-1.453152027f, -1.453152027f});
     p = __builtin_elementwise_fma(p, t, (apad_f32x2){1.421413741f, 1.421413741f});
     p = __builtin_elementwise_fma(p, t, (apad_f32x2){-0.284496736f, -0.284496736f});
     p = __builtin_elementwise_fma(p, t, (apad_f32x2){0.254829592f, 0.254829592f});
-    const apad_f32x2 a2 = az * az * -1.4426950408889634f;
-    const apad_f32x2 e = {__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};
-    const apad_f32x2 r = __builtin_elementwise_fma(p * t, -e, (apad_f32x2){1.0f, 1.0f});  // erf(|z|)
+    const apad_f32x2 q = z * z;
+    const apad_f32x2 e = {__builtin_amdgcn_exp2f(-q[0]), __builtin_amdgcn_exp2f(-q[1])};
+    const apad_f32x2 r = __builtin_elementwise_fma(p * t, -e, (apad_f32x2){1.0f, 1.0f});  // erf(|x| / sqrt 2)
     const apad_f32x2 hx = x * 0.5f;
     // 0.5 x (1 + sign(x) erf|z|) = hx + |hx| * erf|z|
     const apad_f32x2 ahx = {fabsf(hx[0]), fabsf(hx[1])};

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(512, 1) void geglu3_kernel(G3P p) {
         u32x4 bq[4], f0[2], f1[2], f2[2];  // fragments two steps ahead (eight waves share the LDS pipe: one step ahead left every step waiting on it)
         if (G3_ABL & 64) f0[0] = f0[1] = f1[0] = f1[1] = f2[0] = f2[1] = u32x4{0u, 0u, 0u, 0u};
         V8 hn;
-        M3Geglu gg;
+        M3Geglu<DT> gg;
         m3_read<0>(bq[0], ta);
         m3_read<16>(bq[1], ta);
         m3_read<32>(bq[2], ta);
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(512, 1) void geglu3_kernel(G3P p) {
     // ---- the last chunk's GEGLU (a0 after an even number of iterations) ----
     {
         V8 hn;
-        M3Geglu gg;
+        M3Geglu<DT> gg;
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");  // (the accumulators were written by the MFMAs right above)
 #pragma unroll
         for (int r = 0; r < 8; r += 2) {
@@ -353,11 +353,12 @@ __global__ void geglu3_pack_kernel(const uint8_t* w1, const uint8_t* b1, uint8_t
         const int ch = (int)(e / (G3_STAGE / 2)), r = (int)(e % (G3_STAGE / 2));  // ch = part * 24 + chunk: units 16 ch .. 16 ch + 15
         const int ks = r / 512, rem = r % 512, lane = rem / 8, j = rem % 8, hf = lane >> 5, l31 = lane & 31;
         const int row = l31 < 16 ? ch * 16 + l31 : G3_HID + ch * 16 + (l31 - 16);
-        reinterpret_cast<elem*>(wpk)[e] = reinterpret_cast<const elem*>(w1)[(int64_t)row * G3_C + ks * 16 + hf * 8 + j];
+        const elem v = reinterpret_cast<const elem*>(w1)[(int64_t)row * G3_C + ks * 16 + hf * 8 + j];
+        reinterpret_cast<elem*>(wpk)[e] = l31 < 16 ? (elem)((float)v * m3_value_scale<DT>()) : v;  // (the value rows carry GEGLU's 1/2: M3GegluT<PRE>)
     }
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < G3_PARTS * G3_NCH * 32; t += gridDim.x * blockDim.x) {
         const int ch = t / 32, hf = (t % 32) / 16, r = t % 16, u = ((r & 7) & 3) + 8 * ((r & 7) >> 2) + 4 * hf;
-        b1p[t] = b1 != nullptr ? (float)reinterpret_cast<const elem*>(b1)[(r < 8 ? 0 : G3_HID) + ch * 16 + u] : 0.f;
+        b1p[t] = b1 != nullptr ? (float)reinterpret_cast<const elem*>(b1)[(r < 8 ? 0 : G3_HID) + ch * 16 + u] * (r < 8 ? m3_value_scale<DT>() : 1.0f) : 0.f;
     }
 }
 

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(Mlp3P p) {
         __builtin_amdgcn_sched_barrier(0);
 
         using EL = typename E::elem;
-        M3Geglu gg;
+        M3Geglu<DT> gg;
         // one step of gemm2 (chunk i - 2): output-column tiles ct, ct + 1 x two panels, the GEGLU of hidden units r, r + 1 of panel 0 between the MFMAs
         auto step2 = [&](const u32x4 (&f)[2], int ct, int r, int q) __attribute__((always_inline)) {
             const V8 w0 = __builtin_bit_cast(V8, f[0]), w1 = __builtin_bit_cast(V8, f[1]);
@@ -322,6 +322,7 @@ __global__ void mlp3_pack_kernel(const uint8_t* w1, const uint8_t* b1, const uin
             if (i < M3_NCH) {
                 const int row = l31 < 16 ? i * 16 + l31 : M3_HID + i * 16 + (l31 - 16);
                 v = reinterpret_cast<const elem*>(w1)[(int64_t)row * M3_C + frag * 16 + hf * 8 + j];
+                if (l31 < 16) v = (elem)((float)v * m3_value_scale<DT>());  // (the value rows carry GEGLU's 1/2: M3GegluT<PRE>)
             }
         } else {  // W2 of chunk i - 2, output-column tile frag - 16: the k slot (half, j) holds hidden unit (j & 3) + 8 (j >> 2) + 4 half
             const int c = i - 2, ct = frag - 16;
@@ -332,7 +333,7 @@ __global__ void mlp3_pack_kernel(const uint8_t* w1, const uint8_t* b1, const uin
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < M3_NIT * 32; t += gridDim.x * blockDim.x) {
         const int i = t / 32, hf = (t % 32) / 16, r = t % 16, u = ((r & 7) & 3) + 8 * ((r & 7) >> 2) + 4 * hf;
         float v = 0.f;
-        if (i < M3_NCH && b1 != nullptr) v = (float)reinterpret_cast<const elem*>(b1)[(r < 8 ? 0 : M3_HID) + i * 16 + u];
+        if (i < M3_NCH && b1 != nullptr) v = (float)reinterpret_cast<const elem*>(b1)[(r < 8 ? 0 : M3_HID) + i * 16 + u] * (r < 8 ? m3_value_scale<DT>() : 1.0f);
         b1p[t] = v;
     }
 }

@@ -3,10 +3,6 @@
 #pragma once
 #include "rp_shared.h"
 
-#ifndef M3_NOZ
-#define M3_NOZ 0       // 1: erf argument scale folded into the constants (one multiply less per value; not bit-equal to gelu_erf_2 any more)
-#endif
-
 namespace {
 
 typedef __attribute__((address_space(3))) void* m3_lds_ptr;
@@ -29,25 +25,22 @@ template <int N> __device__ __forceinline__ void m3_wait_lgkm() {
 // (A&S 7.1.26) in the same operation order -> the same bits as mlp_kernel / mlp2_kernel.
 // (a packed-math form of these phases -- v_pk_mul / v_pk_fma, 22 instead of 31 instructions per pair -- measured SLOWER, 113.0 -> 122.5 us: the
 //  dependent packed operations need hazard s_nops and cost more issue time beside the MFMAs than the scalar ones they replace)
-struct M3Geglu {
+// PRE: the value half arrives pre-multiplied by 0.5 (apad_mlp_pack / apad_geglu_pack halve the value rows of W1 and b1 for bf16 -- exact: a power of
+// two commutes with every rounding on the way), so gelu(g) v = (g + |g| erf) (v / 2) needs no `0.5 g`; f16 keeps the multiply (halving a weight
+// below 2^-14 would lose its last bit).  Either way the same bits as gelu_erf_2's  (h + |h| erf) v,  h = g / 2.
+template <bool PRE> struct M3GegluT {
     float g0, g1, t0, t1, q0, q1, e0, e1, p0, p1, r0, r1;
     __device__ __forceinline__ void ph1(float ga, float gb) {
         g0 = ga; g1 = gb;
-#if M3_NOZ
-        t0 = __builtin_amdgcn_rcpf(fmaf(fabsf(g0), 0.3275911f * 0.70710678118654752440f, 1.0f));
-        t1 = __builtin_amdgcn_rcpf(fmaf(fabsf(g1), 0.3275911f * 0.70710678118654752440f, 1.0f));
-        q0 = g0 * g0; q1 = g1 * g1;
-#else
-        const float z0 = g0 * 0.70710678118654752440f, z1 = g1 * 0.70710678118654752440f;
-        t0 = __builtin_amdgcn_rcpf(fmaf(fabsf(z0), 0.3275911f, 1.0f));
-        t1 = __builtin_amdgcn_rcpf(fmaf(fabsf(z1), 0.3275911f, 1.0f));
+        const float z0 = g0 * APAD_GELU_K1, z1 = g1 * APAD_GELU_K1;
+        t0 = __builtin_amdgcn_rcpf(fmaf(fabsf(z0), APAD_GELU_P1, 1.0f));
+        t1 = __builtin_amdgcn_rcpf(fmaf(fabsf(z1), APAD_GELU_P1, 1.0f));
         q0 = z0 * z0; q1 = z1 * z1;
-#endif
         asm volatile("" : "+v"(t0), "+v"(t1), "+v"(q0), "+v"(q1));  // (anchors: the phase is computed HERE, between the MFMAs around it)
     }
     __device__ __forceinline__ void ph2() {
-        e0 = __builtin_amdgcn_exp2f(q0 * (M3_NOZ ? -0.5f * 1.4426950408889634f : -1.4426950408889634f));
-        e1 = __builtin_amdgcn_exp2f(q1 * (M3_NOZ ? -0.5f * 1.4426950408889634f : -1.4426950408889634f));
+        e0 = __builtin_amdgcn_exp2f(-q0);
+        e1 = __builtin_amdgcn_exp2f(-q1);
         p0 = fmaf(fmaf(t0, 1.061405429f, -1.453152027f), t0, 1.421413741f);
         p1 = fmaf(fmaf(t1, 1.061405429f, -1.453152027f), t1, 1.421413741f);
         asm volatile("" : "+v"(e0), "+v"(e1), "+v"(p0), "+v"(p1));
@@ -61,10 +54,13 @@ struct M3Geglu {
     }
     template <typename V8, typename EL> __device__ __forceinline__ void ph4(float v0, float v1, V8& hn, int r) {
         // (one value after the other: the SLP vectoriser pairs them into v_pk_* otherwise, each followed by a hazard s_nop)
-        float h0 = g0 * 0.5f;
-        asm volatile("" : "+v"(h0));
-        float h1 = g1 * 0.5f;
-        asm volatile("" : "+v"(h1));
+        float h0 = g0, h1 = g1;
+        if (!PRE) {
+            h0 *= 0.5f;
+            asm volatile("" : "+v"(h0));
+            h1 *= 0.5f;
+            asm volatile("" : "+v"(h1));
+        }
         float u0 = fmaf(fabsf(h0), r0, h0);
         asm volatile("" : "+v"(u0));
         float u1 = fmaf(fabsf(h1), r1, h1);
@@ -77,6 +73,8 @@ struct M3Geglu {
         hn[r + 1] = (EL)u1;
     }
 };
+template <int DT> using M3Geglu = M3GegluT<DT == APAD_BF16>;
+template <int DT> constexpr float m3_value_scale() { return DT == APAD_BF16 ? 0.5f : 1.0f; }
 
 // gemm1's MFMAs are inline asm with VGPR accumulators: the compiler's MFMAs of this function are the AGPR form (the 256 output accumulators fill the
 // AGPR file), and an AGPR-form accumulator for gemm1 would have to be copied out through v_accvgpr_read for the GEGLU arithmetic (and, with 320
