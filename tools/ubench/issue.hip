@@ -8,7 +8,7 @@
 typedef float V16 __attribute__((ext_vector_type(16)));
 typedef short B8 __attribute__((ext_vector_type(8)));
 
-enum { K_FMA = 0, K_EXP = 1, K_PKFMA = 2, K_CVT = 3, K_DSREAD = 4, K_MUL = 5 };
+enum { K_FMA = 0, K_EXP = 1, K_PKFMA = 2, K_CVT = 3, K_DSREAD = 4, K_MUL = 5, K_PKADD = 6, K_DOT2BF = 7, K_ADD = 8 };
 
 template <int NV, int KIND, bool ACC_A, bool OPB_A, bool MF>
 __global__ __launch_bounds__(512) void k(uint64_t* out, int iters) {
@@ -48,6 +48,9 @@ __global__ __launch_bounds__(512) void k(uint64_t* out, int iters) {
                 if (KIND == K_MUL) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x[j & 7]) : "v"(c1));
                 if (KIND == K_EXP) asm volatile("v_exp_f32 %0, %0" : "+v"(x[j & 7]));
                 if (KIND == K_PKFMA) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(y[j & 7]) : "v"(y[(j + 1) & 7]));
+                if (KIND == K_PKADD) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(y[j & 7]) : "v"(y[(j + 1) & 7]));
+                if (KIND == K_DOT2BF) asm volatile("v_dot2_f32_bf16 %0, %1, %2, %0" : "+v"(x[j & 7]) : "v"(c1), "v"(c2));
+                if (KIND == K_ADD) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[j & 7]) : "v"(c1));
                 if (KIND == K_CVT) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(x[j & 7]) : "v"(c1));
                 if (KIND == K_DSREAD) asm volatile("ds_read_b128 %0, %1" : "=v"(d[j & 7]) : "v"(laddr));
             }
@@ -86,9 +89,15 @@ void sweep(const char* name, uint64_t* dout) {
     }
 }
 
-int main() {
+int main(int argc, char** argv) {
     uint64_t* dout;
     hipMalloc(&dout, 8 * 1000016);
+    if (argc > 1) {  // the softmax-denominator candidates only
+        sweep<K_ADD, false, false>("add", dout);
+        sweep<K_PKADD, false, false>("pk_add", dout);
+        sweep<K_DOT2BF, false, false>("dot2_bf16", dout);
+        return 0;
+    }
     sweep<K_FMA, false, false>("fma", dout);
     sweep<K_FMA, true, false>("fma", dout);
     sweep<K_FMA, false, true>("fma", dout);
