@@ -25,7 +25,7 @@ namespace {
 constexpr int G3_C = 384, G3_KS = G3_C / 16, G3_HID = 4 * G3_C, G3_PARTS = 4, G3_NCH = G3_HID / 16 / G3_PARTS;  // 24 k-steps; 24 chunks per part
 constexpr int G3_NW = 8;                           // waves per workgroup: 32 tokens each, two per SIMD
 constexpr int G3_STAGE = G3_KS * 1024;             // 24 576: the 24 fragments of one chunk
-constexpr int G3_NS = 3;                            // ring slots: stage i + 2 is written (from registers) while stage i is read
+constexpr int G3_NS = 6;
 constexpr int G3_RING = G3_NS * G3_STAGE;          // 147 456
 constexpr int G3_B1_BYTES = G3_NCH * 2 * 16 * 4;   // this part's b1, fp32 [chunk][half][16] in C-layout register order
 constexpr int G3_TROWS = 32 * 400;                 // a wave's transposition region (32 rows of 384 bytes + 16 of padding)
@@ -100,27 +100,19 @@ __global__ __launch_bounds__(512, 1) void geglu3_kernel(G3P p) {
     const int64_t mw0 = ((int64_t)mtile * G3_NW + wave) * 32;
     G3_STAMP(0);
 
-    // the weight stream reaches LDS THROUGH REGISTERS: a wave fetches its three 1 KB pieces of stage i + 2 right behind iteration i's barrier (16-byte loads,
-    // 4 cycles of issue each) and writes them at the iteration's end.  The LDS-DMA (`buffer_load ... lds`) fills at the same rate but holds the issuing wave
-    // for 98 cycles per piece (tools/ubench/dmaissue.hip) -- 294 of an iteration's ~2 300 cycles on the SIMD's shared issue port.
-    typedef const __attribute__((address_space(1))) uint8_t* g3_wptr;
-    typedef const __attribute__((address_space(1))) u32x4* g3_wptr16;
-    g3_wptr wsrc;
-    {
-        const uint64_t wa_ = reinterpret_cast<uint64_t>(p.wpk) + (uint64_t)part * (G3_NCH * G3_STAGE) + (uint64_t)wave * 3072;
-        const uint32_t wlo = __builtin_amdgcn_readfirstlane((uint32_t)wa_), whi = __builtin_amdgcn_readfirstlane((uint32_t)(wa_ >> 32));
-        wsrc = (g3_wptr)(((uint64_t)whi << 32) | wlo);
-    }
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.wpk), 0, G3_PARTS * G3_NCH * G3_STAGE, 0x00020000);
     const uint32_t dvoff = (uint32_t)(lane * 16);
-    auto stage_load = [&](u32x4 (&w)[3], int stage) __attribute__((always_inline)) {
-#pragma unroll
-        for (int q = 0; q < 3; ++q) w[q] = *(g3_wptr16)(wsrc + (uint32_t)(stage * G3_STAGE + q * 1024) + dvoff);
-    };
-    auto stage_write = [&](const u32x4 (&w)[3], int slot) __attribute__((always_inline)) {
-        const uint32_t a_ = (uint32_t)(size_t)(m3_lds_ptr)smem + (uint32_t)(slot * G3_STAGE + wave * 3072) + dvoff;
-        g3_write<0>(a_, w[0]);
-        g3_write<1024>(a_, w[1]);
-        g3_write<2048>(a_, w[2]);
+    const int part_off = part * G3_NCH * G3_STAGE;
+    auto dma = [&](int stage, int slot, int q) __attribute__((always_inline)) {
+        if (G3_ABL & 8) return;
+        // (the immediate offset moves the memory address AND the LDS address: the wave's three 1 KB pieces of a stage share one M0 / scalar offset)
+        const m3_lds_ptr lp = (m3_lds_ptr)(smem + slot * G3_STAGE + wave * 3072);
+        const int so = part_off + stage * G3_STAGE + wave * 3072;
+        switch (q) {
+            case 0: __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, lp, 16, dvoff, so, 0, 0); break;
+            case 1: __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, lp, 16, dvoff, so, 1024, 0); break;
+            default: __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, lp, 16, dvoff, so, 2048, 0); break;
+        }
     };
 
     // ---- the wave's 32 rows of x: 24 COALESCED 16-byte loads per lane (a load instruction covers 1 KB in runs of 384 bytes; the fragment layout --
@@ -153,6 +145,10 @@ __global__ __launch_bounds__(512, 1) void geglu3_kernel(G3P p) {
         const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b1p), 0, G3_PARTS * G3_B1_BYTES, 0x00020000);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (m3_lds_ptr)(smem + G3_B1_OFF + wave * 1024), 16, dvoff, part * G3_B1_BYTES + wave * 1024, 0, 0);
     }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) dma(s, s, q);  // (stages 0, 1 -> slots 0, 1; slots 2.. hold the transposition until the barrier below)
     G3_STAMP(2);
     V8 xf[G3_KS];
     {
@@ -196,14 +192,11 @@ __global__ __launch_bounds__(512, 1) void geglu3_kernel(G3P p) {
     uint8_t* const orow = p.out + ((m0 < p.M ? m0 : 0) * G3_HID + part * (G3_NCH * 16) + 8 * half) * 2;
     const bool ok = m0 < p.M;
     G3_STAMP(4);
-    {   // stages 0, 1 -> slots 0, 1 (below the transposition regions)
-        u32x4 w0[3], w1[3];
-        stage_load(w0, 0);
-        stage_load(w1, 1);
-        stage_write(w0, 0);
-        stage_write(w1, 1);
-    }
-    __syncthreads();  // the bias table and the first two stages are in LDS, every wave is done with the transposition region
+    __syncthreads();  // the bias table is in LDS, every wave is done with the transposition region
+#pragma unroll
+    for (int s = 2; s < G3_NS - 1; ++s)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) dma(s, s, q);
     G3_STAMP(5);
 
     // the activated chunk c (C layout: units 4 half + {0..3}, 8 + 4 half + {0..3}) -> 8 consecutive units per lane -> one 16-byte store
@@ -217,16 +210,15 @@ __global__ __launch_bounds__(512, 1) void geglu3_kernel(G3P p) {
     // iteration i: the 24 MFMAs of chunk i into `anxt` with the GEGLU of chunk i - 1 (`acur`) one phase behind each of the first 16, then the wave's
     // three DMA pieces of chunk i + 5 and the store of chunk i - 1.  Two waves share a SIMD: one wave's phase covers the other's MFMA.
     auto iteration = [&](int i, int slot, f32x16& acur, f32x16& anxt) __attribute__((always_inline)) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (this wave's pieces of stage i + 1, written at the end of the last iteration, are in LDS)
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // stage i has landed for this wave's pieces (stores only make the count stricter)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         if (!(G3_ABL & 16)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         const uint32_t fa = fbase + (uint32_t)(slot * G3_STAGE);
         const uint32_t ta = tbase + (uint32_t)(i * 128);
-        const bool more = i + 2 < G3_NCH;  // (wave-uniform)
-        const int nslot = slot == 0 ? G3_NS - 1 : slot - 1;  // = (i + 2) % 3
-        u32x4 wst[3];
-        if (more) stage_load(wst, i + 2);
+        const int nstage = i + G3_NS - 1 < G3_NCH ? i + G3_NS - 1 : G3_NCH - 1;  // (past the end: a dummy re-load keeps the vmcnt arithmetic uniform)
+        const int nslot = slot == 0 ? G3_NS - 1 : slot - 1;
 
         u32x4 bq[4], f0[2], f1[2], f2[2];  // fragments two steps ahead (eight waves share the LDS pipe: one step ahead left every step waiting on it)
         if (G3_ABL & 64) f0[0] = f0[1] = f1[0] = f1[1] = f2[0] = f2[1] = u32x4{0u, 0u, 0u, 0u};
@@ -253,6 +245,8 @@ __global__ __launch_bounds__(512, 1) void geglu3_kernel(G3P p) {
                     else if ((ph & 3) == 2) gg.ph3();
                     else gg.template ph4<V8, EL>(acur[r], acur[r + 1], hn, r);
                 }
+            } else if (g >= 1 && g <= 3) {
+                dma(nstage, nslot, g - 1);
             }
         };
         auto mf = [&](int m, const V8& w) __attribute__((always_inline)) {
@@ -317,7 +311,6 @@ __global__ __launch_bounds__(512, 1) void geglu3_kernel(G3P p) {
         step(f1, 20);
         m3_wait_lgkm<0>();
         step(f2, 22);
-        if (more) stage_write(wst, nslot);
         if (i >= 1) store_h(hn, i - 1);
     };
 
@@ -347,6 +340,7 @@ __global__ __launch_bounds__(512, 1) void geglu3_kernel(G3P p) {
         }
         store_h(hn, G3_NCH - 1);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the tail's dummy re-loads must land before the workgroup's LDS is released)
     G3_STAMP(37);
 }
 
