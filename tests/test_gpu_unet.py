@@ -352,11 +352,15 @@ def _independent_of_batch(dev, full_pipe, La):
     perm = torch.randperm(32, generator=torch.Generator().manual_seed(1)).to(dev)
     permuted = _run(full_pipe, _rows(d, perm))
     assert torch.equal(permuted, full[perm]), "a clip's result depends on its row in the batch"
-    idx = torch.tensor([3, 17, 30, 8], device=dev)
-    small = _run(full_pipe, _rows(d, idx))
-    err = rel_err(small, full[idx])
-    print(f"\n[batch 4 vs batch 32, La={La}] rel err {err:.3e} (bit-equal: {torch.equal(small, full[idx])})")
-    assert err < 1e-2
+    # batch sizes a sharded job's LAST batch can have: every kernel form a smaller launch selects (the 128-token feed-forward instead of the packed one,
+    # the row-panel GEGLU instead of geglu3, the tiled GEMM / convolution kernels instead of the big-tile ones, other GroupNorm splits) is bit-equal to
+    # the full-batch form, so the clip's latents are the same BITS
+    for rows in ([3, 17, 30, 8], [11], [5, 29, 0, 14, 22, 9, 31]):
+        idx = torch.tensor(rows, device=dev)
+        small = _run(full_pipe, _rows(d, idx))
+        eq = torch.equal(small, full[idx])
+        print(f"\n[batch {len(rows)} vs batch 32, La={La}] rel err {rel_err(small, full[idx]):.3e} (bit-equal: {eq})")
+        assert eq, f"a clip's result depends on the size of its batch ({len(rows)} vs 32)"
 
 
 @pytest.mark.parametrize("B", [4, 32])
