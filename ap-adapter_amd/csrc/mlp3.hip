@@ -52,6 +52,11 @@ struct Mlp3P {
     float eps;
 };
 
+template <int VM_, bool DMA_, bool G1_, bool GG_> struct M3It {
+    static constexpr int VM = VM_;
+    static constexpr bool DMA = DMA_, G1 = G1_, GG = GG_;
+};
+
 template <int DT, bool LN>
 __global__ __launch_bounds__(256, 1) void mlp3_kernel(Mlp3P p) {
     using E = ET<DT>;
@@ -122,9 +127,10 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(Mlp3P p) {
 
     // one iteration.  acur*: gemm1 result (+ b1) of chunk i - 1 -> activated here; anxt*: gemm1 of chunk i accumulates here;
     // hp*: activations of chunk i - 2 (gemm2's B operand); hn*: activations of chunk i - 1 (written here)
-    auto iteration = [&](int i, int slot, f32x16& acur0, f32x16& acur1, f32x16& anxt0, f32x16& anxt1, const V8& hp0, const V8& hp1, V8& hn0, V8& hn1) __attribute__((always_inline)) {
-        // stage i has landed for this wave's pieces (24 younger pieces may stay in flight); every wave is past its reads of stage i - 1
-        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    auto iteration = [&](auto cfg, int i, int slot, f32x16& acur0, f32x16& acur1, f32x16& anxt0, f32x16& anxt1, const V8& hp0, const V8& hp1, V8& hn0, V8& hn1) __attribute__((always_inline)) {
+        using CF = decltype(cfg);  // M3It<VM, DMA, G1, GG>: outstanding pieces allowed at the top, DMA issue / gemm1 / GEGLU of this iteration on or off
+        // stage i has landed for this wave's pieces (VM younger requests may stay in flight); every wave is past its reads of stage i - 1
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CF::VM) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         if (!(M3_ABL & 16)) __builtin_amdgcn_s_barrier();
@@ -143,45 +149,45 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(Mlp3P p) {
         // one step of gemm2 (chunk i - 2): output-column tiles ct, ct + 1 x two panels, the GEGLU of hidden units r, r + 1 of panel 0 between the MFMAs
         auto step2 = [&](const u32x4 (&f)[2], int ct, int r, int q) __attribute__((always_inline)) {
             const V8 w0 = __builtin_bit_cast(V8, f[0]), w1 = __builtin_bit_cast(V8, f[1]);
-            if (!M3_DMA_BARE) dma(nstage, nslot, q);
+            if (CF::DMA && !M3_DMA_BARE) dma(nstage, nslot, q);
             if (!(M3_ABL & 4)) y0[ct] = E::mfma32(w0, hp0, y0[ct]);
             M3_PIN();
-            if (!(M3_ABL & 1)) gg.ph1(acur0[8 + r], acur0[9 + r]);
+            if (CF::GG && !(M3_ABL & 1)) gg.ph1(acur0[8 + r], acur0[9 + r]);
             M3_PIN();
             if (!(M3_ABL & 4)) y1[ct] = E::mfma32(w0, hp1, y1[ct]);
             M3_PIN();
-            if (!(M3_ABL & 1)) gg.ph2();
+            if (CF::GG && !(M3_ABL & 1)) gg.ph2();
             M3_PIN();
             if (!(M3_ABL & 4)) y0[ct + 1] = E::mfma32(w1, hp0, y0[ct + 1]);
             M3_PIN();
-            if (!(M3_ABL & 1)) gg.ph3();
+            if (CF::GG && !(M3_ABL & 1)) gg.ph3();
             M3_PIN();
             if (!(M3_ABL & 4)) y1[ct + 1] = E::mfma32(w1, hp1, y1[ct + 1]);
             M3_PIN();
-            if (!(M3_ABL & 1)) gg.template ph4<V8, EL>(acur0[r], acur0[r + 1], hn0, r);
+            if (CF::GG && !(M3_ABL & 1)) gg.template ph4<V8, EL>(acur0[r], acur0[r + 1], hn0, r);
             M3_PIN();
         };
         // one step of gemm1 (chunk i): k-steps ks, ks + 1 x two panels; r >= 0: the GEGLU of hidden units r, r + 1 of panel 1 between the MFMAs
         auto step1 = [&](const u32x4 (&f)[2], int ks, int r, int q, int q2) __attribute__((always_inline)) {
             const V8 w0 = __builtin_bit_cast(V8, f[0]), w1 = __builtin_bit_cast(V8, f[1]);
-            if (!M3_DMA_BARE && q >= 0) dma(nstage, nslot, q);
-            if (!(M3_ABL & 2)) M3Asm<DT>::acc(anxt0, w0, xf0[ks]);
+            if (CF::DMA && !M3_DMA_BARE && q >= 0) dma(nstage, nslot, q);
+            if (CF::G1 && !(M3_ABL & 2)) M3Asm<DT>::acc(anxt0, w0, xf0[ks]);
             M3_PIN();
-            if (M3_DMA_BARE && q >= 0) dma(nstage, nslot, q);
-            if (r >= 0 && !(M3_ABL & 1)) gg.ph1(acur1[8 + r], acur1[9 + r]);
+            if (CF::DMA && M3_DMA_BARE && q >= 0) dma(nstage, nslot, q);
+            if (CF::GG && r >= 0 && !(M3_ABL & 1)) gg.ph1(acur1[8 + r], acur1[9 + r]);
             M3_PIN();
-            if (!(M3_ABL & 2)) M3Asm<DT>::acc(anxt1, w0, xf1[ks]);
+            if (CF::G1 && !(M3_ABL & 2)) M3Asm<DT>::acc(anxt1, w0, xf1[ks]);
             M3_PIN();
-            if (r >= 0 && !(M3_ABL & 1)) gg.ph2();
+            if (CF::GG && r >= 0 && !(M3_ABL & 1)) gg.ph2();
             M3_PIN();
-            if (!(M3_ABL & 2)) M3Asm<DT>::acc(anxt0, w1, xf0[ks + 1]);
+            if (CF::G1 && !(M3_ABL & 2)) M3Asm<DT>::acc(anxt0, w1, xf0[ks + 1]);
             M3_PIN();
-            if (M3_DMA_BARE && q2 >= 0) dma(nstage, nslot, q2);
-            if (r >= 0 && !(M3_ABL & 1)) gg.ph3();
+            if (CF::DMA && M3_DMA_BARE && q2 >= 0) dma(nstage, nslot, q2);
+            if (CF::GG && r >= 0 && !(M3_ABL & 1)) gg.ph3();
             M3_PIN();
-            if (!(M3_ABL & 2)) M3Asm<DT>::acc(anxt1, w1, xf1[ks + 1]);
+            if (CF::G1 && !(M3_ABL & 2)) M3Asm<DT>::acc(anxt1, w1, xf1[ks + 1]);
             M3_PIN();
-            if (r >= 0 && !(M3_ABL & 1)) gg.template ph4<V8, EL>(acur1[r], acur1[r + 1], hn1, r);
+            if (CF::GG && r >= 0 && !(M3_ABL & 1)) gg.template ph4<V8, EL>(acur1[r], acur1[r + 1], hn1, r);
             M3_PIN();
         };
 
@@ -195,15 +201,20 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(Mlp3P p) {
         m3_read2<22>(fB, fa);
         m3_wait_lgkm<2>();
         step2(fA, 4, 4, 2);
-        m3_read2<0>(fA, fa);  // W1 k-steps 0, 1; then b1 of chunk i (C-layout register order): short-lived, read just ahead of its use
-        m3_read<0>(bq[0], ta);
-        m3_read<16>(bq[1], ta);
-        m3_read<32>(bq[2], ta);
-        m3_read<48>(bq[3], ta);
-        m3_wait_lgkm<6>();
+        if (CF::G1) {
+            m3_read2<0>(fA, fa);  // W1 k-steps 0, 1; then b1 of chunk i (C-layout register order): short-lived, read just ahead of its use
+            m3_read<0>(bq[0], ta);
+            m3_read<16>(bq[1], ta);
+            m3_read<32>(bq[2], ta);
+            m3_read<48>(bq[3], ta);
+            m3_wait_lgkm<6>();
+        } else {
+            m3_wait_lgkm<0>();
+            bq[0] = bq[1] = bq[2] = bq[3] = fA[0] = fA[1] = u32x4{0u, 0u, 0u, 0u};
+        }
         step2(fB, 6, 6, 3);
         // ---- gemm1 of chunk i (8 steps; b1 is the C operand of the first MFMA of each panel) with the activation of panel 1 under it ----
-        m3_read2<2>(fB, fa);
+        if (CF::G1) m3_read2<2>(fB, fa);
         m3_wait_lgkm<2>();
         {
             f32x16 bias;
@@ -212,46 +223,46 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(Mlp3P p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) bias[qd * 4 + e] = __uint_as_float(bq[qd][e]);
             const V8 w0 = __builtin_bit_cast(V8, fA[0]), w1 = __builtin_bit_cast(V8, fA[1]);
-            if (!M3_DMA_BARE) dma(nstage, nslot, 4);
-            if (!(M3_ABL & 2)) {
+            if (CF::DMA && !M3_DMA_BARE) dma(nstage, nslot, 4);
+            if (CF::G1 && !(M3_ABL & 2)) {
                 M3Asm<DT>::first(anxt0, w0, xf0[0], bias);
                 M3Asm<DT>::first(anxt1, w0, xf1[0], bias);
                 // (a vector write to a register an in-flight MFMA still reads as its C operand is a software hazard -- 13 wait states for a 32x32
                 //  MFMA --, and the compiler, which does not see an MFMA in the asm, is free to recycle the b1 registers right here)
                 asm volatile("s_nop 7\n\ts_nop 6" ::: "memory");
-            } else {
+            } else if (CF::G1) {
                 anxt0 = bias;
                 anxt1 = bias;
             }
             M3_PIN();
-            if (!(M3_ABL & 1)) gg.ph1(acur1[8], acur1[9]);
-            if (!(M3_ABL & 1)) gg.ph2();
+            if (CF::GG && !(M3_ABL & 1)) gg.ph1(acur1[8], acur1[9]);
+            if (CF::GG && !(M3_ABL & 1)) gg.ph2();
             M3_PIN();
-            if (!(M3_ABL & 2)) M3Asm<DT>::acc(anxt0, w1, xf0[1]);
+            if (CF::G1 && !(M3_ABL & 2)) M3Asm<DT>::acc(anxt0, w1, xf0[1]);
             M3_PIN();
-            if (!(M3_ABL & 1)) gg.ph3();
+            if (CF::GG && !(M3_ABL & 1)) gg.ph3();
             M3_PIN();
-            if (!(M3_ABL & 2)) M3Asm<DT>::acc(anxt1, w1, xf1[1]);
+            if (CF::G1 && !(M3_ABL & 2)) M3Asm<DT>::acc(anxt1, w1, xf1[1]);
             M3_PIN();
-            if (!(M3_ABL & 1)) gg.template ph4<V8, EL>(acur1[0], acur1[1], hn1, 0);
+            if (CF::GG && !(M3_ABL & 1)) gg.template ph4<V8, EL>(acur1[0], acur1[1], hn1, 0);
             M3_PIN();
         }
-        m3_read2<4>(fA, fa);
+        if (CF::G1) m3_read2<4>(fA, fa);
         m3_wait_lgkm<2>();
         step1(fB, 2, -1, M3_DMA_BARE ? 0 : 5, M3_DMA_BARE ? 1 : -1);
-        m3_read2<6>(fB, fa);
+        if (CF::G1) m3_read2<6>(fB, fa);
         m3_wait_lgkm<2>();
         step1(fA, 4, 2, -1, -1);
-        m3_read2<8>(fA, fa);
+        if (CF::G1) m3_read2<8>(fA, fa);
         m3_wait_lgkm<2>();
         step1(fB, 6, -1, M3_DMA_BARE ? 2 : -1, M3_DMA_BARE ? 3 : -1);
-        m3_read2<10>(fB, fa);
+        if (CF::G1) m3_read2<10>(fB, fa);
         m3_wait_lgkm<2>();
         step1(fA, 8, 4, -1, -1);
-        m3_read2<12>(fA, fa);
+        if (CF::G1) m3_read2<12>(fA, fa);
         m3_wait_lgkm<2>();
         step1(fB, 10, -1, M3_DMA_BARE ? 4 : -1, M3_DMA_BARE ? 5 : -1);
-        m3_read2<14>(fB, fa);
+        if (CF::G1) m3_read2<14>(fB, fa);
         m3_wait_lgkm<2>();
         step1(fA, 12, 6, -1, -1);
         m3_wait_lgkm<0>();
@@ -259,25 +270,47 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(Mlp3P p) {
     };
 
     int slot = 0;
+    constexpr int M3_NLOOP = M3_NCH;  // 64 uniform iterations (past stage 65 they re-request it: the wait count stays uniform)
 #pragma unroll 1
-    for (int i = 0; i < M3_NIT; i += 2) {
-        iteration(i, slot, a0, a1, b0, b1, h0a, h1a, h0b, h1b);
+    for (int i = 0; i < M3_NLOOP; i += 2) {
+        iteration(M3It<24, true, true, true>{}, i, slot, a0, a1, b0, b1, h0a, h1a, h0b, h1b);
         slot = slot == M3_NS - 1 ? 0 : slot + 1;
-        iteration(i + 1, slot, b0, b1, a0, a1, h0b, h1b, h0a, h1a);
+        iteration(M3It<24, true, true, true>{}, i + 1, slot, b0, b1, a0, a1, h0b, h1b, h0a, h1a);
         slot = slot == M3_NS - 1 ? 0 : slot + 1;
     }
-    static_assert(M3_NIT % 2 == 0, "the loop body is two iterations");
-
-    // ---- epilogue: the residual rows requested first; y + b2 -> storage type -> this wave's [64][256] tile in the dead ring -> + x -> whole-row stores ----
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the tail's dummy re-loads have landed: the ring is dead)
-    uint4 res[32];
+    static_assert(M3_NLOOP % 2 == 0 && M3_NIT == M3_NLOOP + 2 && M3_NS == 6, "the tail below is written out for these counts");
+    // ---- the last two iterations, written out: no first GEMM (the x panels are dead: the residual rows are requested into their registers one iteration
+    // ahead of the epilogue), no requests, and the last one no activation.  In flight at the top of 65: stage 65, 18 re-requests, then NEARLY of the 32 row requests (the rest at the epilogue's start: the allocator spilled a longer prefetch).
+    auto next_slot = [&]() __attribute__((always_inline)) { slot = slot == M3_NS - 1 ? 0 : slot + 1; };
+    __builtin_amdgcn_sched_barrier(0);
+    // (buffer addressing: row (lane >> 5) + 2 v, 16-byte chunk lane & 31 = byte lane * 16 + v * 1024 of the wave's 32 KB of rows; the resource ends with
+    //  the rows that exist, so a ragged last tile needs no clamps or predicates -- reads past it return 0, writes past it are dropped)
+    // (the lane id is derived AGAIN here, opaquely: lane-derived values computed in the prologue and kept for the epilogue were spilled across the loop)
+    int lane_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    const int l31_e = lane_e & 31, half_e = lane_e >> 5;
+    const int64_t nrow64 = p.M - mw0;
+    const uint32_t nrow = (uint32_t)(nrow64 < 0 ? 0 : (nrow64 > 64 ? 64 : nrow64));
+    const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.x) + mw0 * (M3_C * 2), 0, (int)(nrow * (M3_C * 2)), 0x00020000);
+    const uint32_t roff = (uint32_t)(lane_e * 16);
+    const int rrow0 = half_e;
+    const uint32_t rcol = (uint32_t)(l31_e * 16);
+    constexpr int NEARLY = DT == APAD_BF16 ? 16 : 0;  // row requests sent one iteration ahead (what the register allocator holds without spilling; f16's epilogue is tighter)
+    u32x4 res[32];
+    __builtin_amdgcn_sched_barrier(0);
+    iteration(M3It<24, false, false, true>{}, M3_NLOOP, slot, a0, a1, b0, b1, h0a, h1a, h0b, h1b);  // GEGLU of chunk 63, gemm2 of 62
+    next_slot();
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int v = 0; v < 32; ++v) {
-        const int idx = lane + v * 64, row = idx >> 5, ch = idx & 31;
-        int64_t m = mw0 + row;
-        m = m < p.M ? m : p.M - 1;
-        res[v] = *reinterpret_cast<const uint4*>(p.x + (m * M3_C + ch * 8) * 2);
-    }
+    for (int v = 0; v < NEARLY; ++v) res[v] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, roff, v * 1024, 0));
+    __builtin_amdgcn_sched_barrier(0);
+    iteration(M3It<18 + NEARLY, false, false, false>{}, M3_NLOOP + 1, slot, b0, b1, a0, a1, h0b, h1b, h0a, h1a);  // gemm2 of chunk 63
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- epilogue: y + b2 -> storage type -> this wave's [64][256] tile in the dead ring -> + x (requested above) -> whole-row stores ----
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int v = NEARLY; v < 32; ++v) res[v] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, roff, v * 1024, 0));
     __syncthreads();
     uint8_t* const tile = smem + wave * (64 * M3_OROWB);
 #pragma unroll
@@ -287,25 +320,26 @@ __global__ __launch_bounds__(256, 1) void mlp3_kernel(Mlp3P p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x16& ya = pn == 0 ? y0[ct] : y1[ct];
-                const float4 b4 = *reinterpret_cast<const float4*>(lb2 + ct * 32 + 8 * g + 4 * half);
+                const float4 b4 = *reinterpret_cast<const float4*>(lb2 + ct * 32 + 8 * g + 4 * half_e);
                 typename E::v4 yv;
                 yv[0] = (typename E::elem)(ya[4 * g + 0] + b4.x);
                 yv[1] = (typename E::elem)(ya[4 * g + 1] + b4.y);
                 yv[2] = (typename E::elem)(ya[4 * g + 2] + b4.z);
                 yv[3] = (typename E::elem)(ya[4 * g + 3] + b4.w);
-                *reinterpret_cast<uint2*>(tile + (pn * 32 + l31) * M3_OROWB + (ct * 32 + 8 * g + 4 * half) * 2) = __builtin_bit_cast(uint2, yv);
+                *reinterpret_cast<uint2*>(tile + (pn * 32 + l31_e) * M3_OROWB + (ct * 32 + 8 * g + 4 * half_e) * 2) = __builtin_bit_cast(uint2, yv);
             }
     // (a wave reads back only its own tile: its own LDS writes are ordered before its reads)
+    {
+        const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(p.out + mw0 * (M3_C * 2), 0, (int)(nrow * (M3_C * 2)), 0x00020000);
 #pragma unroll
-    for (int v = 0; v < 32; ++v) {
-        const int idx = lane + v * 64, row = idx >> 5, ch = idx & 31;
-        const int64_t m = mw0 + row;
-        float f[8], r[8];
-        unpack8<DT>(*reinterpret_cast<const uint4*>(tile + row * M3_OROWB + ch * 16), f);
-        unpack8<DT>(res[v], r);
+        for (int v = 0; v < 32; ++v) {
+            float f[8], r[8];
+            unpack8<DT>(*reinterpret_cast<const uint4*>(tile + (rrow0 + 2 * v) * M3_OROWB + rcol), f);
+            unpack8<DT>(__builtin_bit_cast(uint4, res[v]), r);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] += r[e];
-        if (m < p.M) *reinterpret_cast<uint4*>(p.out + (m * M3_C + ch * 8) * 2) = pack8<DT>(f);
+            for (int e = 0; e < 8; ++e) f[e] += r[e];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pack8<DT>(f)), rout, roff, v * 1024, 0);
+        }
     }
 }
 
