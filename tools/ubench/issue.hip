@@ -8,7 +8,7 @@
 typedef float V16 __attribute__((ext_vector_type(16)));
 typedef short B8 __attribute__((ext_vector_type(8)));
 
-enum { K_FMA = 0, K_EXP = 1, K_PKFMA = 2, K_CVT = 3, K_DSREAD = 4, K_MUL = 5, K_PKADD = 6, K_DOT2BF = 7, K_ADD = 8 };
+enum { K_FMA = 0, K_EXP = 1, K_PKFMA = 2, K_CVT = 3, K_DSREAD = 4, K_MUL = 5, K_PKADD = 6, K_DOT2BF = 7, K_ADD = 8, K_MFMA4 = 9 };
 
 template <int NV, int KIND, bool ACC_A, bool OPB_A, bool MF>
 __global__ __launch_bounds__(512) void k(uint64_t* out, int iters) {
@@ -22,6 +22,8 @@ __global__ __launch_bounds__(512) void k(uint64_t* out, int iters) {
     F2 y[8];
     for (int i = 0; i < 8; ++i) y[i] = F2{x[i], x[i] + 1};
     float c1 = 1.0001f, c2 = 0.5f;
+    typedef float F4 __attribute__((ext_vector_type(4)));
+    F4 q4[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     uint32_t laddr = (uint32_t)(uintptr_t)sm + threadIdx.x * 16;
     typedef uint32_t U4 __attribute__((ext_vector_type(4)));
     U4 d[8];
@@ -50,6 +52,7 @@ __global__ __launch_bounds__(512) void k(uint64_t* out, int iters) {
                 if (KIND == K_PKFMA) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(y[j & 7]) : "v"(y[(j + 1) & 7]));
                 if (KIND == K_PKADD) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(y[j & 7]) : "v"(y[(j + 1) & 7]));
                 if (KIND == K_DOT2BF) asm volatile("v_dot2_f32_bf16 %0, %1, %2, %0" : "+v"(x[j & 7]) : "v"(c1), "v"(c2));
+                if (KIND == K_MFMA4) asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %0" : "+v"(q4[j & 3]) : "v"(y[(j + 1) & 7]), "v"(y[(j + 2) & 7]));
                 if (KIND == K_ADD) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[j & 7]) : "v"(c1));
                 if (KIND == K_CVT) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(x[j & 7]) : "v"(c1));
                 if (KIND == K_DSREAD) asm volatile("ds_read_b128 %0, %1" : "=v"(d[j & 7]) : "v"(laddr));
@@ -62,6 +65,7 @@ __global__ __launch_bounds__(512) void k(uint64_t* out, int iters) {
     if (ACC_A) { asm volatile("" : "+a"(acc0), "+a"(acc1)); }
     for (int i = 0; i < 16; ++i) s += acc0[i] + acc1[i];
     for (int i = 0; i < 8; ++i) s += x[i] + y[i][0] + y[i][1] + __uint_as_float(d[i][0]);
+    for (int i = 0; i < 4; ++i) s += q4[i][0] + q4[i][3];
     if (s == 1234.5678f) out[1000000] = 1;
     if ((threadIdx.x & 63) == 0 && threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
 }
@@ -96,6 +100,7 @@ int main(int argc, char** argv) {
         sweep<K_ADD, false, false>("add", dout);
         sweep<K_PKADD, false, false>("pk_add", dout);
         sweep<K_DOT2BF, false, false>("dot2_bf16", dout);
+        sweep<K_MFMA4, false, false>("mfma4x4x4", dout);
         return 0;
     }
     sweep<K_FMA, false, false>("fma", dout);
