@@ -7,8 +7,8 @@
 //   * one wave owns 32 queries of one (batch, head); 4 waves per workgroup -> 128 queries per workgroup
 //   * K / V^T tiles of 64 keys are staged ONCE per workgroup in LDS (coalesced 16-byte global loads issued one tile
 //     ahead into registers, written after the MFMAs of the current tile: global latency hides under compute) and
-//     shared by the 4 waves; row strides are padded to an odd number of slots, so the ds_read_b128 (K rows) and
-//     ds_read_b64 (V^T rows) fragment reads are bank-conflict free
+//     shared by the 4 waves; row strides are padded to an odd number of 16-byte slots, so the ds_read_b128 fragment reads (K rows;
+//     V^T rows, whose keys are stored permuted inside every 16-key step: Lay::VROW) are bank-conflict free
 //   * scores are computed TRANSPOSED, S^T = K . Q^T, so that after the MFMA each lane holds 32 keys of ONE query
 //     (column = lane&31): the softmax max/sum are in-lane reductions plus one cross-half exchange per 64 keys
 //   * P^T stays in registers: the C-layout of S^T (keys (r&3)+8*(r>>2)+4*half) is re-used directly as the B operand
@@ -57,7 +57,10 @@ template <int D> struct Lay {
     static constexpr int K_BYTES = KT * KROW;
     static constexpr int DT_TILES = (D + 31) / 32;
     static constexpr int VROWS = DT_TILES * 32;        // rows >= D are zeroed once; they feed discarded output rows
-    static constexpr int VROW = (KT + 4) * 2;          // V^T tile row stride (bytes): 17 eight-byte slots (odd)
+    static constexpr int VROW = (KT + 8) * 2;          // V^T tile row stride (bytes): 9 sixteen-byte slots (odd).  Inside every 16-key step the keys are stored
+                                                       // as 0-3, 8-11, 4-7, 12-15: the 8 keys a half-wave multiplies with the C-layout probabilities
+                                                       // (4 half + {0..3}, 8 + 4 half + {0..3}) are ONE 16-byte read (a ds_read holds a wave's issue ~18
+                                                       // cycles whatever its width: two 8-byte reads per fragment cost twice that)
     static constexpr int V_BYTES = VROWS * VROW;
     static constexpr int BUF = K_BYTES + V_BYTES;
     static constexpr int KCH = KT * (D / 8);           // 16-byte chunks of a K tile
@@ -124,11 +127,11 @@ __device__ __forceinline__ void tile_store(const u32x4 (&rk)[Lay<D>::NK], const 
     for (int i = 0; i < Y::NV; ++i) {
         const int idx = tid + 256 * i;
         const int row = idx >> 3, ch = idx & 7;
-        if (idx < Y::VCH) {  // row stride is 8 (mod 16): two 8-byte stores
+        if (idx < Y::VCH) {  // keys 8 ch .. 8 ch + 7 of the row: two 8-byte stores into the permuted 16-key step (Lay::VROW)
             u32x2 lo = {rv[i][0], rv[i][1]}, hi = {rv[i][2], rv[i][3]};
-            uint8_t* dst = buf + Y::K_BYTES + row * Y::VROW + ch * 16;
+            uint8_t* dst = buf + Y::K_BYTES + row * Y::VROW + (ch >> 1) * 32 + (ch & 1) * 8;
             *reinterpret_cast<u32x2*>(dst) = lo;
-            *reinterpret_cast<u32x2*>(dst + 8) = hi;
+            *reinterpret_cast<u32x2*>(dst + 16) = hi;
         }
     }
 }
@@ -239,13 +242,9 @@ __device__ __forceinline__ void tile_compute(const uint8_t* buf, int key0, int L
         typename E::v8 pf;
 #pragma unroll
         for (int j = 0; j < 8; ++j) pf[j] = (typename E::elem)s[st >> 1][(st & 1) * 8 + j];
-        const int kcol = st * 16 + 4 * half;  // tile-local keys kcol..kcol+3 and kcol+8..kcol+11
 #pragma unroll
         for (int dt = 0; dt < Y::DT_TILES; ++dt) {
-            const uint8_t* vp = vtile + (dt * 32 + l31) * Y::VROW + kcol * 2;
-            uint2 v0 = *reinterpret_cast<const uint2*>(vp);
-            uint2 v1 = *reinterpret_cast<const uint2*>(vp + 16);
-            typename E::v8 vf = as_v8<DT>(make_uint4(v0.x, v0.y, v1.x, v1.y));
+            typename E::v8 vf = as_v8<DT>(*reinterpret_cast<const uint4*>(vtile + (dt * 32 + l31) * Y::VROW + (st * 16 + 8 * half) * 2));
             if (APAD_ABL & 4) o[dt][st] += (float)vf[0] * (float)pf[0];
             else o[dt] = E::mfma32(vf, pf, o[dt]);
         }
@@ -462,10 +461,7 @@ __device__ __forceinline__ void tile_compute2(const uint8_t* buf, int key0, int 
 #pragma unroll
         for (int dt = 0; dt < Y::DT_TILES; ++dt) {
             if (APAD_ABL & 32) { vf[st][dt] = qf[1][0]; continue; }
-            const uint8_t* vp = buf + Y::K_BYTES + (dt * 32 + l31) * Y::VROW + (st * 16 + 4 * half) * 2;
-            const uint2 v0 = *reinterpret_cast<const uint2*>(vp);
-            const uint2 v1 = *reinterpret_cast<const uint2*>(vp + 16);
-            vf[st][dt] = as_v8<DT>(make_uint4(v0.x, v0.y, v1.x, v1.y));
+            vf[st][dt] = as_v8<DT>(*reinterpret_cast<const uint4*>(buf + Y::K_BYTES + (dt * 32 + l31) * Y::VROW + (st * 16 + 8 * half) * 2));
         }
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt)
@@ -710,10 +706,10 @@ __device__ __forceinline__ void attn2q_body(const AttnP& p, uint8_t* smem) {
             } else {
                 if (isK) {
                     *reinterpret_cast<u32x4*>(buf + srow * Y::KROW + sch * 16) = sreg;
-                } else {  // V^T row stride is 8 (mod 16): two 8-byte stores
-                    uint8_t* dst = buf + Y::K_BYTES + srow * Y::VROW + sch * 16;
+                } else {  // keys 8 sch .. 8 sch + 7 of the row: two 8-byte stores into the permuted 16-key step (Lay::VROW)
+                    uint8_t* dst = buf + Y::K_BYTES + srow * Y::VROW + (sch >> 1) * 32 + (sch & 1) * 8;
                     *reinterpret_cast<u32x2*>(dst) = (u32x2){sreg[0], sreg[1]};
-                    *reinterpret_cast<u32x2*>(dst + 8) = (u32x2){sreg[2], sreg[3]};
+                    *reinterpret_cast<u32x2*>(dst + 16) = (u32x2){sreg[2], sreg[3]};
                 }
             }
         };
@@ -967,6 +963,7 @@ __global__ __launch_bounds__(NW * 64) void sattn_fused_kernel(SfP p) {
                 const float rstd = (SF_ABL & 4) ? (ok ? 1.f : 0.f) : (ok ? rsqrtf(var + p.eps) : 0.f), nmr = (SF_ABL & 4) ? 0.f : -mean * rstd, okf = ok ? 1.f : 0.f;
                 uint8_t* const kt = smem + (key >> 6) * Y::BUF;
                 const int krow = key & 63;
+                const int kpos = (krow & ~12) | ((krow & 4) << 1) | ((krow & 8) >> 1);  // position of the key inside the tile's V^T rows (Lay::VROW: bits 2, 3 swapped)
 #pragma unroll
                 for (int j = 0; j < NT3; ++j) {
 #pragma unroll
@@ -995,7 +992,7 @@ __global__ __launch_bounds__(NW * 64) void sattn_fused_kernel(SfP p) {
                             if (pan[n] < npan) {
 #pragma unroll
                                 for (int e = 0; e < 4; ++e)
-                                    *reinterpret_cast<typename E::elem*>(kt + Y::K_BYTES + (8 * G + 4 * half + e) * Y::VROW + krow * 2) = (typename E::elem)y[e];
+                                    *reinterpret_cast<typename E::elem*>(kt + Y::K_BYTES + (8 * G + 4 * half + e) * Y::VROW + kpos * 2) = (typename E::elem)y[e];
                             }
                         }
                     }
