@@ -32,7 +32,8 @@ class GemmDesc(C.Structure):
                [(n, _i32) for n in ("taps", "dilation", "pad", "transposed", "a_pre_act")] + [("a_pre_slope", _f32)] + \
                [("conv_asym_pad", _i32), ("reserved_conv", _i32)] + \
                [(n, _vp) for n in ("rowstat_out", "rowstat_in", "ln_colsum", "ln_bias")] + [("rowstat_in_tiles", _i32), ("ln_eps", _f32)] + \
-               [("a2", _vp), ("lda2", _i64), ("k_split", _i32), ("a_row_mod", _i32), ("a2_row_mod", _i32), ("reserved_a2", _i32), ("out4", _vp)]
+               [("a2", _vp), ("lda2", _i64), ("k_split", _i32), ("a_row_mod", _i32), ("a2_row_mod", _i32), ("reserved_a2", _i32), ("out4", _vp),
+                ("w_halo", _vp)]
 
 
 class AttnDesc(C.Structure):
@@ -127,6 +128,8 @@ SYMBOLS = {
     "apad_xattn_packed_kv_bytes": (_i64, [_i32, _i32]),
     "apad_xattn_pack_kv": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp]),
     "apad_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
+    "apad_conv_halo_pack": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp]),
+    "apad_hconv_launch_count": (_i64, []),
     "apad_attention": (C.c_int, [C.POINTER(AttnDesc), _vp]),
     "apad_layernorm": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _i64, _f32, _i32, _vp]),
     "apad_groupnorm_workspace_bytes": (_i64, [_i32, _i32, _i32]),
@@ -198,7 +201,7 @@ def lib():
                 fn = getattr(h, name)  # AttributeError if the ABI lost a symbol
                 fn.restype = res
                 fn.argtypes = args
-            if h.apad_abi_version() != 8:
+            if h.apad_abi_version() != 9:
                 raise RuntimeError("libapadapter_hip.so ABI version mismatch")
             if h.apad_sizeof_gemm_desc() != C.sizeof(GemmDesc) or h.apad_sizeof_attn_desc() != C.sizeof(AttnDesc) \
                     or h.apad_sizeof_rp_desc() != C.sizeof(RpDesc) \

@@ -140,3 +140,5 @@ int apad_check_launch(const char* what);
 int apad_ensure_dyn_lds(const void* kern, int bytes, unsigned* devmask);
 // big-tile GEMM / implicit convolution (cgemm.hip): 1 = not applicable, 0 = launched, < 0 = error
 int apad_cgemm_try(const apad_gemm_desc* d, hipStream_t s);
+// halo-resident 3x3 convolution (hconv.hip), same convention; needs apad_gemm_desc::w_halo
+int apad_hconv_try(const apad_gemm_desc* d, hipStream_t s);

@@ -1056,6 +1056,10 @@ extern "C" int apad_gemm(const apad_gemm_desc* d, void* stream) {
         APAD_CHECK(d->ln_colsum && d->ln_bias && d->rowstat_in_tiles > 0 && d->a_mode == APAD_A_PLAIN && !d->bias,
                    "apad_gemm: rowstat_in (folded LayerNorm) needs ln_colsum, ln_bias (which carries the layer's bias), rowstat_in_tiles, a plain A operand");
     hipStream_t s = (hipStream_t)stream;
+    {  // 3x3 convolutions whose packed weight form came along: the halo-resident kernel (every row count of an eligible layer)
+        const int rc = apad_hconv_try(d, s);
+        if (rc <= 0) return rc;
+    }
     {  // the compute-bound launches (large-M 3x3 convolutions, plain GEMMs with N % 128 == 0): the big-tile LDS-DMA kernel
         const int rc = apad_cgemm_try(d, s);
         if (rc <= 0) return rc;

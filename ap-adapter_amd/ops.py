@@ -46,7 +46,8 @@ def set_gemm_ring(mode):
 
 def gemm(a, w, *, M, N, K, lda, out, ldo, bias=None, residual=None, ldr=0, act=None, rowgroup_bias=None, ld_rg=0,
          rows_per_group=0, step_ptr=None, a_mode=L.A_PLAIN, out_mode=L.OUT_ROWMAJOR, conv=None, vt=None, ldw=None,
-         residual_row_mod=0, asym_pad=False, rowstat_out=None, ln_fold=None, a2=None, lda2=0, k_split=0, a_row_mod=0, a2_row_mod=0):
+         residual_row_mod=0, asym_pad=False, rowstat_out=None, ln_fold=None, a2=None, lda2=0, k_split=0, a_row_mod=0, a2_row_mod=0,
+         w_halo=None):
     """Raw descriptor call; the typed helpers below are what the model code uses.  rowstat_out: fp32 [M, N/64, 2] side output
     (row statistics of the stored rows); ln_fold = (rowstat_in [M, T, 2], colsum, bias_fp32, eps): LayerNorm by algebra."""
     d = L.GemmDesc()
@@ -69,6 +70,7 @@ def gemm(a, w, *, M, N, K, lda, out, ldo, bias=None, residual=None, ldr=0, act=N
     if a2 is not None:
         d.a2, d.lda2, d.k_split = a2.data_ptr(), lda2, k_split
     d.a_row_mod, d.a2_row_mod = a_row_mod, a2_row_mod
+    d.w_halo = _ptr(w_halo)
     L.check(L.lib().apad_gemm(C.byref(d), _stream()), "apad_gemm")
     return out
 
@@ -710,6 +712,34 @@ def linear_qkv(x, w_qkv, B, Lk, heads, q, k, vt, bias=None, ln=None, v=None):
     return q, k, vt
 
 
+HCONV = True  # route eligible 3x3 convolutions through the halo-resident kernel (csrc/hconv.hip); a module attribute a test may flip
+_halo_cache = {}
+
+
+def conv_halo_eligible(Cin, Cout, Wout, stride, dtype, src_batch_mod=0, asym_pad=False):
+    """the LAYER-level part of apad_hconv_try's envelope (never the row count): what decides whether the packed form is built"""
+    return (HCONV and stride == 1 and not asym_pad and src_batch_mod == 0 and dtype in FUSED_DTYPES and Cin % 64 == 0 and Cout % 128 == 0
+            and Wout in (4, 8, 16))
+
+
+def conv_halo_weight(w_packed):
+    """w_packed [Cout, 9 * Cin] -> apad_conv_halo_pack's form (same element count), cached per weight tensor version"""
+    key = id(w_packed)
+    sig = (w_packed.data_ptr(), w_packed._version, w_packed.dtype, w_packed.device, tuple(w_packed.shape))
+    hit = _halo_cache.get(key)
+    if hit is None or hit[0] != sig or hit[2]() is not w_packed:
+        if len(_halo_cache) > 512:
+            for k in [k for k, v in _halo_cache.items() if v[2]() is None]:
+                del _halo_cache[k]
+        wc = w_packed.detach().contiguous()
+        out = torch.empty_like(wc)
+        Cout, K = wc.shape
+        L.check(L.lib().apad_conv_halo_pack(wc.data_ptr(), out.data_ptr(), Cout, K // 9, _DT[wc.dtype], _stream()), "apad_conv_halo_pack")
+        hit = (sig, out, _weakref.ref(w_packed))
+        _halo_cache[key] = hit
+    return hit[1]
+
+
 def conv3x3(x, w_packed, bias, B, Hin, Win, stride=1, up=None, residual=None, rowgroup_bias=None, rows_per_group=0,
             step_ptr=None, src_batch_mod=0, out=None, asym_pad=False):
     """NHWC implicit-GEMM 3x3 convolution, padding 1.  x [Bsrc, Hin*Win, Cin]; w_packed [Cout, 9*Cin] in
@@ -725,7 +755,8 @@ def conv3x3(x, w_packed, bias, B, Hin, Win, stride=1, up=None, residual=None, ro
     M = B * Hout * Wout
     if out is None:
         out = torch.empty(B, Hout * Wout, Cout, dtype=x.dtype, device=x.device)
-    gemm(x, w_packed, M=M, N=Cout, K=9 * Cin, lda=0, out=out, ldo=Cout, bias=bias,
+    wh = conv_halo_weight(w_packed) if conv_halo_eligible(Cin, Cout, Wout, stride, w_packed.dtype, src_batch_mod, asym_pad) else None
+    gemm(x, w_packed, M=M, N=Cout, K=9 * Cin, lda=0, out=out, ldo=Cout, bias=bias, w_halo=wh,
          residual=residual, ldr=Cout, rowgroup_bias=rowgroup_bias,
          ld_rg=(rowgroup_bias.stride(0) if rowgroup_bias is not None else 0), rows_per_group=rows_per_group,
          step_ptr=step_ptr, a_mode=L.A_CONV3X3, asym_pad=asym_pad,

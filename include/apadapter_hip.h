@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define APAD_ABI_VERSION 8
+#define APAD_ABI_VERSION 9
 
 /* element types of activations / weights */
 enum { APAD_BF16 = 0, APAD_F16 = 1, APAD_F32 = 2 };
@@ -130,6 +130,12 @@ typedef struct apad_gemm_desc {
     int32_t reserved_a2;
     void* out4;                /* APAD_OUT_QKV: optional v ROW-MAJOR [M][C] (ldo) beside the v^T of out3 -- the training step keeps both forms;
                                   NULL: not written (ABI 6) */
+    const void* w_halo;        /* APAD_A_CONV3X3, optional (ABI 9): the same weights in the form apad_conv_halo_pack writes.  When it is given and the
+                                  layer is inside the halo kernel's envelope (stride 1, zero padding 1, image width a power of two 4 .. 16, Cin % 64 == 0,
+                                  N % 128 == 0, plain epilogue; a nearest-up-sampled source included), the convolution keeps the input pixels of a
+                                  workgroup's image rows resident in LDS and fetches them ONCE per 64-channel chunk instead of once per filter tap
+                                  (csrc/hconv.hip).  The choice depends on the layer only, never on the row count M.  Summation order: 64-channel
+                                  chunk, tap, channel (w: tap, channel).  NULL: the im2col forms. */
 } apad_gemm_desc;
 
 typedef struct apad_attn_desc {
@@ -382,6 +388,14 @@ int apad_sizeof_mlp_desc(void);
 int apad_echo_mlp_desc(const apad_mlp_desc* d, double* out, int cap);
 
 int apad_gemm(const apad_gemm_desc* d, void* stream);
+/* apad_gemm_desc::w_halo: w [N][ky][kx][Cin] (the conv form of apad_gemm_desc::w) -> out, the same N * 9 * Cin elements as
+   [Cin / 64][tap][32-channel half][N][32 channels] with the four 16-byte slots of every 64-byte record XOR-ed by (n >> 2) & 3 (the LDS image the
+   kernel's weight stages are copied into verbatim).  Cin % 64 == 0; 16-bit dtypes.  One-off, per parameter version.
+   Replaces nothing in the reference: it is a re-layout of ResnetBlock2D.conv1 / conv2 / Upsample2D.conv weights (modeling_audioldm2.py call sites
+   as for apad_gemm). */
+int apad_conv_halo_pack(const void* w, void* out, int64_t N, int64_t Cin, int32_t dtype, void* stream);
+/* diagnostic: how many apad_gemm calls of this process went to the halo kernel (tests assert the route with it) */
+int64_t apad_hconv_launch_count(void);
 int apad_attention(const apad_attn_desc* d, void* stream);
 /* returns -3 (and sets the error text) when the shape is outside the kernel's envelope; callers then use apad_gemm */
 int apad_rowpanel_gemm(const apad_rp_desc* d, void* stream);

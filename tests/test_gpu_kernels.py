@@ -126,6 +126,53 @@ def test_conv3x3_big_tile_kernel(dev, dtype, B, H, W, Cin, Cout):
 
 
 @pytest.mark.parametrize("dtype", DTYPES16)
+@pytest.mark.parametrize("B,H,W,Cin,Cout,up,temb", [
+    (3, 250, 16, 128, 128, None, "table"),    # the 4000-pixel level: 256 x 128 tiles, a sample boundary inside a tile, ragged last tile
+    (5, 125, 8, 256, 256, None, "table"),     # the 1000-pixel level: 256 x 256 tiles
+    (7, 63, 4, 384, 384, None, "sample"),     # the 252-pixel level (N = 384: three 128-wide tiles), up to two sample boundaries per tile
+    (2, 125, 8, 256, 256, (250, 16), None),   # Upsample2D: the nearest-x2 source folded into the halo fill
+    (3, 63, 4, 384, 256, (125, 8), None),     # ... with an odd target size
+    (9, 32, 2, 640, 384, (63, 4), None),
+    (1, 5, 4, 64, 128, None, "sample"),       # a tile holding many tiny samples' rows ... here ONE sample smaller than a tile
+    (40, 5, 4, 64, 128, None, "table"),       # 13 separator rows per tile
+    (2, 40, 16, 640, 256, None, "table"),     # ten 64-channel chunks
+])
+def test_conv3x3_halo_kernel(dev, dtype, B, H, W, Cin, Cout, up, temb):
+    """csrc/hconv.hip: the halo-resident 3x3 convolution (input rows of a tile resident in LDS, nine taps as nine shifts of the same tile,
+    packed weight stream) against fp32 torch: borders, sample boundaries inside tiles, ragged last tile, bias + time-embedding row (table
+    and per-sample form) + residual, nearest-up-sampled sources; the route is asserted"""
+    from ap_adapter_amd import ops, _lib as L
+    x = q(R(B, Cin, H, W, seed=14), dtype)
+    w = q(R(Cout, Cin, 3, 3, seed=15, std=0.04), dtype)
+    b = q(R(Cout, seed=16), dtype)
+    Ho, Wo = up if up is not None else (H, W)
+    t = q(R(B if temb == "sample" else 4, Cout, seed=17), dtype)
+    r = q(R(B, Cout, Ho, Wo, seed=18), dtype)
+    ref = _conv_ref(x, w, b, 1, up)
+    if temb == "table":
+        ref = ref + t[3][None, :, None, None]
+    elif temb == "sample":
+        ref = ref + t[:, :, None, None]
+    ref = q(ref, dtype) + r
+    nhwc = lambda a: a.permute(0, 2, 3, 1).reshape(a.shape[0], a.shape[2] * a.shape[3], -1).contiguous().to(dev, dtype)
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(dev, dtype)
+    step = torch.tensor([3 if temb == "table" else 0], dtype=torch.int32, device=dev)
+    kw = {}
+    if temb is not None:
+        kw = dict(rowgroup_bias=t.to(dev, dtype), rows_per_group=(1 << 40) if temb == "table" else Ho * Wo, step_ptr=step)
+    n0 = L.lib().apad_hconv_launch_count()
+    out, Ho2, Wo2 = ops.conv3x3(nhwc(x), wp, b.to(dev, dtype), B, H, W, up=up, residual=nhwc(r), **kw)
+    assert L.lib().apad_hconv_launch_count() == n0 + 1, "not on the halo kernel"
+    assert (Ho2, Wo2) == (Ho, Wo)
+    assert rel_err(out.reshape(B, Ho, Wo, Cout).permute(0, 3, 1, 2), ref) < TOL[dtype]
+    # the same pixels inside a larger batch: bit-equal (one kernel, one summation order, whatever the row count)
+    if up is None and B >= 3:
+        out1, _, _ = ops.conv3x3(nhwc(x)[1:2].contiguous(), wp, b.to(dev, dtype), 1, H, W, residual=nhwc(r)[1:2].contiguous(),
+                                 **(dict(kw, rowgroup_bias=t[1:2].to(dev, dtype)) if temb == "sample" else kw))
+        assert torch.equal(out1[0], out[1])
+
+
+@pytest.mark.parametrize("dtype", DTYPES16)
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 32, 2, 640, 640), (5, 32, 2, 1280, 640), (3, 63, 4, 384, 384), (1, 9, 7, 256, 64), (7, 13, 5, 320, 192)])
 def test_conv3x3_small_tile_ring_kernel(dev, dtype, B, H, W, Cin, Cout):
     """csrc/cgemm.hip, small-tile form (64 x 64 tile, four-stage LDS-DMA ring): the long-reduction 3x3 convolutions below 16000 output

@@ -46,6 +46,8 @@ for B, H, W, Cin, Cout, what in [(64, 250, 16, 128, 128, "4000-px level"), (64, 
                                  (64, 125, 8, 640, 256, "1000-px up (640 in)"), (64, 63, 4, 384, 384, "252-px level (M = 16128: below the default threshold)")]:
     x = (torch.randn(B, H * W, Cin, device=dev) * 0.5).to(dt)
     w = (torch.randn(Cout, 3, 3, Cin, device=dev) * 0.02).to(dt)
+    if os.environ.get("CGEMM_ZERO"):  # all-zero operands: what the data-dependent power draw costs (MFMA clocks)
+        x.zero_(), w.zero_()
     b = (torch.randn(Cout, device=dev) * 0.1).to(dt)
     out, Ho, Wo = ops.conv3x3(x, w.reshape(Cout, -1), b, B, H, W)
     ms = time_kernel_graphed(lambda: ops.conv3x3(x, w.reshape(Cout, -1), b, B, H, W, out=out))
