@@ -130,29 +130,40 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnSrc x, float* partial
     }
 }
 
+// Between the passes (gn_finalize_kernel): thread (b, g) sums the chunk partials of its group in chunk order ONCE -> stats[b][g] = (mean, rstd).
+// (Until round 6 every workgroup of the apply pass repeated that sum -- 63 dependent-latency loads in front of its first pixel at the
+// 4000-pixel level, where the pass ran at 2.5 TB/s.)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* partial, float* stats, int BG, int G, int nchunk, float n, float eps) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= BG) return;
+    const int b = i / G, g = i - b * G;
+    const float* pp = partial + ((int64_t)b * nchunk * G + g) * 2;
+    float s = 0.f, ss = 0.f;
+    for (int k = 0; k < nchunk; ++k) {
+        s += pp[(int64_t)k * G * 2];
+        ss += pp[(int64_t)k * G * 2 + 1];
+    }
+    const float mean = s / n;
+    const float var = fmaxf(ss / n - mean * mean, 0.f);
+    stats[i * 2] = mean;
+    stats[i * 2 + 1] = rsqrtf(var + eps);
+}
+
+constexpr int GN_APPLY_CHUNK = 256;  // pixels per workgroup of the apply pass
+
 template <int DT, bool SILU>
-__global__ __launch_bounds__(256) void gn_apply_kernel(GnSrc x, const float* partial, const uint8_t* gamma,
-                                                       const uint8_t* beta, uint8_t* out, int HW, int C, int G, int nchunk,
-                                                       float eps) {
+__global__ __launch_bounds__(256) void gn_apply_kernel(GnSrc x, const float* stats, const uint8_t* gamma,
+                                                       const uint8_t* beta, uint8_t* out, int HW, int C, int G) {
     __shared__ float lm[64], lr[64];
     const int chunk = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x;
     const int cg = C / G, vpr = C >> 3;
     if (tid < G) {
-        float s = 0.f, ss = 0.f;
-        const float* pp = partial + ((int64_t)b * nchunk * G + tid) * 2;
-        for (int k = 0; k < nchunk; ++k) {
-            s += pp[(int64_t)k * G * 2];
-            ss += pp[(int64_t)k * G * 2 + 1];
-        }
-        const float n = (float)HW * (float)cg;
-        const float mean = s / n;
-        const float var = fmaxf(ss / n - mean * mean, 0.f);
-        lm[tid] = mean;
-        lr[tid] = rsqrtf(var + eps);
+        lm[tid] = stats[((int64_t)b * G + tid) * 2];
+        lr[tid] = stats[((int64_t)b * G + tid) * 2 + 1];
     }
     __syncthreads();
-    const int p0 = chunk * GN_CHUNK, p1 = min(p0 + GN_CHUNK, HW);
+    const int p0 = chunk * GN_APPLY_CHUNK, p1 = min(p0 + GN_APPLY_CHUNK, HW);
     if (256 % vpr == 0) {
         // a thread keeps ONE channel vector and walks the chunk's pixels: gamma / beta / the two groups' statistics are loaded once
         // and the loop carries no integer division (the generic loop below spends as many instructions on idx % vpr, c0 / cg as on
@@ -166,20 +177,31 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnSrc x, const float* par
         const uint8_t* src = gn_vec(x, b, HW, 0, c0);
         const int64_t pstride = (c0 < x.Ca ? x.Ca : x.Cb) * 2;
         uint8_t* dst = out + ((int64_t)b * HW * C + c0) * 2;
-        for (int px = p0 + py; px < p1; px += PY) {
-            float v[8], y[8];
-            unpack8<DT>(*reinterpret_cast<const uint4*>(src + (int64_t)px * pstride), v);
+        for (int px0 = p0 + py; px0 < p1; px0 += 4 * PY) {  // four pixels per trip: the loads go out together
+            uint4 raw[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float mean = e < 4 ? m0 : m1, rstd = e < 4 ? r0 : r1;
-                float t = (v[e] - mean) * rstd * g[e] + bt[e];
-                if (SILU) {
-                    t = (float)(typename ET<DT>::elem)t;
-                    t = silu_f(t);
-                }
-                y[e] = t;
+            for (int u = 0; u < 4; ++u) {
+                const int px = px0 + u * PY;
+                if (px < p1) raw[u] = *reinterpret_cast<const uint4*>(src + (int64_t)px * pstride);
             }
-            *reinterpret_cast<uint4*>(dst + (int64_t)px * C * 2) = pack8<DT>(y);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int px = px0 + u * PY;
+                if (px >= p1) break;
+                float v[8], y[8];
+                unpack8<DT>(raw[u], v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float mean = e < 4 ? m0 : m1, rstd = e < 4 ? r0 : r1;
+                    float t = (v[e] - mean) * rstd * g[e] + bt[e];
+                    if (SILU) {
+                        t = (float)(typename ET<DT>::elem)t;
+                        t = silu_f(t);
+                    }
+                    y[e] = t;
+                }
+                *reinterpret_cast<uint4*>(dst + (int64_t)px * C * 2) = pack8<DT>(y);
+            }
         }
         return;
     }
@@ -351,12 +373,17 @@ template <int DT> int gn_launch(const GnSrc& x, const void* gamma, const void* b
     hipLaunchKernelGGL((gn_partial_kernel<DT>), dim3(nchunk, B), dim3(256), 0, s, x, ws, HW, C, G, nchunk);
     int rc = apad_check_launch("apad_groupnorm(stats)");
     if (rc) return rc;
+    float* stats = ws + (int64_t)B * nchunk * G * 2;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * G + 255) / 256), dim3(256), 0, s, ws, stats, B * G, G, nchunk, (float)HW * (float)(C / G), eps);
+    rc = apad_check_launch("apad_groupnorm(finalize)");
+    if (rc) return rc;
+    const int achunk = (HW + GN_APPLY_CHUNK - 1) / GN_APPLY_CHUNK;
     if (silu)
-        hipLaunchKernelGGL((gn_apply_kernel<DT, true>), dim3(nchunk, B), dim3(256), 0, s, x, ws,
-                           (const uint8_t*)gamma, (const uint8_t*)beta, (uint8_t*)out, HW, C, G, nchunk, eps);
+        hipLaunchKernelGGL((gn_apply_kernel<DT, true>), dim3(achunk, B), dim3(256), 0, s, x, stats,
+                           (const uint8_t*)gamma, (const uint8_t*)beta, (uint8_t*)out, HW, C, G);
     else
-        hipLaunchKernelGGL((gn_apply_kernel<DT, false>), dim3(nchunk, B), dim3(256), 0, s, x, ws,
-                           (const uint8_t*)gamma, (const uint8_t*)beta, (uint8_t*)out, HW, C, G, nchunk, eps);
+        hipLaunchKernelGGL((gn_apply_kernel<DT, false>), dim3(achunk, B), dim3(256), 0, s, x, stats,
+                           (const uint8_t*)gamma, (const uint8_t*)beta, (uint8_t*)out, HW, C, G);
     return apad_check_launch("apad_groupnorm(apply)");
 }
 
@@ -378,7 +405,7 @@ extern "C" int apad_layernorm(const void* x, const void* gamma, const void* beta
 }
 
 extern "C" int64_t apad_groupnorm_workspace_bytes(int32_t B, int32_t HW, int32_t G) {
-    return (int64_t)B * ((HW + GN_CHUNK - 1) / GN_CHUNK) * G * 2 * sizeof(float);
+    return ((int64_t)B * ((HW + GN_CHUNK - 1) / GN_CHUNK) * G * 2 + (int64_t)B * G * 2) * sizeof(float);  // chunk partials + (mean, rstd)
 }
 
 extern "C" int apad_groupnorm2(const void* xa, const void* xb, const void* gamma, const void* beta, void* out, void* workspace,
