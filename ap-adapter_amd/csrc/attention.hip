@@ -1261,7 +1261,7 @@ template <int DT, int D> int launch_d(const AttnP& p, bool dual, dim3 grid, hipS
             }
             dim3 g2((unsigned)(((p.N + 255) / 256) * 8 * ((p.B + 7) / 8) * p.H));  // (sample-major XCD order: attn2q_body)
             if constexpr (D == 32) {
-                // pre-scaled q: the softmax without per-score max / scale instructions (APAD_ATTN_DIRECT=0: A/B switch).  d = 48 (the
+                // pre-scaled q: the softmax without per-score max / scale instructions.  d = 48 (the
                 // 252-token level) keeps the classic two-tile form: its direct form needs 256 VGPRs and measured slower in-step
                 // (44.82 vs 44.69 ms)
                 constexpr int direct = 1;

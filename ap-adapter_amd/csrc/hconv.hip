@@ -121,7 +121,10 @@ template <int WAVES_M_, int WAVES_N_, int MI_, int NJ_, int KS_> struct HcT {
     static constexpr int PBW = STAGE_B / 1024 / NW;    // weight DMA pieces per wave and stage
     static constexpr int SPT = 4 / KS;                 // stages per tap
     static constexpr int SPC = 9 * SPT;                // stages per 64-channel chunk
-    static constexpr int OFF_B = 2 * ABUF, OFF_Z = OFF_B + NSTG * STAGE_B, SMEM = OFF_Z + 128;
+    // LDS: [halo buffer 0][ring slots 0 .. 3][halo buffer 1][zero region]: ring slot 3 and halo buffer 1 -- both idle while a tile's epilogue
+    // runs -- are adjacent, the epilogue's transposition tiles live there
+    static constexpr int OFF_B = ABUF, OFF_A1 = OFF_B + NSTG * STAGE_B, OFF_Z = OFF_A1 + ABUF, SMEM = OFF_Z + 128;
+    static constexpr int OFF_STG = OFF_B + (NSTG - 1) * STAGE_B, STG_BYTES = STAGE_B + ABUF;
     static_assert(STAGE_B % (1024 * NW) == 0 && (KS == 2 || KS == 4) && SMEM <= 160 * 1024, "tile shape");
     static_assert(NJ * 2048 + SUBB < 65536, "immediate offsets of the weight fragment reads");
 };
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(T::NT) void hconv_kernel(HcP p) {
         }
     };
     auto issue_a = [&](int l, int buf, int chunk) {  // (wave-uniform arguments)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(smem + buf * T::ABUF + (l * NW + wave) * 1024), 16, aoff[l], chunk * 128, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(smem + buf * T::OFF_A1 + (l * NW + wave) * 1024), 16, aoff[l], chunk * 128, 0, 0);
     };
     // weight stage (chunk c, stage s of the chunk) -> ring slot: its KS / 2 sub-blocks [N][64 bytes] of the packed form
     const uint32_t lane16 = (uint32_t)(lane * 16);
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(T::NT) void hconv_kernel(HcP p) {
     auto tap_address = [&](int i, int tap, int buf) -> uint32_t {
         const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
         const uint32_t ps = pbase[i] + (uint32_t)(dy * W + dx);
-        uint32_t a = lds0 + (uint32_t)(buf * T::ABUF) + (ps << 7) + ((((ps >> 1) & 7) ^ (uint32_t)half) << 4);
+        uint32_t a = lds0 + (uint32_t)(buf * T::OFF_A1) + (ps << 7) + ((((ps >> 1) & 7) ^ (uint32_t)half) << 4);
         if (dx < 0) a = x_first ? zaddr : a;
         if (dx > 0) a = x_last ? zaddr : a;
         return a;
@@ -373,8 +376,8 @@ __global__ __launch_bounds__(T::NT) void hconv_kernel(HcP p) {
     constexpr int EROW = NJ * 64 + 16;          // staged row: NJ x 32 channels + 16 bytes of padding (bank spread of the 8-byte writes)
     constexpr int LPR = NJ * 4;                 // lanes per staged row on the way out (16 bytes each)
     constexpr int RPI = 64 / LPR;               // rows per store instruction
-    static_assert(32 * EROW * NW <= T::ABUF, "the epilogue tiles of all waves fit one halo buffer");
-    const uint32_t stg = lds0 + (uint32_t)(T::ABUF + wave * (32 * EROW));
+    static_assert(32 * EROW * NW <= T::STG_BYTES, "the epilogue tiles of all waves fit ring slot 3 + halo buffer 1");
+    const uint32_t stg = lds0 + (uint32_t)(T::OFF_STG + wave * (32 * EROW));
     const uint32_t stg_w = stg + (uint32_t)(l31 * EROW + 8 * half), stg_r = stg + (uint32_t)((lane / LPR) * EROW + (lane % LPR) * 16);
     const int cn_w = cn0 + wn * NJ * 32;        // first column of this wave
     float bv[4][4][4], tv[4][4][4];             // [j][g][e]: bias / table row of this lane's channels
@@ -532,8 +535,11 @@ int apad_hconv_try(const apad_gemm_desc* d, hipStream_t s) {
     if (d->Hup != 0 && (d->Hup != H || d->Wup != W)) return 1;
     if (d->M % ((int64_t)H * W) != 0 || d->M >= (1LL << 30) || d->N % 128 != 0) return 1;
     if (d->ldo % 8 != 0 || (d->residual && d->ldr % 8 != 0)) return 1;
-    const bool cfgA = d->N % 256 == 0;
+    // tile shape by the LAYER (never the row count): 256 x 256 when N % 256 == 0, else 256 x 128.  (A four-wave 128 x 192 shape for N = 384 --
+    // 252 instead of 189 workgroups at batch 32 -- measured slower, 51.8 vs 48.2 us: one wave per SIMD does not cover its own barrier bubbles.)
+    const int cfg = d->N % 256 == 0 ? 0 : 1;
     constexpr int BM = 256;
+    const int BNc = cfg == 0 ? HcA::BN : HcB::BN;
     const int R = BM / W, S = (R - 1) / H + 1;
     if ((R + 2 + S) * W > HcA::NPX) return 1;
     const int64_t Btot = d->M / ((int64_t)H * W);
@@ -546,8 +552,8 @@ int apad_hconv_try(const apad_gemm_desc* d, hipStream_t s) {
     p.ldo = d->ldo; p.ldr = d->ldr; p.ld_rg = d->ld_rg; p.rows_per_group = d->rows_per_group;
     p.M = (int32_t)d->M; p.N = (int32_t)d->N; p.Cin = d->Cin;
     p.H = H; p.W = W; p.Wlog = __builtin_ctz((unsigned)W); p.Hs = d->Hin; p.Ws = d->Win; p.Btot = (int32_t)Btot;
-    p.m_tiles = (int32_t)((d->M + BM - 1) / BM); p.n_tiles = (int32_t)(d->N / (cfgA ? HcA::BN : HcB::BN)); p.nchunks = d->Cin / 64;
+    p.m_tiles = (int32_t)((d->M + BM - 1) / BM); p.n_tiles = (int32_t)(d->N / BNc); p.nchunks = d->Cin / 64;
     p.a_bytes = (uint32_t)a_bytes; p.w_bytes = (uint32_t)w_bytes; p.trace = g_hconv_trace;
-    if (d->dtype == APAD_BF16) return cfgA ? hc_launch<APAD_BF16, HcA>(p, s) : hc_launch<APAD_BF16, HcB>(p, s);
-    return cfgA ? hc_launch<APAD_F16, HcA>(p, s) : hc_launch<APAD_F16, HcB>(p, s);
+    if (d->dtype == APAD_BF16) return cfg == 0 ? hc_launch<APAD_BF16, HcA>(p, s) : hc_launch<APAD_BF16, HcB>(p, s);
+    return cfg == 0 ? hc_launch<APAD_F16, HcA>(p, s) : hc_launch<APAD_F16, HcB>(p, s);
 }

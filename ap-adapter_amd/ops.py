@@ -79,7 +79,7 @@ import os as _os
 import weakref as _weakref
 
 # LayerNorm folded into the Linear behind it where no fused row-panel kernel covers the width (the 640-wide level): the producing
-# GEMM emits row statistics, the consuming GEMM applies (x - mean) * rstd * gamma + beta by algebra.  APAD_LN_FOLD=0: A/B switch
+# GEMM emits row statistics, the consuming GEMM applies (x - mean) * rstd * gamma + beta by algebra
 LN_FOLD = True  # (module attribute only: no environment switch since round 5)
 _fold_cache = {}
 

@@ -223,10 +223,9 @@ class AudioLDM2Pipeline:
             unet.set_kv_cache(True, clear=False)
             unet.precompute_time_tables(sched.timesteps.to(dev), step_ptr)
             e["tables"] = unet._time_tables  # the captured step keeps reading these
-            if use_graph and unet.low_res_streams is None and B >= 8:
-                # the 64-token section of the UNet is latency-bound at any batch: its two batch halves run on two streams
-                # inside the captured step (measured -1.1 % per step at batch 32; no effect on the arithmetic of a sample)
-                unet.low_res_streams = (torch.cuda.Stream(), torch.cuda.Stream())
+            # (the 64-token section stays on the one captured stream: four sub-layer workgroups per sample fill the chip at the CFG batch
+            #  -- same-box A/B 37.35 vs 37.49 ms with two half-batch streams -- and this is the configuration bench.py measures;
+            #  ``unet.low_res_streams`` remains an opt-in attribute)
 
             def step():
                 eps2 = unet.forward_nhwc(unet_in, H, W, None, gen, pe, None, mask, batch_repeat=2)

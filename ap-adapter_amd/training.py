@@ -263,8 +263,10 @@ class AdapterTrainer:
         self._scale_epoch += 1  # (captured micro-steps hold the scale as a kernel argument: they re-capture on their next replay)
 
     def _update_loss_scale(self):
-        """GradScaler.update() without a host sync: the device counter of APPLIED updates is copied to pinned memory behind every
-        optimizer step and read one step later, when the copy has long landed -- the scale backs off one step after the overflow"""
+        """GradScaler.update() without a host sync (``dynamic_loss_scale`` only): the device counter of APPLIED updates is copied to pinned
+        memory behind every optimizer step and read one step later, when the copy has long landed -- the scale backs off, and the LR schedule
+        is rewound by the skipped update, one boundary after the overflow.  (Without ``dynamic_loss_scale`` a skipped update still advances
+        the schedule, like the reference's unconditional ``lr_scheduler.step()``.)"""
         if self._applied_evt is not None and self._applied_evt.query():
             applied = int(self._applied_host[0])
             skipped = (self._applied_expect - applied) - self._applied_seen
@@ -338,9 +340,14 @@ class AdapterTrainer:
 
     # ---- checkpoint / resume of the trainable state (reference: accelerator.save_state, :988-1011) ----
     def state_dict(self):
+        """``scheduler_step`` is derived from the SYNCHRONISED count of applied updates (``step_t.item()`` is read here anyway): with
+        ``dynamic_loss_scale`` a skipped update is rewound out of the schedule one boundary late (``_update_loss_scale``), so the running
+        ``_sched_step`` may still count a skip that has not been read back; without it the schedule advances on every boundary like the
+        reference's ``lr_scheduler.step()`` (train_apadapter_v2.py:978)."""
+        applied = int(self.step_t.item())
+        sched = applied * self._sched_per_update if self.dynamic_loss_scale else self._sched_step
         return {"master": self.master.cpu(), "exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(),
-                "step": int(self.step_t.item()), "global_step": self.global_step, "scheduler_step": self._sched_step,
-                "loss_scale": self.loss_scale}
+                "step": applied, "global_step": self.global_step, "scheduler_step": sched, "loss_scale": self.loss_scale}
 
     def load_state_dict(self, sd):
         self.master.copy_(sd["master"])

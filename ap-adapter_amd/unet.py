@@ -158,10 +158,10 @@ class FeedForward(nn.Module):
 
     def _packed_weights(self):
         """the weight stream of apad_geglu_mlp_packed (ops.mlp_pack), re-packed when a parameter is re-assigned, moved, cast or updated"""
-        ps = (self.net[0].proj.weight, self.net[0].proj.bias, self.net[2].weight)
-        key = tuple((id(p), p.data_ptr(), p._version, p.dtype, p.device) for p in ps)
+        ps = (self.net[0].proj.weight, self.net[0].proj.bias, self.net[2].weight)  # (a bias-free GEGLU projection: ps[1] is None)
+        key = tuple(None if p is None else (id(p), p.data_ptr(), p._version, p.dtype, p.device) for p in ps)
         if getattr(self, "_mlp3_key", None) != key:
-            self._mlp3_w = ops.mlp_pack(ps[0].detach(), ps[1].detach(), ps[2].detach())
+            self._mlp3_w = ops.mlp_pack(ps[0].detach(), None if ps[1] is None else ps[1].detach(), ps[2].detach())
             self._mlp3_key = key
         return self._mlp3_w
 
@@ -189,9 +189,9 @@ class FeedForward(nn.Module):
                 and x.numel() // x.shape[-1] >= ops.GEGLU_PACKED_MIN_M):
             # the 384-wide level at full size: LayerNorm + GEGLU projection on the 64-token register-block kernel from packed weights
             ps = (self.net[0].proj.weight, self.net[0].proj.bias)
-            key = tuple((id(p), p.data_ptr(), p._version, p.dtype, p.device) for p in ps)
+            key = tuple(None if p is None else (id(p), p.data_ptr(), p._version, p.dtype, p.device) for p in ps)
             if getattr(self, "_geglu3_key", None) != key:
-                self._geglu3_w = ops.geglu_pack(ps[0].detach(), ps[1].detach())
+                self._geglu3_w = ops.geglu_pack(ps[0].detach(), None if ps[1] is None else ps[1].detach())
                 self._geglu3_key = key
             h = ops.layernorm_geglu_packed(x, self._geglu3_w[0], self._geglu3_w[1], ln=ln)
         else:

@@ -136,6 +136,7 @@ def test_conv3x3_big_tile_kernel(dev, dtype, B, H, W, Cin, Cout):
     (1, 5, 4, 64, 128, None, "sample"),       # a tile holding many tiny samples' rows ... here ONE sample smaller than a tile
     (40, 5, 4, 64, 128, None, "table"),       # 13 separator rows per tile
     (2, 40, 16, 640, 256, None, "table"),     # ten 64-channel chunks
+    (5, 63, 4, 128, 128, None, "table"),      # 256 x 128 tiles on a 4-wide image
 ])
 def test_conv3x3_halo_kernel(dev, dtype, B, H, W, Cin, Cout, up, temb):
     """csrc/hconv.hip: the halo-resident 3x3 convolution (input rows of a tile resident in LDS, nine taps as nine shifts of the same tile,
@@ -867,9 +868,9 @@ def test_fused_cross_attention(dev, dtype, B, N, Lt, La, masked):
     et = q(R(B, Lt, 768, seed=211), dtype)
     ea = q(R(B, La, 768, seed=212), dtype) if La else None
     if La > 128:
-        # the chunked form moves its running maximum only on a jump: audio tokens late in the segment that dominate the scores (a few rows scaled
-        # up so that later 64-key chunks raise some queries' maxima by far more than the 2^8 window) force the rescale branch; the other samples
-        # keep ordinary data (the no-rescale path)
+        # the chunked form carries a running maximum / sum across its 64-key chunks and rescales the accumulator on every chunk: audio tokens late
+        # in the segment that dominate the scores (a few rows scaled up so that later chunks raise some queries' maxima by a large factor) exercise
+        # a rescale that is not ~1; the other samples keep ordinary data
         ea[0, 70:74] *= 6.0
         ea[0, La - 30:La - 27] *= 12.0
         ea = q(ea, dtype)
@@ -899,6 +900,44 @@ def test_fused_cross_attention(dev, dtype, B, N, Lt, La, masked):
     od = ops.attention(qd, k1, v1t, Lt, H, key_bias=None if bias is None else bias.to(dev), k2=k2, vt2=v2t, L2=La, scale2=0.55)
     chain = ops.fused_linear(od, D(wo), D(bo), residual=D(x))
     assert rel_err(out, chain.float().cpu()) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES16)
+@pytest.mark.parametrize("shift,outlier", [(50.0, 1.0), (0.0, 40.0), (-30.0, 25.0)])
+def test_fused_cross_attention_rows_with_a_large_mean(dev, dtype, shift, outlier):
+    """the one-launch attn2 kernel applies its LayerNorm by algebra on the RAW rows (q = rstd (W' x) - mean rstd rowsum(W') + W beta): residual
+    streams whose rows have |mean| >> std and a few outlier channels -- where that form cancels in fp32 -- against fp32 torch and the chain"""
+    from ap_adapter_amd import ops
+    B, N, Lt, La, C, H = 2, 300, 8, 32, 256, 8
+    x = R(B, N, C, seed=401) + shift
+    x[:, :, 7] *= outlier
+    x[:, :, 130] -= 3.0 * outlier
+    x = q(x, dtype)
+    g, be = q(1 + 0.1 * R(C, seed=402), dtype), q(0.1 * R(C, seed=403), dtype)
+    wq, wo, bo = q(R(C, C, seed=404, std=0.06), dtype), q(R(C, C, seed=405, std=0.06), dtype), q(R(C, seed=406, std=0.3), dtype)
+    wk, wv = q(R(C, 768, seed=407, std=0.04), dtype), q(R(C, 768, seed=408, std=0.04), dtype)
+    wki, wvi = q(R(C, 768, seed=409, std=0.04), dtype), q(R(C, 768, seed=410, std=0.04), dtype)
+    et, ea = q(R(B, Lt, 768, seed=411), dtype), q(R(B, La, 768, seed=412), dtype)
+    ref = _xattn_ref(x, g, be, wq, wo, bo, et, wk, wv, H, None, ea, wki, wvi, 0.55)
+    D = lambda t: t.to(dev, dtype)
+    k1, k2 = ops.linear(D(et), D(wk)), ops.linear(D(ea), D(wki))
+    v1t = torch.zeros(B, H, C // H, ops.round_up(Lt, 32), device=dev, dtype=dtype)
+    v2t = torch.zeros(B, H, C // H, ops.round_up(La, 32), device=dev, dtype=dtype)
+    ops.linear_vt(D(et), D(wv), B, Lt, H, v1t)
+    ops.linear_vt(D(ea), D(wvi), B, La, H, v2t)
+    (wq_p, q_fold), wo_p = ops.xattn_pack_weight(D(wq), (D(g), D(be), 1e-5)), ops.xattn_pack_weight(D(wo))
+    out = ops.fused_cross_attention(D(x), wq_p, wo_p, D(bo), ops.xattn_pack_kv(k1, v1t, Lt), Lt, H, ln=(D(g), D(be), 1e-5),
+                                    kv2_packed=ops.xattn_pack_kv(k2, v2t, La), L2=La, scale2=0.55, q_fold=q_fold)
+    # the residual dominates the output (|x| up to shift + outliers): the attention contribution is what has to be right
+    delta, dref = out.float().cpu() - x.float(), ref - x.float()
+    assert float((delta - dref).abs().max() / dref.abs().max()) < 3 * TOL[dtype] + float(x.abs().max()) * 2 ** -8 / float(dref.abs().max())
+    qd = ops.fused_linear(D(x), D(wq), ln=(D(g), D(be), 1e-5))
+    od = ops.attention(qd, k1, v1t, Lt, H, k2=k2, vt2=v2t, L2=La, scale2=0.55)
+    chain = ops.fused_linear(od, D(wo), D(bo), residual=D(x))
+    dchain = chain.float().cpu() - x.float()
+    print(f"shift {shift} outlier {outlier}: fused vs fp32 {float((delta - dref).abs().max() / dref.abs().max()):.3e}, chain vs fp32 "
+          f"{float((dchain - dref).abs().max() / dref.abs().max()):.3e}")
+    assert float((delta - dref).abs().max()) < 2.0 * float((dchain - dref).abs().max()) + 1e-6
 
 
 @pytest.mark.parametrize("dtype", DTYPES16)
