@@ -728,6 +728,47 @@ def test_geglu_mlp_packed(dev, dtype, M, ln, bias):
     assert torch.equal(ops.geglu_mlp_packed(xd, wp, bp, dv(b2), ln=lnp, out=xd), out)
 
 
+def test_geglu_mlp_packed_at_the_product_launch_size(dev):
+    """apad_geglu_mlp_packed at the size the denoise step launches it (63 993 rows: 250 workgroups, a buffer-addressed ragged tail) DIRECTLY
+    against fp32 torch on the storage-rounded operands (reference evaluated in fp32 on the device: 67 GFLOP)"""
+    from ap_adapter_amd import ops
+    dtype, C, M = torch.bfloat16, 256, 63993
+    x = q(R(M, C, seed=556), dtype)
+    w1, b1 = q(R(8 * C, C, seed=557, std=0.08), dtype), q(R(8 * C, seed=558, std=0.5), dtype)
+    w2, b2 = q(R(C, 4 * C, seed=559, std=0.04), dtype), q(R(C, seed=560, std=0.5), dtype)
+    g, be = q(1 + 0.1 * R(C, seed=561), dtype), q(0.1 * R(C, seed=562), dtype)
+    f = lambda t: t.to(dev, torch.float32)
+    xin = F.layer_norm(f(x), (C,), f(g), f(be), 1e-5).to(dtype).float()
+    a, gate = F.linear(xin, f(w1), f(b1)).chunk(2, dim=-1)
+    ref = (f(x) + F.linear(a * F.gelu(gate), f(w2), f(b2))).cpu()
+    dv = lambda t: t.to(dev, dtype)
+    wp, bp = ops.mlp_pack(dv(w1), dv(b1), dv(w2))
+    out = ops.geglu_mlp_packed(dv(x), wp, bp, dv(b2), ln=(dv(g), dv(be), 1e-5))
+    assert rel_err(out, ref) < TOL[dtype]
+    # every row block on its own, the last (ragged) workgroups included
+    err = (out.float().cpu() - ref).abs().amax(dim=1)
+    assert float(err[-300:].max()) < TOL[dtype] * float(ref.abs().max()) and float(err[:300].max()) < TOL[dtype] * float(ref.abs().max())
+
+
+def test_layernorm_geglu_packed_at_the_product_launch_size_ragged(dev):
+    """apad_layernorm_geglu_packed at 16 100 rows (the 252-token level's launch size with a ragged last tile) directly against fp32 torch"""
+    from ap_adapter_amd import ops
+    dtype, C, M = torch.bfloat16, 384, 16100
+    x = q(R(M, C, seed=656), dtype)
+    w1, b1 = q(R(8 * C, C, seed=657, std=0.06), dtype), q(R(8 * C, seed=658, std=0.5), dtype)
+    g, be = q(1 + 0.1 * R(C, seed=661), dtype), q(0.1 * R(C, seed=662), dtype)
+    f = lambda t: t.to(dev, torch.float32)
+    xin = F.layer_norm(f(x), (C,), f(g), f(be), 1e-5).to(dtype).float()
+    a, gate = F.linear(xin, f(w1), f(b1)).chunk(2, dim=-1)
+    ref = (a * F.gelu(gate)).cpu()
+    dv = lambda t: t.to(dev, dtype)
+    wp, bp = ops.geglu_pack(dv(w1), dv(b1))
+    out = ops.layernorm_geglu_packed(dv(x), wp, bp, ln=(dv(g), dv(be), 1e-5))
+    assert out.shape == ref.shape and rel_err(out, ref) < TOL[dtype]
+    err = (out.float().cpu() - ref).abs().amax(dim=1)
+    assert float(err[-300:].max()) < TOL[dtype] * float(ref.abs().max())
+
+
 def test_geglu_mlp_packed_route_and_repack(dev, monkeypatch):
     """FeedForward takes the packed kernel from ops.MLP_PACKED_MIN_M rows, packs once, and re-packs when a parameter is updated in place"""
     from ap_adapter_amd import ops

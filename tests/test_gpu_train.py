@@ -323,6 +323,11 @@ def _batch(B, La, dtype):
 
 # (bf16: a rounding-noise bound through ~200 rounded layers; its realisation moves with the kernels' summation orders -- worst tensor
 #  0.078 with three input-gradient GEMMs for q / k / v, 0.084 with the single stacked one; the exactness claim is the fp32 row)
+# per-tensor relative L2 bound on top of the max-abs one (round 6; measured 5.1e-2 / 6.2e-3 / 8.3e-6): the max-abs bound of a 16-bit mode is set by
+# the single worst entry of a rounding-noise field, the L2 norm is what the optimizer step feels
+L2TOL = {torch.bfloat16: 7e-2, torch.float16: 9e-3, torch.float32: 3e-5}
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1e-1), (torch.float16, 2e-2), (torch.float32, 2e-4)])
 def test_adapter_gradients_small_unet_vs_oracle(dev, dtype, tol):
     """loss and d loss / d to_{k,v}_ip.weight of all 32 adapted sites after a backward through the whole frozen UNet
@@ -341,6 +346,7 @@ def test_adapter_gradients_small_unet_vs_oracle(dev, dtype, tol):
     names = [n for n, p in u.attn_processors.items() if hasattr(p, "to_k_ip")]
     assert len(names) == 32 and len(tr.params) == 64
     flat_ref = []
+    worst_l2 = 0.0
     for i, n in enumerate(names):
         for j, which in enumerate(("to_k_ip", "to_v_ip")):
             p = tr.params[2 * i + j]
@@ -348,7 +354,11 @@ def test_adapter_gradients_small_unet_vs_oracle(dev, dtype, tol):
             want = ref_grads[f"{n}.{which}.weight"]
             assert float(want.abs().max()) > 0
             assert rel_err(got, want) < tol, (n, which)
+            l2 = float((got.float().cpu() - want).norm() / want.norm())
+            worst_l2 = max(worst_l2, l2)
             flat_ref.append(want.reshape(-1))
+    print(f"worst per-tensor relative L2 gradient error ({dtype}): {worst_l2:.3e}")
+    assert worst_l2 < L2TOL[dtype]
     flat_ref = torch.cat(flat_ref)
     cos = F.cosine_similarity(tr.grad.cpu().double(), flat_ref.double(), dim=0)
     assert 1 - float(cos) < (1e-8 if dtype == torch.float32 else 2e-3)
