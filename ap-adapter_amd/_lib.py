@@ -33,7 +33,7 @@ class GemmDesc(C.Structure):
                [("conv_asym_pad", _i32), ("reserved_conv", _i32)] + \
                [(n, _vp) for n in ("rowstat_out", "rowstat_in", "ln_colsum", "ln_bias")] + [("rowstat_in_tiles", _i32), ("ln_eps", _f32)] + \
                [("a2", _vp), ("lda2", _i64), ("k_split", _i32), ("a_row_mod", _i32), ("a2_row_mod", _i32), ("reserved_a2", _i32), ("out4", _vp),
-                ("w_halo", _vp)]
+                ("w_halo", _vp), ("workspace", _vp), ("workspace_bytes", _i64)]
 
 
 class AttnDesc(C.Structure):
@@ -130,6 +130,7 @@ SYMBOLS = {
     "apad_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "apad_conv_halo_pack": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp]),
     "apad_hconv_launch_count": (_i64, []),
+    "apad_conv_halo_workspace_bytes": (_i64, [_i64, _i64, _i64, _i32]),
     "apad_attention": (C.c_int, [C.POINTER(AttnDesc), _vp]),
     "apad_layernorm": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _i64, _f32, _i32, _vp]),
     "apad_groupnorm_workspace_bytes": (_i64, [_i32, _i32, _i32]),

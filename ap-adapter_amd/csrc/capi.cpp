@@ -64,7 +64,7 @@ extern "C" int apad_echo_gemm_desc(const apad_gemm_desc* d, double* out, int cap
     PUT(d->conv_asym_pad); PUT(d->reserved_conv);
     PUTP(d->rowstat_out); PUTP(d->rowstat_in); PUTP(d->ln_colsum); PUTP(d->ln_bias); PUT(d->rowstat_in_tiles); PUT(d->ln_eps);
     PUTP(d->a2); PUT(d->lda2); PUT(d->k_split); PUT(d->a_row_mod); PUT(d->a2_row_mod); PUT(d->reserved_a2);
-    PUTP(d->out4); PUTP(d->w_halo);
+    PUTP(d->out4); PUTP(d->w_halo); PUTP(d->workspace); PUT(d->workspace_bytes);
     return n;
 }
 

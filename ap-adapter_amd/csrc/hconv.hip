@@ -48,6 +48,8 @@ struct HcP {
     int32_t Hs, Ws;      // the source image
     int32_t Btot;
     int32_t m_tiles, n_tiles, nchunks;
+    int32_t ksplit;   // K slices per output tile (whole 64-channel chunks each); > 1: fp32 partial slabs, summed in slice order by hconv_reduce_kernel
+    float* partial;   // [ksplit][M][N]
     uint32_t a_bytes, w_bytes;
     unsigned long long* trace;  // (probe builds, HC_TRACE: 32 s_memtime stamps per workgroup; tools/hconv_trace.py)
 };
@@ -145,13 +147,18 @@ __global__ __launch_bounds__(T::NT) void hconv_kernel(HcP p) {
     const uint32_t lds0 = (uint32_t)(size_t)(lds_ptr)smem;
 
     // ---- per tile: origin, halo DMA sources, the lanes' pixel records.  Persistent workgroups: tile tl, tl + gridDim.x, ... ----
-    int m0 = 0, n0 = 0;
+    int m0 = 0, n0 = 0, c_begin = 0, c_end = 0, kslice = 0;
     uint32_t aoff[5];   // piece l of this wave fills pixel records (l NW + wave) 8 .. + 8; lane -> (record, 16-byte slot); the slot holds source
                         // chunk slot ^ ((record >> 1) & 7).  Record pp <-> (tile row j = pp / W, x): virtual row v = y0 - 1 + j in a coordinate
                         // where every sample owns H rows + one separator
     uint32_t pbase[4];  // this lane's output pixel of MFMA tile i sits at record pbase[i]; tap (dy, dx) reads record pbase + dy W + dx
                         // (MI used.  Fixed bounds: a template-dependent array bound captured by the lambdas below loses the kernel's host stub -- hipcc 7.2)
-    auto setup_tile = [&](int tl) {
+    auto setup_tile = [&](int tl_ks) {
+        // the K slice (fastest index) and its range of 64-channel chunks
+        const int tl = tl_ks / p.ksplit;
+        kslice = tl_ks - tl * p.ksplit;
+        c_begin = kslice * p.nchunks / p.ksplit;
+        c_end = (kslice + 1) * p.nchunks / p.ksplit;
         // XCD-aware tile order (speed only): all N-tiles of one M-tile share tl % 8 -- one XCD's L2 serves their common halo
         int mt, nt;
         {
@@ -253,14 +260,14 @@ __global__ __launch_bounds__(T::NT) void hconv_kernel(HcP p) {
     // ---- a tile's prologue requests: halo chunk 0 -> buffer 0, weight stages 0 .. 2 -> ring slots 0 .. 2 ----
     auto issue_prologue = [&]() {
 #pragma unroll
-        for (int l = 0; l < NLD; ++l) issue_a(l, 0, 0);
+        for (int l = 0; l < NLD; ++l) issue_a(l, 0, c_begin);
 #pragma unroll
         for (int s = 0; s < 3; ++s)
 #pragma unroll
-            for (int i = 0; i < PBW; ++i) issue_b(0, s, s, i);
+            for (int i = 0; i < PBW; ++i) issue_b(c_begin, s, s, i);
     };
     if (tid < 8) *reinterpret_cast<uint4*>(smem + T::OFF_Z + tid * 16) = make_uint4(0, 0, 0, 0);  // the zero region
-    const int nchunks = (HC_ABL & 16) ? 1 : p.nchunks, ntiles = p.m_tiles * p.n_tiles;
+    const int ntiles = p.m_tiles * p.n_tiles * p.ksplit;
     HC_STAMP(0);
     setup_tile(blockIdx.x);
     issue_prologue();
@@ -268,7 +275,7 @@ __global__ __launch_bounds__(T::NT) void hconv_kernel(HcP p) {
     int tstamp = 2;
 #pragma unroll 1
     for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
-    const int cm0 = m0, cn0 = n0;  // (the next tile's setup overwrites m0 / n0 before this tile's epilogue)
+    const int cm0 = m0, cn0 = n0, cks = kslice, cb = c_begin, ce = c_end;  // (the next tile's setup overwrites them before this tile's epilogue)
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -291,9 +298,9 @@ __global__ __launch_bounds__(T::NT) void hconv_kernel(HcP p) {
     // ---- main loop: chunks (run time) x SPC stages (unrolled) ----
     int slot = 0;  // ring slot of the current stage
 #pragma unroll 1
-    for (int c = 0; c < nchunks; ++c) {
-        const bool last = c + 1 == nchunks;
-        const int buf = c & 1;
+    for (int c = cb; c < ce; ++c) {
+        const bool last = c + 1 == ce;
+        const int buf = (c - cb) & 1;
         auto stage = [&](auto s_tag) {
             constexpr int S = decltype(s_tag)::value;
             constexpr int TAP = S / SPT, KS0 = (S % SPT) * KS;  // first MFMA step (of the chunk's four) of this stage
@@ -388,8 +395,8 @@ __global__ __launch_bounds__(T::NT) void hconv_kernel(HcP p) {
             const int n = cn_w + j * 32 + 8 * g + 4 * half;
 #pragma unroll
             for (int e = 0; e < 4; ++e) bv[j][g][e] = tv[j][g][e] = 0.f;
-            if (p.bias) ld4(p.bias, n, bv[j][g]);
-            if (rg_table) ld4(p.rg, step * p.ld_rg + n, tv[j][g]);
+            if (p.bias && p.ksplit == 1) ld4(p.bias, n, bv[j][g]);
+            if (rg_table && p.ksplit == 1) ld4(p.rg, step * p.ld_rg + n, tv[j][g]);
         }
     abl_reads_off = false;
     HC_STAMP(tstamp + 1);  // main loop done
@@ -405,6 +412,24 @@ __global__ __launch_bounds__(T::NT) void hconv_kernel(HcP p) {
     //      the next tile's first stage barrier) -> (+ residual) -> full-line stores.  Lane (pixel l31, half) holds channels 8 g + 4 half + (0..3)
     //      of a 32-channel block in accumulators 4 g .. 4 g + 3: one ds_write_b64 per group; a row of the wave's NJ x 32 channels is then read
     //      back by NJ x 4 lanes as 16-byte pieces, so one store instruction writes whole rows of the wave's column range ----
+    if (p.ksplit > 1) {
+        // a K slice: the raw fp32 accumulators go to this slice's slab (lane: 4 consecutive channels per group = one 16-byte store); bias, time
+        // embedding, rounding and the residual belong to hconv_reduce_kernel, which sums the slabs in slice order
+        float* slab = p.partial + (int64_t)cks * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = cm0 + (wm * MI + i) * 32 + l31;
+            if (m < p.M) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 v = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
+                        *reinterpret_cast<f32x4*>(slab + (int64_t)m * p.N + cn_w + j * 32 + 8 * g + 4 * half) = v;
+                    }
+            }
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int mrow0 = cm0 + (wm * MI + i) * 32;  // first pixel of the block
@@ -458,6 +483,7 @@ __global__ __launch_bounds__(T::NT) void hconv_kernel(HcP p) {
         }
         if (HC_TRACE && ntiles <= (int)gridDim.x) HC_STAMP(8 + 2 * i + 1);
     }
+    }
     HC_STAMP(tstamp + 4);  // epilogue issued
     tstamp += 5;
     }  // tiles
@@ -483,6 +509,52 @@ __global__ void hconv_pack_kernel(const TE* __restrict__ w, TE* __restrict__ out
 int64_t g_hconv_launches = 0;
 unsigned long long* g_hconv_trace = nullptr;  // (tests assert the route with it; not synchronised: a diagnostic)
 
+// out = ((sum over the K slices, in slice order) + bias) + time-embedding row -> storage type -> + residual: the epilogue of a split convolution.
+// Thread = 8 consecutive channels of one pixel.
+template <int DT>
+__global__ __launch_bounds__(256) void hconv_reduce_kernel(HcP p) {
+    const int vpr = p.N >> 3;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)p.M * vpr) return;
+    const int m = (int)(idx / vpr), n = (int)(idx - (int64_t)m * vpr) * 8;
+    float a[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = 0.f;
+    for (int ks = 0; ks < p.ksplit; ++ks) {
+        const float* src = p.partial + ((int64_t)ks * p.M + m) * p.N + n;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a[e] += v0[e];
+            a[e + 4] += v1[e];
+        }
+    }
+    if (p.bias) {
+        float b[8];
+        unpack8<DT>(*reinterpret_cast<const uint4*>(p.bias + n * 2), b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += b[e];
+    }
+    if (p.rg) {
+        const int64_t step = p.step_ptr ? (int64_t)*p.step_ptr : 0;
+        const int64_t grp = (p.rows_per_group >= p.M ? 0 : m / p.rows_per_group) + step;
+        float t[8];
+        unpack8<DT>(*reinterpret_cast<const uint4*>(p.rg + (grp * p.ld_rg + n) * 2), t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += t[e];
+    }
+    uint4 o = pack8<DT>(a);
+    if (p.residual) {
+        float f[8], rr[8];
+        unpack8<DT>(o, f);
+        unpack8<DT>(*reinterpret_cast<const uint4*>(p.residual + ((int64_t)m * p.ldr + n) * 2), rr);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] += rr[e];
+        o = pack8<DT>(f);
+    }
+    *reinterpret_cast<uint4*>(p.out + ((int64_t)m * p.ldo + n) * 2) = o;
+}
+
 template <int DT, class T> int hc_launch(const HcP& p, hipStream_t s) {
     auto kern = hconv_kernel<DT, T>;
     ++g_hconv_launches;
@@ -498,15 +570,29 @@ template <int DT, class T> int hc_launch(const HcP& p, hipStream_t s) {
         cus[dev] = n;
     }
     static const int grid_cap = [] { const char* e = getenv("APAD_HCONV_GRID"); return e ? atoi(e) : 0; }();  // A/B knob: workgroups (0 = one per CU)
-    const int tiles = p.m_tiles * p.n_tiles, cap = grid_cap > 0 ? grid_cap : cus[dev];
+    const int tiles = p.m_tiles * p.n_tiles * p.ksplit, cap = grid_cap > 0 ? grid_cap : cus[dev];
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles < cap ? tiles : cap)), dim3(T::NT), T::SMEM, s, p);
-    return apad_check_launch("apad_gemm(halo convolution)");
+    int rc = apad_check_launch("apad_gemm(halo convolution)");
+    if (rc || p.ksplit == 1) return rc;
+    const int64_t vecs = (int64_t)p.M * (p.N / 8);
+    hipLaunchKernelGGL(hconv_reduce_kernel<DT>, dim3((unsigned)((vecs + 255) / 256)), dim3(256), 0, s, p);
+    return apad_check_launch("apad_gemm(halo convolution, slice sum)");
 }
 
 using HcA = HcT<2, 4, 4, 2, 2>;  // 256 x 256, waves 128 x 64   (N % 256 == 0: the 1000-pixel level)
 using HcB = HcT<4, 2, 2, 2, 4>;  // 256 x 128, waves  64 x 64   (N % 128 == 0: the 4000-pixel level)
 
 }  // namespace
+
+// K slices of a layer (a function of the LAYER only -- image width and input channels --, never of the row count): the 2-wide images of the
+// 64-token level have 4 samples per 256-pixel tile, so a CFG batch of 64 is 16 row tiles x 5 column tiles = 80 workgroups of 90 .. 180 stages; three
+// slices of whole 64-channel chunks make it 240 workgroups, the slabs are summed in slice order (hconv_reduce_kernel)
+static int hconv_ksplit(int W, int Cin) { return W == 2 && Cin / 64 >= 3 ? 3 : 1; }
+
+extern "C" int64_t apad_conv_halo_workspace_bytes(int64_t M, int64_t N, int64_t Cin, int32_t Wout) {
+    const int ks = hconv_ksplit(Wout, (int)Cin);
+    return ks > 1 ? ks * M * N * (int64_t)sizeof(float) : 0;
+}
 
 extern "C" int64_t apad_hconv_launch_count(void) { return g_hconv_launches; }
 // probe builds (-DHC_TRACE=1) only: device buffer of 32 x workgroups uint64 time stamps; not part of the ABI header
@@ -530,7 +616,10 @@ int apad_hconv_try(const apad_gemm_desc* d, hipStream_t s) {
     if (d->epilogue != APAD_EPI_NONE || d->out_mode != APAD_OUT_ROWMAJOR || d->rowstat_out || d->rowstat_in) return 1;
     if (d->stride != 1 || d->src_batch_mod != 0 || d->conv_asym_pad || d->residual_row_mod != 0 || d->Cin % 64 != 0 || d->K != 9 * (int64_t)d->Cin) return 1;
     const int H = d->Hout, W = d->Wout;
-    if (W < 4 || W > 16 || (W & (W - 1)) != 0 || H < 1) return 1;
+    if (W < 2 || W > 16 || (W & (W - 1)) != 0 || H < 1) return 1;
+    const int ksplit = hconv_ksplit(W, d->Cin);
+    if (ksplit > 1 && (!d->workspace || d->workspace_bytes < ksplit * d->M * d->N * (int64_t)sizeof(float))) return 1;  // (the caller sizes it with
+                                                                                                                       //  apad_conv_halo_workspace_bytes)
     if (d->Hup == 0 && (d->Hin != H || d->Win != W)) return 1;
     if (d->Hup != 0 && (d->Hup != H || d->Wup != W)) return 1;
     if (d->M % ((int64_t)H * W) != 0 || d->M >= (1LL << 30) || d->N % 128 != 0) return 1;
@@ -553,6 +642,7 @@ int apad_hconv_try(const apad_gemm_desc* d, hipStream_t s) {
     p.M = (int32_t)d->M; p.N = (int32_t)d->N; p.Cin = d->Cin;
     p.H = H; p.W = W; p.Wlog = __builtin_ctz((unsigned)W); p.Hs = d->Hin; p.Ws = d->Win; p.Btot = (int32_t)Btot;
     p.m_tiles = (int32_t)((d->M + BM - 1) / BM); p.n_tiles = (int32_t)(d->N / BNc); p.nchunks = d->Cin / 64;
+    p.ksplit = ksplit; p.partial = (float*)d->workspace;
     p.a_bytes = (uint32_t)a_bytes; p.w_bytes = (uint32_t)w_bytes; p.trace = g_hconv_trace;
     if (d->dtype == APAD_BF16) return cfg == 0 ? hc_launch<APAD_BF16, HcA>(p, s) : hc_launch<APAD_BF16, HcB>(p, s);
     return cfg == 0 ? hc_launch<APAD_F16, HcA>(p, s) : hc_launch<APAD_F16, HcB>(p, s);

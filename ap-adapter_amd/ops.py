@@ -47,7 +47,7 @@ def set_gemm_ring(mode):
 def gemm(a, w, *, M, N, K, lda, out, ldo, bias=None, residual=None, ldr=0, act=None, rowgroup_bias=None, ld_rg=0,
          rows_per_group=0, step_ptr=None, a_mode=L.A_PLAIN, out_mode=L.OUT_ROWMAJOR, conv=None, vt=None, ldw=None,
          residual_row_mod=0, asym_pad=False, rowstat_out=None, ln_fold=None, a2=None, lda2=0, k_split=0, a_row_mod=0, a2_row_mod=0,
-         w_halo=None):
+         w_halo=None, workspace=None):
     """Raw descriptor call; the typed helpers below are what the model code uses.  rowstat_out: fp32 [M, N/64, 2] side output
     (row statistics of the stored rows); ln_fold = (rowstat_in [M, T, 2], colsum, bias_fp32, eps): LayerNorm by algebra."""
     d = L.GemmDesc()
@@ -71,6 +71,8 @@ def gemm(a, w, *, M, N, K, lda, out, ldo, bias=None, residual=None, ldr=0, act=N
         d.a2, d.lda2, d.k_split = a2.data_ptr(), lda2, k_split
     d.a_row_mod, d.a2_row_mod = a_row_mod, a2_row_mod
     d.w_halo = _ptr(w_halo)
+    if workspace is not None:
+        d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     L.check(L.lib().apad_gemm(C.byref(d), _stream()), "apad_gemm")
     return out
 
@@ -719,7 +721,7 @@ _halo_cache = {}
 def conv_halo_eligible(Cin, Cout, Wout, stride, dtype, src_batch_mod=0, asym_pad=False):
     """the LAYER-level part of apad_hconv_try's envelope (never the row count): what decides whether the packed form is built"""
     return (HCONV and stride == 1 and not asym_pad and src_batch_mod == 0 and dtype in FUSED_DTYPES and Cin % 64 == 0 and Cout % 128 == 0
-            and Wout in (4, 8, 16))
+            and Wout in (2, 4, 8, 16))
 
 
 def conv_halo_weight(w_packed):
@@ -755,8 +757,13 @@ def conv3x3(x, w_packed, bias, B, Hin, Win, stride=1, up=None, residual=None, ro
     M = B * Hout * Wout
     if out is None:
         out = torch.empty(B, Hout * Wout, Cout, dtype=x.dtype, device=x.device)
-    wh = conv_halo_weight(w_packed) if conv_halo_eligible(Cin, Cout, Wout, stride, w_packed.dtype, src_batch_mod, asym_pad) else None
-    gemm(x, w_packed, M=M, N=Cout, K=9 * Cin, lda=0, out=out, ldo=Cout, bias=bias, w_halo=wh,
+    wh = ws = None
+    if conv_halo_eligible(Cin, Cout, Wout, stride, w_packed.dtype, src_batch_mod, asym_pad):
+        wh = conv_halo_weight(w_packed)
+        nws = L.lib().apad_conv_halo_workspace_bytes(M, Cout, Cin, Wout)  # (the K-sliced layers of the 64-token level: fp32 slabs)
+        if nws:
+            ws = torch.empty(nws // 4, dtype=torch.float32, device=x.device)
+    gemm(x, w_packed, M=M, N=Cout, K=9 * Cin, lda=0, out=out, ldo=Cout, bias=bias, w_halo=wh, workspace=ws,
          residual=residual, ldr=Cout, rowgroup_bias=rowgroup_bias,
          ld_rg=(rowgroup_bias.stride(0) if rowgroup_bias is not None else 0), rows_per_group=rows_per_group,
          step_ptr=step_ptr, a_mode=L.A_CONV3X3, asym_pad=asym_pad,

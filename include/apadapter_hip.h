@@ -136,6 +136,9 @@ typedef struct apad_gemm_desc {
                                   workgroup's image rows resident in LDS and fetches them ONCE per 64-channel chunk instead of once per filter tap
                                   (csrc/hconv.hip).  The choice depends on the layer only, never on the row count M.  Summation order: 64-channel
                                   chunk, tap, channel (w: tap, channel).  NULL: the im2col forms. */
+    void* workspace;           /* w_halo layers that are summed in K slices (apad_conv_halo_workspace_bytes(M, N, Cin, Wout) > 0: the 2-pixel-wide
+                                  images of the 64-token level): that many bytes of scratch for the fp32 slabs; NULL / too small: the im2col forms */
+    int64_t workspace_bytes;
 } apad_gemm_desc;
 
 typedef struct apad_attn_desc {
@@ -394,6 +397,8 @@ int apad_gemm(const apad_gemm_desc* d, void* stream);
    Replaces nothing in the reference: it is a re-layout of ResnetBlock2D.conv1 / conv2 / Upsample2D.conv weights (modeling_audioldm2.py call sites
    as for apad_gemm). */
 int apad_conv_halo_pack(const void* w, void* out, int64_t N, int64_t Cin, int32_t dtype, void* stream);
+/* scratch a w_halo convolution of this geometry needs in apad_gemm_desc::workspace (0: none) */
+int64_t apad_conv_halo_workspace_bytes(int64_t M, int64_t N, int64_t Cin, int32_t Wout);
 /* diagnostic: how many apad_gemm calls of this process went to the halo kernel (tests assert the route with it) */
 int64_t apad_hconv_launch_count(void);
 int apad_attention(const apad_attn_desc* d, void* stream);

@@ -27,7 +27,7 @@ def _knobs_do_not_leak():
     monkeypatch.setattr): a leaked switch silently changes which kernels the REST of the suite exercises"""
     import importlib
     mods = {}
-    for name, attrs in (("ap_adapter_amd.processors", ("USE_FUSED_XATTN", "USE_XATTN_ROWS")), ("ap_adapter_amd.ops", ("XATTN_MAXL", "MLP_C", "XROWS_C", "RP_K", "FUSED_DTYPES", "HS_ATTN", "HS_FF", "HS_FF2", "SATTN_FUSED", "MLP_PACKED", "MLP_PACKED_MIN_M", "GEGLU_PACKED_MIN_M")),
+    for name, attrs in (("ap_adapter_amd.processors", ("USE_FUSED_XATTN", "USE_XATTN_ROWS")), ("ap_adapter_amd.ops", ("XATTN_MAXL", "MLP_C", "XROWS_C", "RP_K", "FUSED_DTYPES", "HS_ATTN", "HS_FF", "HS_FF2", "SATTN_FUSED", "MLP_PACKED", "MLP_PACKED_MIN_M", "GEGLU_PACKED_MIN_M", "HCONV")),
                         ("ap_adapter_amd.unet", ("CFG_SHARED_PREFIX", "NO_CAT"))):
         try:
             m = importlib.import_module(name)

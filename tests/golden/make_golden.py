@@ -22,7 +22,7 @@ sys.path.insert(0, HERE)
 sys.dont_write_bytecode = True
 sys.path.insert(0, "/root/reference")
 
-from cases import CASES, BLOCK_CASES, R4_BLOCK_CASES, R4_CASES, R5_BLOCK_CASES, R5_CASES, LN_EPS, make_inputs  # noqa: E402
+from cases import CASES, BLOCK_CASES, R4_BLOCK_CASES, R4_CASES, R5_BLOCK_CASES, R5_CASES, R6_BLOCK_CASES, LN_EPS, make_inputs  # noqa: E402
 from APadapter.ap_adapter.attention_processor import AttnProcessor2_0, IPAttnProcessor2_0  # noqa: E402
 from safetensors.torch import save_file  # noqa: E402
 
@@ -130,6 +130,9 @@ def main():
 if __name__ == "__main__":
     if "--r4" in sys.argv:
         main_r4()
+        sys.exit(0)
+    if "--r6" in sys.argv:
+        main_r4(R6_BLOCK_CASES, "attn_r6.safetensors", "--r6")
         sys.exit(0)
     if "--r5" in sys.argv:
         main_r4(R5_BLOCK_CASES + R5_CASES, "attn_r5.safetensors", "--r5")

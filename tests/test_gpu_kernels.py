@@ -137,6 +137,10 @@ def test_conv3x3_big_tile_kernel(dev, dtype, B, H, W, Cin, Cout):
     (40, 5, 4, 64, 128, None, "table"),       # 13 separator rows per tile
     (2, 40, 16, 640, 256, None, "table"),     # ten 64-channel chunks
     (5, 63, 4, 128, 128, None, "table"),      # 256 x 128 tiles on a 4-wide image
+    (7, 32, 2, 640, 640, None, "table"),      # the 64-token level: three K slices of whole chunks, fp32 slabs summed in slice order
+    (5, 32, 2, 384, 640, None, "sample"),     # ... two chunks per slice, per-sample time-embedding rows in the slice sum
+    (3, 16, 2, 1280, 128, (32, 2), None),     # ... up-sampled source, 20 chunks in slices of 6 / 7 / 7
+    (2, 32, 2, 128, 128, None, "table"),      # a 2-wide image with fewer than three chunks: no slices
 ])
 def test_conv3x3_halo_kernel(dev, dtype, B, H, W, Cin, Cout, up, temb):
     """csrc/hconv.hip: the halo-resident 3x3 convolution (input rows of a tile resident in LDS, nine taps as nine shifts of the same tile,

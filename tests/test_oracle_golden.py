@@ -6,7 +6,7 @@ import pytest
 import torch
 from safetensors.torch import load_file
 
-from cases import BLOCK_CASES, CASES, LN_EPS, R4_BLOCK_CASES, R4_CASES, R5_BLOCK_CASES, R5_CASES, make_inputs
+from cases import BLOCK_CASES, CASES, LN_EPS, R4_BLOCK_CASES, R4_CASES, R5_BLOCK_CASES, R5_CASES, R6_BLOCK_CASES, make_inputs
 from oracle.attention import attn_processor_2_0, ip_attn_processor_2_0
 
 GOLD = load_file(os.path.join(os.path.dirname(__file__), "golden", "attn_processors.safetensors"))
@@ -16,8 +16,9 @@ GOLD_BLK.update({k: v for k, v in load_file(os.path.join(os.path.dirname(__file_
 _R5 = load_file(os.path.join(os.path.dirname(__file__), "golden", "attn_r5.safetensors"))  # round 5's additions (make_golden.py --r5)
 GOLD.update({k: v for k, v in _R5.items() if not k.startswith("blk_")})
 GOLD_BLK.update({k: v for k, v in _R5.items() if k.startswith("blk_")})
+GOLD_BLK.update(load_file(os.path.join(os.path.dirname(__file__), "golden", "attn_r6.safetensors")))  # round 6's additions (make_golden.py --r6)
 R4_CASES = R4_CASES + R5_CASES
-R4_BLOCK_CASES = R4_BLOCK_CASES + R5_BLOCK_CASES
+R4_BLOCK_CASES = R4_BLOCK_CASES + R5_BLOCK_CASES + R6_BLOCK_CASES
 
 
 def run_oracle(c, t, **over):

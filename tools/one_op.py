@@ -91,6 +91,11 @@ elif op in ("xrows", "xrows_chain"):
             qd = ops.fused_linear(x, wq, ln=(g, be, 1e-5))
             od = ops.attention(qd, k1, v1t, Lt, H, k2=k2, vt2=v2t, L2=La, scale2=0.55)
             return ops.fused_linear(od, wo, bo, residual=x, out=out)
+elif op in ("hconv256", "hconv128", "hconv640"):  # the halo-resident 3x3 convolution (csrc/hconv.hip) at the 1000- / 4000- / 64-pixel level
+    H_, W_, Ci, Co = {"hconv256": (125, 8, 256, 256), "hconv128": (250, 16, 128, 128), "hconv640": (32, 2, 640, 640)}[op]
+    x = R(B2, H_ * W_, Ci, std=0.5); w = R(Co, 9 * Ci, std=0.02); b = R(Co, std=0.1); r = R(B2, H_ * W_, Co)
+    out = torch.empty(B2, H_ * W_, Co, device=dev, dtype=dt)
+    fn = lambda: ops.conv3x3(x, w, b, B2, H_, W_, residual=r, out=out)
 for _ in range(iters):
     fn()
 torch.cuda.synchronize()
