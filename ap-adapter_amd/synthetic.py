@@ -24,6 +24,19 @@ def init_synthetic_(module: nn.Module, seed=100, w_std=0.02, bias_std=0.0, norm_
         else:
             t.copy_(torch.randn(t.shape, generator=g, dtype=torch.float32) * std)
 
+    # thousands of small CPU draws / scalings / copies: with the intra-op pool of a many-core host (128 threads on the GPU boxes) every one of
+    # them pays the pool's wake-up -- 10.7 s for the tests' small UNet against 0.4 s on one thread, bit-identical values (the CPU generator's
+    # stream does not depend on the thread count)
+    n_threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        _fill(module, rn, w_std, bias_std, norm_jitter)
+    finally:
+        torch.set_num_threads(n_threads)
+    return module
+
+
+def _fill(module, rn, w_std, bias_std, norm_jitter):
     with torch.no_grad():
         for _, m in module.named_modules():
             if isinstance(m, (nn.Linear, nn.Conv2d)):
@@ -37,7 +50,6 @@ def init_synthetic_(module: nn.Module, seed=100, w_std=0.02, bias_std=0.0, norm_
         for name, p in module.named_parameters():
             if name.endswith("cls_token") or name.endswith("pos_embed"):
                 rn(p, w_std)
-    return module
 
 
 def synthetic_inputs(batch, La, t5_len=16, seed=0, latent_hw=(250, 16), channels=8):
