@@ -11,6 +11,14 @@ for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle's intra-op pool: the GPU hosts expose 128+ hardware threads, and torch's default of one worker per thread makes the oracle's
+    # many small operators pay the pool's wake-up -- measured on such a host: the same five oracle-heavy tests 174 s at the default, 29 s with 32
+    # threads, 23 s with 8.  (Affects test infrastructure only: the product path runs no CPU arithmetic.)
+    try:
+        import torch
+        torch.set_num_threads(min(torch.get_num_threads(), 8))
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")
