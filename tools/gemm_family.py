@@ -58,7 +58,7 @@ class Proxy:
         def g(dref, stream):
             d = dref._obj
             key = (AM.get(d.a_mode, d.a_mode), d.M, d.K, d.N, d.Cin, d.stride, d.Hup, d.epilogue, d.out_mode, bool(d.residual), bool(d.a2),
-                   bool(d.rowstat_in), bool(d.rowstat_out), bool(d.rowgroup_bias))
+                   bool(d.rowstat_in), bool(d.rowstat_out), bool(d.rowgroup_bias), bool(d.w_halo))
             if key not in seen:
                 seen[key] = [0, bytes(C.string_at(C.addressof(d), C.sizeof(d)))]
             seen[key][0] += 1
@@ -77,7 +77,7 @@ with torch.no_grad():
 
 min_us = float(sys.argv[1]) if len(sys.argv) > 1 else 0.0
 print(f"# apad_gemm launches of one denoise step (batch {B}, La {La}); isolated, hipGraph-timed (warm L2 / Infinity Cache); peak 2500 TF/s")
-print("# per_step  a_mode    M       K      N     Cin  stride up  epi out res a2  lnfold stat_out tab |   us     TF/s   frac  | step_us")
+print("# per_step  a_mode    M       K      N     Cin  stride up  epi out res a2  lnfold stat_out tab halo |   us     TF/s   frac  | step_us")
 tot = 0.0
 rows = []
 # the step's own operands are gone by now: every pointer of a recorded descriptor is re-aimed at scratch of sufficient size
@@ -112,9 +112,10 @@ for key, (cnt, raw) in seen.items():
     if d.ln_colsum: d.ln_colsum = scratch("lnc", d.N * 16 + 4096, fill=0)
     if d.ln_bias: d.ln_bias = scratch("lnb", d.N * 16 + 4096, fill=0)
     if d.a2: d.a2 = scratch("a2", d.M * max(d.lda2, 1) * 2 + 4096)
+    if d.workspace: d.workspace = scratch("ws", d.workspace_bytes + 4096, fill=0)  # (w_halo stays: the packed weights are cached by ops)
     fn = lambda: L.check(h.apad_gemm(C.byref(d), ops._stream()), "apad_gemm")
     ms = time_kernel_graphed(fn)
-    am_, M, K, N, Cin, stride, Hup, epi, om, res, a2, lnf, so, tab = key
+    am_, M, K, N, Cin, stride, Hup, epi, om, res, a2, lnf, so, tab, halo = key
     fl = 2.0 * M * K * N * (2 if epi in (3, 7) else 1)
     tf = fl / (ms * 1e-3) / 1e12
     rows.append((cnt * ms * 1e3, cnt, key, ms * 1e3, tf))
@@ -122,6 +123,6 @@ for key, (cnt, raw) in seen.items():
 for su, cnt, key, us, tf in sorted(rows, key=lambda r: -r[0]):
     if us < min_us:
         continue
-    am_, M, K, N, Cin, stride, Hup, epi, om, res, a2, lnf, so, tab = key
-    print(f"  {cnt:5d}     {am_:8s} {M:7d} {K:6d} {N:5d} {Cin:5d}   {stride}    {int(Hup > 0)}   {epi}   {om}   {int(res)}   {int(a2)}    {int(lnf)}      {int(so)}      {int(tab)}  | {us:7.1f} {tf:7.1f}  {tf / 2500:5.3f} | {su:8.1f}")
+    am_, M, K, N, Cin, stride, Hup, epi, om, res, a2, lnf, so, tab, halo = key
+    print(f"  {cnt:5d}     {am_:8s} {M:7d} {K:6d} {N:5d} {Cin:5d}   {stride}    {int(Hup > 0)}   {epi}   {om}   {int(res)}   {int(a2)}    {int(lnf)}      {int(so)}      {int(tab)}   {int(halo)}  | {us:7.1f} {tf:7.1f}  {tf / 2500:5.3f} | {su:8.1f}")
 print(f"# total {tot / 1e3:.3f} ms per step over {sum(r[1] for r in rows)} launches")
