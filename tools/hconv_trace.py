@@ -1,5 +1,5 @@
 """s_memtime stamps of the halo convolution kernel (probe build: tools/ab_build.sh hctrace hconv.hip -DHC_TRACE=1; run with
-APAD_LIB_PATH=exp/lib_hctrace.so): per-tile phases of a few workgroups, in microseconds (100 MHz counter).
+APAD_LIB_PATH=exp/lib_hctrace.so): per-tile phases of a few workgroups, in thousands of SHADER cycles (s_memtime counts shader clocks: about 1.6 per ns on real operands).
 usage: python tools/hconv_trace.py [B H W Cin Cout]"""
 import ctypes as C
 import os
@@ -29,6 +29,6 @@ names = ["start", "setup+requests"]
 for wg in (0, 1, 100, 255):
     r = t[wg]
     base = int(r[0])
-    vals = [(int(v) - base) / 100.0 for v in r if int(v) != 0]
+    vals = [(int(v) - base) / 1000.0 for v in r if int(v) != 0]
     print(f"wg {wg:3d}: " + " ".join(f"{v:6.2f}" for v in vals))
-print("columns: start, first requests out | per tile: loop start, loop end, barrier, next tile's setup + requests out, epilogue issued   (us)")
+print("columns: start, first requests out | per tile: loop start, loop end, barrier, next tile's setup + requests out, epilogue issued   (k cycles)")
