@@ -84,6 +84,7 @@ template <int N_> __device__ __forceinline__ void h_wait_vm() {
     else if constexpr (N_ == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else if constexpr (N_ == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else if constexpr (N_ == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N_ == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else if constexpr (N_ == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else static_assert(N_ == 0, "add the count");
 }
@@ -459,8 +460,7 @@ __global__ __launch_bounds__(T::NT) void hconv_kernel(HcP p) {
                 const uint2 u2 = __builtin_bit_cast(uint2, h4);
                 asm volatile("ds_write_b64 %0, %1" ::"v"(stg_w + (uint32_t)((j * 32 + 8 * g) * 2)), "v"(u2) : "memory");
             }
-        // wave-private tile: no barrier; this wave's writes are complete behind lgkmcnt(0)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // wave-private tile: no barrier, and no wait between this wave's writes and its reads (the LDS executes one wave's instructions in issue order)
         u32x4 orow[32 / RPI];
 #pragma unroll
         for (int k = 0; k < 32 / RPI; ++k) asm volatile("ds_read_b128 %0, %1" : "=v"(orow[k]) : "v"(stg_r + (uint32_t)(RPI * k * EROW)));
@@ -508,6 +508,187 @@ __global__ void hconv_pack_kernel(const TE* __restrict__ w, TE* __restrict__ out
 
 int64_t g_hconv_launches = 0;
 unsigned long long* g_hconv_trace = nullptr;  // (tests assert the route with it; not synchronised: a diagnostic)
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Narrow form: N <= 16 output channels (the UNet's conv_out, 128 -> 8 at 4000 pixels; modeling_audioldm2.py:867).  The im2col kernels pad N to a
+// 64-column tile (92.6 us for 2.4 GF of useful work); here the WEIGHTS are the stationary operand -- all 9 x Cin / 32 fragments of a 16-row MFMA A
+// operand (rows >= N zero) live in each wave's registers for the whole launch -- and the pixels stream: the same halo tiles as above (three
+// 40 KB buffers, two 64-channel chunks ahead, one barrier per chunk), B fragments of v_mfma_f32_16x16x32 (16 pixels x 32 channels) read with the
+// tap's shift.  The kernel is bound by the halo stream (the level's activations once) -- the 16-row MFMAs at a quarter of their rows are 6 us of it.
+struct HnP {
+    const uint8_t* a;
+    const uint8_t* wp;   // [Cin / 64][tap][2][64 lanes][8 elements]: A-operand fragments, lane = (row n = lane & 15, k-group lane >> 4)
+    uint8_t* out;
+    const uint8_t* bias;
+    int64_t ldo;
+    int32_t M, N, Cin, H, W, Wlog, Hs, Ws, Btot, m_tiles, nchunks;
+    uint32_t a_bytes;
+};
+
+template <int DT> __device__ __forceinline__ f32x4 hn_mfma(u32x4 a, u32x4 b, f32x4 c) {
+    if constexpr (DT == APAD_BF16) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
+template <int DT, int NCH>  // NCH = Cin / 64 (1 or 2): 18 NCH weight fragments in registers
+__global__ __launch_bounds__(512) void hnarrow_kernel(HnP p) {
+    constexpr int NW = 8, NLD = 5, NPX = NLD * NW * 8, ABUF = NPX * 128, NBUF = 3, OFF_Z = NBUF * ABUF, BM = 256;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    using E = ET<DT>;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int W = p.W, H = p.H, Wlog = p.Wlog, R = BM >> Wlog;
+    const __amdgpu_buffer_rsrc_t ra = h_rsrc(p.a, p.a_bytes);
+    const uint32_t lds0 = (uint32_t)(size_t)(lds_ptr)smem;
+
+    // the stationary operand
+    u32x4 wf[NCH * 18];
+#pragma unroll
+    for (int i = 0; i < NCH * 18; ++i) wf[i] = *reinterpret_cast<const u32x4*>(p.wp + ((int64_t)i * 64 + lane) * 16);
+
+    // halo DMA sources of a tile (as in hconv_kernel) and this lane's two pixels (16-pixel blocks 2 wave, 2 wave + 1 of the tile)
+    auto tile_sources = [&](int mt, uint32_t (&ao)[5]) {
+        const int g0 = mt * R, b0 = g0 / H, y0 = g0 - b0 * H;
+#pragma unroll
+        for (int l = 0; l < NLD; ++l) {
+            const int pp = (l * NW + wave) * 8 + (lane >> 3), slot = lane & 7;
+            const int j = pp >> Wlog, x = pp & (W - 1), v = y0 - 1 + j;
+            const int q = v >= 0 ? v / (H + 1) : 0, r = v - q * (H + 1);
+            const bool valid = v >= 0 && r != H && b0 + q < p.Btot;
+            const int sy = p.Hs == H ? r : (r * p.Hs) / H, sx = p.Ws == W ? x : (x * p.Ws) / W;
+            const uint32_t src = (uint32_t)(((b0 + q) * p.Hs + sy) * p.Ws + sx) * (uint32_t)(p.Cin * 2) + (uint32_t)((slot ^ ((pp >> 1) & 7)) << 4);
+            ao[l] = valid ? src : H_OOB;
+        }
+    };
+    auto pixel_records = [&](int mt, uint32_t (&pb)[2]) {
+        const int g0 = mt * R, b0 = g0 / H, y0 = g0 - b0 * H;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int ml = wave * 32 + b * 16 + l15, ir = ml >> Wlog, x = ml & (W - 1);
+            pb[b] = (uint32_t)(((1 + ir + (y0 + ir) / H) << Wlog) + x);
+        }
+    };
+    const bool x_first = (l15 & (W - 1)) == 0, x_last = (l15 & (W - 1)) == W - 1;  // (16 % W == 0: the same for both blocks)
+    const uint32_t zaddr = lds0 + (uint32_t)OFF_Z + (uint32_t)(kg << 4);
+    if (tid < 8) *reinterpret_cast<uint4*>(smem + OFF_Z + tid * 16) = make_uint4(0, 0, 0, 0);
+
+    // the stream of (tile, chunk) pairs of this workgroup: chunk counter gc -> buffer gc % 3, requested two chunks ahead
+    const int ntiles = p.m_tiles, tstride = (int)gridDim.x;
+    uint32_t ao_cur[5], ao_next[5];
+    auto request = [&](const uint32_t (&ao)[5], int chunk, int buf) {
+#pragma unroll
+        for (int l = 0; l < NLD; ++l)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(smem + buf * ABUF + (l * NW + wave) * 1024), 16, ao[l], chunk * 128, 0, 0);
+    };
+    int tl = blockIdx.x;
+    tile_sources(tl, ao_cur);
+    if (tl + tstride < ntiles) tile_sources(tl + tstride, ao_next);
+    // prologue: the first two chunks of the stream
+    int gc = 0;
+    request(ao_cur, 0, 0);
+    if (NCH == 2) request(ao_cur, 1, 1);
+    else if (tl + tstride < ntiles) request(ao_next, 0, 1);
+#pragma unroll 1
+    for (; tl < ntiles; tl += tstride) {
+        uint32_t pb[2];
+        pixel_records(tl, pb);
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        const bool more = tl + tstride < ntiles, more2 = tl + 2 * tstride < ntiles;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c, ++gc) {
+            const int buf = gc % NBUF;
+            // chunk gc has landed: only the pieces of chunk gc + 1 (if the stream has one) may still be outstanding
+            const bool has_next = c + 1 < NCH || more;
+            if (has_next) h_wait_vm<NLD>();
+            else h_wait_vm<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            H_BARRIER();  // every wave's pieces of chunk gc are in LDS, and every wave is past its reads of chunk gc - 1: that buffer takes chunk gc + 2
+            {
+                const int c2 = c + 2;  // chunk gc + 2 of the stream: of this tile, of the next one, or of the one after (NCH == 1)
+                const int nbuf = (gc + 2) % NBUF;
+                if (c2 < NCH) request(ao_cur, c2, nbuf);
+                else if (c2 - NCH < NCH) { if (more) request(ao_next, c2 - NCH, nbuf); }
+                else if (more2) {  // (NCH == 1: two tiles ahead -- its sources are computed here, the registers of ao_cur are free after the request below)
+                    uint32_t ao2[5];
+                    tile_sources(tl + 2 * tstride, ao2);
+                    request(ao2, 0, nbuf);
+                }
+            }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+                uint32_t a0[2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const uint32_t ps = pb[b] + (uint32_t)(dy * W + dx);
+                    uint32_t a = lds0 + (uint32_t)(buf * ABUF) + (ps << 7) + ((((ps >> 1) & 7) ^ (uint32_t)kg) << 4);
+                    if (dx < 0) a = x_first ? zaddr : a;
+                    if (dx > 0) a = x_last ? zaddr : a;
+                    a0[b] = a;
+                }
+                u32x4 fb[2][2];
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[kk][b]) : "v"(a0[b] ^ (uint32_t)(kk << 6)));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc[b] = hn_mfma<DT>(wf[(c * 9 + tap) * 2 + kk], fb[kk][b], acc[b]);
+            }
+        }
+        // epilogue: lane (pixel l15 of block b, rows 4 kg .. 4 kg + 3): + bias -> storage type -> 8 bytes
+        if (4 * kg < p.N) {
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[e] = ld_elem<DT>(p.bias, 4 * kg + e);
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int m = tl * BM + wave * 32 + b * 16 + l15;
+                typename E::v4 h4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h4[e] = (typename E::elem)(acc[b][e] + bv[e]);
+                if (m < p.M) *reinterpret_cast<uint2*>(p.out + ((int64_t)m * p.ldo + 4 * kg) * 2) = __builtin_bit_cast(uint2, h4);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int l = 0; l < NLD; ++l) ao_cur[l] = ao_next[l];
+            if (more2) tile_sources(tl + 2 * tstride, ao_next);
+        }
+    }
+}
+
+// w [N][tap][Cin] -> the narrow form's A-operand fragments (rows >= N zero)
+template <typename TE>
+__global__ void hnarrow_pack_kernel(const TE* __restrict__ w, TE* __restrict__ out, int N, int Cin, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one lane's 16 bytes
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    const int f = (int)(idx >> 6), kk = f & 1, tap = (f >> 1) % 9, c = (f >> 1) / 9;
+    const int n = lane & 15, ch = c * 64 + kk * 32 + 8 * (lane >> 4);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (n < N) v = *reinterpret_cast<const uint4*>(w + ((int64_t)n * 9 + tap) * Cin + ch);
+    *reinterpret_cast<uint4*>(out + idx * 8) = v;
+}
+
+template <int DT, int NCH> int hn_launch(const HnP& p, hipStream_t s) {
+    auto kern = hnarrow_kernel<DT, NCH>;
+    constexpr int SMEM = 3 * 5 * 8 * 8 * 128 + 128;
+    static unsigned devs = 0;
+    if (apad_ensure_dyn_lds(reinterpret_cast<const void*>(kern), SMEM, &devs) != 0) return -1;
+    ++g_hconv_launches;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus <= 0) cus = 256;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.m_tiles < cus ? p.m_tiles : cus)), dim3(512), SMEM, s, p);
+    return apad_check_launch("apad_gemm(halo convolution, narrow form)");
+}
 
 // out = ((sum over the K slices, in slice order) + bias) + time-embedding row -> storage type -> + residual: the epilogue of a split convolution.
 // Thread = 8 consecutive channels of one pixel.
@@ -598,9 +779,18 @@ extern "C" int64_t apad_hconv_launch_count(void) { return g_hconv_launches; }
 // probe builds (-DHC_TRACE=1) only: device buffer of 32 x workgroups uint64 time stamps; not part of the ABI header
 extern "C" void apad_hconv_set_trace(void* buf) { g_hconv_trace = (unsigned long long*)buf; }
 
+// bytes of the packed form: the wide form re-lays the N * 9 * Cin elements; the narrow form (N <= 16) is 18 fragments of 1 KB per 64-channel chunk
+extern "C" int64_t apad_conv_halo_packed_bytes(int64_t N, int64_t Cin) { return N <= 16 ? (Cin / 64) * 18 * 1024 : N * 9 * Cin * 2; }
+
 extern "C" int apad_conv_halo_pack(const void* w, void* out, int64_t N, int64_t Cin, int32_t dtype, void* stream) {
     APAD_CHECK(w && out && N > 0 && Cin > 0 && Cin % 64 == 0, "apad_conv_halo_pack: needs Cin %% 64 == 0");
     APAD_CHECK(dtype == APAD_BF16 || dtype == APAD_F16, "apad_conv_halo_pack: 16-bit weights only");
+    if (N <= 16) {  // the narrow form: A-operand fragments of the 16-row MFMA, rows >= N zero
+        const int64_t total = (Cin / 64) * 18 * 64;
+        hipLaunchKernelGGL(hnarrow_pack_kernel<uint16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const uint16_t*)w, (uint16_t*)out, (int)N, (int)Cin, total);
+        return apad_check_launch("apad_conv_halo_pack(narrow)");
+    }
     const int64_t total = N * 9 * Cin / 8;
     hipLaunchKernelGGL(hconv_pack_kernel<uint16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const uint16_t*)w, (uint16_t*)out, (int)N, (int)Cin, total);
@@ -622,7 +812,22 @@ int apad_hconv_try(const apad_gemm_desc* d, hipStream_t s) {
                                                                                                                        //  apad_conv_halo_workspace_bytes)
     if (d->Hup == 0 && (d->Hin != H || d->Win != W)) return 1;
     if (d->Hup != 0 && (d->Hup != H || d->Wup != W)) return 1;
-    if (d->M % ((int64_t)H * W) != 0 || d->M >= (1LL << 30) || d->N % 128 != 0) return 1;
+    if (d->M % ((int64_t)H * W) != 0 || d->M >= (1LL << 30)) return 1;
+    if (d->N <= 16) {  // the narrow form (conv_out): weights stationary in registers
+        if (d->N % 8 != 0 || (d->Cin != 64 && d->Cin != 128) || W < 4 || d->residual || d->rowgroup_bias || d->ldo % 8 != 0) return 1;
+        const int R = 256 / W, S = (R - 1) / H + 1;
+        if ((R + 2 + S) * W > 320) return 1;
+        const int64_t Btot = d->M / ((int64_t)H * W);
+        const int64_t a_bytes = Btot * d->Hin * d->Win * (int64_t)d->Cin * 2;
+        if (a_bytes >= (1LL << 31)) return 1;
+        HnP q;
+        q.a = (const uint8_t*)d->a; q.wp = (const uint8_t*)d->w_halo; q.out = (uint8_t*)d->out; q.bias = (const uint8_t*)d->bias; q.ldo = d->ldo;
+        q.M = (int32_t)d->M; q.N = (int32_t)d->N; q.Cin = d->Cin; q.H = H; q.W = W; q.Wlog = __builtin_ctz((unsigned)W); q.Hs = d->Hin; q.Ws = d->Win;
+        q.Btot = (int32_t)Btot; q.m_tiles = (int32_t)((d->M + 255) / 256); q.nchunks = d->Cin / 64; q.a_bytes = (uint32_t)a_bytes;
+        if (d->dtype == APAD_BF16) return d->Cin == 64 ? hn_launch<APAD_BF16, 1>(q, s) : hn_launch<APAD_BF16, 2>(q, s);
+        return d->Cin == 64 ? hn_launch<APAD_F16, 1>(q, s) : hn_launch<APAD_F16, 2>(q, s);
+    }
+    if (d->N % 128 != 0) return 1;
     if (d->ldo % 8 != 0 || (d->residual && d->ldr % 8 != 0)) return 1;
     // tile shape by the LAYER (never the row count): 256 x 256 when N % 256 == 0, else 256 x 128.  (A four-wave 128 x 192 shape for N = 384 --
     // 252 instead of 189 workgroups at batch 32 -- measured slower, 51.8 vs 48.2 us: one wave per SIMD does not cover its own barrier bubbles.)

@@ -720,8 +720,9 @@ _halo_cache = {}
 
 def conv_halo_eligible(Cin, Cout, Wout, stride, dtype, src_batch_mod=0, asym_pad=False):
     """the LAYER-level part of apad_hconv_try's envelope (never the row count): what decides whether the packed form is built"""
-    return (HCONV and stride == 1 and not asym_pad and src_batch_mod == 0 and dtype in FUSED_DTYPES and Cin % 64 == 0 and Cout % 128 == 0
-            and Wout in (2, 4, 8, 16))
+    wide = Cout % 128 == 0 and Wout in (2, 4, 8, 16)
+    narrow = Cout in (8, 16) and Cin in (64, 128) and Wout in (4, 8, 16)  # conv_out: stationary weights (the narrow form)
+    return HCONV and stride == 1 and not asym_pad and src_batch_mod == 0 and dtype in FUSED_DTYPES and Cin % 64 == 0 and (wide or narrow)
 
 
 def conv_halo_weight(w_packed):
@@ -734,8 +735,8 @@ def conv_halo_weight(w_packed):
             for k in [k for k, v in _halo_cache.items() if v[2]() is None]:
                 del _halo_cache[k]
         wc = w_packed.detach().contiguous()
-        out = torch.empty_like(wc)
         Cout, K = wc.shape
+        out = torch.empty(L.lib().apad_conv_halo_packed_bytes(Cout, K // 9) // 2, dtype=wc.dtype, device=wc.device)
         L.check(L.lib().apad_conv_halo_pack(wc.data_ptr(), out.data_ptr(), Cout, K // 9, _DT[wc.dtype], _stream()), "apad_conv_halo_pack")
         hit = (sig, out, _weakref.ref(w_packed))
         _halo_cache[key] = hit

@@ -397,6 +397,9 @@ int apad_gemm(const apad_gemm_desc* d, void* stream);
    Replaces nothing in the reference: it is a re-layout of ResnetBlock2D.conv1 / conv2 / Upsample2D.conv weights (modeling_audioldm2.py call sites
    as for apad_gemm). */
 int apad_conv_halo_pack(const void* w, void* out, int64_t N, int64_t Cin, int32_t dtype, void* stream);
+/* bytes apad_conv_halo_pack writes: N * 9 * Cin elements in the wide form; N <= 16 (the narrow form of csrc/hconv.hip: conv_out, stationary weights as
+   16-row MFMA A-operand fragments, rows >= N zero): Cin / 64 * 18 KB */
+int64_t apad_conv_halo_packed_bytes(int64_t N, int64_t Cin);
 /* scratch a w_halo convolution of this geometry needs in apad_gemm_desc::workspace (0: none) */
 int64_t apad_conv_halo_workspace_bytes(int64_t M, int64_t N, int64_t Cin, int32_t Wout);
 /* diagnostic: how many apad_gemm calls of this process went to the halo kernel (tests assert the route with it) */

@@ -178,6 +178,35 @@ def test_conv3x3_halo_kernel(dev, dtype, B, H, W, Cin, Cout, up, temb):
 
 
 @pytest.mark.parametrize("dtype", DTYPES16)
+@pytest.mark.parametrize("B,H,W,Cin,Cout,up", [
+    (3, 250, 16, 128, 8, None),     # conv_out: two 64-channel chunks, a sample boundary inside a tile, ragged last tile, persistent workgroups (47 tiles)
+    (70, 250, 16, 128, 8, None),    # ... more tiles than CUs: the chunk stream crosses tiles (1094 tiles)
+    (5, 63, 4, 64, 16, None),       # one chunk per tile (the request two TILES ahead), 16 output channels
+    (2, 125, 8, 128, 16, None),
+    (2, 63, 4, 128, 8, (125, 8)),   # up-sampled source
+])
+def test_conv3x3_halo_kernel_narrow_form(dev, dtype, B, H, W, Cin, Cout, up):
+    """csrc/hconv.hip, narrow form (N <= 16: weights stationary in registers as 16-row MFMA fragments, the pixels stream through three halo
+    buffers): against fp32 torch, route asserted, a sample bit-equal inside and outside a batch"""
+    from ap_adapter_amd import ops, _lib as L
+    x = q(R(B, Cin, H, W, seed=24), dtype)
+    w = q(R(Cout, Cin, 3, 3, seed=25, std=0.04), dtype)
+    b = q(R(Cout, seed=26), dtype)
+    ref = _conv_ref(x, w, b, 1, up)
+    Ho, Wo = up if up is not None else (H, W)
+    nhwc = lambda a: a.permute(0, 2, 3, 1).reshape(a.shape[0], a.shape[2] * a.shape[3], -1).contiguous().to(dev, dtype)
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(dev, dtype)
+    n0 = L.lib().apad_hconv_launch_count()
+    out, Ho2, Wo2 = ops.conv3x3(nhwc(x), wp, b.to(dev, dtype), B, H, W, up=up)
+    assert L.lib().apad_hconv_launch_count() == n0 + 1, "not on the halo kernel"
+    assert (Ho2, Wo2) == (Ho, Wo)
+    assert rel_err(out.reshape(B, Ho, Wo, Cout).permute(0, 3, 1, 2), ref) < TOL[dtype]
+    if up is None and B >= 3:
+        out1, _, _ = ops.conv3x3(nhwc(x)[1:2].contiguous(), wp, b.to(dev, dtype), 1, H, W)
+        assert torch.equal(out1[0], out[1])
+
+
+@pytest.mark.parametrize("dtype", DTYPES16)
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 32, 2, 640, 640), (5, 32, 2, 1280, 640), (3, 63, 4, 384, 384), (1, 9, 7, 256, 64), (7, 13, 5, 320, 192)])
 def test_conv3x3_small_tile_ring_kernel(dev, dtype, B, H, W, Cin, Cout):
     """csrc/cgemm.hip, small-tile form (64 x 64 tile, four-stage LDS-DMA ring): the long-reduction 3x3 convolutions below 16000 output

@@ -45,7 +45,7 @@ for B, H, W, Cin, Cout, what in [(64, 250, 16, 128, 128, "4000-px level"), (64, 
                                  (64, 125, 8, 128, 256, "1000-px down"), (64, 125, 8, 256, 256, "1000-px level"), (64, 125, 8, 512, 256, "1000-px up"),
                                  (64, 125, 8, 640, 256, "1000-px up (640 in)"), (64, 63, 4, 384, 384, "252-px level (M = 16128: below the default threshold)"),
                                  (64, 63, 4, 768, 384, "252-px up (768 in)"), (64, 63, 4, 1024, 384, "252-px up (1024 in)"),
-                                 (64, 32, 2, 384, 640, "64-px down (384 in)"), (64, 32, 2, 640, 640, "64-px level"), (64, 32, 2, 1280, 640, "64-px up (1280 in)")]:
+                                 (64, 250, 16, 128, 8, "conv_out"), (64, 32, 2, 384, 640, "64-px down (384 in)"), (64, 32, 2, 640, 640, "64-px level"), (64, 32, 2, 1280, 640, "64-px up (1280 in)")]:
     x = (torch.randn(B, H * W, Cin, device=dev) * 0.5).to(dt)
     w = (torch.randn(Cout, 3, 3, Cin, device=dev) * 0.02).to(dt)
     if os.environ.get("CGEMM_ZERO"):  # all-zero operands: what the data-dependent power draw costs (MFMA clocks)
