@@ -10,7 +10,7 @@
 //   * a workgroup owns BM consecutive output pixels (= BM / W whole image rows) and keeps, per 64-channel chunk, their (rows + 2) x W
 //     input pixels in LDS: the nine taps read the same halo tile at nine uniform pixel shifts.  Zero padding: rows above / below a sample
 //     are zero rows of the tile (one separator row between two samples of a tile, written as zeros by the DMA's range check); the left /
-//     right image border re-aims the border lanes of the dx = -1 / +1 taps at a 128-byte zero region
+//     right image border re-aims the border lanes of the dx = -1 / +1 taps at a 256-byte zero region (the zero slot of the lane's own bank)
 //   * summation order: 64-channel chunk (outer), tap, four 16-deep MFMA steps -- this kernel's own order, identical for every tile shape
 //   * the halo tile is double buffered (the next chunk's five 1 KB DMA pieces per wave are issued over the first stages of the current
 //     chunk); weights stream through a four-stage LDS ring from the packed form [chunk][tap][32-channel half][N][32] (contiguous,
@@ -126,7 +126,7 @@ template <int WAVES_M_, int WAVES_N_, int MI_, int NJ_, int KS_> struct HcT {
     static constexpr int SPC = 9 * SPT;                // stages per 64-channel chunk
     // LDS: [halo buffer 0][ring slots 0 .. 3][halo buffer 1][zero region]: ring slot 3 and halo buffer 1 -- both idle while a tile's epilogue
     // runs -- are adjacent, the epilogue's transposition tiles live there
-    static constexpr int OFF_B = ABUF, OFF_A1 = OFF_B + NSTG * STAGE_B, OFF_Z = OFF_A1 + ABUF, SMEM = OFF_Z + 128;
+    static constexpr int OFF_B = ABUF, OFF_A1 = OFF_B + NSTG * STAGE_B, OFF_Z = OFF_A1 + ABUF, SMEM = OFF_Z + 256;
     static constexpr int OFF_STG = OFF_B + (NSTG - 1) * STAGE_B, STG_BYTES = STAGE_B + ABUF;
     static_assert(STAGE_B % (1024 * NW) == 0 && (KS == 2 || KS == 4) && SMEM <= 160 * 1024, "tile shape");
     static_assert(NJ * 2048 + SUBB < 65536, "immediate offsets of the weight fragment reads");
@@ -214,7 +214,9 @@ __global__ __launch_bounds__(T::NT) void hconv_kernel(HcP p) {
 
     // ---- fragment addressing ----
     const bool x_first = (l31 & (W - 1)) == 0, x_last = (l31 & (W - 1)) == W - 1;
-    const uint32_t zaddr = lds0 + (uint32_t)T::OFF_Z + (uint32_t)(half << 4);
+    // the zero region: 256 bytes = all 16 slot banks.  A border lane reads the zero slot in ITS OWN bank (address bits 4..7 kept): re-aimed at one fixed
+    // slot it collided with the lane that owns that bank -- 20 % of the kernel's LDS cycles were bank-conflict cycles (profiles/r06_pmc_hconv256_v1.txt)
+    const uint32_t zbase = lds0 + (uint32_t)T::OFF_Z;
     // weights: row n of the tile, k-chunk (ks' 2 + half) of a 64-byte record, slot XOR-ed by (n >> 2) & 3
     uint32_t bfo[2];
     {
@@ -231,8 +233,8 @@ __global__ __launch_bounds__(T::NT) void hconv_kernel(HcP p) {
         const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
         const uint32_t ps = pbase[i] + (uint32_t)(dy * W + dx);
         uint32_t a = lds0 + (uint32_t)(buf * T::OFF_A1) + (ps << 7) + ((((ps >> 1) & 7) ^ (uint32_t)half) << 4);
-        if (dx < 0) a = x_first ? zaddr : a;
-        if (dx > 0) a = x_last ? zaddr : a;
+        if (dx < 0) a = x_first ? (zbase | (a & 0xF0u)) : a;
+        if (dx > 0) a = x_last ? (zbase | (a & 0xF0u)) : a;
         return a;
     };
     // ONE fragment read of MFMA step KSI (0..3 of the chunk; k-chunk 2 KSI + half) into register set SET: IDX < MI the pixel tile IDX (from
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(T::NT) void hconv_kernel(HcP p) {
 #pragma unroll
             for (int i = 0; i < PBW; ++i) issue_b(c_begin, s, s, i);
     };
-    if (tid < 8) *reinterpret_cast<uint4*>(smem + T::OFF_Z + tid * 16) = make_uint4(0, 0, 0, 0);  // the zero region
+    if (tid < 16) *reinterpret_cast<uint4*>(smem + T::OFF_Z + tid * 16) = make_uint4(0, 0, 0, 0);  // the zero region
     const int ntiles = p.m_tiles * p.n_tiles * p.ksplit;
     HC_STAMP(0);
     setup_tile(blockIdx.x);
@@ -375,12 +377,6 @@ __global__ __launch_bounds__(T::NT) void hconv_kernel(HcP p) {
     using elem = typename E::elem;
     const bool rg_table = p.rg && p.rows_per_group >= p.M;  // one time-embedding row for every pixel (the denoise loop's table form)
     const bool rg_rows = p.rg && !rg_table;                  // the per-sample form: row m / rows_per_group
-    auto ld4 = [&](const uint8_t* base, int64_t idx, float (&v)[4]) {  // 4 consecutive elements (8 bytes, 8-byte aligned)
-        const uint2 u = *reinterpret_cast<const uint2*>(base + idx * 2);
-        const typename E::v4 h4 = __builtin_bit_cast(typename E::v4, u);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (float)h4[e];
-    };
     constexpr int EROW = NJ * 64 + 16;          // staged row: NJ x 32 channels + 16 bytes of padding (bank spread of the 8-byte writes)
     constexpr int LPR = NJ * 4;                 // lanes per staged row on the way out (16 bytes each)
     constexpr int RPI = 64 / LPR;               // rows per store instruction
@@ -388,31 +384,34 @@ __global__ __launch_bounds__(T::NT) void hconv_kernel(HcP p) {
     const uint32_t stg = lds0 + (uint32_t)(T::OFF_STG + wave * (32 * EROW));
     const uint32_t stg_w = stg + (uint32_t)(l31 * EROW + 8 * half), stg_r = stg + (uint32_t)((lane / LPR) * EROW + (lane % LPR) * 16);
     const int cn_w = cn0 + wn * NJ * 32;        // first column of this wave
-    float bv[4][4][4], tv[4][4][4];             // [j][g][e]: bias / table row of this lane's channels
+    uint2 braw[4][4], traw[4][4];               // [j][g]: bias / table row of this lane's 4 channels of a group, in the storage type (two registers a group)
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int n = cn_w + j * 32 + 8 * g + 4 * half;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) bv[j][g][e] = tv[j][g][e] = 0.f;
-            if (p.bias && p.ksplit == 1) ld4(p.bias, n, bv[j][g]);
-            if (rg_table && p.ksplit == 1) ld4(p.rg, step * p.ld_rg + n, tv[j][g]);
+            braw[j][g] = traw[j][g] = make_uint2(0, 0);
+            if (p.bias && p.ksplit == 1) braw[j][g] = *reinterpret_cast<const uint2*>(p.bias + (int64_t)n * 2);
+            if (rg_table && p.ksplit == 1) traw[j][g] = *reinterpret_cast<const uint2*>(p.rg + (step * p.ld_rg + n) * 2);
         }
     abl_reads_off = false;
     HC_STAMP(tstamp + 1);  // main loop done
     H_BARRIER();
     HC_STAMP(tstamp + 2);
+    if constexpr (HC_AGPR) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results before the compiler's v_accvgpr_read
+    // the next tile's setup + requests go out first: their DMA latency runs under this tile's epilogue.  (The 256 x 256 form keeps 164 bytes per lane of
+    // loop-invariant addressing state in scratch -- written in the prologue, reloaded here: profiles/r06_pmc_hconv256_v1.txt shows it as 22 MB of WRITE_SIZE
+    // beside the 32.8 MB output; moving this setup behind the epilogue or packing the results first did not remove it -- the main loop's 128 accumulators +
+    // 48 fragment registers + addressing are what fill the file.)
     if (tl + (int)gridDim.x < ntiles) {
         setup_tile(tl + (int)gridDim.x);
         issue_prologue();
     }
     HC_STAMP(tstamp + 3);  // next tile's setup + requests
-    if constexpr (HC_AGPR) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results before the compiler's v_accvgpr_read
-    // ---- epilogue: (acc + bias) + time-embedding row -> storage type -> transposed through a wave-private LDS tile (halo buffer 1: free until
-    //      the next tile's first stage barrier) -> (+ residual) -> full-line stores.  Lane (pixel l31, half) holds channels 8 g + 4 half + (0..3)
-    //      of a 32-channel block in accumulators 4 g .. 4 g + 3: one ds_write_b64 per group; a row of the wave's NJ x 32 channels is then read
-    //      back by NJ x 4 lanes as 16-byte pieces, so one store instruction writes whole rows of the wave's column range ----
+    // ---- epilogue: (acc + bias) + time-embedding row -> storage type -> transposed through a wave-private LDS tile (ring slot 3 + halo buffer 1: idle until
+    //      the next tile's first stage barrier) -> (+ residual) -> full-line stores.  Lane (pixel l31, half) holds channels 8 g + 4 half + (0..3) of a
+    //      32-channel block in accumulators 4 g .. 4 g + 3: one ds_write_b64 per group; a row of the wave's NJ x 32 channels is then read back by NJ x 4
+    //      lanes as 16-byte pieces, so one store instruction writes whole rows of the wave's column range ----
     if (p.ksplit > 1) {
         // a K slice: the raw fp32 accumulators go to this slice's slab (lane: 4 consecutive channels per group = one 16-byte store); bias, time
         // embedding, rounding and the residual belong to hconv_reduce_kernel, which sums the slabs in slice order
@@ -451,11 +450,12 @@ __global__ __launch_bounds__(T::NT) void hconv_kernel(HcP p) {
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                float t[4] = {tv[j][g][0], tv[j][g][1], tv[j][g][2], tv[j][g][3]};
-                if (rg_rows) ld4(p.rg, grp * p.ld_rg + cn_w + j * 32 + 8 * g + 4 * half, t);
+                uint2 tr = traw[j][g];
+                if (rg_rows) tr = *reinterpret_cast<const uint2*>(p.rg + (grp * p.ld_rg + cn_w + j * 32 + 8 * g + 4 * half) * 2);
+                const typename E::v4 b4 = __builtin_bit_cast(typename E::v4, braw[j][g]), t4 = __builtin_bit_cast(typename E::v4, tr);
                 typename E::v4 h4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) h4[e] = (elem)((acc[j][i][4 * g + e] + bv[j][g][e]) + t[e]);
+                for (int e = 0; e < 4; ++e) h4[e] = (elem)((acc[j][i][4 * g + e] + (float)b4[e]) + (float)t4[e]);
                 // (inline asm: an LDS access the compiler can see is ordered behind the next tile's DMA in flight -- s_waitcnt vmcnt(0))
                 const uint2 u2 = __builtin_bit_cast(uint2, h4);
                 asm volatile("ds_write_b64 %0, %1" ::"v"(stg_w + (uint32_t)((j * 32 + 8 * g) * 2)), "v"(u2) : "memory");
@@ -570,8 +570,8 @@ __global__ __launch_bounds__(512) void hnarrow_kernel(HnP p) {
         }
     };
     const bool x_first = (l15 & (W - 1)) == 0, x_last = (l15 & (W - 1)) == W - 1;  // (16 % W == 0: the same for both blocks)
-    const uint32_t zaddr = lds0 + (uint32_t)OFF_Z + (uint32_t)(kg << 4);
-    if (tid < 8) *reinterpret_cast<uint4*>(smem + OFF_Z + tid * 16) = make_uint4(0, 0, 0, 0);
+    const uint32_t zbase = lds0 + (uint32_t)OFF_Z;  // 256 bytes of zeros: a border lane reads the zero slot of its own bank
+    if (tid < 16) *reinterpret_cast<uint4*>(smem + OFF_Z + tid * 16) = make_uint4(0, 0, 0, 0);
 
     // the stream of (tile, chunk) pairs of this workgroup: chunk counter gc -> buffer gc % 3, requested two chunks ahead
     const int ntiles = p.m_tiles, tstride = (int)gridDim.x;
@@ -623,8 +623,8 @@ __global__ __launch_bounds__(512) void hnarrow_kernel(HnP p) {
                 for (int b = 0; b < 2; ++b) {
                     const uint32_t ps = pb[b] + (uint32_t)(dy * W + dx);
                     uint32_t a = lds0 + (uint32_t)(buf * ABUF) + (ps << 7) + ((((ps >> 1) & 7) ^ (uint32_t)kg) << 4);
-                    if (dx < 0) a = x_first ? zaddr : a;
-                    if (dx > 0) a = x_last ? zaddr : a;
+                    if (dx < 0) a = x_first ? (zbase | (a & 0xF0u)) : a;
+                    if (dx > 0) a = x_last ? (zbase | (a & 0xF0u)) : a;
                     a0[b] = a;
                 }
                 u32x4 fb[2][2];
@@ -679,7 +679,7 @@ __global__ void hnarrow_pack_kernel(const TE* __restrict__ w, TE* __restrict__ o
 
 template <int DT, int NCH> int hn_launch(const HnP& p, hipStream_t s) {
     auto kern = hnarrow_kernel<DT, NCH>;
-    constexpr int SMEM = 3 * 5 * 8 * 8 * 128 + 128;
+    constexpr int SMEM = 3 * 5 * 8 * 8 * 128 + 256;
     static unsigned devs = 0;
     if (apad_ensure_dyn_lds(reinterpret_cast<const void*>(kern), SMEM, &devs) != 0) return -1;
     ++g_hconv_launches;

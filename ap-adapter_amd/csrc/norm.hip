@@ -130,23 +130,30 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnSrc x, float* partial
     }
 }
 
-// Between the passes (gn_finalize_kernel): thread (b, g) sums the chunk partials of its group in chunk order ONCE -> stats[b][g] = (mean, rstd).
+// Between the passes (gn_finalize_kernel): wave (b, g) sums the chunk partials of its group ONCE, in a fixed order -> stats[b][g] = (mean, rstd).
 // (Until round 6 every workgroup of the apply pass repeated that sum -- 63 dependent-latency loads in front of its first pixel at the
 // 4000-pixel level, where the pass ran at 2.5 TB/s.)
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* partial, float* stats, int BG, int G, int nchunk, float n, float eps) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    // one WAVE per (sample, group): lane k takes chunks k, k + 64, ..., then a fixed butterfly (a thread per pair walking its 63 chunks was 63
+    // dependent L2 latencies: 17.9 us in-step for 2048 pairs)
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= BG) return;
     const int b = i / G, g = i - b * G;
     const float* pp = partial + ((int64_t)b * nchunk * G + g) * 2;
     float s = 0.f, ss = 0.f;
-    for (int k = 0; k < nchunk; ++k) {
+    for (int k = lane; k < nchunk; k += 64) {
         s += pp[(int64_t)k * G * 2];
         ss += pp[(int64_t)k * G * 2 + 1];
     }
-    const float mean = s / n;
-    const float var = fmaxf(ss / n - mean * mean, 0.f);
-    stats[i * 2] = mean;
-    stats[i * 2 + 1] = rsqrtf(var + eps);
+    s = wave_sum(s);
+    ss = wave_sum(ss);
+    if (lane == 0) {
+        const float mean = s / n;
+        const float var = fmaxf(ss / n - mean * mean, 0.f);
+        stats[i * 2] = mean;
+        stats[i * 2 + 1] = rsqrtf(var + eps);
+    }
 }
 
 constexpr int GN_APPLY_CHUNK = 256;  // pixels per workgroup of the apply pass
@@ -235,11 +242,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnSrc x, const float* sta
 // two-pass schedule above launches only HW/64 x B workgroups there (32 at the 64-pixel level) and pays two launches;
 // here a workgroup reads the [HW][4 groups] slab of its sample ONCE into registers (thread (vc, py) keeps the 16-byte
 // vectors of pixels py, py+PY, ...), reduces it in a fixed order through LDS, and normalises from the registers.
-constexpr int GN1_GPB = 4;
+constexpr int GN1_GPB = 4;  // groups per workgroup of the default form; GPB = 8 / 16: the full-line form for 8- / 4-channel groups (below)
 
-template <int DT, bool SILU, int NTH, int MAXP>
+template <int DT, bool SILU, int NTH, int MAXP, int GPB = GN1_GPB>
 __global__ __launch_bounds__(NTH) void gn_onepass_kernel(GnSrc x, const uint8_t* gamma, const uint8_t* beta,
                                                          uint8_t* out, int HW, int C, int G, float eps) {
+    constexpr int GN1_GPB = GPB;  // (shadows the default)
     __shared__ float lh[NTH][4];   // per thread: (sum, sumsq) of the low and of the high 4 channels of its vector
     __shared__ float lcol[2][48];  // per 4-channel column of the slab (4 groups x cg <= 40 channels / 4)
     __shared__ float lm[GN1_GPB], lr[GN1_GPB];
@@ -332,7 +340,18 @@ bool gn_onepass_launch(const GnSrc& x, const void* gamma, const void* beta, void
                        hipStream_t s) {
     constexpr int max_hw = 1024;
     const int cg = C / G;
-    if (HW > max_hw || G % GN1_GPB != 0 || cg % 4 != 0 || cg > 40) return false;
+    // full-line form (round 6): with 8- (4-) channel groups the default slab of 4 groups is 64 (32) bytes per pixel -- every 128-byte line is
+    // fetched by two (four) workgroups at different times; 8 (16) groups per workgroup make the slab one whole line per pixel, 512 threads keep it
+    if (HW <= max_hw && (cg == 8 || cg == 4) && G % (64 / cg) == 0 && x.Cb == 0) {
+        dim3 grid(G / (64 / cg), B);
+        if (cg == 8)
+            hipLaunchKernelGGL((gn_onepass_kernel<DT, SILU, 512, 16, 8>), grid, dim3(512), 0, s, x, (const uint8_t*)gamma, (const uint8_t*)beta,
+                               (uint8_t*)out, HW, C, G, eps);
+        else
+            hipLaunchKernelGGL((gn_onepass_kernel<DT, SILU, 512, 16, 16>), grid, dim3(512), 0, s, x, (const uint8_t*)gamma, (const uint8_t*)beta,
+                               (uint8_t*)out, HW, C, G, eps);
+        return true;
+    }
     const int vps = GN1_GPB * cg / 8;
     dim3 grid(G / GN1_GPB, B);
     if ((HW + 256 / vps - 1) / (256 / vps) <= 24) {
@@ -374,7 +393,7 @@ template <int DT> int gn_launch(const GnSrc& x, const void* gamma, const void* b
     int rc = apad_check_launch("apad_groupnorm(stats)");
     if (rc) return rc;
     float* stats = ws + (int64_t)B * nchunk * G * 2;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * G + 255) / 256), dim3(256), 0, s, ws, stats, B * G, G, nchunk, (float)HW * (float)(C / G), eps);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * G + 3) / 4), dim3(256), 0, s, ws, stats, B * G, G, nchunk, (float)HW * (float)(C / G), eps);
     rc = apad_check_launch("apad_groupnorm(finalize)");
     if (rc) return rc;
     const int achunk = (HW + GN_APPLY_CHUNK - 1) / GN_APPLY_CHUNK;

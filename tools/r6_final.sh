@@ -8,5 +8,7 @@ bash tools/round_profile.sh $TAG "round 6: halo-resident 3x3 convolutions (csrc/
 bash tools/round_pmc_step.sh $TAG "round 6" > gpurun_out/${TAG}_pmcstep.log 2>&1
 timeout 1200 bash tools/round_pmc_traffic.sh $TAG > gpurun_out/${TAG}_pmctraffic.log 2>&1
 for spec in "xattn xattn_kernel" "hconv256 hconv_kernel" "hconv128 hconv_kernel"; do set -- $spec
-  timeout 600 bash tools/pmc_kernel.sh $1 $2 ${TAG}_$1 > gpurun_out/${TAG}_pmc_$1.txt 2>&1; done
+  timeout 600 bash tools/pmc_kernel.sh $1 $2 ${TAG}_$1 > gpurun_out/${TAG}_pmc_$1.txt 2>&1
+  rm -rf gpurun_out/pmc_${TAG}_$1; done   # (the counter databases: tens of MB each; gpurun copies back at most 64 MiB)
+find gpurun_out -name "*.db" -delete 2>/dev/null; du -sh gpurun_out
 tail -c 600 gpurun_out/${TAG}_bench.json; head -12 gpurun_out/${TAG}_bench_kernel_stats.txt | cut -c1-140
