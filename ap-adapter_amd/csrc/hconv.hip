@@ -309,6 +309,7 @@ __global__ __launch_bounds__(T::NT) void hconv_kernel(HcP p) {
             constexpr int TAP = S / SPT, KS0 = (S % SPT) * KS;  // first MFMA step (of the chunk's four) of this stage
             // (1) stage t + 1 has landed: at most what the previous iteration issued may be outstanding (the halo piece goes first in an
             //     iteration, so a halo piece is covered two iterations after its issue)
+            if (HC_TRACE && tl == (int)blockIdx.x && c == cb + 1 && S < 12) HC_STAMP(19 + S);  // (probe: the stages of the tile's SECOND chunk)
             constexpr bool prevA = S >= 1 && S - 1 < NLD;  // the previous iteration issued a halo piece (not in the last chunk)
             if (!last) h_wait_vm<PBW + (prevA ? 1 : 0)>();
             else if (S == 0 || S - 1 + 3 < SPC) h_wait_vm<PBW>();

@@ -22,6 +22,10 @@ __device__ unsigned long long ws_trace_buf[1024][16];
 #define WS_STAMP(i_)
 #endif
 
+#ifndef APAD_WS_XCD
+#define APAD_WS_XCD 1  // (0: the plain block order, for A/B builds)
+#endif
+
 template <int KC> struct WsCfg {
     static constexpr int NS = (KC <= 16) ? 256 : 128;  // weight rows resident in LDS per workgroup
     static constexpr int NTILES = NS / 32;             // MFMA tiles per slice
@@ -45,7 +49,26 @@ __global__ __launch_bounds__(512) void wsgemm_kernel(RpP p) {
     const int half = lane >> 5, l31 = lane & 31;
     constexpr int COLS_PER_TILE = GEGLU ? 16 : 32;
     const int nslices = p.nsplit;
-    const int slice = blockIdx.x % nslices, rgrp = blockIdx.x / nslices, ngrp = gridDim.x / nslices;
+    // (row group, weight slice) of this workgroup.  XCD-aware (speed only; round 6): the nslices workgroups of ONE row group share blockIdx % 8, i.e. one
+    // XCD's L2 fetches their common x panels once -- with the plain order (slice fastest) the three slices of the 384-wide level sat on three XCDs and
+    // each pulled the panels through the fabric: 49.6 MB read per launch for 25 MB of operands (profiles/r06_pmc_traffic_v1.json)
+    const int ngrp = gridDim.x / nslices;
+    int slice, rgrp;
+    {
+        const int b = blockIdx.x, full = (ngrp / 8) * 8 * nslices;
+        if (APAD_WS_XCD && b < full) {
+            const int g = b / (8 * nslices), rem = b - g * 8 * nslices;
+            slice = rem >> 3;
+            rgrp = g * 8 + (rem & 7);
+        } else if (APAD_WS_XCD) {
+            const int rem = b - full, tail = ngrp - (ngrp / 8) * 8;
+            slice = rem / tail;
+            rgrp = (ngrp / 8) * 8 + rem - slice * tail;
+        } else {
+            slice = b % nslices;
+            rgrp = b / nslices;
+        }
+    }
     const int t0 = slice * W::NTILES;  // first MFMA tile (global tile index) of this slice
     WS_STAMP(0);
     constexpr bool PREFETCH = W::PREFETCH && !RES;

@@ -29,6 +29,11 @@ names = ["start", "setup+requests"]
 for wg in (0, 1, 100, 255):
     r = t[wg]
     base = int(r[0])
-    vals = [(int(v) - base) / 1000.0 for v in r if int(v) != 0]
+    vals = [(int(v) - base) / 1000.0 for v in r[:19] if int(v) != 0]
     print(f"wg {wg:3d}: " + " ".join(f"{v:6.2f}" for v in vals))
+for wg in (0, 100):
+    r = t[wg]
+    st = [int(v) for v in r[19:31]]
+    if all(st):
+        print(f"wg {wg:3d} stage starts of the first tile's second chunk, deltas in cycles: " + " ".join(str(b - a) for a, b in zip(st[:-1], st[1:])))
 print("columns: start, first requests out | per tile: loop start, loop end, barrier, next tile's setup + requests out, epilogue issued   (k cycles)")
