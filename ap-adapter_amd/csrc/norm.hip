@@ -352,6 +352,7 @@ bool gn_onepass_launch(const GnSrc& x, const void* gamma, const void* beta, void
                                (uint8_t*)out, HW, C, G, eps);
         return true;
     }
+    if (HW > max_hw || G % GN1_GPB != 0 || cg % 4 != 0 || cg > 40) return false;
     const int vps = GN1_GPB * cg / 8;
     dim3 grid(G / GN1_GPB, B);
     if ((HW + 256 / vps - 1) / (256 / vps) <= 24) {
