@@ -1694,12 +1694,11 @@ extern "C" int apad_cross_attention_rows(const apad_xrows_desc* d, void* stream)
     p.k1 = (const uint8_t*)d->k1; p.vt1 = (const uint8_t*)d->vt1; p.bias1 = d->key_bias;
     p.k2 = (const uint8_t*)d->k2; p.vt2 = (const uint8_t*)d->vt2; p.out = (uint8_t*)d->out;
     p.B = d->B; p.N = d->N; p.L1 = d->L1; p.Lpad1 = d->Lpad1; p.L2 = d->L2; p.Lpad2 = d->Lpad2;
-    static const int xr_nw = [] { const char* e = getenv("APAD_XROWS_NW"); return e ? atoi(e) : 8; }();  // A/B knob: 4 = one 32-token quartet per workgroup
-    const int tm = xr_nw == 4 ? 32 : 64;  // tokens per workgroup (xattn_rows_kernel, 8 / 4 waves)
+    const int tm = 64;  // tokens per workgroup (xattn_rows_kernel, 8 waves)
     p.tiles_per_sample = (d->N + tm - 1) / tm;
     p.eps = d->ln_eps; p.scale_log2 = d->softmax_scale * LOG2E; p.scale2 = d->scale2;
     hipStream_t s = (hipStream_t)stream;
-    // (8 waves: 35.8 us at the bench geometry vs 42.5 with 4 waves x 2 panels; deeper weight prefetch -- 6 / 8 register sets -- within 1 us)
-    if (xr_nw == 4) return d->dtype == APAD_BF16 ? xattn_rows_launch<APAD_BF16, 384, 4, 3>(p, s) : xattn_rows_launch<APAD_F16, 384, 4, 3>(p, s);
+    // (8 waves: 35.8 us at the bench geometry vs 42.5 with 4 waves x 2 panels; deeper weight prefetch -- 6 / 8 register sets -- within 1 us; round 6: 4 waves x
+    //  ONE 32-token panel -- 504 workgroups, three resident per CU -- is step-neutral: 34.54 / 34.52 vs 34.58 / 34.55 ms on the same box)
     return d->dtype == APAD_BF16 ? xattn_rows_launch<APAD_BF16, 384, 8, 3>(p, s) : xattn_rows_launch<APAD_F16, 384, 8, 3>(p, s);
 }
