@@ -130,6 +130,7 @@ SYMBOLS = {
     "apad_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "apad_conv_halo_pack": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp]),
     "apad_hconv_launch_count": (_i64, []),
+    "apad_probe_mfma": (C.c_int, [_vp, _i32, _i32, C.POINTER(C.c_double), _vp]),
     "apad_conv_halo_packed_bytes": (_i64, [_i64, _i64]),
     "apad_conv_halo_workspace_bytes": (_i64, [_i64, _i64, _i64, _i32]),
     "apad_attention": (C.c_int, [C.POINTER(AttnDesc), _vp]),

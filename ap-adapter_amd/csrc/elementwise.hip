@@ -305,3 +305,47 @@ extern "C" int apad_step_advance(int32_t* step_ptr, void* stream) {
     hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_ptr);
     return apad_check_launch("apad_step_advance");
 }
+
+// ---- measurement probe (bench.py's `mfma_ceiling`): four independent v_mfma_f32_32x32x16_bf16 chains per wave, two waves per SIMD, no memory
+//      traffic; operands zero (mode 0) or eight rotating register sets of pseudo-random bf16 in [-1, 1) (mode 1).  The dense rate this chip delivers
+//      depends on the operand data (power management: tools/ubench/mfma_data.hip); the bench line states it next to the nominal peak. ----
+namespace {
+__device__ __forceinline__ uint32_t probe_hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__global__ __launch_bounds__(256) void mfma_probe_kernel(float* sink, int mode, int iters) {
+    bf16x8_t a[8], b[8];
+    for (int s = 0; s < 8; ++s)
+        for (int i = 0; i < 8; ++i) {
+            float va = 0.f, vb = 0.f;
+            if (mode == 1) {
+                va = (float)(probe_hash32(threadIdx.x * 131u + s * 17u + i) & 0xffff) / 32768.f - 1.f;
+                vb = (float)(probe_hash32(threadIdx.x * 977u + s * 29u + i + 7u) & 0xffff) / 32768.f - 1.f;
+            }
+            a[s][i] = (__bf16)va;
+            b[s][i] = (__bf16)vb;
+        }
+    f32x16 acc[4];
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b[(s + c) & 7], acc[c], 0, 0, 0);
+    }
+    float t = 0.f;
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 16; ++r) t += acc[c][r];
+    if (t == 12345.678f) sink[0] = t;
+}
+}  // namespace
+
+// launches the probe on 512 workgroups of 256 threads; returns the FLOPs of the launch through *flops (2 x 32 x 32 x 16 per MFMA)
+extern "C" int apad_probe_mfma(void* sink, int32_t mode, int32_t iters, double* flops, void* stream) {
+    APAD_CHECK(sink && iters > 0 && (mode == 0 || mode == 1), "apad_probe_mfma: bad arguments");
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, (float*)sink, mode, iters);
+    if (flops) *flops = 512.0 * 4 * iters * 32 * 2.0 * 32 * 32 * 16;
+    return apad_check_launch("apad_probe_mfma");
+}

@@ -445,6 +445,32 @@ def dominant_kernel_roofline(dev, dtype, B2, in_step=None, in_step_how=None):
             "traffic_source": (tsrc + " (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes over the step)") if traffic else None}
 
 
+def mfma_ceiling(dev):
+    """What the matrix pipe of THIS device delivers on a memory-free stream of dense bf16 MFMAs (apad_probe_mfma: four chains per wave, two waves per
+    SIMD), on zero operands and on pseudo-random ones, ~15 ms launches timed with HIP events: the rate is power-managed and depends on the operand data
+    (tools/ubench/mfma_data.hip).  `peak` in the roofline objects stays the nominal 2.5 PF; this object says how much of it real activations can reach."""
+    import ctypes as C
+    from ap_adapter_amd import _lib as L
+    h = L.lib()
+    sink = torch.zeros(4, device=dev)
+    out = {}
+    for mode, name in ((0, "zero_operands"), (1, "random_operands")):
+        fl = C.c_double(0.0)
+        st = torch.cuda.current_stream().cuda_stream
+        L.check(h.apad_probe_mfma(sink.data_ptr(), mode, 200, C.byref(fl), st), "apad_probe_mfma")
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(h.apad_probe_mfma(sink.data_ptr(), mode, 12000, C.byref(fl), st), "apad_probe_mfma")
+        e1.record()
+        torch.cuda.synchronize()
+        tf = fl.value / (e0.elapsed_time(e1) * 1e-3) / 1e12
+        out[name] = {"tflops": round(tf, 1), "frac_of_nominal": round(tf / MFMA_PEAK_TFLOPS, 4)}
+    out["what"] = ("memory-free dense bf16 MFMA stream (v_mfma_f32_32x32x16_bf16, 4 chains per wave, 2 waves per SIMD), measured live on this device: the "
+                   "rate on random operands is the ceiling of every MFMA-bound kernel of the step (power-managed clocks)")
+    return out
+
+
 def fused_attn2_roofline(dev, dtype, B2, La, ap_scale, in_step=None, in_step_how=None):
     """The adapter's own kernel, the one the north star names: apad_fused_cross_attention -- LayerNorm + to_q + decoupled
     attention (8 text + La audio keys, two softmaxes blended by ap_scale) + to_out + bias + residual of one attn2
@@ -863,6 +889,10 @@ def main():
                     "fused_attn2_ip": ("fused_cross_attention", lambda x, *a, **kw: kw.get("L2", 0) > 0),
                     "fused_attn2_t5": ("fused_cross_attention", lambda x, *a, **kw: not kw.get("L2", 0))})
         line["roofline"] = dominant_kernel_roofline(dev, dtype, 2 * B, ins.get("self_attn_1000"), how)
+        try:
+            line["mfma_ceiling"] = mfma_ceiling(dev)
+        except Exception as e:  # noqa: BLE001
+            line["mfma_ceiling"] = {"error": repr(e)}
         line["roofline_top_line"] = profile_top_line()
         nst = len(unet.low_res_streams) if getattr(unet, "low_res_streams", None) else 1
         line["level64_kernels"] = level64_from_profile(2 * B, nst)

@@ -402,6 +402,10 @@ int apad_conv_halo_pack(const void* w, void* out, int64_t N, int64_t Cin, int32_
 int64_t apad_conv_halo_packed_bytes(int64_t N, int64_t Cin);
 /* scratch a w_halo convolution of this geometry needs in apad_gemm_desc::workspace (0: none) */
 int64_t apad_conv_halo_workspace_bytes(int64_t M, int64_t N, int64_t Cin, int32_t Wout);
+/* measurement probe (no reference counterpart): a memory-free stream of dense bf16 MFMAs on zero (mode 0) or pseudo-random (mode 1) operands on 512
+   workgroups; *flops = the FLOPs of the launch.  bench.py times it to state the matrix-pipe rate THIS device delivers on real operand data next to the
+   nominal peak (the rate is power-managed and depends on the data: tools/ubench/mfma_data.hip). */
+int apad_probe_mfma(void* sink, int32_t mode, int32_t iters, double* flops, void* stream);
 /* diagnostic: how many apad_gemm calls of this process went to the halo kernel (tests assert the route with it) */
 int64_t apad_hconv_launch_count(void);
 int apad_attention(const apad_attn_desc* d, void* stream);
