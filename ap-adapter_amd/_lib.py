@@ -127,6 +127,8 @@ SYMBOLS = {
     "apad_xattn_pack_weight": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "apad_xattn_packed_kv_bytes": (_i64, [_i32, _i32]),
     "apad_xattn_pack_kv": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp]),
+    "apad_rows_packed_kv_bytes": (_i64, [_i32, _i32, _i32, _i32]),
+    "apad_rows_pack_kv": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "apad_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "apad_conv_halo_pack": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp]),
     "apad_hconv_launch_count": (_i64, []),
@@ -204,7 +206,7 @@ def lib():
                 fn = getattr(h, name)  # AttributeError if the ABI lost a symbol
                 fn.restype = res
                 fn.argtypes = args
-            if h.apad_abi_version() != 9:
+            if h.apad_abi_version() != 10:
                 raise RuntimeError("libapadapter_hip.so ABI version mismatch")
             if h.apad_sizeof_gemm_desc() != C.sizeof(GemmDesc) or h.apad_sizeof_attn_desc() != C.sizeof(AttnDesc) \
                     or h.apad_sizeof_rp_desc() != C.sizeof(RpDesc) \

@@ -1322,7 +1322,7 @@ struct XrP {
     const uint8_t* wq;  // packed: [C / 32 row tiles][C / 16 k-steps][64 lanes][8]
     const uint8_t* wo;
     const uint8_t* bo;
-    const uint8_t* k1;
+    const uint8_t* k1;  // vt1 == nullptr: apad_rows_pack_kv's fragment packing of the segment (KvPacked); else apad_attention's layout (KvRaw)
     const uint8_t* vt1;
     const float* bias1;
     const uint8_t* k2;
@@ -1422,7 +1422,14 @@ __global__ __launch_bounds__(NW * 64) void xattn_rows_kernel(XrP p) {
     uint8_t* const Q = smem + XR_TM * ROWB;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.x / p.tiles_per_sample, row0 = (blockIdx.x - b * p.tiles_per_sample) * XR_TM;
+    // XCD-aware (speed only; round 6): workgroup i runs on XCD i % 8, so the tiles of ONE sample -- which read the same key / value sets, 0.9 MB per sample at
+    // 512 audio keys -- are given to one XCD's L2 instead of four (the plain order had every set fetched through the fabric four times)
+    int bid = blockIdx.x;
+    {
+        const int per = gridDim.x >> 3;
+        if (bid < per * 8) bid = (bid & 7) * per + (bid >> 3);
+    }
+    const int b = bid / p.tiles_per_sample, row0 = (bid - b * p.tiles_per_sample) * XR_TM;
     const int nrows = p.N - row0 < XR_TM ? p.N - row0 : XR_TM;
     const uint8_t* const xb = p.x + ((int64_t)b * p.N + row0) * C * 2;
 
@@ -1483,14 +1490,22 @@ __global__ __launch_bounds__(NW * 64) void xattn_rows_kernel(XrP p) {
     // ---- 3. attention, heads 2 w and 2 w + 1: Q -> X.  All K / V^T fragments of a head (both segments) are requested before any of its
     //         arithmetic, and the first head's before the barrier: one exposed L2 round trip per wave ----
     constexpr bool BIG2 = NS2 > 2;  // the second segment's fragments are requested as they are used (short_segment_ns)
+    constexpr bool LONG2 = NS2 > 4;  // ... in 64-key chunks with a running maximum / sum (long_segment: 129 .. 512 audio keys)
     constexpr int NSB = (DUAL && !BIG2) ? NS2 : 1;
     ShortFr<DT, D, NS1> f1;
     ShortFr<DT, D, NSB> f2;
     // (two sub-tiles in both segments: both fragment sets at once do not fit the 256 registers of two waves per SIMD -- that form keeps
-    //  attn_short_kernel's load-as-you-go segment routine)
+    //  the load-as-you-go segment routine)
     constexpr bool SPLITF = DUAL && !BIG2 && NS1 + NS2 > 3;
-#define XR_FETCH1(h_) short_load<DT, D, NS1>(f1, p.k1 + ((int64_t)b * p.L1 * C + (h_) * D) * 2, C, p.vt1 + ((int64_t)(b * H + (h_)) * D * p.Lpad1) * 2, p.L1, p.Lpad1, l31, half)
-#define XR_FETCH2(h_) short_load<DT, D, NSB>(f2, p.k2 + ((int64_t)b * p.L2 * C + (h_) * D) * 2, C, p.vt2 + ((int64_t)(b * H + (h_)) * D * p.Lpad2) * 2, p.L2, p.Lpad2, l31, half)
+    // the fragment sources of a head's two segments: fragment-packed sets (round 6) or apad_attention's row-major / transposed tensors
+    const bool pk1 = p.vt1 == nullptr, pk2 = DUAL && p.vt2 == nullptr;
+    const int64_t hb1 = kv_packed_head_bytes(D, p.L1), hb2 = kv_packed_head_bytes(D, p.L2);
+#define XR_RAW1(h_) KvRaw<DT, D>{p.k1 + ((int64_t)b * p.L1 * C + (h_) * D) * 2, C, p.vt1 + ((int64_t)(b * H + (h_)) * D * p.Lpad1) * 2, p.L1, p.Lpad1}
+#define XR_RAW2(h_) KvRaw<DT, D>{p.k2 + ((int64_t)b * p.L2 * C + (h_) * D) * 2, C, p.vt2 + ((int64_t)(b * H + (h_)) * D * p.Lpad2) * 2, p.L2, p.Lpad2}
+#define XR_PK1(h_) KvPacked<DT, D>{p.k1 + (int64_t)(b * H + (h_)) * hb1, p.L1, (p.L1 + 31) & ~31}
+#define XR_PK2(h_) KvPacked<DT, D>{p.k2 + (int64_t)(b * H + (h_)) * hb2, p.L2, (p.L2 + 31) & ~31}
+#define XR_FETCH1(h_) do { if (pk1) short_load<DT, D, NS1>(f1, XR_PK1(h_), l31, half); else short_load<DT, D, NS1>(f1, XR_RAW1(h_), l31, half); } while (0)
+#define XR_FETCH2(h_) do { if (pk2) short_load<DT, D, NSB>(f2, XR_PK2(h_), l31, half); else short_load<DT, D, NSB>(f2, XR_RAW2(h_), l31, half); } while (0)
     // (macros, not lambdas: a fragment struct captured by a lambda is kept in scratch by this compiler)
     if (!(XR_ABL & 2) && !SPLITF) {
         XR_FETCH1((wave & 3) * 2);
@@ -1518,10 +1533,10 @@ __global__ __launch_bounds__(NW * 64) void xattn_rows_kernel(XrP p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
             float inv = 1.f;
-            if constexpr (SPLITF)
-                short_segment<DT, D>(p.k1 + ((int64_t)b * p.L1 * C + h * D) * 2, C, p.vt1 + ((int64_t)(b * H + h) * D * p.Lpad1) * 2, p.L1, p.Lpad1, bias1,
-                                     p.scale_log2, qf, o, inv, l31, half);
-            else
+            if constexpr (SPLITF) {
+                if (pk1) short_segment_ns<DT, D, 2>(XR_PK1(h), bias1, p.scale_log2, qf, o, inv, l31, half);
+                else short_segment_ns<DT, D, 2>(XR_RAW1(h), bias1, p.scale_log2, qf, o, inv, l31, half);
+            } else
                 short_compute<DT, D, NS1>(f1, p.L1, bias1, p.scale_log2, qf, o, inv, half);
 #pragma unroll
             for (int dt = 0; dt < DTT; ++dt)
@@ -1534,13 +1549,14 @@ __global__ __launch_bounds__(NW * 64) void xattn_rows_kernel(XrP p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o2[dt][r] = 0.f;
                 float inv2 = 1.f;
-                if constexpr (BIG2)
-                    short_segment_ns<DT, D, NS2>(p.k2 + ((int64_t)b * p.L2 * C + h * D) * 2, C, p.vt2 + ((int64_t)(b * H + h) * D * p.Lpad2) * 2, p.L2,
-                                                 p.Lpad2, nullptr, p.scale_log2, qf, o2, inv2, l31, half);
-                else if constexpr (SPLITF)
-                    short_segment<DT, D>(p.k2 + ((int64_t)b * p.L2 * C + h * D) * 2, C, p.vt2 + ((int64_t)(b * H + h) * D * p.Lpad2) * 2, p.L2, p.Lpad2,
-                                         nullptr, p.scale_log2, qf, o2, inv2, l31, half);
-                else
+                if constexpr (LONG2) {
+                    if (pk2) long_segment<DT, D>(XR_PK2(h), p.scale_log2, qf, o2, inv2, l31, half);
+                    else long_segment<DT, D>(XR_RAW2(h), p.scale_log2, qf, o2, inv2, l31, half);
+                } else if constexpr (BIG2 || SPLITF) {
+                    constexpr int NSX = BIG2 ? NS2 : 2;
+                    if (pk2) short_segment_ns<DT, D, NSX>(XR_PK2(h), nullptr, p.scale_log2, qf, o2, inv2, l31, half);
+                    else short_segment_ns<DT, D, NSX>(XR_RAW2(h), nullptr, p.scale_log2, qf, o2, inv2, l31, half);
+                } else
                     short_compute<DT, D, NSB>(f2, p.L2, nullptr, p.scale_log2, qf, o2, inv2, half);
                 // (as attn_short_kernel: each branch, and scale * audio, rounded to the storage type before the add)
 #pragma unroll
@@ -1568,6 +1584,10 @@ __global__ __launch_bounds__(NW * 64) void xattn_rows_kernel(XrP p) {
     }
 #undef XR_FETCH1
 #undef XR_FETCH2
+#undef XR_RAW1
+#undef XR_RAW2
+#undef XR_PK1
+#undef XR_PK2
     __syncthreads();
 
     // ---- 4. to_out(O) + bias -> Q, then + residual -> out ----
@@ -1598,16 +1618,58 @@ template <int DT, int C, int NW, int NSET> int xattn_rows_launch(const XrP& p, h
     };
     // sub-tile counts of the two segments are compile-time (the fragment registers of an unused sub-tile would not fit beside the rest)
     const int ns1 = p.L1 > 32 ? 2 : 1, ns2 = (p.L2 + 31) / 32;
-    if (ns2 > 2) return go(xattn_rows_kernel<DT, C, 1, 4, NW, NSET>);  // (ns1 == 1: checked by the caller) 8 text + 65 .. 128 audio keys
+    // (ns1 == 1: checked by the caller) 8 text + 65 .. 512 audio keys, in 64-key chunks (round 6; the one-tile form of 65 .. 128 keys -- NS2 = 4, its fragments
+    //  requested as they are used -- was slower at 128 keys than the chunked form at 256: 50 vs 54 us)
+    if (ns2 > 2) return go(xattn_rows_kernel<DT, C, 1, 16, NW, NSET>);
     if (ns1 == 1 && ns2 == 0) return go(xattn_rows_kernel<DT, C, 1, 0, NW, NSET>);
     if (ns1 == 1 && ns2 == 1) return go(xattn_rows_kernel<DT, C, 1, 1, NW, NSET>);
     if (ns2 == 0) return go(xattn_rows_kernel<DT, C, 2, 0, NW, NSET>);
     return go(xattn_rows_kernel<DT, C, 2, 2, NW, NSET>);
 }
 
+// apad_rows_pack_kv: one wave per MFMA operand fragment of KvPacked's layout (short_seg.h); blockIdx.y = (sample, head)
+__global__ __launch_bounds__(64) void rows_pack_kv_kernel(const uint8_t* k, const uint8_t* vt, uint8_t* out, int H, int D, int L, int Lpad_in) {
+    const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
+    const int KC = D / 16, DTT = (D + 31) / 32, NU = (L + 31) / 32, C = H * D;
+    const int bh = blockIdx.y, b = bh / H, h = bh - b * H, f = blockIdx.x;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (f < NU * KC) {
+        const int u = f / KC, cc = f - u * KC;
+        const int key = u * 32 + l31;
+        v = *reinterpret_cast<const uint4*>(k + (((int64_t)b * L + (key < L ? key : L - 1)) * C + h * D + cc * 16 + half * 8) * 2);
+    } else {
+        const int g = f - NU * KC, st = g / DTT, dt = g - st * DTT;
+        const int d = dt * 32 + l31;
+        if (d < D) {  // (st * 16 + 4 half + 11 < 32 NU <= Lpad_in)
+            const uint8_t* vp = vt + (((int64_t)bh * D + d) * Lpad_in + st * 16 + 4 * half) * 2;
+            const uint2 v0 = *reinterpret_cast<const uint2*>(vp), v1 = *reinterpret_cast<const uint2*>(vp + 16);
+            v = make_uint4(v0.x, v0.y, v1.x, v1.y);
+        }
+    }
+    *reinterpret_cast<uint4*>(out + (int64_t)bh * kv_packed_head_bytes(D, L) + ((int64_t)f * 64 + lane) * 16) = v;
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
+
+extern "C" int64_t apad_rows_packed_kv_bytes(int32_t B, int32_t heads, int32_t head_dim, int32_t L) {
+    if (B <= 0 || heads <= 0 || head_dim <= 0 || head_dim % 16 != 0 || L <= 0) return 0;
+    return (int64_t)B * heads * kv_packed_head_bytes(head_dim, L);
+}
+
+extern "C" int apad_rows_pack_kv(const void* k, const void* vt, void* out, int32_t B, int32_t heads, int32_t head_dim, int32_t L, int32_t Lpad, int32_t dtype,
+                                 void* stream) {
+    APAD_CHECK(dtype == APAD_BF16 || dtype == APAD_F16, "apad_rows_pack_kv: dtype %d not supported (16-bit only)", dtype);
+    APAD_CHECK(k && vt && out && B > 0 && heads > 0 && L > 0, "apad_rows_pack_kv: null operand / empty problem");
+    APAD_CHECK(head_dim > 0 && head_dim % 16 == 0, "apad_rows_pack_kv: head_dim %d must be a multiple of 16", head_dim);
+    APAD_CHECK(Lpad >= L && Lpad % 32 == 0, "apad_rows_pack_kv: Lpad must be >= L and a multiple of 32");
+    APAD_CHECK(al16(k) && al16(vt) && al16(out), "apad_rows_pack_kv: pointers must be 16-byte aligned");
+    const int nfrag = ((L + 31) / 32) * (head_dim / 16 + 2 * ((head_dim + 31) / 32));
+    hipLaunchKernelGGL(rows_pack_kv_kernel, dim3((unsigned)nfrag, (unsigned)(B * heads)), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)k, (const uint8_t*)vt,
+                       (uint8_t*)out, heads, head_dim, L, Lpad);
+    return apad_check_launch("apad_rows_pack_kv");
+}
 
 extern "C" int apad_attention(const apad_attn_desc* d, void* stream) {
     APAD_CHECK(d != nullptr, "apad_attention: null descriptor");
@@ -1674,16 +1736,17 @@ extern "C" int apad_cross_attention_rows(const apad_xrows_desc* d, void* stream)
         apad_set_error("apad_cross_attention_rows: C=%d heads=%d outside the kernel envelope (384, 8)", d->C, d->heads);
         return -3;
     }
-    APAD_CHECK(d->x && d->wq_packed && d->wo_packed && d->k1 && d->vt1 && d->out, "apad_cross_attention_rows: null operand");
+    APAD_CHECK(d->x && d->wq_packed && d->wo_packed && d->k1 && d->out, "apad_cross_attention_rows: null operand");
     APAD_CHECK((d->ln_gamma == nullptr) == (d->ln_beta == nullptr), "apad_cross_attention_rows: LayerNorm needs gamma and beta");
     APAD_CHECK(d->B > 0 && d->N > 0, "apad_cross_attention_rows: empty problem B=%d N=%d", d->B, d->N);
-    APAD_CHECK(d->L1 >= 1 && d->L1 <= 64 && d->L2 >= 0 && (d->L2 <= 64 || (d->L2 <= 128 && d->L1 <= 32)),
-               "apad_cross_attention_rows: segment lengths %d / %d outside 1..64 / 0..64 (0..128 beside <= 32 keys in segment 1)", d->L1, d->L2);
-    APAD_CHECK(d->Lpad1 >= d->L1 && d->Lpad1 % 32 == 0, "apad_cross_attention_rows: Lpad1 must be >= L1 and a multiple of 32");
+    APAD_CHECK(d->L1 >= 1 && d->L1 <= 64 && d->L2 >= 0 && (d->L2 <= 64 || (d->L2 <= 512 && d->L1 <= 32)),
+               "apad_cross_attention_rows: segment lengths %d / %d outside 1..64 / 0..64 (0..512 beside <= 32 keys in segment 1)", d->L1, d->L2);
+    // (vtN == NULL: kN is the segment's apad_rows_pack_kv set, LpadN unused)
+    APAD_CHECK(d->vt1 == nullptr || (d->Lpad1 >= d->L1 && d->Lpad1 % 32 == 0), "apad_cross_attention_rows: Lpad1 must be >= L1 and a multiple of 32");
     const bool dual = d->L2 > 0;
     if (dual) {
-        APAD_CHECK(d->k2 && d->vt2, "apad_cross_attention_rows: segment 2 needs k2 / vt2");
-        APAD_CHECK(d->Lpad2 >= d->L2 && d->Lpad2 % 32 == 0, "apad_cross_attention_rows: Lpad2 must be >= L2 and a multiple of 32");
+        APAD_CHECK(d->k2, "apad_cross_attention_rows: segment 2 needs k2 / vt2 (or its packed set in k2)");
+        APAD_CHECK(d->vt2 == nullptr || (d->Lpad2 >= d->L2 && d->Lpad2 % 32 == 0), "apad_cross_attention_rows: Lpad2 must be >= L2 and a multiple of 32");
     }
     APAD_CHECK(al16(d->x) && al16(d->out) && al16(d->wq_packed) && al16(d->wo_packed) && al16(d->k1) && al16(d->vt1) && al16(d->k2) && al16(d->vt2) &&
                    al16(d->ln_gamma) && al16(d->ln_beta),

@@ -354,21 +354,32 @@ __global__ __launch_bounds__(512) void hs_attn_kernel(HsP p) {
     // ---- 3. attention: wave (h, panel), waves 0 .. 3.  Cross-attention: every K / V^T fragment of the head is requested before the barrier ----
     const int h = (wave >> 1) & 1, mt = wave & 1, hg = pr * 2 + h;
     constexpr bool BIG2 = NS2 > 2;  // the second segment's fragments are requested as they are used (short_segment_ns)
+    constexpr bool LONG2 = NS2 > 4;  // ... in 64-key chunks with a running maximum / sum (long_segment: 129 .. 512 audio keys)
     constexpr bool SPLITF = DUAL && !BIG2 && NS1 + NS2 > 3;  // both resident sets would not fit: the second segment loads as it goes too
     constexpr int NSB = (DUAL && !BIG2 && !SPLITF) ? NS2 : 1;
     const bool att = wave < 4 && !(HS_ABL & 2);
     ShortFr<DT, D, NS1> f1;
     ShortFr<DT, D, NSB> f2;
+    // the fragment sources of the head's two segments: fragment-packed sets (vtN == nullptr: apad_rows_pack_kv, round 6) or apad_attention's tensors
+    const bool pk1 = !SELF && p.vt1 == nullptr, pk2 = DUAL && p.vt2 == nullptr;
+    const int64_t hb1 = kv_packed_head_bytes(D, SELF ? 32 : p.L1), hb2 = kv_packed_head_bytes(D, DUAL ? p.L2 : 32);
+#define HS_RAW1 KvRaw<DT, D>{p.k1 + ((int64_t)b * p.L1 * HS_C + hg * D) * 2, HS_C, p.vt1 + ((int64_t)(b * HS_H + hg) * D * p.Lpad1) * 2, p.L1, p.Lpad1}
+#define HS_RAW2 KvRaw<DT, D>{p.k2 + ((int64_t)b * p.L2 * HS_C + hg * D) * 2, HS_C, p.vt2 + ((int64_t)(b * HS_H + hg) * D * p.Lpad2) * 2, p.L2, p.Lpad2}
+#define HS_PK1 KvPacked<DT, D>{p.k1 + (int64_t)(b * HS_H + hg) * hb1, p.L1, (p.L1 + 31) & ~31}
+#define HS_PK2 KvPacked<DT, D>{p.k2 + (int64_t)(b * HS_H + hg) * hb2, p.L2, (p.L2 + 31) & ~31}
     if (!SELF && att) {
-        short_load<DT, D, NS1>(f1, p.k1 + ((int64_t)b * p.L1 * HS_C + hg * D) * 2, HS_C, p.vt1 + ((int64_t)(b * HS_H + hg) * D * p.Lpad1) * 2, p.L1, p.Lpad1, l31, half);
-        if (DUAL && !BIG2 && !SPLITF)
-            short_load<DT, D, NSB>(f2, p.k2 + ((int64_t)b * p.L2 * HS_C + hg * D) * 2, HS_C, p.vt2 + ((int64_t)(b * HS_H + hg) * D * p.Lpad2) * 2, p.L2, p.Lpad2, l31, half);
+        if (pk1) short_load<DT, D, NS1>(f1, HS_PK1, l31, half);
+        else short_load<DT, D, NS1>(f1, HS_RAW1, l31, half);
+        if (DUAL && !BIG2 && !SPLITF) {
+            if (pk2) short_load<DT, D, NSB>(f2, HS_PK2, l31, half);
+            else short_load<DT, D, NSB>(f2, HS_RAW2, l31, half);
+        }
     }
     HS_STAMP(0, 5);
     __syncthreads();
     HS_STAMP(0, 6);
     if (att) {
-        if (SELF) short_load<DT, D, NS1>(f1, K + h * D * 2, QROWB / 2, VT + h * D * VROWB, N, VROWB / 2, l31, half);
+        if (SELF) short_load<DT, D, NS1>(f1, KvRaw<DT, D>{K + h * D * 2, QROWB / 2, VT + h * D * VROWB, N, VROWB / 2}, l31, half);
         typename E::v8 qf[KC];
         {
             const uint8_t* qp = Q + (mt * 32 + l31) * QROWB + (h * D + half * 8) * 2;
@@ -394,9 +405,16 @@ __global__ __launch_bounds__(512) void hs_attn_kernel(HsP p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o2[dt][r] = 0.f;
             float inv2 = 1.f;
-            if constexpr (BIG2 || SPLITF)
-                short_segment_ns<DT, D, (NS2 > 0 ? NS2 : 1)>(p.k2 + ((int64_t)b * p.L2 * HS_C + hg * D) * 2, HS_C, p.vt2 + ((int64_t)(b * HS_H + hg) * D * p.Lpad2) * 2, p.L2,
-                                                              p.Lpad2, nullptr, p.scale_log2, qf, o2, inv2, l31, half);
+            if constexpr (LONG2) {
+                // (splitting the chunks over the four waves that idle in this phase was measured: no change -- at 64 samples x 8 heads x 520 keys the launch moves
+                //  its 85 MB of key / value sets at 5.8 TB/s)
+                if (pk2) long_segment<DT, D>(HS_PK2, p.scale_log2, qf, o2, inv2, l31, half);
+                else long_segment<DT, D>(HS_RAW2, p.scale_log2, qf, o2, inv2, l31, half);
+            } else if constexpr (BIG2 || SPLITF) {
+                constexpr int NSX = NS2 > 0 ? NS2 : 1;
+                if (pk2) short_segment_ns<DT, D, NSX>(HS_PK2, nullptr, p.scale_log2, qf, o2, inv2, l31, half);
+                else short_segment_ns<DT, D, NSX>(HS_RAW2, nullptr, p.scale_log2, qf, o2, inv2, l31, half);
+            }
             else
                 short_compute<DT, D, NSB>(f2, p.L2, nullptr, p.scale_log2, qf, o2, inv2, half);
             // (as attn_short_kernel: each branch, and scale * audio, rounded to the storage type before the add)
@@ -424,6 +442,10 @@ __global__ __launch_bounds__(512) void hs_attn_kernel(HsP p) {
                 }
             }
     }
+#undef HS_RAW1
+#undef HS_RAW2
+#undef HS_PK1
+#undef HS_PK2
     __syncthreads();
     // ---- 4. O(pair) [64][160] -> HBM, whole 16-byte chunks ----
     hs_tile_to_rows(Q, p.out + (int64_t)b * N * HS_C * 2, pr * HS_PW, N, tid);
@@ -857,7 +879,7 @@ template <int DT> int hs_attn_launch(const HsP& p, bool self, hipStream_t s) {
     if (self) return p.N > 32 ? hs_attn_go<DT, true, 2, 0>(p, s) : hs_attn_go<DT, true, 1, 0>(p, s);
     // sub-tile counts of the two segments are compile-time (the fragment registers of an unused sub-tile would not fit beside the rest)
     const int ns1 = p.L1 > 32 ? 2 : 1, ns2 = (p.L2 + 31) / 32;
-    if (ns2 > 2) return hs_attn_go<DT, false, 1, 4>(p, s);  // (ns1 == 1: checked by the caller) 8 text + 65 .. 128 audio keys
+    if (ns2 > 2) return hs_attn_go<DT, false, 1, 16>(p, s);  // (ns1 == 1: checked by the caller) 8 text + 65 .. 512 audio keys, in 64-key chunks (long_segment)
     if (ns1 == 1 && ns2 == 0) return hs_attn_go<DT, false, 1, 0>(p, s);
     if (ns1 == 1 && ns2 == 1) return hs_attn_go<DT, false, 1, 1>(p, s);
     if (ns2 == 0) return hs_attn_go<DT, false, 2, 0>(p, s);
@@ -914,13 +936,13 @@ extern "C" int apad_hs_attention(const apad_hs_attn_desc* d, void* stream) {
     APAD_CHECK(d->B > 0, "apad_hs_attention: empty batch");
     const bool self = d->self_attention != 0;
     if (!self) {
-        APAD_CHECK(d->k1 && d->vt1, "apad_hs_attention: cross-attention needs k1 / vt1");
-        APAD_CHECK(d->L1 >= 1 && d->L1 <= 64 && d->L2 >= 0 && (d->L2 <= 64 || (d->L2 <= 128 && d->L1 <= 32)),
-                   "apad_hs_attention: segment lengths %d / %d outside 1..64 / 0..64 (0..128 beside <= 32 keys in segment 1)", d->L1, d->L2);
-        APAD_CHECK(d->Lpad1 >= d->L1 && d->Lpad1 % 32 == 0, "apad_hs_attention: Lpad1 must be >= L1 and a multiple of 32");
+        APAD_CHECK(d->k1, "apad_hs_attention: cross-attention needs k1 / vt1 (or the segment's apad_rows_pack_kv set in k1, vt1 = NULL)");
+        APAD_CHECK(d->L1 >= 1 && d->L1 <= 64 && d->L2 >= 0 && (d->L2 <= 64 || (d->L2 <= 512 && d->L1 <= 32)),
+                   "apad_hs_attention: segment lengths %d / %d outside 1..64 / 0..64 (0..512 beside <= 32 keys in segment 1)", d->L1, d->L2);
+        APAD_CHECK(d->vt1 == nullptr || (d->Lpad1 >= d->L1 && d->Lpad1 % 32 == 0), "apad_hs_attention: Lpad1 must be >= L1 and a multiple of 32");
         if (d->L2 > 0) {
-            APAD_CHECK(d->k2 && d->vt2, "apad_hs_attention: segment 2 needs k2 / vt2");
-            APAD_CHECK(d->Lpad2 >= d->L2 && d->Lpad2 % 32 == 0, "apad_hs_attention: Lpad2 must be >= L2 and a multiple of 32");
+            APAD_CHECK(d->k2, "apad_hs_attention: segment 2 needs k2 / vt2 (or its packed set in k2)");
+            APAD_CHECK(d->vt2 == nullptr || (d->Lpad2 >= d->L2 && d->Lpad2 % 32 == 0), "apad_hs_attention: Lpad2 must be >= L2 and a multiple of 32");
         }
     } else {
         APAD_CHECK(d->key_bias == nullptr && d->L2 == 0, "apad_hs_attention: self-attention takes no key bias / second segment");

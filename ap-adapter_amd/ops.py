@@ -302,7 +302,7 @@ def fused_cross_attention(x, wq_packed, wo_packed, bo, kv1_packed, L1, heads, ln
 
 # envelope of apad_cross_attention_rows: 8 heads, C = 384, <= 64 keys per segment (...
 XROWS_C, XROWS_MAXL = (384,), 64
-XROWS_MAXL2 = 128                 # ... <= 128 in the second segment beside <= 32 in the first: the adapter's 8 text + 128 audio keys)
+XROWS_MAXL2 = 512                 # ... <= 512 in the second segment beside <= 32 in the first: the adapter's 8 text + 128 audio keys; 64-key chunks with a running maximum above 128)
 
 
 def xrows_ok(C_, heads, L1, L2=0):
@@ -319,31 +319,79 @@ def xrows_pack_weight(w):
     return w.detach().reshape(N // 32, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().reshape(-1)
 
 
+ROWS_KV_PACKED = True  # the processors hand the row-tile cross-attention kernels fragment-packed key / value sets (False: the (k, vt) pair; module attribute only)
+
+
+class RowsKV:
+    """One key / value set of a cross-attention site in apad_rows_pack_kv's layout: every MFMA operand fragment of every (sample, head) one contiguous
+    KB (``rows_pack_kv``).  ``cross_attention_rows`` / ``hs_attention`` take it in place of the (k, vt) pair of ops.attention's layout."""
+    __slots__ = ("data", "B", "L", "heads", "head_dim")
+
+    def __init__(self, data, B, L, heads, head_dim):
+        self.data, self.B, self.L, self.heads, self.head_dim = data, B, L, heads, head_dim
+
+    @property
+    def dtype(self):
+        return self.data.dtype
+
+    @property
+    def shape(self):  # (batch, keys, channels): what the routers ask of a key tensor
+        return (self.B, self.L, self.heads * self.head_dim)
+
+
+def rows_pack_kv(k, vt):
+    """k [B, L, C] row-major, vt [B, heads, d, Lpad] (ops.linear / ops.linear_vt of the hoisted projections) -> RowsKV: the fragment-major packing the
+    row-tile cross-attention kernels of the 384- and 640-wide levels read with whole-line loads (a fragment load from the row-major pair touches 32 - 64
+    cache lines, 8 from the packing).  Done once per site with the hoisted projections."""
+    _req(k, "rows_pack_kv.k")
+    _req(vt, "rows_pack_kv.vt", k.dtype)
+    B, Lk, Cc = k.shape
+    heads, hd = vt.shape[1], vt.shape[2]
+    if k.dtype not in FUSED_DTYPES or not k.is_contiguous() or not vt.is_contiguous() or vt.shape[0] != B or heads * hd != Cc or hd % 16 or Lk < 1 \
+            or vt.shape[3] < Lk or vt.shape[3] % 32:
+        raise ValueError(f"rows_pack_kv: k {tuple(k.shape)} {k.dtype}, vt {tuple(vt.shape)} outside the packing's envelope")
+    nbytes = L.lib().apad_rows_packed_kv_bytes(B, heads, hd, Lk)
+    out = torch.empty(nbytes // k.element_size(), dtype=k.dtype, device=k.device)
+    L.check(L.lib().apad_rows_pack_kv(k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, heads, hd, Lk, vt.shape[3], _DT[k.dtype], _stream()), "apad_rows_pack_kv")
+    return RowsKV(out, B, Lk, heads, hd)
+
+
+def _rows_kv_args(k, vt, B, heads, hd, dtype, what):
+    """(k pointer, vt pointer or 0, L, Lpad) of one segment given as a RowsKV (vt = None) or as the (k, vt) pair of ops.attention's layout"""
+    if isinstance(k, RowsKV):
+        if vt is not None or (k.B, k.heads, k.head_dim) != (B, heads, hd) or k.dtype != dtype:
+            raise ValueError(f"{what}: a RowsKV stands for the (k, vt) pair and must have the batch / heads / type of x")
+        return k.data.data_ptr(), 0, k.L, 0
+    for t in (k, vt):
+        if t is None or not t.is_contiguous() or t.dtype != dtype:
+            raise ValueError(f"{what}: must be contiguous {dtype}")
+    if k.shape[0] != B or tuple(vt.shape[:3]) != (B, heads, hd):
+        raise ValueError(f"{what}: key / value sets must have the batch of x")
+    return k.data_ptr(), vt.data_ptr(), k.shape[1], vt.shape[-1]
+
+
 def cross_attention_rows(x, wq_packed, wo_packed, bo, k1, vt1, heads, ln=None, key_bias=None, k2=None, vt2=None, scale2=0.0, out=None):
     """The fused cross-attention sub-layer at the 384-wide level: out = x + to_out(A(q, k1, v1, bias) [+ scale2 * A(q, k2, v2)]) + bo,
     q = to_q(LayerNorm(x)), one launch (csrc/attention.hip, xattn_rows_kernel).  x [B, N, C]; k* [B, L, C] row-major, vt* [B, heads, d,
-    Lpad] as ops.attention takes them; weights from xrows_pack_weight."""
+    Lpad] as ops.attention takes them, or k* = a RowsKV (rows_pack_kv) and vt* = None; weights from xrows_pack_weight."""
     _req(x, "cross_attention_rows.x", wq_packed.dtype)
     B, N, Cc = x.shape
     L1, L2 = k1.shape[1], (0 if k2 is None else k2.shape[1])
     if not xrows_ok(Cc, heads, L1, L2) or x.dtype not in FUSED_DTYPES:
         raise ValueError(f"cross_attention_rows: C={Cc} heads={heads} L1={L1} L2={L2} {x.dtype} outside the kernel envelope")
-    for t, n in ((x, "x"), (k1, "k1"), (vt1, "vt1"), (k2, "k2"), (vt2, "vt2")):
-        if t is not None and (not t.is_contiguous() or t.dtype != x.dtype):
-            raise ValueError(f"cross_attention_rows.{n}: must be contiguous {x.dtype}")
-    if k1.shape[0] != B or tuple(vt1.shape[:3]) != (B, heads, Cc // heads) or (k2 is not None and (k2.shape[0] != B or tuple(vt2.shape[:3]) != (B, heads, Cc // heads))):
-        raise ValueError("cross_attention_rows: key / value sets must have the batch of x")
+    if not x.is_contiguous():
+        raise ValueError(f"cross_attention_rows.x: must be contiguous {x.dtype}")
     if out is None:
         out = torch.empty_like(x)
     d = L.XrowsDesc()
-    d.x, d.wq_packed, d.wo_packed, d.bo, d.k1, d.vt1, d.out = (x.data_ptr(), wq_packed.data_ptr(), wo_packed.data_ptr(), _ptr(bo), k1.data_ptr(),
-                                                               vt1.data_ptr(), out.data_ptr())
+    d.x, d.wq_packed, d.wo_packed, d.bo, d.out = x.data_ptr(), wq_packed.data_ptr(), wo_packed.data_ptr(), _ptr(bo), out.data_ptr()
+    d.k1, d.vt1, d.L1, d.Lpad1 = _rows_kv_args(k1, vt1, B, heads, Cc // heads, x.dtype, "cross_attention_rows.k1 / vt1")
     if ln is not None:
         d.ln_gamma, d.ln_beta, d.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), float(ln[2])
     d.key_bias = _ptr(key_bias)
-    d.B, d.N, d.C, d.heads, d.L1, d.Lpad1 = B, N, Cc, heads, L1, vt1.shape[-1]
+    d.B, d.N, d.C, d.heads = B, N, Cc, heads
     if L2 > 0:
-        d.k2, d.vt2, d.L2, d.Lpad2 = k2.data_ptr(), vt2.data_ptr(), L2, vt2.shape[-1]
+        d.k2, d.vt2, d.L2, d.Lpad2 = _rows_kv_args(k2, vt2, B, heads, Cc // heads, x.dtype, "cross_attention_rows.k2 / vt2")
     d.dtype, d.softmax_scale, d.scale2 = _DT[x.dtype], 1.0 / math.sqrt(Cc // heads), float(scale2)
     L.check(L.lib().apad_cross_attention_rows(C.byref(d), _stream()), "apad_cross_attention_rows")
     return out
@@ -419,7 +467,7 @@ def hs_rows_ok(x):
 
 
 def hs_cross_lengths_ok(L1, L2=0):
-    return 1 <= L1 <= 64 and (0 <= L2 <= 64 or (L2 <= 128 and L1 <= 32))
+    return 1 <= L1 <= 64 and (0 <= L2 <= 64 or (L2 <= XROWS_MAXL2 and L1 <= 32))
 
 
 def _hs_frag(w):
@@ -525,7 +573,7 @@ def hs_attention(x, w_packed, w_bias, *, self_attention, normalize=True, ln_eps=
                  scale2=0.0, q_prescaled=False, out=None):
     """O = heads' softmax attention of the 64-token level in ONE launch (apad_hs_attention): rows of x normalised (the LayerNorm's affine
     part lives in w_packed / w_bias: hs_pack_qkv / hs_pack_rows), q|k|v (self) or q (cross: k*, vt* = the hoisted sets in ops.attention's
-    layout) projected per head pair, both heads attended, O [B, N, 640] written.  to_out + residual: ``hs_out``."""
+    layout, or k* = a RowsKV and vt* = None) projected per head pair, both heads attended, O [B, N, 640] written.  to_out + residual: ``hs_out``."""
     _req(x, "hs_attention.x", w_packed.dtype)
     B, N, Cc = x.shape
     if Cc != HS_C or N > HS_MAXN or x.dtype not in FUSED_DTYPES or not x.is_contiguous():
@@ -538,14 +586,10 @@ def hs_attention(x, w_packed, w_bias, *, self_attention, normalize=True, ln_eps=
         L1, L2 = k1.shape[1], (0 if k2 is None else k2.shape[1])
         if not hs_cross_lengths_ok(L1, L2):
             raise ValueError(f"hs_attention: segment lengths {L1} / {L2} outside the kernel envelope")
-        for t, n in ((k1, "k1"), (vt1, "vt1"), (k2, "k2"), (vt2, "vt2")):
-            if t is not None and (not t.is_contiguous() or t.dtype != x.dtype):
-                raise ValueError(f"hs_attention.{n}: must be contiguous {x.dtype}")
-        if k1.shape[0] != B or tuple(vt1.shape[:3]) != (B, HS_HEADS, 80) or (k2 is not None and (k2.shape[0] != B or tuple(vt2.shape[:3]) != (B, HS_HEADS, 80))):
-            raise ValueError("hs_attention: key / value sets must have the batch of x")
-        d.k1, d.vt1, d.key_bias, d.L1, d.Lpad1 = k1.data_ptr(), vt1.data_ptr(), _ptr(key_bias), L1, vt1.shape[-1]
+        d.k1, d.vt1, d.L1, d.Lpad1 = _rows_kv_args(k1, vt1, B, HS_HEADS, 80, x.dtype, "hs_attention.k1 / vt1")
+        d.key_bias = _ptr(key_bias)
         if L2 > 0:
-            d.k2, d.vt2, d.L2, d.Lpad2 = k2.data_ptr(), vt2.data_ptr(), L2, vt2.shape[-1]
+            d.k2, d.vt2, d.L2, d.Lpad2 = _rows_kv_args(k2, vt2, B, HS_HEADS, 80, x.dtype, "hs_attention.k2 / vt2")
     if out is None:
         out = torch.empty_like(x)
     d.out = out.data_ptr()

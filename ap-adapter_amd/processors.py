@@ -75,6 +75,17 @@ def _hs_route(attn, hidden_states, residual, ln):
             and (residual is None or (residual.shape == hidden_states.shape and residual.is_contiguous())))
 
 
+def _rows_kv_route(attn, hidden_states, residual, ln, L1, L2=0):
+    """the site's cross-attention runs on a row-tile kernel that reads fragment-packed key / value sets (ops.rows_pack_kv): the 384-wide level's
+    one-launch kernel or the 64-token level's head-sliced pair"""
+    return ops.ROWS_KV_PACKED and (_xrows_ok(attn, hidden_states, residual, ln, L1, L2)
+                                   or (_hs_route(attn, hidden_states, residual, ln) and ops.hs_cross_lengths_ok(L1, L2)))
+
+
+def _rows_kv(pk, B, Lk, attn):
+    return ops.RowsKV(pk, B, Lk, attn.heads, attn.to_out[0].weight.shape[0] // attn.heads)
+
+
 def _hs_weights(attn, ln, self_attention):
     """(packed projection weights, their fp32 bias, packed to_out[0]) of apad_hs_attention / apad_hs_out, cached on the Attention module and
     re-packed when a parameter (the LayerNorm's included: it is folded into the projection) is re-assigned, moved, cast or updated in place"""
@@ -326,11 +337,13 @@ class AttnProcessor2_0(nn.Module):
             # (set_attn_processor(proc)) -- and are valid for one condition content and one pair of to_k / to_v weights
             # (re-assigned or stepped weights, an in-place update of the condition -> recomputed, in place)
             fused = _fused_xattn_ok(attn, hidden_states, _residual, _ln, Lk)
+            rows = not fused and ehs.shape[0] == B and _rows_kv_route(attn, hidden_states, _residual, _ln, Lk)
             persistent = self.kv_cache_enabled
 
-            def make(attn=attn, ehs=ehs, fused=fused, persistent=persistent):
+            def make(attn=attn, ehs=ehs, fused=fused, rows=rows, persistent=persistent):
                 k_, vt_ = self._project_kv(attn, ehs, None if persistent else "cross")
-                return (k_, vt_, ops.xattn_pack_kv(k_, vt_, ehs.shape[1]) if fused else None)  # packed with the projection
+                # packed with the projection: the weight-stationary kernel's layout, or the row-tile kernels' fragment sets
+                return (k_, vt_, ops.xattn_pack_kv(k_, vt_, ehs.shape[1]) if fused else (ops.rows_pack_kv(k_, vt_).data if rows else None))
 
             k, vt, pk = self._hoisted(_loose_key(attn, ehs), lambda attn=attn, ehs=ehs: (ehs._version, _pkey(attn.to_k.weight, attn.to_v.weight)), make)
         if attention_mask is not None:
@@ -343,6 +356,8 @@ class AttnProcessor2_0(nn.Module):
         if encoder_hidden_states is not None and fused and pk is not None:
             wq_p, q_fold, wo_p = _xattn_weights(attn, _ln)
             return ops.fused_cross_attention(hidden_states, wq_p, wo_p, attn.to_out[0].bias, pk, Lk, heads, ln=_ln, key_bias=bias, q_fold=q_fold)
+        if encoder_hidden_states is not None and rows and pk is not None:
+            k, vt = _rows_kv(pk, B, Lk, attn), None
         if encoder_hidden_states is not None and _xrows_ok(attn, hidden_states, _residual, _ln, Lk) and k.shape[0] == B:
             wq_p, wo_p = _xrows_weights(attn)
             return ops.cross_attention_rows(hidden_states, wq_p, wo_p, attn.to_out[0].bias, k, vt, heads, ln=_ln, key_bias=bias)
@@ -463,12 +478,15 @@ class IPAttnProcessor2_0(nn.Module):
         # projection weights, so a re-assigned to_k_ip / to_v_ip (inference.py:56-57) or an optimizer step is never served stale K/V
         Lt0 = min(self.num_tokens, ehs.shape[1])
         fused = _fused_xattn_ok(attn, hidden_states, _residual, _ln, Lt0, ehs.shape[1] - Lt0, attention_mask is not None)  # (no activation captured below)
+        rows = not fused and ehs.shape[0] == B and _rows_kv_route(attn, hidden_states, _residual, _ln, Lt0, ehs.shape[1] - Lt0)
 
-        def make(attn=attn, ehs=ehs, fused=fused):
+        def make(attn=attn, ehs=ehs, fused=fused, rows=rows):
             kv_ = self._project(attn, ehs)
             k_t_, vt_t_, Lt_, k_a_, vt_a_, La_ = kv_[:6]
             if fused:  # packed once, with the hoisted projection
                 kv_ = kv_[:6] + (ops.xattn_pack_kv(k_t_, vt_t_, Lt_), ops.xattn_pack_kv(k_a_, vt_a_, La_) if La_ > 0 else None)
+            elif rows:  # ... or into the fragment sets the row-tile kernels of the 384- / 640-wide levels read
+                kv_ = kv_[:6] + (ops.rows_pack_kv(k_t_, vt_t_).data, ops.rows_pack_kv(k_a_, vt_a_).data if La_ > 0 else None)
             return kv_
 
         sig = lambda attn=attn, ehs=ehs: (ehs._version, self.num_tokens,
@@ -484,6 +502,10 @@ class IPAttnProcessor2_0(nn.Module):
             wq_p, q_fold, wo_p = _xattn_weights(attn, _ln)
             return ops.fused_cross_attention(hidden_states, wq_p, wo_p, attn.to_out[0].bias, pk_t, Lt, attn.heads, ln=_ln,
                                              key_bias=bias, kv2_packed=pk_a, L2=La, scale2=self.scale, q_fold=q_fold)
+        if rows and pk_t is not None:
+            k_t, vt_t = _rows_kv(pk_t, B, Lt, attn), None
+            if La > 0:
+                k_a, vt_a = _rows_kv(pk_a, B, La, attn), None
         if _xrows_ok(attn, hidden_states, _residual, _ln, Lt, La) and k_t.shape[0] == B:
             wq_p, wo_p = _xrows_weights(attn)
             return ops.cross_attention_rows(hidden_states, wq_p, wo_p, attn.to_out[0].bias, k_t, vt_t, attn.heads, ln=_ln, key_bias=bias,

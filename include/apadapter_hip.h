@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define APAD_ABI_VERSION 9
+#define APAD_ABI_VERSION 10
 
 /* element types of activations / weights */
 enum { APAD_BF16 = 0, APAD_F16 = 1, APAD_F32 = 2 };
@@ -251,8 +251,11 @@ int apad_fused_cross_attention(const apad_xattn_desc* d, void* stream);
 /* The same sub-layer for the 384-wide level (252 tokens per sample, 8 heads of 48), where the weights do not fit the weight-stationary
  * registers of apad_fused_cross_attention: 64-token row tiles stay in LDS through LayerNorm -> to_q -> attention -> to_out -> + residual
  * (attention.hip, xattn_rows_kernel).  K / V sets as apad_attention takes them (k [B][L][C] row-major, vt [B][heads][d][Lpad] zero-padded);
- * <= 64 keys per segment, or <= 128 in segment 2 beside <= 32 in segment 1 (8 text + 128 audio keys: the timbre / accompaniment presets);
- * longer segments: the un-fused chain.  The two weights FRAGMENT-PACKED:
+ * <= 64 keys per segment, or <= 512 in segment 2 beside <= 32 in segment 1 (8 text + 128 audio keys: the timbre / accompaniment presets; 129 .. 512: pooling 1
+ * and the mixed poolings, run in 64-key chunks with a running maximum / sum, ABI 10); longer segments: the un-fused chain.
+ * ABI 10: a segment may instead be given FRAGMENT-PACKED (apad_rows_pack_kv below): kN = the packed set, vtN = NULL, LpadN unused -- every fragment
+ * load of the attention phase is then one contiguous KB instead of 32 - 64 cache lines (the K / V sets are timestep-invariant: packed once per site).
+ * The two weights FRAGMENT-PACKED:
  *   packed[(rt * (C / 16) + ks) * 512 + lane * 8 + e] = W[rt * 32 + (lane & 31)][ks * 16 + (lane >> 5) * 8 + e]   (elements)
  * i.e. W.view(C/32, 32, C/16, 2, 8).permute(0, 2, 3, 1, 4): every MFMA operand fragment is one contiguous KB.  Envelope: C = 384 (64-token
  * tiles) or 640 (32-token tiles; the Python side routes it only on request), 8 heads, 16-bit (else -3).  Replaces, per site, to_q + scaled_dot_product_attention (x 2 for the adapter) + to_out[0] of attention_processor.py:387-457
@@ -264,7 +267,7 @@ typedef struct apad_xrows_desc {
     const void* wq_packed; /* attn.to_q.weight, fragment-packed                         */
     const void* wo_packed; /* attn.to_out[0].weight, fragment-packed                    */
     const void* bo;        /* [C] or NULL                                               */
-    const void* k1;        /* [B][L1][C]                                                */
+    const void* k1;        /* [B][L1][C]; or the apad_rows_pack_kv set with vt1 = NULL  */
     const void* vt1;       /* [B][heads][C / heads][Lpad1]                              */
     const float* key_bias; /* [B][L1] fp32 additive bias on segment 1, or NULL          */
     const void* k2;        /* segment 2 (to_k_ip / to_v_ip of the audio tokens) or NULL */
@@ -277,6 +280,14 @@ typedef struct apad_xrows_desc {
 } apad_xrows_desc;
 int apad_sizeof_xrows_desc(void);
 int apad_cross_attention_rows(const apad_xrows_desc* d, void* stream);
+/* (ABI 10) One key / value set of a cross-attention site -- k [B][L][heads * head_dim] row-major, vt [B][heads][head_dim][Lpad], i.e. what to_k / to_v
+ * (to_k_ip / to_v_ip) of attention_processor.py:256-259 / :432-433 produce, in apad_attention's layout -- re-ordered into the MFMA operand fragments
+ * apad_cross_attention_rows and apad_hs_attention read, per (sample, head), NU = ceil(L / 32):
+ *   K   fragment (u < NU, cc < head_dim / 16):          lane -> k[key = min(32 u + lane % 32, L - 1)][16 cc + 8 (lane / 32) .. + 8]
+ *   V^T fragment (st < 2 NU, dt < ceil(head_dim / 32)): lane -> vt[d = 32 dt + lane % 32][16 st + 4 (lane / 32) + {0..3, 8..11}]   (zeros for d >= head_dim)
+ * 1 KB each, K fragments first; apad_rows_packed_kv_bytes = B * heads * NU * (head_dim / 16 + 2 ceil(head_dim / 32)) KB.  head_dim % 16 == 0, 16-bit. */
+int64_t apad_rows_packed_kv_bytes(int32_t B, int32_t heads, int32_t head_dim, int32_t L);
+int apad_rows_pack_kv(const void* k, const void* vt, void* out, int32_t B, int32_t heads, int32_t head_dim, int32_t L, int32_t Lpad, int32_t dtype, void* stream);
 /* The attention sub-layers of the 64-token level (C = 640, 8 heads of 80, <= 64 tokens per sample) in TWO launches (hsattn.hip; ABI 7):
  *   apad_hs_attention  workgroup = (sample, head pair): LayerNorm(x) (normalisation here, affine part folded into the weights) -> the pair's q|k|v (self-attention) or q (cross-attention over the
  *                      hoisted K / V^T sets of apad_attention's layout) -> softmax attention of its two heads (one segment, a masked
@@ -294,7 +305,7 @@ typedef struct apad_hs_attn_desc {
     const void* x;         /* [B*N][640] hidden states                                                */
     const void* w_packed;  /* see above                                                               */
     const float* w_bias;   /* [4][NTILE * 32] fp32 in the packed row order (W . ln_beta + bias), or NULL */
-    const void* k1;        /* cross: [B][L1][640]; self: NULL                                         */
+    const void* k1;        /* cross: [B][L1][640]; self: NULL.  ABI 10: or the segment's apad_rows_pack_kv set with vt1 = NULL (also k2 / vt2) */
     const void* vt1;       /* cross: [B][8][80][Lpad1]                                                */
     const float* key_bias; /* cross: [B][L1] fp32 additive bias on segment 1, or NULL                 */
     const void* k2;        /* cross: segment 2 (to_k_ip / to_v_ip of the audio tokens) or NULL        */

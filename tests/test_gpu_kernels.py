@@ -1019,11 +1019,13 @@ def test_fused_cross_attention_rows_with_a_large_mean(dev, dtype, shift, outlier
     (2, 252, 8, 32, False, 384), (3, 100, 8, 8, False, 384), (2, 252, 16, 0, True, 384), (1, 33, 8, 64, False, 384), (5, 64, 40, 0,
     False, 384), (2, 130, 8, 33, False, 384), (9, 252, 8, 32, True, 384), (2, 31, 64, 50, True, 384), (64, 252, 8, 32, False, 384),
     (2, 65, 1, 1, False, 384), (2, 252, 8, 128, False, 384), (3, 100, 8, 70, True, 384), (64, 252, 8, 128, False, 384), (2, 60, 32,
-    97, False, 384)])
+    97, False, 384), (2, 252, 8, 256, False, 384), (3, 100, 8, 129, False, 384), (2, 70, 8, 200, True, 384), (64, 252, 8, 512, False, 384),
+    (2, 33, 32, 320, False, 384)])
 def test_cross_attention_rows(dev, dtype, B, N, Lt, La, masked, C, monkeypatch):
     """the 384- and 640-wide levels' single-launch form (apad_cross_attention_rows: 64- / 32-token row tiles in LDS through LayerNorm, to_q,
     attention, to_out, residual): ragged last tiles, one- and two-segment forms, the masked forms of both, the 8 + 128-key form of the timbre /
-    accompaniment presets (second segment's fragments requested as they are used), full CFG batch; against fp32 torch on
+    accompaniment presets (second segment's fragments requested as they are used), 129 .. 512 audio keys in 64-key chunks with a running maximum /
+    sum (pooling 1 and the mixed poolings, ragged last chunk), full CFG batch; against fp32 torch on
     storage-rounded operands and against the three-kernel chain it replaces"""
     from ap_adapter_amd import ops
     H = 8
@@ -1054,6 +1056,11 @@ def test_cross_attention_rows(dev, dtype, B, N, Lt, La, masked, C, monkeypatch):
     out = ops.cross_attention_rows(xd, wq_p, wo_p, D(bo), k1, v1t, H, ln=(D(g), D(be), 1e-5), key_bias=bd, k2=k2, vt2=v2t, scale2=0.55)
     assert out.shape == ref.shape
     assert rel_err(out, ref) < 1.5 * TOL[dtype]
+    # the same launch over the fragment-packed key / value sets (what the processors hand it): the same fragments, bit-equal
+    p1, p2 = ops.rows_pack_kv(k1, v1t), (ops.rows_pack_kv(k2, v2t) if La else None)
+    assert torch.equal(ops.cross_attention_rows(xd, wq_p, wo_p, D(bo), p1, None, H, ln=(D(g), D(be), 1e-5), key_bias=bd, k2=p2, scale2=0.55), out)
+    if La:  # ... and mixed: one segment packed, the other not
+        assert torch.equal(ops.cross_attention_rows(xd, wq_p, wo_p, D(bo), k1, v1t, H, ln=(D(g), D(be), 1e-5), key_bias=bd, k2=p2, scale2=0.55), out)
     qd = ops.fused_linear(xd, D(wq), ln=(D(g), D(be), 1e-5))
     od = ops.attention(qd, k1, v1t, Lt, H, key_bias=bd, k2=k2, vt2=v2t, L2=La, scale2=0.55)
     chain = ops.fused_linear(od, D(wo), D(bo), residual=xd)
@@ -1071,7 +1078,7 @@ def test_cross_attention_rows_outside_envelope(dev, monkeypatch):
     assert ops.XROWS_C == (384,)
     bf = torch.bfloat16
     assert ops.xrows_ok(384, 8, 8, 32) and ops.xrows_ok(384, 8, 64, 64) and ops.xrows_ok(384, 8, 16)
-    assert ops.xrows_ok(384, 8, 8, 128) and ops.xrows_ok(384, 8, 32, 128) and not ops.xrows_ok(384, 8, 40, 128) and not ops.xrows_ok(384, 8, 8, 129)
+    assert ops.xrows_ok(384, 8, 8, 128) and ops.xrows_ok(384, 8, 32, 128) and not ops.xrows_ok(384, 8, 40, 128) and ops.xrows_ok(384, 8, 8, 129) and ops.xrows_ok(384, 8, 8, 512) and not ops.xrows_ok(384, 8, 8, 513)
     assert not ops.xrows_ok(640, 8, 8, 32) and not ops.xrows_ok(1280, 8, 8, 32) and not ops.xrows_ok(256, 8, 8, 32)
     assert not ops.xrows_ok(384, 4, 8, 32) and not ops.xrows_ok(384, 8, 65)
     x = torch.zeros(1, 64, 512, device=dev, dtype=bf)
@@ -1080,13 +1087,49 @@ def test_cross_attention_rows_outside_envelope(dev, monkeypatch):
         ops.cross_attention_rows(x, w, w, None, torch.zeros(1, 8, 512, device=dev, dtype=bf), torch.zeros(1, 8, 64, 32, device=dev, dtype=bf), 8)
     x = torch.zeros(1, 64, 384, device=dev, dtype=bf)
     w = ops.xrows_pack_weight(torch.zeros(384, 384, device=dev, dtype=bf))
-    with pytest.raises(ValueError):  # 512 audio keys: the chain's job
+    with pytest.raises(ValueError):  # more than 512 audio keys: the chain's job
         ops.cross_attention_rows(x, w, w, None, torch.zeros(1, 8, 384, device=dev, dtype=bf), torch.zeros(1, 8, 48, 32, device=dev, dtype=bf), 8,
-                                 k2=torch.zeros(1, 512, 384, device=dev, dtype=bf), vt2=torch.zeros(1, 8, 48, 512, device=dev, dtype=bf))
+                                 k2=torch.zeros(1, 576, 384, device=dev, dtype=bf), vt2=torch.zeros(1, 8, 48, 576, device=dev, dtype=bf))
     # the packing: fragment (row tile rt, k-step ks) = one contiguous KB, lane = (k half, row)
     wt = torch.arange(384 * 384, dtype=torch.float32).reshape(384, 384).to(dev)
     pk = ops.xrows_pack_weight(wt).reshape(12, 24, 2, 32, 8)
     assert torch.equal(pk[5, 7, 1, 9], wt[5 * 32 + 9, 7 * 16 + 8: 7 * 16 + 16])
+
+
+@pytest.mark.parametrize("H,hd,Lk", [(8, 48, 8), (8, 48, 40), (8, 80, 128), (8, 80, 200), (2, 32, 33)])
+def test_rows_pack_kv_layout(dev, H, hd, Lk):
+    """apad_rows_pack_kv against the layout include/apadapter_hip.h states, element by element (bf16 values are exact small integers)"""
+    from ap_adapter_amd import ops
+    B, Cc, Lpad = 3, H * hd, ops.round_up(Lk, 32) + 32  # (a vt buffer wider than the packing needs)
+    k = (torch.arange(B * Lk * Cc, dtype=torch.float32) % 251).reshape(B, Lk, Cc).to(dev, torch.bfloat16)
+    vt = torch.zeros(B, H, hd, Lpad, device=dev, dtype=torch.bfloat16)
+    vt[..., :Lk] = ((torch.arange(B * H * hd * Lk, dtype=torch.float32) * 7) % 253).reshape(B, H, hd, Lk).to(dev, torch.bfloat16)
+    pk = ops.rows_pack_kv(k, vt)
+    NU, KC, DTT = (Lk + 31) // 32, hd // 16, (hd + 31) // 32
+    assert pk.data.numel() * 2 == L_bytes(ops, B, H, hd, Lk) == B * H * NU * (KC + 2 * DTT) * 1024 and pk.shape == (B, Lk, Cc)
+    d = pk.data.reshape(B, H, NU * (KC + 2 * DTT), 64, 8).cpu().float()
+    kc, vc = k.cpu().float(), vt.cpu().float()
+    lane = torch.arange(64)
+    l31, half = lane % 32, lane // 32
+    for b, h in ((0, 0), (B - 1, H - 1)):
+        for u in range(NU):
+            for cc in range(KC):
+                key = torch.clamp(u * 32 + l31, max=Lk - 1)
+                exp = torch.stack([kc[b, key, h * hd + cc * 16 + half * 8 + e] for e in range(8)], 1)
+                assert torch.equal(d[b, h, u * KC + cc], exp)
+        for st in range(2 * NU):
+            for dt in range(DTT):
+                dd = dt * 32 + l31
+                cols = [st * 16 + 4 * half + e for e in range(4)] + [st * 16 + 4 * half + 8 + e for e in range(4)]
+                exp = torch.stack([torch.where(dd < hd, vc[b, h, torch.clamp(dd, max=hd - 1), c], torch.zeros(64)) for c in cols], 1)
+                assert torch.equal(d[b, h, NU * KC + st * DTT + dt], exp)
+    with pytest.raises(ValueError):
+        ops.rows_pack_kv(k, vt[..., :Lpad - 16])
+
+
+def L_bytes(ops, B, H, hd, Lk):
+    from ap_adapter_amd import _lib
+    return _lib.lib().apad_rows_packed_kv_bytes(B, H, hd, Lk)
 
 
 def test_fused_cross_attention_outside_envelope(dev):
@@ -1194,10 +1237,11 @@ def test_hs_self_attention_sublayer(dev, dtype, B, N):
 
 @pytest.mark.parametrize("dtype", DTYPES16)
 @pytest.mark.parametrize("B,N,Lt,La,masked", [(2, 64, 8, 32, False), (3, 64, 8, 8, False), (2, 64, 16, 0, True), (5, 16, 8, 64, False), (2, 64, 40, 0, True),
-                                               (2, 40, 8, 33, False), (64, 64, 8, 32, False), (2, 64, 40, 50, True), (3, 64, 8, 128, False), (2, 64, 32, 100, False)])
+                                               (2, 40, 8, 33, False), (64, 64, 8, 32, False), (2, 64, 40, 50, True), (3, 64, 8, 128, False), (2, 64, 32, 100, False),
+                                               (3, 64, 8, 256, False), (2, 40, 8, 129, False), (64, 64, 8, 512, False), (2, 64, 32, 200, True)])
 def test_hs_cross_attention_sublayer(dev, dtype, B, N, Lt, La, masked):
     """the cross-attention form: q of the head pair projected in the launch, K / V^T the hoisted sets in apad_attention's layout -- the
-    adapter's text + scale * audio pair at every pooling rate it covers (8 / 32 / 64 / 128 audio keys), the masked T5 segment (one and two
+    adapter's text + scale * audio pair at every pooling rate (8 / 32 / 64 / 128 audio keys in one tile, 129 .. 512 in 64-key chunks), the masked T5 segment (one and two
     key sub-tiles), ragged samples, the CFG batch"""
     from ap_adapter_amd import ops
     C, H = 640, 8
@@ -1229,6 +1273,9 @@ def test_hs_cross_attention_sublayer(dev, dtype, B, N, Lt, La, masked):
     o = ops.hs_attention(xd, wq_p, qb, self_attention=False, ln_eps=1e-5, k1=k1, vt1=v1t, key_bias=bd, k2=k2, vt2=v2t, scale2=0.55)
     out = ops.hs_out(o, wo_p, D(bo), xd)
     assert out.shape == ref.shape and rel_err(out, ref) < 1.5 * TOL[dtype]
+    # the same launch over the fragment-packed key / value sets (what the processors hand it): bit-equal
+    p1, p2 = ops.rows_pack_kv(k1, v1t), (ops.rows_pack_kv(k2, v2t) if La else None)
+    assert torch.equal(ops.hs_attention(xd, wq_p, qb, self_attention=False, ln_eps=1e-5, k1=p1, key_bias=bd, k2=p2, scale2=0.55), o)
     qd = ops.linear(ops.layer_norm(xd, *ln), D(wq))
     chain = ops.linear(ops.attention(qd, k1, v1t, Lt, H, key_bias=bd, k2=k2, vt2=v2t, L2=La, scale2=0.55), D(wo), D(bo), residual=xd)
     assert rel_err(out, chain.float().cpu()) < TOL[dtype]
@@ -1305,14 +1352,14 @@ def test_hs_attention_outside_envelope(dev):
     x = torch.zeros(2, 64, 640, device=dev, dtype=bf)
     assert ops.hs_ok(x, 8, 640) and not ops.hs_ok(x, 4, 640) and not ops.hs_ok(x.float(), 8, 640) and not ops.hs_ok(torch.zeros(2, 65, 640, device=dev, dtype=bf), 8, 640)
     assert not ops.hs_ok(torch.zeros(2, 64, 384, device=dev, dtype=bf), 8, 384)
-    assert ops.hs_cross_lengths_ok(8, 32) and ops.hs_cross_lengths_ok(64, 64) and ops.hs_cross_lengths_ok(8, 128) and not ops.hs_cross_lengths_ok(8, 512) and not ops.hs_cross_lengths_ok(40, 128)
+    assert ops.hs_cross_lengths_ok(8, 32) and ops.hs_cross_lengths_ok(64, 64) and ops.hs_cross_lengths_ok(8, 128) and ops.hs_cross_lengths_ok(8, 512) and not ops.hs_cross_lengths_ok(8, 513) and not ops.hs_cross_lengths_ok(40, 128)
     w = torch.zeros(640, 640, device=dev, dtype=bf)
     pk, _ = ops.hs_pack_rows(w)
     with pytest.raises(ValueError):
         ops.hs_attention(torch.zeros(2, 65, 640, device=dev, dtype=bf), pk, None, self_attention=True)
-    with pytest.raises(ValueError):  # 512 audio keys: the chain's job
+    with pytest.raises(ValueError):  # more than 512 audio keys: the chain's job
         ops.hs_attention(x, pk, None, self_attention=False, k1=torch.zeros(2, 8, 640, device=dev, dtype=bf), vt1=torch.zeros(2, 8, 80, 32, device=dev, dtype=bf),
-                         k2=torch.zeros(2, 512, 640, device=dev, dtype=bf), vt2=torch.zeros(2, 8, 80, 512, device=dev, dtype=bf))
+                         k2=torch.zeros(2, 576, 640, device=dev, dtype=bf), vt2=torch.zeros(2, 8, 80, 576, device=dev, dtype=bf))
     # the packing: quarter p, row tile t, k-step ks = one contiguous KB, lane = (k half, row)
     wt = torch.arange(640 * 640, dtype=torch.float32).reshape(640, 640).to(dev)
     pk = ops.hs_pack_rows(wt)[0].reshape(4, 5, 40, 2, 32, 8)
