@@ -812,6 +812,17 @@ __device__ __forceinline__ sf_gptr sf_sgpr_ptr(const uint8_t* p) {
 #ifndef SF_NSET
 #define SF_NSET 0  // (0: per-geometry default)
 #endif
+#ifndef SF_NSET48
+#define SF_NSET48 1  // weight / token fragment register sets of the projection loop at d = 48 (1: one rolling set, re-requested behind the k-step's MFMAs -- what fits
+                     // beside 160 accumulator registers when two workgroups share a CU; 2 spills 124 registers there)
+#endif
+#ifndef SF_DIRECT
+#define SF_DIRECT(D_) ((D_) == 32)  // the key loop's direct form (running max through the score MFMA's C operand: 32 more registers) per head size: at d = 48 /
+                                    // 252 tokens (four key tiles) the classic two-tile form keeps the kernel inside 256 registers
+#endif
+#ifndef SF_OCC
+#define SF_OCC 2  // waves per SIMD the fused self-attention kernel is compiled for (1: the compiler's own choice, for A/B builds)
+#endif
 #ifndef SF_NPP48
 #define SF_NPP48 2  // panels projected at once at d = 48 (2: 160 accumulator registers; 47.7 -> 42.4 us at 64 x 252 tokens: every weight fragment feeds two panels)
 #endif
@@ -889,8 +900,10 @@ __device__ __forceinline__ void sf_project(sf_gptr wb, uint32_t loff, const uint
 #undef SF_MM
 }
 
+// (two waves per SIMD by contract: at d = 48 the four-wave workgroups need TWO per CU -- round 6 found the kernel at 256 + 44 registers, i.e. one workgroup per
+//  CU and its 512 workgroups in two rounds of 22 us; SF_OCC = 1 re-creates that build)
 template <int DT, int D, int KC, int NW, int NPP, int NSET>
-__global__ __launch_bounds__(NW * 64) void sattn_fused_kernel(SfP p) {
+__global__ __launch_bounds__(NW * 64, SF_OCC) void sattn_fused_kernel(SfP p) {
     using E = ET<DT>;
     using Y = Lay<D>;
     // the head's q | k | v rows are packed DENSELY: 3 d virtual rows in ceil(3 d / 32) row tiles (d = 48: 4.5 -> 5 tiles, not 3 x 2); an 8-row
@@ -919,10 +932,12 @@ __global__ __launch_bounds__(NW * 64) void sattn_fused_kernel(SfP p) {
     const sf_gptr wb = sf_sgpr_ptr(p.w + (int64_t)h * NT3 * KC * 1024);
     const uint32_t loff = (uint32_t)lane * 16u;
     const uint8_t* const xb = p.x + (int64_t)b * N * C * 2;
-    typename E::v8 qkeep[2][NPW][KCD];  // [round][panel of the pair][k-step]: this wave's q fragments, projection -> key loop
+    // rounds of (NPW x NW) panels a workgroup needs: 1024 tokens / 8 waves = 2; the 384-wide level's <= 256 tokens / 4 waves = 1 (apad_self_attention_fused's envelope)
+    constexpr int MAXR = D == 32 ? 2 : 1;
+    typename E::v8 qkeep[MAXR][NPW][KCD];  // [round][panel of the pair][k-step]: this wave's q fragments, projection -> key loop
     // ---- 1. projection: K, V^T -> LDS tiles; Q -> registers ----
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < MAXR; ++r) {
         if (r >= rounds) break;
 #pragma unroll
         for (int g0 = 0; g0 < NPW; g0 += NPP) {
@@ -1005,7 +1020,7 @@ __global__ __launch_bounds__(NW * 64) void sattn_fused_kernel(SfP p) {
     SF_STAMP(6);
     // ---- 2. attention over the resident tiles: two query panels per wave and round ----
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < MAXR; ++r) {
         if (r >= rounds) break;
         const int pa = (r * NPW) * NW + wave, pb = pa + NW;
         if (pa >= npan || (SF_ABL & 1)) continue;  // (wave-uniform; pb >= npan: its lanes carry the clamped last row and are not stored)
@@ -1026,8 +1041,8 @@ __global__ __launch_bounds__(NW * 64) void sattn_fused_kernel(SfP p) {
         }
         int t = 0;
 #pragma unroll 1
-        for (; t < nfull; ++t) tile_compute2<DT, D, false, true>(smem + t * Y::BUF, t * KT, N, 1.0f, qkeep[r], o, osum, m, mi, l31, half);
-        if (t < ntiles) tile_compute2<DT, D, true, true>(smem + t * Y::BUF, t * KT, N, 1.0f, qkeep[r], o, osum, m, mi, l31, half);
+        for (; t < nfull; ++t) tile_compute2<DT, D, false, SF_DIRECT(D)>(smem + t * Y::BUF, t * KT, N, 1.0f, qkeep[r], o, osum, m, mi, l31, half);
+        if (t < ntiles) tile_compute2<DT, D, true, SF_DIRECT(D)>(smem + t * Y::BUF, t * KT, N, 1.0f, qkeep[r], o, osum, m, mi, l31, half);
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             const int q = (qt == 0 ? pa : pb) * 32 + l31;
@@ -1724,7 +1739,7 @@ extern "C" int apad_self_attention_fused(const void* x, const void* w_packed, co
     SfP p;
     p.x = (const uint8_t*)x; p.w = (const uint8_t*)w_packed; p.csbb = colsum_bias; p.out = (uint8_t*)out; p.B = B; p.N = N; p.H = heads; p.eps = ln_eps;
     hipStream_t s = (hipStream_t)stream;
-    constexpr int NS32 = SF_NSET ? SF_NSET : 4, NS48 = SF_NSET ? SF_NSET : 2;
+    constexpr int NS32 = SF_NSET ? SF_NSET : 4, NS48 = SF_NSET ? SF_NSET : SF_NSET48;
     if (g256) return dtype == APAD_BF16 ? sf_go<APAD_BF16, 32, 16, 8, 2, NS32>(p, s) : sf_go<APAD_F16, 32, 16, 8, 2, NS32>(p, s);
     return dtype == APAD_BF16 ? sf_go<APAD_BF16, 48, 24, 4, SF_NPP48, NS48>(p, s) : sf_go<APAD_F16, 48, 24, 4, SF_NPP48, NS48>(p, s);
 }
