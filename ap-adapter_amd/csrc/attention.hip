@@ -816,6 +816,16 @@ __device__ __forceinline__ sf_gptr sf_sgpr_ptr(const uint8_t* p) {
 #define SF_NSET48 1  // weight / token fragment register sets of the projection loop at d = 48 (1: one rolling set, re-requested behind the k-step's MFMAs -- what fits
                      // beside 160 accumulator registers when two workgroups share a CU; 2 spills 124 registers there)
 #endif
+#ifndef SF_STG_NSW
+#define SF_STG_NSW 1  // weight-fragment register sets of the staged projection loop (1: one rolling set; 137 us at d = 32 against 145 with 2 -- registers)
+#endif
+#ifndef SF_STAGE
+#define SF_STAGE(D_) ((D_) == 32)  // token fragments of the projection staged through LDS (sf_project_stg) per head size
+#endif
+#ifndef SF_STAT
+#define SF_STAT 1  // row statistics of the projection loop: 0 = shifted sums on the vector ALU (8 x (convert, subtract, add, fma) per fragment), 1 = un-shifted sums on
+                   // the dot-product instruction (8 instructions per fragment)
+#endif
 #ifndef SF_DIRECT
 #define SF_DIRECT(D_) ((D_) == 32)  // the key loop's direct form (running max through the score MFMA's C operand: 32 more registers) per head size: at d = 48 /
                                     // 252 tokens (four key tiles) the classic two-tile form keeps the kernel inside 256 registers
@@ -847,6 +857,15 @@ __device__ unsigned long long sf_trace_buf[1024][16];
 #define SF_STAMP(i_)
 #endif
 
+// sum / sum of squares of a pair of 16-bit values on the dot-product instruction (v_dot2c_f32_bf16 / _f16): no conversion, two values per instruction
+typedef __bf16 sf_bf2 __attribute__((ext_vector_type(2)));
+typedef _Float16 sf_h2 __attribute__((ext_vector_type(2)));
+template <int DT> __device__ __forceinline__ float sf_dot2(uint32_t a, uint32_t b, float c) {
+    if constexpr (DT == APAD_BF16) return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(sf_bf2, a), __builtin_bit_cast(sf_bf2, b), c, false);
+    else return __builtin_amdgcn_fdot2(__builtin_bit_cast(sf_h2, a), __builtin_bit_cast(sf_h2, b), c, false);
+}
+template <int DT> __device__ __forceinline__ uint32_t sf_ones2() { return DT == APAD_BF16 ? 0x3f803f80u : 0x3c003c00u; }
+
 // acc[n][j] += W_tile_j . x_panel_n^T over the KC k-steps (raw x), with the row statistics of the panels summed on the way (shifted by the row's
 // first element: both halves of a row use the same shift)
 template <int DT, int NT3, int NPP, int KC, int NSET>
@@ -861,7 +880,12 @@ __device__ __forceinline__ void sf_project(sf_gptr wb, uint32_t loff, const uint
 #define SF_MM(i_)                                                                                   \
     _Pragma("unroll") for (int n = 0; n < NPP; ++n) {                                               \
         _Pragma("unroll") for (int j = 0; j < NT3; ++j) acc[n][j] = E::mfma32(wf[i_][j], xf[i_][n], acc[n][j]); \
-        if (!(SF_ABL & 4)) _Pragma("unroll") for (int e = 0; e < 8; ++e) {                          \
+        if (!(SF_ABL & 4) && SF_STAT == 1) _Pragma("unroll") for (int w_ = 0; w_ < 4; ++w_) {       \
+            const uint32_t pr_ = __builtin_bit_cast(u32x4, xf[i_][n])[w_];                          \
+            ssum[n] = sf_dot2<DT>(pr_, sf_ones2<DT>(), ssum[n]);                                    \
+            sq[n] = sf_dot2<DT>(pr_, pr_, sq[n]);                                                   \
+        }                                                                                           \
+        if (!(SF_ABL & 4) && SF_STAT == 0) _Pragma("unroll") for (int e = 0; e < 8; ++e) {          \
             const float d_ = (float)xf[i_][n][e] - shift[n];                                        \
             ssum[n] += d_;                                                                          \
             sq[n] = __builtin_fmaf(d_, d_, sq[n]);                                                  \
@@ -871,7 +895,7 @@ __device__ __forceinline__ void sf_project(sf_gptr wb, uint32_t loff, const uint
     for (int i = 0; i < NSET; ++i) { SF_LD(i, i); }
 #pragma unroll
     for (int n = 0; n < NPP; ++n) {
-        shift[n] = half_lo((float)xf[0][n][0]);
+        shift[n] = SF_STAT == 1 ? 0.f : half_lo((float)xf[0][n][0]);
         ssum[n] = 0.f;
         sq[n] = 0.f;
     }
@@ -900,9 +924,101 @@ __device__ __forceinline__ void sf_project(sf_gptr wb, uint32_t loff, const uint
 #undef SF_MM
 }
 
+// The same contraction with the token fragments STAGED THROUGH LDS (round 6).  A B-operand fragment straight from global memory is 32 rows x 32 bytes: 32 cache
+// lines per load instruction, and the vector memory pipe takes about a cycle per line -- with the statistics on the dot-product instruction (SF_STAT) that gather is
+// what bounds the projection phase (probe build with whole-row loads, SF_ABL = 64: 144 -> 131 us at d = 32).  Here the wave fetches its 64 rows of a four-k-step
+// chunk as whole 128-byte pieces (8 rows per instruction = 8 lines), parks them in a private 8 KB LDS window (128-byte row records, 16-byte slot s of row r at
+// s ^ ((r >> 1) & 7): conflict-free for the b128 writes and the fragment reads) and reads the fragments back one k-step ahead; the chunk after next is in flight in
+// registers meanwhile.  Same MFMA order, same operands: bit-equal to sf_project.  The window aliases key tiles (sf_go picks the instantiation only where no finished
+// round has written them; the kernel fences it from the round's own epilogue).
+template <int DT, int NT3, int NPP, int KC>
+__device__ __forceinline__ void sf_project_stg(sf_gptr wb, uint32_t loff, const uint8_t* xb, const int (&pan)[NPP], int N, uint8_t* stg, int lane,
+                                               f32x16 (&acc)[NPP][NT3], float (&ssum)[NPP], float (&sq)[NPP], float (&shift)[NPP]) {
+    using E = ET<DT>;
+    constexpr int C = KC * 16, KCH = 4, BR = KCH * 32, LPR = BR / 16, RPI = 64 / LPR, NI = NPP * 32 / RPI, NCH = KC / KCH, NSW = SF_STG_NSW;
+    static_assert(KC % KCH == 0 && BR == 128 && KCH % NSW == 0, "128-byte row records; the weight sets rotate inside a chunk");
+    const int half = lane >> 5, l31 = lane & 31;
+    // lane -> (row lane / 8 of an 8-row group, 16-byte piece lane % 8); the per-instruction offsets are re-derived where they are used (registers)
+    const int rsub = lane / LPR, piece = lane % LPR;
+    uint32_t raddr[NPP], rsw[NPP];
+#pragma unroll
+    for (int n = 0; n < NPP; ++n) {
+        const int row = n * 32 + l31;
+        raddr[n] = row * BR;
+        rsw[n] = (row >> 1) & 7;
+    }
+    u32x4 st[NI];
+    typename E::v8 wf[NSW][NT3], xf[2][NPP];  // token fragments: this k-step's and the next one's
+#define SFS_GLOAD(c_)                                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                                                      \
+        int tok_ = pan[(i * RPI) >> 5] * 32 + ((i * RPI) & 31) + rsub;                                                    \
+        tok_ = tok_ < N ? tok_ : N - 1;                                                                                   \
+        st[i] = *reinterpret_cast<const u32x4*>(xb + (uint32_t)tok_ * (C * 2) + piece * 16 + (c_) * BR);                  \
+    }
+#define SFS_WRITE()                                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                                                      \
+        const int row_ = i * RPI + rsub;                                                                                  \
+        *reinterpret_cast<u32x4*>(stg + row_ * BR + ((piece ^ ((row_ >> 1) & 7)) << 4)) = st[i];                          \
+    }
+#define SFS_READ(s_, kl_)                                                                                                 \
+    _Pragma("unroll") for (int n = 0; n < NPP; ++n)                                                                       \
+        xf[s_][n] = as_v8<DT>(*reinterpret_cast<const uint4*>(stg + raddr[n] + ((((uint32_t)((kl_) * 2 + half)) ^ rsw[n]) << 4)));
+#define SFS_LDW(i_, kk_) _Pragma("unroll") for (int j = 0; j < NT3; ++j) wf[i_][j] = __builtin_bit_cast(typename E::v8, *(sf_gptr16)(wb + (j * KC + (kk_)) * 1024 + loff));
+    SFS_GLOAD(0);
+#pragma unroll
+    for (int i = 0; i < NSW; ++i) { SFS_LDW(i, i); }
+    SFS_WRITE();
+    if (NCH > 1) { SFS_GLOAD(1); }
+    SFS_READ(0, 0);
+#pragma unroll
+    for (int n = 0; n < NPP; ++n) {
+        shift[n] = SF_STAT == 1 ? 0.f : half_lo((float)xf[0][n][0]);
+        ssum[n] = 0.f;
+        sq[n] = 0.f;
+    }
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            if (i + 1 < KCH) { SFS_READ((i + 1) & 1, i + 1); }
+#pragma unroll
+            for (int n = 0; n < NPP; ++n) {
+#pragma unroll
+                for (int j = 0; j < NT3; ++j) acc[n][j] = E::mfma32(wf[i % NSW][j], xf[i & 1][n], acc[n][j]);
+                if (SF_STAT == 1) {
+#pragma unroll
+                    for (int w_ = 0; w_ < 4; ++w_) {
+                        const uint32_t pr_ = __builtin_bit_cast(u32x4, xf[i & 1][n])[w_];
+                        ssum[n] = sf_dot2<DT>(pr_, sf_ones2<DT>(), ssum[n]);
+                        sq[n] = sf_dot2<DT>(pr_, pr_, sq[n]);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float d_ = (float)xf[i & 1][n][e] - shift[n];
+                        ssum[n] += d_;
+                        sq[n] = __builtin_fmaf(d_, d_, sq[n]);
+                    }
+                }
+            }
+            const int kn = c * KCH + i + NSW;  // (past the end: the last k-step again, never used)
+            SFS_LDW(i % NSW, kn < KC ? kn : KC - 1);
+        }
+        if (c + 1 < NCH) {  // the next chunk: registers -> the window (every read of this chunk is issued), the one after it -> registers
+            SFS_WRITE();
+            if (c + 2 < NCH) { SFS_GLOAD(c + 2); }
+            SFS_READ(0, 0);
+        }
+    }
+#undef SFS_GLOAD
+#undef SFS_WRITE
+#undef SFS_READ
+#undef SFS_LDW
+}
+
 // (two waves per SIMD by contract: at d = 48 the four-wave workgroups need TWO per CU -- round 6 found the kernel at 256 + 44 registers, i.e. one workgroup per
 //  CU and its 512 workgroups in two rounds of 22 us; SF_OCC = 1 re-creates that build)
-template <int DT, int D, int KC, int NW, int NPP, int NSET>
+template <int DT, int D, int KC, int NW, int NPP, int NSET, bool STAGED>
 __global__ __launch_bounds__(NW * 64, SF_OCC) void sattn_fused_kernel(SfP p) {
     using E = ET<DT>;
     using Y = Lay<D>;
@@ -953,7 +1069,13 @@ __global__ __launch_bounds__(NW * 64, SF_OCC) void sattn_fused_kernel(SfP p) {
                 if (SF_ABL & 64) xrow[n] = xb + ((int64_t)min(pan[n] * 32 + half, N - 32) * C + l31 * 8) * 2;  // (timing only: two whole rows per load instruction)
                 act = act || pan[n] < npan;
             }
-            if (!act) continue;  // (wave-uniform)
+            // STAGED (sf_project_stg): every wave's 8 KB window at the END of the key-tile region.  sf_go launches this instantiation only where no EARLIER round
+            // has written tiles there (1000 tokens: round 0 fills tiles 0 .. 7, the windows sit in tiles 9 .. 15); a round whose own epilogue writes into the
+            // region is fenced from it by a workgroup barrier, behind which the zero paddings the windows overwrote are restored (disjoint from what the epilogues write)
+            constexpr int STG = NPP * 32 * 128, TILES_R = NPW * NW * 32 / KT;
+            static_assert(!STAGED || NPP == NPW, "a wave stages the 64 rows of both of its panels");
+            const int stg_off = ntiles * Y::BUF - NW * STG;
+            const bool fence = STAGED && ((r + 1) * TILES_R < ntiles ? (r + 1) * TILES_R : ntiles) * Y::BUF > stg_off;  // (workgroup-uniform)
             f32x16 acc[NPP][NT3];
 #pragma unroll
             for (int n = 0; n < NPP; ++n)
@@ -965,9 +1087,24 @@ __global__ __launch_bounds__(NW * 64, SF_OCC) void sattn_fused_kernel(SfP p) {
             if (SF_ABL & 2) {
 #pragma unroll
                 for (int n = 0; n < NPP; ++n) ssum[n] = sq[n] = shift[n] = 1.f;
-            } else
-            sf_project<DT, NT3, NPP, KC, NSET>(wb, loff, xrow, acc, ssum, sq, shift);
+            } else if (act) {  // (wave-uniform)
+                if constexpr (STAGED) sf_project_stg<DT, NT3, NPP, KC>(wb, loff, xb, pan, N, smem + stg_off + wave * STG, lane, acc, ssum, sq, shift);
+                else sf_project<DT, NT3, NPP, KC, NSET>(wb, loff, xrow, acc, ssum, sq, shift);
+            }
             SF_STAMP(2 + 2 * r);
+            if (fence) {
+                __syncthreads();
+                if (Y::VROWS > D) {
+                    for (int t = 0; t < ntiles; ++t)
+                        for (int i = tid; i < (Y::VROWS - D) * Y::VROW / 4; i += NW * 64) reinterpret_cast<uint32_t*>(smem + t * Y::BUF + Y::K_BYTES + D * Y::VROW)[i] = 0u;
+                }
+                if (npan & 1) {  // keys 32 .. 63 of the last tile belong to no panel: K rows 32 .. 63, bytes 64 .. 127 of every V^T row
+                    uint8_t* const lt = smem + (ntiles - 1) * Y::BUF;
+                    for (int i = tid; i < 32 * Y::KROW / 4; i += NW * 64) reinterpret_cast<uint32_t*>(lt + 32 * Y::KROW)[i] = 0u;
+                    for (int i = tid; i < Y::VROWS * 16; i += NW * 64) reinterpret_cast<uint32_t*>(lt + Y::K_BYTES + (i >> 4) * Y::VROW + 64)[i & 15] = 0u;
+                }
+            }
+            if (act) {
 #pragma unroll
             for (int n = 0; n < NPP; ++n) {
                 const int key = pan[n] * 32 + l31;
@@ -1012,6 +1149,7 @@ __global__ __launch_bounds__(NW * 64, SF_OCC) void sattn_fused_kernel(SfP p) {
                         }
                     }
                 }
+            }
             }
             SF_STAMP(3 + 2 * r);
         }
@@ -1073,12 +1211,17 @@ extern "C" int apad_sf_trace_read(void* dst, int bytes) {
 }
 #endif
 
-template <int DT, int D, int KC, int NW, int NPP, int NSET> int sf_go(const SfP& p, hipStream_t s) {
+template <int DT, int D, int KC, int NW, int NPP, int NSET, bool STAGED = false> int sf_go(const SfP& p, hipStream_t s) {
     using Y = Lay<D>;
     constexpr int NT3 = (3 * D + 31) / 32;
     const int ntiles = (p.N + KT - 1) / KT;
+    if constexpr (!STAGED && SF_STAGE(D) && NPP == 2) {
+        // the LDS-staged projection (sf_project_stg) where every wave's 8 KB window fits behind the tiles the earlier rounds fill
+        const int npan = (p.N + 31) / 32, rounds = (npan + 2 * NW - 1) / (2 * NW), stg_off = ntiles * Y::BUF - NW * NPP * 32 * 128;
+        if (stg_off >= (rounds - 1) * (2 * NW * 32 / KT) * Y::BUF) return sf_go<DT, D, KC, NW, NPP, NSET, true>(p, s);
+    }
     const int lds = ntiles * Y::BUF + 2 * NT3 * 32 * 4;
-    auto kern = sattn_fused_kernel<DT, D, KC, NW, NPP, NSET>;
+    auto kern = sattn_fused_kernel<DT, D, KC, NW, NPP, NSET, STAGED>;
     static unsigned devs = 0;
     constexpr int MAXT = D == 32 ? 16 : 4;  // key tiles of the largest routed sequence (1024 / 256 tokens)
     if (apad_ensure_dyn_lds(reinterpret_cast<const void*>(kern), MAXT * Y::BUF + 2 * NT3 * 32 * 4, &devs) != 0) return -1;
