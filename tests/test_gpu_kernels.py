@@ -1180,6 +1180,36 @@ def test_self_attention_fused(dev, dtype, B, N, C):
     assert torch.equal(ops.self_attention_fused(xd[i:i + 1].contiguous(), pk, csbb, H, 1e-5)[0], out[i])
 
 
+@pytest.mark.parametrize("dtype", DTYPES16)
+@pytest.mark.parametrize("N,C,shift,outlier", [(1000, 256, 8.0, 1.0), (1000, 256, -30.0, 1.0), (1000, 256, 0.0, 25.0), (252, 384, 30.0, 1.0), (252, 384, -8.0, 20.0)])
+def test_self_attention_fused_rows_with_a_large_mean(dev, dtype, N, C, shift, outlier):
+    """apad_self_attention_fused takes its row statistics as UN-shifted fp32 sums (sum x, sum x^2 on the dot-product instruction) and applies the
+    LayerNorm by algebra on the accumulators: rows with |mean| >> std and outlier channels -- where E[x^2] - mean^2 and (W' x) - mean colsum(W')
+    cancel -- against fp32 torch on the same stored rows and against the two-launch route (LayerNorm in registers, two-pass statistics)"""
+    from ap_adapter_amd import ops
+    B, H = 2, 8
+    x = R(B, N, C, seed=471) + shift
+    x[:, :, 5] *= outlier
+    x[:, :, C // 2 + 3] -= 2.0 * outlier
+    x = q(x, dtype)
+    g, be = q(1 + 0.1 * R(C, seed=472), dtype), q(0.1 * R(C, seed=473), dtype)
+    wq, wk, wv = (q(R(C, C, seed=474 + i, std=0.06), dtype) for i in range(3))
+    hs = F.layer_norm(x, (C,), g, be, 1e-5)
+    sp = lambda t: t.reshape(B, N, H, C // H).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sp(F.linear(hs, wq)), sp(F.linear(hs, wk)), sp(F.linear(hs, wv))).transpose(1, 2).reshape(B, N, C)
+    D = lambda t: t.to(dev, dtype)
+    xd, ln = D(x), (D(g), D(be), 1e-5)
+    pk, csbb = ops.sattn_pack(D(wq), D(wk), D(wv), ln, H)
+    out = ops.self_attention_fused(xd, pk, csbb, H, 1e-5).float().cpu()
+    hn = ops.layer_norm(xd, *ln)
+    vt = torch.zeros(B, H, C // H, ops.round_up(N, 32), device=dev, dtype=dtype)
+    ops.linear_vt(hn, D(wv), B, N, H, vt)
+    chain = ops.attention(ops.linear(hn, D(wq)), ops.linear(hn, D(wk)), vt, N, H).float().cpu()
+    e_f, e_c = float((out - ref).abs().max() / ref.abs().max()), float((chain - ref).abs().max() / ref.abs().max())
+    print(f"N {N} C {C} shift {shift} outlier {outlier}: fused vs fp32 {e_f:.3e}, two-launch route vs fp32 {e_c:.3e}")
+    assert torch.isfinite(out).all() and e_f < 3 * TOL[dtype] and e_f < 2.0 * e_c + 1e-3
+
+
 # ---- the 64-token level's attention sub-layers: apad_hs_attention (head-sliced) + apad_hs_out ----
 def _hs_self_ref(x, g, be, wq, wk, wv, wo, bo, heads, residual=True):
     B, N, C = x.shape
