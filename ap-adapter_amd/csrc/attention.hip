@@ -820,7 +820,7 @@ __device__ __forceinline__ sf_gptr sf_sgpr_ptr(const uint8_t* p) {
 #define SF_STG_NSW 1  // weight-fragment register sets of the staged projection loop (1: one rolling set; 137 us at d = 32 against 145 with 2 -- registers)
 #endif
 #ifndef SF_STAGE
-#define SF_STAGE(D_) ((D_) == 32)  // token fragments of the projection staged through LDS (sf_project_stg) per head size
+#define SF_STAGE(D_) true  // token fragments of the projection staged through LDS (sf_project_stg) per head size (false: the gathered loads, for A/B builds)
 #endif
 #ifndef SF_STAT
 #define SF_STAT 1  // row statistics of the projection loop: 0 = shifted sums on the vector ALU (8 x (convert, subtract, add, fma) per fragment), 1 = un-shifted sums on
@@ -931,12 +931,15 @@ __device__ __forceinline__ void sf_project(sf_gptr wb, uint32_t loff, const uint
 // s ^ ((r >> 1) & 7): conflict-free for the b128 writes and the fragment reads) and reads the fragments back one k-step ahead; the chunk after next is in flight in
 // registers meanwhile.  Same MFMA order, same operands: bit-equal to sf_project.  The window aliases key tiles (sf_go picks the instantiation only where no finished
 // round has written them; the kernel fences it from the round's own epilogue).
-template <int DT, int NT3, int NPP, int KC>
+template <int DT, int NT3, int NPP, int KC, int KCH>
 __device__ __forceinline__ void sf_project_stg(sf_gptr wb, uint32_t loff, const uint8_t* xb, const int (&pan)[NPP], int N, uint8_t* stg, int lane,
                                                f32x16 (&acc)[NPP][NT3], float (&ssum)[NPP], float (&sq)[NPP], float (&shift)[NPP]) {
     using E = ET<DT>;
-    constexpr int C = KC * 16, KCH = 4, BR = KCH * 32, LPR = BR / 16, RPI = 64 / LPR, NI = NPP * 32 / RPI, NCH = KC / KCH, NSW = SF_STG_NSW;
-    static_assert(KC % KCH == 0 && BR == 128 && KCH % NSW == 0, "128-byte row records; the weight sets rotate inside a chunk");
+    // KCH k-steps per chunk: 4 = 128-byte row records (8 rows = 8 lines per load instruction, 32 staging registers, slot swizzle (row >> 1) & 7);
+    //                        2 = 64-byte records (16 rows per instruction, 16 registers, (row >> 2) & 3) -- what fits beside 160 accumulator registers at d = 48
+    constexpr int C = KC * 16, BR = KCH * 32, LPR = BR / 16, RPI = 64 / LPR, NI = NPP * 32 / RPI, NCH = KC / KCH, NSW = SF_STG_NSW;
+    constexpr int SWS = KCH == 4 ? 1 : 2, SWM = LPR - 1;
+    static_assert(KC % KCH == 0 && (KCH == 4 || KCH == 2) && KCH % NSW == 0, "64- / 128-byte row records; the weight sets rotate inside a chunk");
     const int half = lane >> 5, l31 = lane & 31;
     // lane -> (row lane / 8 of an 8-row group, 16-byte piece lane % 8); the per-instruction offsets are re-derived where they are used (registers)
     const int rsub = lane / LPR, piece = lane % LPR;
@@ -945,7 +948,7 @@ __device__ __forceinline__ void sf_project_stg(sf_gptr wb, uint32_t loff, const 
     for (int n = 0; n < NPP; ++n) {
         const int row = n * 32 + l31;
         raddr[n] = row * BR;
-        rsw[n] = (row >> 1) & 7;
+        rsw[n] = (row >> SWS) & SWM;
     }
     u32x4 st[NI];
     typename E::v8 wf[NSW][NT3], xf[2][NPP];  // token fragments: this k-step's and the next one's
@@ -958,7 +961,7 @@ __device__ __forceinline__ void sf_project_stg(sf_gptr wb, uint32_t loff, const 
 #define SFS_WRITE()                                                                                                       \
     _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                                                      \
         const int row_ = i * RPI + rsub;                                                                                  \
-        *reinterpret_cast<u32x4*>(stg + row_ * BR + ((piece ^ ((row_ >> 1) & 7)) << 4)) = st[i];                          \
+        *reinterpret_cast<u32x4*>(stg + row_ * BR + ((piece ^ ((row_ >> SWS) & SWM)) << 4)) = st[i];                      \
     }
 #define SFS_READ(s_, kl_)                                                                                                 \
     _Pragma("unroll") for (int n = 0; n < NPP; ++n)                                                                       \
@@ -1072,7 +1075,7 @@ __global__ __launch_bounds__(NW * 64, SF_OCC) void sattn_fused_kernel(SfP p) {
             // STAGED (sf_project_stg): every wave's 8 KB window at the END of the key-tile region.  sf_go launches this instantiation only where no EARLIER round
             // has written tiles there (1000 tokens: round 0 fills tiles 0 .. 7, the windows sit in tiles 9 .. 15); a round whose own epilogue writes into the
             // region is fenced from it by a workgroup barrier, behind which the zero paddings the windows overwrote are restored (disjoint from what the epilogues write)
-            constexpr int STG = NPP * 32 * 128, TILES_R = NPW * NW * 32 / KT;
+            constexpr int STG_KCH = D == 32 ? 4 : 2, STG = NPP * 32 * STG_KCH * 32, TILES_R = NPW * NW * 32 / KT;
             static_assert(!STAGED || NPP == NPW, "a wave stages the 64 rows of both of its panels");
             const int stg_off = ntiles * Y::BUF - NW * STG;
             const bool fence = STAGED && ((r + 1) * TILES_R < ntiles ? (r + 1) * TILES_R : ntiles) * Y::BUF > stg_off;  // (workgroup-uniform)
@@ -1088,7 +1091,7 @@ __global__ __launch_bounds__(NW * 64, SF_OCC) void sattn_fused_kernel(SfP p) {
 #pragma unroll
                 for (int n = 0; n < NPP; ++n) ssum[n] = sq[n] = shift[n] = 1.f;
             } else if (act) {  // (wave-uniform)
-                if constexpr (STAGED) sf_project_stg<DT, NT3, NPP, KC>(wb, loff, xb, pan, N, smem + stg_off + wave * STG, lane, acc, ssum, sq, shift);
+                if constexpr (STAGED) sf_project_stg<DT, NT3, NPP, KC, STG_KCH>(wb, loff, xb, pan, N, smem + stg_off + wave * STG, lane, acc, ssum, sq, shift);
                 else sf_project<DT, NT3, NPP, KC, NSET>(wb, loff, xrow, acc, ssum, sq, shift);
             }
             SF_STAMP(2 + 2 * r);
@@ -1217,7 +1220,7 @@ template <int DT, int D, int KC, int NW, int NPP, int NSET, bool STAGED = false>
     const int ntiles = (p.N + KT - 1) / KT;
     if constexpr (!STAGED && SF_STAGE(D) && NPP == 2) {
         // the LDS-staged projection (sf_project_stg) where every wave's 8 KB window fits behind the tiles the earlier rounds fill
-        const int npan = (p.N + 31) / 32, rounds = (npan + 2 * NW - 1) / (2 * NW), stg_off = ntiles * Y::BUF - NW * NPP * 32 * 128;
+        const int npan = (p.N + 31) / 32, rounds = (npan + 2 * NW - 1) / (2 * NW), stg_off = ntiles * Y::BUF - NW * NPP * 32 * (D == 32 ? 128 : 64);
         if (stg_off >= (rounds - 1) * (2 * NW * 32 / KT) * Y::BUF) return sf_go<DT, D, KC, NW, NPP, NSET, true>(p, s);
     }
     const int lds = ntiles * Y::BUF + 2 * NT3 * 32 * 4;
