@@ -1039,14 +1039,28 @@ __global__ __launch_bounds__(NW * 64, SF_OCC) void sattn_fused_kernel(SfP p) {
     const int npan = (N + 31) >> 5, ntiles = (N + KT - 1) / KT, nfull = N / KT;
     const int rounds = (npan + NPW * NW - 1) / (NPW * NW);
     float* const csbb = reinterpret_cast<float*>(smem + ntiles * Y::BUF);  // [2][NT3 * 32]
-    // the head's colsum / bias vectors -> LDS; the last key tile is cleared (its unwritten V^T columns / rows meet zero probabilities)
-    for (int i = tid; i < 2 * NT3 * 32; i += NW * 64) csbb[i] = p.csbb[(int64_t)h * 2 * NT3 * 32 + i];
-    for (int i = tid; i < Y::BUF / 4; i += NW * 64) reinterpret_cast<uint32_t*>(smem + (ntiles - 1) * Y::BUF)[i] = 0u;
-    if (Y::VROWS > D) {  // (d = 48: rows 48 .. 63 of every V^T tile feed discarded output rows, but must be finite)
-        for (int t = 0; t < ntiles - 1; ++t)
-            for (int i = tid; i < (Y::VROWS - D) * Y::VROW / 4; i += NW * 64) reinterpret_cast<uint32_t*>(smem + t * Y::BUF + Y::K_BYTES + D * Y::VROW)[i] = 0u;
+    // the head's colsum / bias vectors -> LDS; the last key tile is cleared (its unwritten V^T columns / rows meet zero probabilities).
+    // STAGED: neither is needed before the first epilogue, which sits behind a workgroup barrier anyway -- the vectors are requested here and parked in LDS behind
+    // the first projection (their HBM round trip under its loads instead of in front of them: 1.5 us per workgroup), the zero paddings are written behind the
+    // last round's fence (the staging windows would overwrite them)
+    constexpr int NCSB = (2 * NT3 * 32 + NW * 64 - 1) / (NW * 64);
+    float csreg[NCSB];
+#pragma unroll
+    for (int k = 0; k < NCSB; ++k) {
+        const int i = tid + k * NW * 64;
+        csreg[k] = i < 2 * NT3 * 32 ? p.csbb[(int64_t)h * 2 * NT3 * 32 + i] : 0.f;
     }
-    __syncthreads();
+    if constexpr (!STAGED) {
+#pragma unroll
+        for (int k = 0; k < NCSB; ++k)
+            if (tid + k * NW * 64 < 2 * NT3 * 32) csbb[tid + k * NW * 64] = csreg[k];
+        for (int i = tid; i < Y::BUF / 4; i += NW * 64) reinterpret_cast<uint32_t*>(smem + (ntiles - 1) * Y::BUF)[i] = 0u;
+        if (Y::VROWS > D) {  // (d = 48: rows 48 .. 63 of every V^T tile feed discarded output rows, but must be finite)
+            for (int t = 0; t < ntiles - 1; ++t)
+                for (int i = tid; i < (Y::VROWS - D) * Y::VROW / 4; i += NW * 64) reinterpret_cast<uint32_t*>(smem + t * Y::BUF + Y::K_BYTES + D * Y::VROW)[i] = 0u;
+        }
+        __syncthreads();
+    }
     SF_STAMP(1);
     const sf_gptr wb = sf_sgpr_ptr(p.w + (int64_t)h * NT3 * KC * 1024);
     const uint32_t loff = (uint32_t)lane * 16u;
@@ -1095,8 +1109,13 @@ __global__ __launch_bounds__(NW * 64, SF_OCC) void sattn_fused_kernel(SfP p) {
                 else sf_project<DT, NT3, NPP, KC, NSET>(wb, loff, xrow, acc, ssum, sq, shift);
             }
             SF_STAMP(2 + 2 * r);
+            if (STAGED && r == 0) {
+#pragma unroll
+                for (int k = 0; k < NCSB; ++k)
+                    if (tid + k * NW * 64 < 2 * NT3 * 32) csbb[tid + k * NW * 64] = csreg[k];
+            }
+            if (fence || (STAGED && r == 0)) __syncthreads();
             if (fence) {
-                __syncthreads();
                 if (Y::VROWS > D) {
                     for (int t = 0; t < ntiles; ++t)
                         for (int i = tid; i < (Y::VROWS - D) * Y::VROW / 4; i += NW * 64) reinterpret_cast<uint32_t*>(smem + t * Y::BUF + Y::K_BYTES + D * Y::VROW)[i] = 0u;
