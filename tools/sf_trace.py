@@ -42,3 +42,9 @@ w0 = wc[:, 0].min()
 st = (wc[:, 0] - w0) / 100
 print(f"   kernel span {(wc[:, 1].max() - w0) / 100:.1f} us; workgroup starts: first wave of workgroups (start < 5 us) {int((st < 5).sum())}, median start of the rest "
       f"{np.median(st[st >= 5]) if (st >= 5).any() else 0:.1f} us; workgroup duration mean {((wc[:, 1] - wc[:, 0]) / 100).mean():.2f} us")
+first = st < 5
+dur = (wc[:, 1] - wc[:, 0]) / 100
+if first.any() and (~first).any():
+    print(f"   first-round workgroups: duration mean {dur[first].mean():.1f} us (end {((wc[first, 1] - w0) / 100).mean():.1f}); later ones: start mean {st[~first].mean():.1f}, "
+          f"duration mean {dur[~first].mean():.1f} us")
+
