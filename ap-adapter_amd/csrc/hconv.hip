@@ -215,7 +215,7 @@ __global__ __launch_bounds__(T::NT) void hconv_kernel(HcP p) {
     // ---- fragment addressing ----
     const bool x_first = (l31 & (W - 1)) == 0, x_last = (l31 & (W - 1)) == W - 1;
     // the zero region: 256 bytes = all 16 slot banks.  A border lane reads the zero slot in ITS OWN bank (address bits 4..7 kept): re-aimed at one fixed
-    // slot it collided with the lane that owns that bank -- 20 % of the kernel's LDS cycles were bank-conflict cycles (profiles/r06_pmc_hconv256_v5.txt)
+    // slot it collided with the lane that owns that bank -- 20 % of the kernel's LDS cycles were bank-conflict cycles (profiles/r06_pmc_hconv256_v6.txt)
     const uint32_t zbase = lds0 + (uint32_t)T::OFF_Z;
     // weights: row n of the tile, k-chunk (ks' 2 + half) of a 64-byte record, slot XOR-ed by (n >> 2) & 3
     uint32_t bfo[2];
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(T::NT) void hconv_kernel(HcP p) {
     HC_STAMP(tstamp + 2);
     if constexpr (HC_AGPR) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results before the compiler's v_accvgpr_read
     // the next tile's setup + requests go out first: their DMA latency runs under this tile's epilogue.  (The 256 x 256 form keeps 164 bytes per lane of
-    // loop-invariant addressing state in scratch -- written in the prologue, reloaded here: profiles/r06_pmc_hconv256_v5.txt shows it as 22 MB of WRITE_SIZE
+    // loop-invariant addressing state in scratch -- written in the prologue, reloaded here: profiles/r06_pmc_hconv256_v6.txt shows it as 22 MB of WRITE_SIZE
     // beside the 32.8 MB output; moving this setup behind the epilogue or packing the results first did not remove it -- the main loop's 128 accumulators +
     // 48 fragment registers + addressing are what fill the file.)
     if (tl + (int)gridDim.x < ntiles) {

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(512) void wsgemm_kernel(RpP p) {
     const int nslices = p.nsplit;
     // (row group, weight slice) of this workgroup.  XCD-aware (speed only; round 6): the nslices workgroups of ONE row group share blockIdx % 8, i.e. one
     // XCD's L2 fetches their common x panels once -- with the plain order (slice fastest) the three slices of the 384-wide level sat on three XCDs and
-    // each pulled the panels through the fabric: 49.6 MB read per launch for 25 MB of operands (profiles/r06_pmc_traffic_v5.json)
+    // each pulled the panels through the fabric: 49.6 MB read per launch for 25 MB of operands (profiles/r06_pmc_traffic_v6.json)
     const int ngrp = gridDim.x / nslices;
     int slice, rgrp;
     {

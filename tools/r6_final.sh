@@ -4,7 +4,7 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}; mkdir -p gpurun_out
 TAG=${1:-r06_v1}
 exp/mfma_data > gpurun_out/${TAG}_ubench_mfma_data.txt 2>&1
-bash tools/round_profile.sh $TAG "round 6: halo-resident 3x3 convolutions (csrc/hconv.hip), K-sliced 64-token-level convolutions, GroupNorm statistics finalised once, attn2 with <= 512 audio keys on the fused routes of every level, two workgroups per CU in sattn_fused at d = 48" > gpurun_out/${TAG}_profile.log 2>&1
+bash tools/round_profile.sh $TAG "round 6: halo-resident 3x3 convolutions (csrc/hconv.hip), K-sliced 64-token-level convolutions, GroupNorm statistics finalised once, attn2 with <= 512 audio keys on the fused routes of every level, sattn_fused: two workgroups per CU at d = 48, statistics on the dot-product instruction, LDS-staged token fragments" > gpurun_out/${TAG}_profile.log 2>&1
 bash tools/round_pmc_step.sh $TAG "round 6" > gpurun_out/${TAG}_pmcstep.log 2>&1
 timeout 1200 bash tools/round_pmc_traffic.sh $TAG > gpurun_out/${TAG}_pmctraffic.log 2>&1
 for spec in "xattn xattn_kernel" "hconv256 hconv_kernel" "hconv128 hconv_kernel"; do set -- $spec
